@@ -1,0 +1,309 @@
+/*
+ * posevo.h -- C ABI of the MI355X attestation-aggregation + LMD-GHOST engine.
+ *
+ * The reference (ethereum/pos-evolution, one file: pos-evolution.md, cited as
+ * pe:N) has no FFI; its "API" for this path is three pyspec signatures over
+ * Python objects:
+ *     get_head(store) -> Root                                   pe:1102
+ *     on_attestation(store, attestation, is_from_block=False)   pe:963 / pe:1423
+ *     process_attestation(state, attestation)                   pe:722
+ * plus the handlers that feed them (get_forkchoice_store pe:1077, on_tick
+ * pe:934, on_block pe:986, on_attester_slashing pe:1447).  Every entry point
+ * below names the reference lines it replaces.  INTEGRATION.md shows the
+ * ctypes / cgo stubs a client maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++ / torch types.  The caller owns every
+ *    buffer it passes; the engine owns its handle and all device memory.
+ *  - every function returns PE_OK (0) or a negative pe_status; nothing throws.
+ *    A failing call leaves the store unmodified ("Invalid calls to handlers
+ *    must not modify store", pe:1041).
+ *  - one thread per handle at a time (the spec is sequential, pe:929-1039).
+ *    Calls are synchronous: they return after the device work has completed.
+ *  - roots are 32 opaque bytes; the all-zero root is "unset" (Root(), pe:943).
+ *  - G1 points cross the boundary in the 96-byte uncompressed form: big-endian
+ *    x (48 B) || big-endian y (48 B); bit 6 of byte 0 set = point at infinity.
+ *    Outputs are canonical (x, y fully reduced mod p), so equality with the
+ *    oracle is integer equality (tolerance 0).
+ *  - bitfields are packed LSB-first (bit i = byte i/8, bit i%8), the SSZ
+ *    Bitlist order without the length delimiter; n_bits travels beside it.
+ */
+#ifndef POSEVO_H
+#define POSEVO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PE_ABI_VERSION 1
+
+typedef struct pe_engine pe_engine;
+
+typedef enum pe_status {
+    PE_OK = 0,
+    PE_ERR_INVALID_ARG = -1,
+    PE_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime failure (message via pe_last_error) */
+    PE_ERR_OOM = -3,
+    PE_ERR_UNKNOWN_PARENT = -4, /* on_block: assert block.parent_root in store.block_states (pe:990) */
+    PE_ERR_FUTURE_BLOCK = -5,   /* on_block: assert get_current_slot(store) >= block.slot (pe:994) */
+    PE_ERR_NOT_AFTER_FINALIZED = -6, /* on_block: assert block.slot > finalized_slot (pe:998) */
+    PE_ERR_NOT_FINALIZED_DESCENDANT = -7, /* on_block: ancestor-at-finalized-slot check (pe:1000) */
+    PE_ERR_DUPLICATE_BLOCK = -8,
+    PE_ERR_UNKNOWN_ROOT = -9,
+    PE_ERR_CAPACITY = -10,
+    PE_ERR_NO_COMMITTEES = -11, /* no committee table loaded for the attestation's target epoch */
+    PE_ERR_NOT_SLASHABLE = -12, /* on_attester_slashing: is_slashable_attestation_data false (pe:1453) */
+    PE_ERR_INVALID_INDEXED = -13, /* is_valid_indexed_attestation false (pe:1455-1456) */
+    PE_ERR_STATE = -14          /* call sequence error (e.g. store not initialised) */
+} pe_status;
+
+/* Per-attestation result codes written by the *_batch calls (0 = applied).  Each
+ * value names the assert that failed; a rejected attestation changes nothing. */
+typedef enum pe_att_status {
+    PE_ATT_OK = 0,
+    PE_ATT_TARGET_EPOCH_NOT_CURRENT_OR_PREVIOUS = 1, /* validate_target_epoch_against_current_time / pe:724 */
+    PE_ATT_TARGET_EPOCH_SLOT_MISMATCH = 2,           /* target.epoch == compute_epoch_at_slot(data.slot), pe:725 */
+    PE_ATT_UNKNOWN_TARGET_ROOT = 3,
+    PE_ATT_UNKNOWN_BEACON_BLOCK_ROOT = 4,
+    PE_ATT_BLOCK_AFTER_ATTESTATION_SLOT = 5,
+    PE_ATT_TARGET_NOT_ANCESTOR = 6,                  /* LMD vote must be consistent with FFG vote target */
+    PE_ATT_SLOT_NOT_IN_PAST = 7,                     /* get_current_slot(store) >= data.slot + 1 */
+    PE_ATT_NO_COMMITTEE_TABLE = 8,
+    PE_ATT_COMMITTEE_INDEX_OUT_OF_RANGE = 9,         /* pe:727 */
+    PE_ATT_BITS_LENGTH_MISMATCH = 10,                /* len(aggregation_bits) == len(committee), pe:730 */
+    PE_ATT_EMPTY_OR_INVALID_INDICES = 11,            /* is_valid_indexed_attestation structural part, pe:736/976 */
+    PE_ATT_BAD_SIGNATURE = 12,                       /* injected pairing result false, pe:736/976 */
+    PE_ATT_INCLUSION_WINDOW = 13,                    /* pe:726 */
+    PE_ATT_SOURCE_MISMATCH = 14                      /* assert is_matching_source (Appendix A.9) */
+} pe_att_status;
+
+/* Constants the reference cites by name only (pe:467, 1021-1022, 1054, ...);
+ * defaults = mainnet preset. */
+typedef struct pe_config {
+    uint64_t slots_per_epoch;                 /* 32, pe:472 */
+    uint64_t seconds_per_slot;                /* 12, pe:1536 */
+    uint64_t intervals_per_slot;              /* 3,  pe:1536 */
+    uint64_t safe_slots_to_update_justified;  /* 8,  pe:1054 */
+    uint64_t proposer_score_boost;            /* 40 (percent of one slot's committee weight), pe:1355 */
+    uint64_t effective_balance_increment;     /* 1e9 Gwei, pe:126 */
+    uint64_t min_attestation_inclusion_delay; /* 1, pe:726 */
+    uint64_t max_validators_per_committee;    /* 2048, pe:715 */
+    uint32_t filter_slashed;                  /* 0: this era's get_latest_attesting_balance ignores `slashed` */
+    int32_t  device;                          /* HIP device ordinal; -1 = current device */
+    uint64_t reserve_validators;              /* capacity hints (0 = grow on demand) */
+    uint32_t reserve_blocks;
+    uint32_t reserved0;
+} pe_config;
+
+/* Validator flag bits (T1: the per-validator byte the vote kernel streams). */
+#define PE_VAL_ACTIVE       0x01u  /* activation_epoch <= current_epoch(justified state) < exit_epoch */
+#define PE_VAL_SLASHED      0x02u  /* Validator.slashed (pe:40) */
+#define PE_VAL_EQUIVOCATING 0x04u  /* in store.equivocating_indices (pe:897); set by the engine */
+
+/* Attestation row: AttestationData (pe:689-697) + where its Bitlist (pe:715) lives
+ * in the caller's bit arena + the injected signature verdict (pe:717). */
+#define PE_ATT_FLAG_SIGNATURE_VALID 0x1u  /* result of the out-of-scope pairing check */
+#define PE_ATT_FLAG_FROM_BLOCK      0x2u  /* is_from_block (pe:1423) */
+typedef struct pe_attestation {
+    uint64_t slot;                  /* data.slot */
+    uint64_t index;                 /* data.index: committee index within the slot */
+    uint8_t  beacon_block_root[32]; /* data.beacon_block_root: the LMD GHOST vote */
+    uint64_t source_epoch;          /* data.source */
+    uint8_t  source_root[32];
+    uint64_t target_epoch;          /* data.target */
+    uint8_t  target_root[32];
+    uint32_t bits_offset;           /* byte offset of aggregation_bits in the arena */
+    uint32_t n_bits;                /* len(aggregation_bits) */
+    uint32_t flags;                 /* PE_ATT_FLAG_* */
+    uint32_t reserved0;
+} pe_attestation;                   /* 144 bytes */
+
+/* The slice of BeaconState that process_attestation (pe:722-754) reads. */
+typedef struct pe_state_ctx {
+    uint64_t slot;                        /* state.slot */
+    uint8_t  chain_tip_root[32];          /* latest block of the state's chain: get_block_root* resolve against it */
+    uint64_t current_justified_epoch;     /* state.current_justified_checkpoint */
+    uint8_t  current_justified_root[32];
+    uint64_t previous_justified_epoch;    /* state.previous_justified_checkpoint */
+    uint8_t  previous_justified_root[32];
+    uint64_t base_reward_per_increment;   /* get_base_reward_per_increment(state) (Appendix A.9) */
+} pe_state_ctx;
+
+/* ---- lifecycle --------------------------------------------------------- */
+uint32_t    pe_abi_version(void);
+void        pe_config_default(pe_config* cfg);
+int         pe_engine_create(const pe_config* cfg, pe_engine** out);
+void        pe_engine_destroy(pe_engine* h);
+const char* pe_strerror(int status);
+const char* pe_last_error(const pe_engine* h);  /* detail of the last failing call on this handle */
+/* Run the engine's kernels on a caller-owned HIP stream (hipStream_t as void*).
+ * NULL = the engine's own stream.  Lets a host framework order its collectives
+ * (RCCL) with the engine's kernels without host synchronisation. */
+int         pe_set_stream(pe_engine* h, void* hip_stream);
+
+/* ---- store: get_forkchoice_store (pe:1077-1095) ------------------------- */
+/* Anchor block + state: justified = finalized = best_justified = (anchor_epoch,
+ * anchor_root); time = genesis_time + SECONDS_PER_SLOT * anchor_slot; no latest
+ * messages; no equivocators; no boost.  Resets any previous store contents. */
+int pe_store_init(pe_engine* h, uint64_t genesis_time, uint64_t anchor_slot,
+                  const uint8_t anchor_root[32]);
+
+/* checkpoint_states[justified_checkpoint].validators (Appendix A.1): balances and
+ * activity of the JUSTIFIED-checkpoint state.  pubkeys96 may be NULL (no G1 work).
+ * Copies the caller's buffers.  Keeps existing votes when n is unchanged/grows. */
+int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96,
+                      const uint64_t* effective_balance, const uint8_t* flags);
+/* Cheap refresh when the justified checkpoint changes: balances + flags only. */
+int pe_set_balances(pe_engine* h, uint64_t n, const uint64_t* effective_balance, const uint8_t* flags);
+
+/* on_tick (pe:934-955): time, boost reset on a new slot, best_justified promotion. */
+int pe_on_tick(pe_engine* h, uint64_t time);
+
+/* on_block (pe:986-1036) minus state_transition: the caller supplies the block's
+ * root and the post-state's current_justified / finalized checkpoints. */
+int pe_on_block(pe_engine* h, const uint8_t root[32], const uint8_t parent_root[32], uint64_t slot,
+                uint64_t post_justified_epoch, const uint8_t post_justified_root[32],
+                uint64_t post_finalized_epoch, const uint8_t post_finalized_root[32]);
+/* Raw insertion (store.blocks[root] = block, pe:1016) with only the structural
+ * checks (known parent, slot > parent.slot); no time/finality/boost handling.
+ * For bulk loading a tree (checkpoint sync, benchmarks). */
+int pe_add_block(pe_engine* h, const uint8_t root[32], const uint8_t parent_root[32], uint64_t slot,
+                 uint64_t post_justified_epoch, const uint8_t post_justified_root[32],
+                 uint64_t post_finalized_epoch, const uint8_t post_finalized_root[32]);
+
+/* Direct setters for store scalars (pe:891-896); root may be the zero root. */
+int pe_set_checkpoints(pe_engine* h, uint64_t justified_epoch, const uint8_t justified_root[32],
+                       uint64_t finalized_epoch, const uint8_t finalized_root[32]);
+int pe_set_proposer_boost(pe_engine* h, const uint8_t root[32]);
+/* on_attester_slashing's effect (pe:1459-1461): equivocating_indices.add(index). */
+int pe_mark_equivocating(pe_engine* h, const uint64_t* indices, uint64_t n);
+/* on_attester_slashing (pe:1447-1461) on two IndexedAttestations: checks
+ * is_slashable_attestation_data (pe:1134-1143) and the structural part of
+ * is_valid_indexed_attestation, then marks the intersection. */
+int pe_on_attester_slashing(pe_engine* h,
+                            const pe_attestation* data_1, const uint64_t* indices_1, uint64_t n_1,
+                            const pe_attestation* data_2, const uint64_t* indices_2, uint64_t n_2);
+
+/* Committee table of one epoch = get_beacon_committee(state, slot, index) for every
+ * (slot, index) of that epoch (Appendix A.6 / compute_committee pe:495-504), as CSR:
+ * committee id = (slot % SLOTS_PER_EPOCH) * committees_per_slot + index,
+ * members[offsets[id] .. offsets[id+1]).  n_committees must be a multiple of
+ * SLOTS_PER_EPOCH.  The engine keeps the four most recent epochs. */
+int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees,
+                      const uint32_t* offsets, const uint32_t* members);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* get_head (pe:1102-1116): full recomputation from the V-entry vote table:
+ * get_filtered_block_tree (Appendix A.3), get_latest_attesting_balance
+ * (Appendix A.1, incl. proposer boost and equivocation mask), heaviest-child
+ * descent with ties to the lexicographically higher root (pe:1114-1116). */
+int pe_get_head(pe_engine* h, uint8_t out_root[32]);
+/* get_latest_attesting_balance(store, root) for every block, in insertion order
+ * (index 0 = anchor).  out must hold pe_num_blocks(h) entries. */
+int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n);
+
+/* on_attestation (pe:963-979, pe:1423-1428) x n, applied AS IF sequentially in
+ * array order: validate_on_attestation (Appendix A.4), committee lookup
+ * (get_indexed_attestation), is_valid_indexed_attestation (structural +
+ * injected signature verdict), update_latest_messages (pe:1435-1441).
+ * status[i] receives a pe_att_status.  out_aggpk96 (nullable, 96*n bytes)
+ * receives sum of the attesters' pubkeys = the G1 sum FastAggregateVerify
+ * consumes (Appendix A.7); out_count (nullable) the number of attesters. */
+int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n,
+                            const uint8_t* bits_arena, uint64_t arena_len,
+                            int32_t* status, uint8_t* out_aggpk96, uint32_t* out_count);
+
+/* Aggregation (validator guide, Appendix A.8; reference prose pe:474/659/715/1536):
+ * attestations with identical AttestationData and n_bits form one group (groups
+ * ordered by first appearance).  Per group: aggregation_bits = OR of the members'
+ * bits; signature = sum of the members' signature points (sig_points96, 96 B per
+ * input attestation, nullable); aggregate pubkey = sum of pubkey[committee[i]]
+ * over the OR-ed bits (needs the epoch's committee table; NULL out to skip).
+ *   out_atts[g]   : the group's data, bits_offset into out_bits_arena
+ *   group_of[i]   : group index of input attestation i (nullable)
+ * Capacities: out_atts has room for n rows, out_bits_arena for out_arena_cap bytes. */
+int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n,
+                 const uint8_t* bits_arena, uint64_t arena_len, const uint8_t* sig_points96,
+                 pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                 uint8_t* out_bits_arena, uint64_t out_arena_cap,
+                 uint8_t* out_sig96, uint8_t* out_aggpk96, uint32_t* out_count);
+
+/* process_attestation (pe:722-754) x n, as if sequentially in array order, on the
+ * engine's working participation arrays: asserts pe:724-730, participation flag
+ * indices (Appendix A.9), flag RMW pe:745-749, and per attestation the
+ * proposer_reward_numerator (pe:744-749).  The caller finishes pe:752-754
+ * (numerator // denominator, increase_balance). */
+int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* state,
+                                 const pe_attestation* atts, uint32_t n,
+                                 const uint8_t* bits_arena, uint64_t arena_len,
+                                 int32_t* status, uint64_t* out_numerators);
+/* state.{current,previous}_epoch_participation of the working state (pe:739-742).
+ * which: 0 = current, 1 = previous. */
+int pe_participation_set(pe_engine* h, int which, const uint8_t* flags, uint64_t n);
+int pe_participation_get(pe_engine* h, int which, uint8_t* out_flags, uint64_t n);
+/* process_participation_flag_updates at an epoch boundary: previous = current, current = 0. */
+int pe_participation_rotate(pe_engine* h);
+
+/* Plain G1 sum over caller-chosen groups: out[g] = sum_{j in [offsets[g], offsets[g+1])}
+ * points[index[j]] (index NULL = identity).  points96 NULL = the validators' pubkeys. */
+int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points,
+              const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, uint8_t* out96);
+
+/* ---- inspection (parity checks) ---------------------------------------- */
+uint32_t pe_num_blocks(const pe_engine* h);
+uint64_t pe_num_validators(const pe_engine* h);
+int pe_block_root_at(const pe_engine* h, uint32_t block_index, uint8_t out_root[32]);
+int pe_block_index_of(const pe_engine* h, const uint8_t root[32], uint32_t* out_index);
+/* store.latest_messages: epoch and block index per validator; block index
+ * 0xFFFFFFFF = no message. */
+int pe_get_latest_messages(pe_engine* h, uint64_t* out_epoch, uint32_t* out_block_index, uint64_t n);
+int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_time,
+                         uint64_t* justified_epoch, uint8_t justified_root[32],
+                         uint64_t* finalized_epoch, uint8_t finalized_root[32],
+                         uint64_t* best_justified_epoch, uint8_t best_justified_root[32],
+                         uint8_t proposer_boost_root[32]);
+
+/* ---- multi-GPU exchange (validator-range shards) ----------- */
+/* Each rank owns a contiguous validator range and the whole (small) block table.
+ * get_head splits at the one exchange point:
+ *   pe_votes_partial  : this shard's direct vote weight per block (tree order),
+ *                       written to a caller-owned DEVICE buffer of pe_num_blocks u64
+ *   <host framework: all-reduce(sum, u64) over ranks -- RCCL via torch.distributed>
+ *   pe_head_from_weights : subtree sums + descent from the reduced DEVICE buffer
+ * total_active_balance / num_active feed the proposer boost (Appendix A.1) and
+ * must be the global (all-shard) values. */
+int pe_votes_partial(pe_engine* h, void* dev_weights_u64, uint32_t n_blocks,
+                     uint64_t* out_local_active_balance, uint64_t* out_local_num_active);
+int pe_head_from_weights(pe_engine* h, const void* dev_weights_u64, uint32_t n_blocks,
+                         uint64_t total_active_balance, uint64_t num_active, uint8_t out_root[32]);
+/* G1: per-group Jacobian partial sums (144 B each, Montgomery form) of this shard's
+ * points into a caller-owned DEVICE buffer; after an all-gather over ranks,
+ * pe_g1_finish adds the n_ranks partials per group and normalises to affine. */
+#define PE_G1_PARTIAL_BYTES 144
+int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups,
+                  void* dev_partials);
+int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups,
+                 uint8_t* out96);
+
+/* ---- profiling hooks (bench.py roofline leg) ----------------------------- */
+/* When enabled, the engine brackets each launch of its kernels with HIP events on
+ * the launch stream and accumulates per-kernel launch counts and durations. */
+#define PE_KERNEL_G1_ACCUMULATE 0
+#define PE_KERNEL_G1_NORMALISE  1
+#define PE_KERNEL_VOTES         2
+#define PE_KERNEL_TREE          3
+#define PE_KERNEL_LMD           4
+#define PE_KERNEL_PARTICIPATION 5
+#define PE_KERNEL_BITS_UNION    6
+#define PE_KERNEL_COUNT         7
+int pe_profile_enable(pe_engine* h, int on);
+int pe_profile_reset(pe_engine* h);
+int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEVO_H */
