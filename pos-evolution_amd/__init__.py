@@ -1,0 +1,16 @@
+"""pos-evolution_amd: MI355X-native attestation aggregation + LMD-GHOST fork choice.
+
+The product is ``libposevo.so`` (HIP kernels + C ABI, ``include/posevo.h``); this package is
+the thin Python host layer above it:
+
+    _abi        ctypes declarations of the C ABI
+    engine      numpy-level wrapper, one method per pe_* entry point
+    forkchoice  the reference's interface (get_head / on_attestation / process_attestation ...)
+    sharded     validator-range sharding over N GPUs (torch.distributed / RCCL exchange)
+
+Import never falls back to a CPU implementation: without the built library it raises.
+"""
+from . import _abi
+from .engine import AttRow, Engine, EngineError, pack_attestations
+
+__all__ = ["Engine", "EngineError", "AttRow", "pack_attestations", "_abi"]

@@ -1,0 +1,1644 @@
+// engine.cpp -- host side of libposevo: the fork-choice store, validation, launch
+// orchestration and the C ABI of include/posevo.h.  Compiled with hipcc (host code +
+// HIP runtime API); all device code lives in g1_kernels.hip / fc_kernels.hip.
+//
+// The store mirrors the reference's `Store` (pe:889-901) as flat tables: a block table
+// (root -> insertion index, parent index, slot, post-state checkpoints), the three
+// checkpoints, time, proposer_boost_root, and per-validator device arrays (latest
+// message, effective balance, flags, pubkey).  Handlers follow the reference line by
+// line where it defines them (on_tick pe:934-955, on_block pe:986-1036,
+// should_update_justified_checkpoint pe:1046-1061, on_attester_slashing pe:1447-1461)
+// and SURVEY.md Appendix A where it only calls them (validate_on_attestation A.4,
+// get_ancestor A.2, participation flags A.9).
+//
+// There is NO CPU fallback: every hot-path entry point fails with PE_ERR_NO_DEVICE when
+// the HIP device is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/posevo.h"
+#include "kernels.h"
+
+using namespace posevo;
+
+namespace {
+
+using Root = std::array<uint8_t, 32>;
+struct RootHash {
+    size_t operator()(const Root& r) const noexcept
+    {
+        uint64_t h;
+        memcpy(&h, r.data(), 8);  // roots are hash outputs: the first 8 bytes are already uniform
+        return (size_t)h;
+    }
+};
+inline Root to_root(const uint8_t* p)
+{
+    Root r;
+    memcpy(r.data(), p, 32);
+    return r;
+}
+inline bool is_zero_root(const Root& r)
+{
+    for (uint8_t b : r)
+        if (b) return false;
+    return true;
+}
+struct Checkpoint {
+    uint64_t epoch = 0;
+    Root root{};
+    bool operator==(const Checkpoint& o) const { return epoch == o.epoch && root == o.root; }
+};
+struct Block {
+    Root root;
+    uint32_t parent;  // insertion index; NONE32 for the anchor
+    uint64_t slot;
+    Checkpoint post_justified, post_finalized;  // block_states[root].{current_justified,finalized}_checkpoint
+};
+
+// Growable device / pinned-host buffers.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr)
+    {
+        if (bytes <= cap) return hipSuccess;
+        size_t ncap = std::max(bytes, cap + cap / 2);
+        ncap = (ncap + 255) & ~size_t(255);
+        void* np = nullptr;
+        hipError_t e = hipMalloc(&np, ncap);
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { (void)hipFree(np); return e; }
+        }
+        if (p) (void)hipFree(p);
+        p = np;
+        cap = ncap;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        size_t ncap = (std::max(bytes, cap * 2) + 4095) & ~size_t(4095);
+        void* np = nullptr;
+        hipError_t e = hipHostMalloc(&np, ncap, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (p) (void)hipHostFree(p);
+        p = np;
+        cap = ncap;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct CommitteeTable {
+    uint64_t epoch = 0;
+    uint32_t n_committees = 0;
+    std::vector<uint32_t> offsets;  // n_committees + 1
+    DevBuf d_members;               // u32[offsets.back()]
+    bool is_partition = false;      // every validator in at most one committee (true for a real shuffling)
+    uint64_t stamp = 0;
+};
+
+struct KernelProfile {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    uint64_t launches = 0;
+    double total_ms = 0;
+};
+
+}  // namespace
+
+struct pe_engine {
+    pe_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string last_error;
+
+    // ---- store scalars (pe:889-897) ----
+    bool initialised = false;
+    uint64_t time = 0, genesis_time = 0;
+    Checkpoint justified, finalized, best_justified;
+    Root boost_root{};
+    std::vector<Block> blocks;
+    std::unordered_map<Root, uint32_t, RootHash> index_of;
+
+    // ---- validators (T1/T2) ----
+    uint64_t n_val = 0;
+    bool have_points = false;
+    DevBuf d_points, d_balance, d_flags, d_incr, d_vote_key, d_vote_block, d_part_cur, d_part_prev;
+    std::vector<uint8_t> h_flags;  // host mirror (equivocating bit is OR-ed in here)
+
+    // ---- tree snapshot (pre-order) ----
+    bool tree_dirty = true;
+    DevBuf d_tsize, d_tparent, d_trank, d_tleaf, d_tpos, d_tidx, d_direct, d_weights, d_totals, d_head;
+    std::vector<uint32_t> h_pos_of_idx;
+    PinBuf h_pin;  // small D2H landing zone
+
+    // ---- committees ----
+    std::vector<CommitteeTable> tables;
+    uint64_t table_stamp = 0;
+
+    // ---- scratch ----
+    DevBuf d_rows, d_arena, d_groups, d_partials, d_out96, d_jac, d_idx, d_tmp_points, d_tmp_be, d_numer, d_nslot,
+        d_ugroups, d_uwords, d_uarena, d_ucount;
+    PinBuf h_stage;  // H2D staging
+
+    // ---- profiling ----
+    bool profiling = false;
+    KernelProfile prof[PE_KERNEL_COUNT];
+};
+
+namespace {
+
+// ------------------------------------------------------------------ errors
+int fail(pe_engine* h, int code, const std::string& msg)
+{
+    if (h) h->last_error = msg;
+    return code;
+}
+int hip_fail(pe_engine* h, hipError_t e, const char* what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    return fail(h, e == hipErrorOutOfMemory ? PE_ERR_OOM : PE_ERR_NO_DEVICE, m);
+}
+#define HIP_TRY(h, expr)                                        \
+    do {                                                        \
+        hipError_t _e = (expr);                                 \
+        if (_e != hipSuccess) return hip_fail((h), _e, #expr);  \
+    } while (0)
+
+struct ProfScope {
+    pe_engine* h;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(pe_engine* h_, int k_) : h(h_), k(k_)
+    {
+        if (!h->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~ProfScope()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, h->stream);
+        h->prof[k].pending.emplace_back(a, b);
+    }
+};
+
+// ------------------------------------------------------------------ spec helpers (A.10)
+inline uint64_t current_slot(const pe_engine* h) { return (h->time - h->genesis_time) / h->cfg.seconds_per_slot; }
+inline uint64_t epoch_at_slot(const pe_engine* h, uint64_t slot) { return slot / h->cfg.slots_per_epoch; }
+inline uint64_t start_slot(const pe_engine* h, uint64_t epoch) { return epoch * h->cfg.slots_per_epoch; }
+inline uint64_t slots_since_epoch_start(const pe_engine* h, uint64_t slot) { return slot % h->cfg.slots_per_epoch; }
+
+inline bool find_block(const pe_engine* h, const Root& r, uint32_t* idx)
+{
+    auto it = h->index_of.find(r);
+    if (it == h->index_of.end()) return false;
+    *idx = it->second;
+    return true;
+}
+// get_ancestor (A.2): walk parent links while block.slot > slot.
+inline uint32_t get_ancestor(const pe_engine* h, uint32_t idx, uint64_t slot)
+{
+    while (h->blocks[idx].slot > slot && h->blocks[idx].parent != NONE32) idx = h->blocks[idx].parent;
+    return idx;
+}
+uint64_t isqrt64(uint64_t n)
+{
+    uint64_t x = n, y = (x + 1) / 2;
+    while (y < x) { x = y; y = (x + n / x) / 2; }
+    return x;
+}
+
+// ------------------------------------------------------------------ tree snapshot
+// DFS pre-order of the block tree + subtree sizes, root ranks and filter_block_tree's leaf test.
+int refresh_tree(pe_engine* h)
+{
+    if (!h->tree_dirty) return PE_OK;
+    const uint32_t n = (uint32_t)h->blocks.size();
+    if (n > (uint32_t)TREE_MAX_BLOCKS)
+        return fail(h, PE_ERR_CAPACITY, "block table exceeds the LDS-resident tree capacity (8192)");
+    std::vector<uint32_t> first_child(n, NONE32), next_sib(n, NONE32), last_child(n, NONE32);
+    for (uint32_t i = 1; i < n; ++i) {  // children in insertion order
+        const uint32_t p = h->blocks[i].parent;
+        if (last_child[p] == NONE32) first_child[p] = i; else next_sib[last_child[p]] = i;
+        last_child[p] = i;
+    }
+    std::vector<uint32_t> pos_of(n), idx_of(n), size(n, 1), parent_pos(n, NONE32), stack;
+    stack.reserve(64);
+    uint32_t pos = 0;
+    stack.push_back(0);
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    while (!stack.empty()) {  // iterative pre-order
+        const uint32_t b = stack.back();
+        stack.pop_back();
+        pos_of[b] = pos;
+        idx_of[pos] = b;
+        ++pos;
+        order.push_back(b);
+        // push children in reverse so the first child is visited first
+        uint32_t cnt = 0;
+        for (uint32_t c = first_child[b]; c != NONE32; c = next_sib[c]) ++cnt;
+        const size_t base = stack.size();
+        stack.resize(base + cnt);
+        uint32_t k = 0;
+        for (uint32_t c = first_child[b]; c != NONE32; c = next_sib[c]) stack[base + cnt - 1 - k++] = c;
+    }
+    for (uint32_t k = n; k-- > 1;) {  // children after parents in pre-order: accumulate sizes bottom-up
+        const uint32_t b = order[k];
+        size[h->blocks[b].parent] += size[b];
+    }
+    std::vector<uint32_t> sz_pos(n), rank_pos(n);
+    std::vector<uint8_t> leaf_pos(n);
+    std::vector<uint32_t> by_root(n);
+    std::iota(by_root.begin(), by_root.end(), 0u);
+    std::sort(by_root.begin(), by_root.end(),
+              [&](uint32_t a, uint32_t b) { return h->blocks[a].root < h->blocks[b].root; });  // lexicographic
+    std::vector<uint32_t> rank(n);
+    for (uint32_t r = 0; r < n; ++r) rank[by_root[r]] = r;
+    for (uint32_t b = 0; b < n; ++b) {
+        const uint32_t p = pos_of[b];
+        sz_pos[p] = size[b];
+        rank_pos[p] = rank[b];
+        parent_pos[p] = h->blocks[b].parent == NONE32 ? NONE32 : pos_of[h->blocks[b].parent];
+        const Block& blk = h->blocks[b];
+        const bool correct_justified = h->justified.epoch == 0 || blk.post_justified == h->justified;
+        const bool correct_finalized = h->finalized.epoch == 0 || blk.post_finalized == h->finalized;
+        leaf_pos[p] = (correct_justified && correct_finalized) ? 1 : 0;
+    }
+    const size_t cap = std::max<size_t>(n, 64);
+    HIP_TRY(h, h->d_tsize.ensure(cap * 4));
+    HIP_TRY(h, h->d_tparent.ensure(cap * 4));
+    HIP_TRY(h, h->d_trank.ensure(cap * 4));
+    HIP_TRY(h, h->d_tleaf.ensure(cap));
+    HIP_TRY(h, h->d_tpos.ensure(cap * 4));
+    HIP_TRY(h, h->d_tidx.ensure(cap * 4));
+    HIP_TRY(h, h->d_direct.ensure(cap * 8));
+    HIP_TRY(h, h->d_weights.ensure(cap * 8));
+    HIP_TRY(h, h->d_totals.ensure(sizeof(VoteTotals)));
+    HIP_TRY(h, h->d_head.ensure(64));
+    hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_tsize.p, sz_pos.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tparent.p, parent_pos.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_trank.p, rank_pos.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tleaf.p, leaf_pos.data(), n, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tpos.p, pos_of.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tidx.p, idx_of.data(), n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipStreamSynchronize(s));  // the host vectors die at scope exit
+    h->h_pos_of_idx = pos_of;
+    h->tree_dirty = false;
+    return PE_OK;
+}
+
+TreeDev tree_dev(const pe_engine* h)
+{
+    TreeDev t;
+    t.size = h->d_tsize.as<uint32_t>();
+    t.parent = h->d_tparent.as<uint32_t>();
+    t.rank = h->d_trank.as<uint32_t>();
+    t.leaf_ok = h->d_tleaf.as<uint8_t>();
+    t.pos_of_idx = h->d_tpos.as<uint32_t>();
+    t.idx_of_pos = h->d_tidx.as<uint32_t>();
+    t.n = (uint32_t)h->blocks.size();
+    return t;
+}
+
+int insert_block(pe_engine* h, const Root& root, uint32_t parent, uint64_t slot, const Checkpoint& pj,
+                 const Checkpoint& pf)
+{
+    Block b;
+    b.root = root;
+    b.parent = parent;
+    b.slot = slot;
+    b.post_justified = pj;
+    b.post_finalized = pf;
+    h->index_of.emplace(root, (uint32_t)h->blocks.size());
+    h->blocks.push_back(b);
+    h->tree_dirty = true;
+    return PE_OK;
+}
+
+CommitteeTable* find_table(pe_engine* h, uint64_t epoch)
+{
+    for (auto& t : h->tables)
+        if (t.epoch == epoch && t.n_committees) return &t;
+    return nullptr;
+}
+
+// Re-pack one attestation's bits into 32-bit words (zero padded, masked to n_use bits); returns popcount.
+uint32_t pack_bits(const uint8_t* src, uint32_t n_use, uint32_t* dst_words)
+{
+    const uint32_t n_words = (n_use + 31) / 32;
+    const uint32_t n_bytes = (n_use + 7) / 8;
+    uint32_t cnt = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t byte = 4 * w + k;
+            if (byte < n_bytes) v |= (uint32_t)src[byte] << (8 * k);
+        }
+        if (w == n_words - 1 && (n_use & 31)) v &= (1u << (n_use & 31)) - 1u;
+        dst_words[w] = v;
+        cnt += (uint32_t)__builtin_popcount(v);
+    }
+    return cnt;
+}
+
+// ------------------------------------------------------------------ G1 plan
+constexpr uint32_t G1_TARGET_LANES = 131072;  // 2 waves per SIMD on 256 CUs
+struct G1Plan {
+    std::vector<G1Group> groups;
+    uint32_t n_slots = 0, n_partials = 0;
+};
+// sizes[g] = members of group g; member_start/bits_word filled by the caller afterwards.
+void plan_g1(const std::vector<uint32_t>& sizes, G1Plan* plan)
+{
+    uint64_t total = 0;
+    for (uint32_t s : sizes) total += s;
+    uint32_t k = (uint32_t)std::max<uint64_t>(4, (total + G1_TARGET_LANES - 1) / G1_TARGET_LANES);
+    plan->groups.resize(sizes.size());
+    uint32_t cursor = 0, out = 0;
+    for (size_t g = 0; g < sizes.size(); ++g) {
+        G1Group& d = plan->groups[g];
+        d.member_start = 0;
+        d.bits_word = NONE32;
+        d.n_members = sizes[g];
+        d.k = k;
+        d.n_tasks = (sizes[g] + k - 1) / k;
+        if (d.n_tasks == 0) {
+            d.log2_block = 0;
+            d.slot_base = cursor;
+            d.out_base = out;
+            continue;
+        }
+        if (d.n_tasks <= (uint32_t)G1_WG) {
+            uint32_t l2 = 0;
+            while ((1u << l2) < d.n_tasks) ++l2;
+            d.log2_block = l2;
+            const uint32_t blk = 1u << l2;
+            cursor = (cursor + blk - 1) & ~(blk - 1);
+            d.slot_base = cursor;
+            cursor += blk;
+            d.out_base = out;
+            out += 1;
+        } else {
+            d.log2_block = 9;  // wide: whole workgroups
+            cursor = (cursor + G1_WG - 1) & ~(uint32_t)(G1_WG - 1);
+            d.slot_base = cursor;
+            const uint32_t wgs = (d.n_tasks + G1_WG - 1) / G1_WG;
+            cursor += wgs * G1_WG;
+            d.out_base = out;
+            out += wgs;
+        }
+    }
+    plan->n_slots = cursor;
+    plan->n_partials = out;
+}
+
+// Run accumulate + finish for a plan whose groups are already complete.  points/members/bit arena are device
+// pointers; out96_host (nullable) receives the affine sums, dev_jac (nullable) the Jacobian sums on device.
+int run_g1(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
+           const G1Plan& plan, uint8_t* out96_host, uint32_t* dev_jac)
+{
+    const uint32_t ng = (uint32_t)plan.groups.size();
+    if (ng == 0) return PE_OK;
+    HIP_TRY(h, h->d_groups.ensure(sizeof(G1Group) * ng));
+    HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(144, 144ull * plan.n_partials)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_groups.p, plan.groups.data(), sizeof(G1Group) * ng, hipMemcpyHostToDevice,
+                              h->stream));
+    {
+        ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE);
+        launch_g1_accumulate(h->stream, d_points, d_members, d_bits, h->d_groups.as<G1Group>(), ng, plan.n_slots,
+                             h->d_partials.as<uint32_t>());
+    }
+    uint8_t* d_out = nullptr;
+    if (out96_host) {
+        HIP_TRY(h, h->d_out96.ensure(96ull * ng));
+        d_out = h->d_out96.as<uint8_t>();
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
+        launch_g1_finish(h->stream, h->d_partials.as<uint32_t>(), h->d_groups.as<G1Group>(), ng, 0, 0, d_out,
+                         dev_jac);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (out96_host) {
+        HIP_TRY(h, h->h_pin.ensure(96ull * ng));
+        HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, d_out, 96ull * ng, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        memcpy(out96_host, h->h_pin.p, 96ull * ng);
+    } else {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));  // plan.groups (host) was the async copy source
+    }
+    return PE_OK;
+}
+
+// ------------------------------------------------------------------ attestation resolution
+struct Resolved {
+    CommitteeTable* table = nullptr;
+    uint32_t pos = 0;        // committee id in the table
+    uint32_t size = 0;       // committee length
+    uint32_t block_idx = 0;  // beacon_block_root
+};
+
+// validate_on_attestation (A.4) + committee resolution for on_attestation (pe:970-976).
+int32_t validate_for_fork_choice(pe_engine* h, const pe_attestation& a, Resolved* out)
+{
+    const bool from_block = (a.flags & PE_ATT_FLAG_FROM_BLOCK) != 0;
+    const uint64_t cur_slot = current_slot(h);
+    if (!from_block) {  // validate_target_epoch_against_current_time
+        const uint64_t cur_epoch = epoch_at_slot(h, cur_slot);
+        const uint64_t prev_epoch = cur_epoch > 0 ? cur_epoch - 1 : 0;
+        if (a.target_epoch != cur_epoch && a.target_epoch != prev_epoch)
+            return PE_ATT_TARGET_EPOCH_NOT_CURRENT_OR_PREVIOUS;
+    }
+    if (a.target_epoch != epoch_at_slot(h, a.slot)) return PE_ATT_TARGET_EPOCH_SLOT_MISMATCH;
+    uint32_t tgt_idx, blk_idx;
+    if (!find_block(h, to_root(a.target_root), &tgt_idx)) return PE_ATT_UNKNOWN_TARGET_ROOT;
+    if (!find_block(h, to_root(a.beacon_block_root), &blk_idx)) return PE_ATT_UNKNOWN_BEACON_BLOCK_ROOT;
+    if (h->blocks[blk_idx].slot > a.slot) return PE_ATT_BLOCK_AFTER_ATTESTATION_SLOT;
+    if (get_ancestor(h, blk_idx, start_slot(h, a.target_epoch)) != tgt_idx) return PE_ATT_TARGET_NOT_ANCESTOR;
+    if (cur_slot < a.slot + 1) return PE_ATT_SLOT_NOT_IN_PAST;
+    // get_indexed_attestation -> get_beacon_committee(target_state, slot, index) (A.6)
+    CommitteeTable* t = find_table(h, a.target_epoch);
+    if (!t) return PE_ATT_NO_COMMITTEE_TABLE;
+    const uint64_t cps = t->n_committees / h->cfg.slots_per_epoch;
+    const uint64_t pos = (a.slot % h->cfg.slots_per_epoch) * cps + a.index;
+    if (pos >= t->n_committees) return PE_ATT_COMMITTEE_INDEX_OUT_OF_RANGE;
+    const uint32_t size = t->offsets[pos + 1] - t->offsets[pos];
+    if (a.n_bits < size) return PE_ATT_BITS_LENGTH_MISMATCH;  // bits[i] would raise for i >= len(bits)
+    out->table = t;
+    out->pos = (uint32_t)pos;
+    out->size = size;
+    out->block_idx = blk_idx;
+    return PE_ATT_OK;
+}
+
+bool att_data_equal(const pe_attestation& a, const pe_attestation& b)
+{
+    return a.slot == b.slot && a.index == b.index && a.source_epoch == b.source_epoch &&
+           a.target_epoch == b.target_epoch && memcmp(a.beacon_block_root, b.beacon_block_root, 32) == 0 &&
+           memcmp(a.source_root, b.source_root, 32) == 0 && memcmp(a.target_root, b.target_root, 32) == 0;
+}
+
+int ensure_validator_arrays(pe_engine* h, uint64_t n)
+{
+    const size_t n4 = (n + 3) & ~size_t(3);
+    HIP_TRY(h, h->d_balance.ensure(std::max<size_t>(64, n4 * 8)));
+    HIP_TRY(h, h->d_flags.ensure(std::max<size_t>(64, n4)));
+    HIP_TRY(h, h->d_incr.ensure(std::max<size_t>(64, n4 * 2)));
+    return PE_OK;
+}
+
+int upload_balances(pe_engine* h, uint64_t n, const uint64_t* bal, const uint8_t* flags)
+{
+    std::vector<uint16_t> incr(n);
+    const uint64_t inc = h->cfg.effective_balance_increment;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t q = bal[i] / inc;
+        if (q > 0xFFFF) return fail(h, PE_ERR_INVALID_ARG, "effective_balance / increment exceeds 65535");
+        incr[i] = (uint16_t)q;
+    }
+    int rc = ensure_validator_arrays(h, n);
+    if (rc) return rc;
+    // keep equivocation marks across balance refreshes (equivocating_indices only grows, pe:1459-1461)
+    std::vector<uint8_t> f(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t v = flags[i] & (PE_VAL_ACTIVE | PE_VAL_SLASHED);
+        if (i < h->h_flags.size() && (h->h_flags[i] & PE_VAL_EQUIVOCATING)) v |= PE_VAL_EQUIVOCATING;
+        f[i] = v;
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_balance.p, bal, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_flags.p, f.data(), n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_incr.p, incr.data(), n * 2, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->h_flags.swap(f);
+    return PE_OK;
+}
+
+int need_init(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    if (!h->initialised) return fail(h, PE_ERR_STATE, "store not initialised: call pe_store_init first");
+    (void)hipSetDevice(h->device);
+    return PE_OK;
+}
+
+// get_head's device part on arbitrary weight buffer.
+int run_tree(pe_engine* h, uint64_t* d_direct, int use_override, uint64_t ov_bal, uint64_t ov_num, uint32_t* head_out)
+{
+    uint32_t just_idx;
+    if (!find_block(h, h->justified.root, &just_idx))
+        return fail(h, PE_ERR_UNKNOWN_ROOT, "justified checkpoint root is not in the store");
+    uint32_t boost_pos = NONE32;
+    if (!is_zero_root(h->boost_root)) {
+        uint32_t bi;
+        if (find_block(h, h->boost_root, &bi)) boost_pos = h->h_pos_of_idx[bi];
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_TREE);
+        launch_tree(h->stream, tree_dev(h), d_direct, h->d_totals.as<VoteTotals>(), ov_bal, ov_num, use_override,
+                    h->h_pos_of_idx[just_idx], boost_pos, h->cfg.slots_per_epoch, h->cfg.proposer_score_boost,
+                    h->cfg.effective_balance_increment, h->d_weights.as<uint64_t>(), h->d_head.as<uint32_t>());
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, h->h_pin.ensure(64));
+    HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_head.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *head_out = *h->h_pin.as<uint32_t>();
+    if (*head_out >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
+    return PE_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+uint32_t pe_abi_version(void) { return PE_ABI_VERSION; }
+
+void pe_config_default(pe_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->slots_per_epoch = 32;
+    c->seconds_per_slot = 12;
+    c->intervals_per_slot = 3;
+    c->safe_slots_to_update_justified = 8;
+    c->proposer_score_boost = 40;
+    c->effective_balance_increment = 1000000000ull;
+    c->min_attestation_inclusion_delay = 1;
+    c->max_validators_per_committee = 2048;
+    c->filter_slashed = 0;
+    c->device = -1;
+}
+
+const char* pe_strerror(int status)
+{
+    switch (status) {
+        case PE_OK: return "ok";
+        case PE_ERR_INVALID_ARG: return "invalid argument";
+        case PE_ERR_NO_DEVICE: return "no HIP device / HIP runtime failure";
+        case PE_ERR_OOM: return "out of memory";
+        case PE_ERR_UNKNOWN_PARENT: return "on_block: parent block unknown";
+        case PE_ERR_FUTURE_BLOCK: return "on_block: block is from the future";
+        case PE_ERR_NOT_AFTER_FINALIZED: return "on_block: block slot not after the finalized slot";
+        case PE_ERR_NOT_FINALIZED_DESCENDANT: return "on_block: block does not descend from the finalized checkpoint";
+        case PE_ERR_DUPLICATE_BLOCK: return "block already in the store";
+        case PE_ERR_UNKNOWN_ROOT: return "unknown root";
+        case PE_ERR_CAPACITY: return "capacity exceeded";
+        case PE_ERR_NO_COMMITTEES: return "no committee table for the epoch";
+        case PE_ERR_NOT_SLASHABLE: return "attestation data not slashable";
+        case PE_ERR_INVALID_INDEXED: return "invalid indexed attestation";
+        case PE_ERR_STATE: return "call sequence error";
+        default: return "unknown status";
+    }
+}
+const char* pe_last_error(const pe_engine* h) { return h ? h->last_error.c_str() : ""; }
+
+int pe_engine_create(const pe_config* cfg, pe_engine** out)
+{
+    if (!out) return PE_ERR_INVALID_ARG;
+    *out = nullptr;
+    pe_config c;
+    if (cfg) c = *cfg; else pe_config_default(&c);
+    if (c.slots_per_epoch == 0 || c.seconds_per_slot == 0 || c.intervals_per_slot == 0 ||
+        c.effective_balance_increment == 0)
+        return PE_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return PE_ERR_NO_DEVICE;  // no CPU fallback
+    int dev = c.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return PE_ERR_NO_DEVICE;
+    }
+    if (dev >= ndev) return PE_ERR_INVALID_ARG;
+    if (hipSetDevice(dev) != hipSuccess) return PE_ERR_NO_DEVICE;
+    pe_engine* h = new (std::nothrow) pe_engine();
+    if (!h) return PE_ERR_OOM;
+    h->cfg = c;
+    h->device = dev;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return PE_ERR_NO_DEVICE;
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return PE_OK;
+}
+
+void pe_engine_destroy(pe_engine* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_vote_key, &h->d_vote_block,
+                      &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
+                      &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_rows,
+                      &h->d_arena, &h->d_groups, &h->d_partials, &h->d_out96, &h->d_jac, &h->d_idx,
+                      &h->d_tmp_points, &h->d_tmp_be, &h->d_numer, &h->d_nslot, &h->d_ugroups, &h->d_uwords,
+                      &h->d_uarena, &h->d_ucount})
+        b->release();
+    for (auto& t : h->tables) t.d_members.release();
+    h->h_pin.release();
+    h->h_stage.release();
+    for (auto& p : h->prof)
+        for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int pe_set_stream(pe_engine* h, void* hip_stream)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- store
+int pe_store_init(pe_engine* h, uint64_t genesis_time, uint64_t anchor_slot, const uint8_t anchor_root[32])
+{
+    if (!h || !anchor_root) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    h->blocks.clear();
+    h->index_of.clear();
+    h->genesis_time = genesis_time;
+    h->time = genesis_time + h->cfg.seconds_per_slot * anchor_slot;       // pe:1085
+    const uint64_t anchor_epoch = anchor_slot / h->cfg.slots_per_epoch;   // get_current_epoch(anchor_state)
+    Checkpoint cp;
+    cp.epoch = anchor_epoch;
+    cp.root = to_root(anchor_root);
+    h->justified = h->finalized = h->best_justified = cp;                 // pe:1081-1082, 1089
+    h->boost_root = Root{};                                               // pe:1083
+    // the anchor's own post-state checkpoints are not given by get_forkchoice_store; the anchor is
+    // only ever a leaf while nothing descends from it, and then get_head returns it regardless.
+    insert_block(h, cp.root, NONE32, anchor_slot, cp, cp);
+    for (auto& f : h->h_flags) f &= (uint8_t)~PE_VAL_EQUIVOCATING;        // equivocating_indices = set()
+    if (h->n_val) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_flags.p, h->h_flags.data(), h->n_val, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_vote_key.p, 0, h->n_val * 8, h->stream));       // latest_messages = {}
+        HIP_TRY(h, hipMemsetAsync(h->d_vote_block.p, 0xFF, h->n_val * 4, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->initialised = true;
+    return PE_OK;
+}
+
+int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const uint64_t* effective_balance,
+                      const uint8_t* flags)
+{
+    if (!h || (n && (!effective_balance || !flags))) return PE_ERR_INVALID_ARG;
+    if (n >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "validator index must fit 32 bits");
+    (void)hipSetDevice(h->device);
+    const uint64_t old_n = h->n_val;
+    int rc = upload_balances(h, n, effective_balance, flags);
+    if (rc) return rc;
+    const size_t n4 = (n + 3) & ~size_t(3);
+    HIP_TRY(h, h->d_vote_key.ensure(std::max<size_t>(64, n4 * 8), true, h->stream));
+    HIP_TRY(h, h->d_vote_block.ensure(std::max<size_t>(64, n4 * 4), true, h->stream));
+    HIP_TRY(h, h->d_part_cur.ensure(std::max<size_t>(64, n4), true, h->stream));
+    HIP_TRY(h, h->d_part_prev.ensure(std::max<size_t>(64, n4), true, h->stream));
+    if (n > old_n) {  // new validators: no latest message, no participation
+        HIP_TRY(h, hipMemsetAsync(h->d_vote_key.as<uint64_t>() + old_n, 0, (n4 - old_n) * 8, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_vote_block.as<uint32_t>() + old_n, 0xFF, (n4 - old_n) * 4, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_part_cur.as<uint8_t>() + old_n, 0, n4 - old_n, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_part_prev.as<uint8_t>() + old_n, 0, n4 - old_n, h->stream));
+    }
+    if (pubkeys96 && n) {
+        HIP_TRY(h, h->d_points.ensure(96ull * n));
+        // convert in chunks through a bounded device staging buffer
+        const uint64_t chunk = std::min<uint64_t>(n, 1u << 20);
+        HIP_TRY(h, h->d_tmp_be.ensure(96ull * chunk));
+        for (uint64_t base = 0; base < n; base += chunk) {
+            const uint64_t m = std::min(chunk, n - base);
+            HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, pubkeys96 + 96ull * base, 96ull * m, hipMemcpyHostToDevice,
+                                      h->stream));
+            launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_points.as<uint32_t>() + 24ull * base, m);
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+        HIP_TRY(h, hipGetLastError());
+        h->have_points = true;
+    } else if (!pubkeys96) {
+        h->have_points = h->have_points && n <= old_n;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_val = n;
+    return PE_OK;
+}
+
+int pe_set_balances(pe_engine* h, uint64_t n, const uint64_t* effective_balance, const uint8_t* flags)
+{
+    if (!h || !effective_balance || !flags) return PE_ERR_INVALID_ARG;
+    if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_set_balances: n differs from the registry size");
+    (void)hipSetDevice(h->device);
+    return upload_balances(h, n, effective_balance, flags);
+}
+
+int pe_on_tick(pe_engine* h, uint64_t time)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (time < h->genesis_time) return fail(h, PE_ERR_INVALID_ARG, "time before genesis");
+    const uint64_t previous_slot = current_slot(h);
+    h->time = time;                                                    // pe:938
+    const uint64_t cur = current_slot(h);
+    if (cur > previous_slot) h->boost_root = Root{};                   // pe:943-944
+    if (!(cur > previous_slot && slots_since_epoch_start(h, cur) == 0)) return PE_OK;  // pe:947-948
+    if (h->best_justified.epoch > h->justified.epoch) {                // pe:951-955
+        const uint64_t finalized_slot = start_slot(h, h->finalized.epoch);
+        uint32_t bj, fi;
+        if (find_block(h, h->best_justified.root, &bj) && find_block(h, h->finalized.root, &fi) &&
+            get_ancestor(h, bj, finalized_slot) == fi) {
+            h->justified = h->best_justified;
+            h->tree_dirty = true;
+        }
+    }
+    return PE_OK;
+}
+
+static int add_block_common(pe_engine* h, const uint8_t* root, const uint8_t* parent_root, uint64_t slot,
+                            uint64_t pj_epoch, const uint8_t* pj_root, uint64_t pf_epoch, const uint8_t* pf_root,
+                            bool handler)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!root || !parent_root || !pj_root || !pf_root) return PE_ERR_INVALID_ARG;
+    uint32_t parent;
+    if (!find_block(h, to_root(parent_root), &parent)) return fail(h, PE_ERR_UNKNOWN_PARENT, "unknown parent");  // pe:990
+    const Root r = to_root(root);
+    if (h->index_of.count(r)) {
+        // store.blocks[root] = block is idempotent in the reference; the table keeps the first insertion
+        return handler ? PE_OK : fail(h, PE_ERR_DUPLICATE_BLOCK, "duplicate block");
+    }
+    if (h->blocks.size() >= (size_t)TREE_MAX_BLOCKS) return fail(h, PE_ERR_CAPACITY, "block table full (8192)");
+    Checkpoint pj, pf;
+    pj.epoch = pj_epoch; pj.root = to_root(pj_root);
+    pf.epoch = pf_epoch; pf.root = to_root(pf_root);
+    if (slot <= h->blocks[parent].slot) return fail(h, PE_ERR_INVALID_ARG, "block slot must exceed its parent's slot");
+    if (handler) {
+        if (current_slot(h) < slot) return fail(h, PE_ERR_FUTURE_BLOCK, "block from the future");          // pe:994
+        const uint64_t finalized_slot = start_slot(h, h->finalized.epoch);
+        if (!(slot > finalized_slot)) return fail(h, PE_ERR_NOT_AFTER_FINALIZED, "slot <= finalized slot");  // pe:998
+        uint32_t fi;
+        if (!find_block(h, h->finalized.root, &fi) || get_ancestor(h, parent, finalized_slot) != fi)
+            return fail(h, PE_ERR_NOT_FINALIZED_DESCENDANT, "not a descendant of the finalized checkpoint");  // pe:1000
+    }
+    insert_block(h, r, parent, slot, pj, pf);                                                               // pe:1016-1018
+    if (!handler) return PE_OK;
+    // proposer boost (pe:1020-1024)
+    const uint64_t time_into_slot = (h->time - h->genesis_time) % h->cfg.seconds_per_slot;
+    const bool before_attesting = time_into_slot < h->cfg.seconds_per_slot / h->cfg.intervals_per_slot;
+    if (current_slot(h) == slot && before_attesting) h->boost_root = r;
+    // justified checkpoint (pe:1027-1031)
+    if (pj.epoch > h->justified.epoch) {
+        if (pj.epoch > h->best_justified.epoch) h->best_justified = pj;
+        // should_update_justified_checkpoint (pe:1046-1061)
+        bool update = false;
+        if (slots_since_epoch_start(h, current_slot(h)) < h->cfg.safe_slots_to_update_justified) {
+            update = true;
+        } else {
+            const uint64_t justified_slot = start_slot(h, h->justified.epoch);
+            uint32_t nj, cj;
+            update = find_block(h, pj.root, &nj) && find_block(h, h->justified.root, &cj) &&
+                     get_ancestor(h, nj, justified_slot) == cj;
+        }
+        if (update) h->justified = pj;
+    }
+    // finalized checkpoint (pe:1034-1036)
+    if (pf.epoch > h->finalized.epoch) {
+        h->finalized = pf;
+        h->justified = pj;
+    }
+    h->tree_dirty = true;
+    return PE_OK;
+}
+
+int pe_on_block(pe_engine* h, const uint8_t root[32], const uint8_t parent_root[32], uint64_t slot,
+                uint64_t pj_epoch, const uint8_t pj_root[32], uint64_t pf_epoch, const uint8_t pf_root[32])
+{
+    return add_block_common(h, root, parent_root, slot, pj_epoch, pj_root, pf_epoch, pf_root, true);
+}
+int pe_add_block(pe_engine* h, const uint8_t root[32], const uint8_t parent_root[32], uint64_t slot,
+                 uint64_t pj_epoch, const uint8_t pj_root[32], uint64_t pf_epoch, const uint8_t pf_root[32])
+{
+    return add_block_common(h, root, parent_root, slot, pj_epoch, pj_root, pf_epoch, pf_root, false);
+}
+
+int pe_set_checkpoints(pe_engine* h, uint64_t je, const uint8_t jr[32], uint64_t fe, const uint8_t fr[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!jr || !fr) return PE_ERR_INVALID_ARG;
+    uint32_t tmp;
+    if (!find_block(h, to_root(jr), &tmp)) return fail(h, PE_ERR_UNKNOWN_ROOT, "justified root unknown");
+    h->justified.epoch = je; h->justified.root = to_root(jr);
+    h->finalized.epoch = fe; h->finalized.root = to_root(fr);
+    if (h->best_justified.epoch < je) h->best_justified = h->justified;
+    h->tree_dirty = true;
+    return PE_OK;
+}
+
+int pe_set_proposer_boost(pe_engine* h, const uint8_t root[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!root) return PE_ERR_INVALID_ARG;
+    const Root r = to_root(root);
+    uint32_t tmp;
+    if (!is_zero_root(r) && !find_block(h, r, &tmp)) return fail(h, PE_ERR_UNKNOWN_ROOT, "boost root unknown");
+    h->boost_root = r;
+    return PE_OK;
+}
+
+int pe_mark_equivocating(pe_engine* h, const uint64_t* indices, uint64_t n)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (n && !indices) return PE_ERR_INVALID_ARG;
+    for (uint64_t i = 0; i < n; ++i)
+        if (indices[i] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "validator index out of range");
+    for (uint64_t i = 0; i < n; ++i) h->h_flags[indices[i]] |= PE_VAL_EQUIVOCATING;
+    if (n) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_flags.p, h->h_flags.data(), h->n_val, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return PE_OK;
+}
+
+static bool sorted_unique_nonempty(const uint64_t* idx, uint64_t n)
+{
+    if (n == 0) return false;
+    for (uint64_t i = 1; i < n; ++i)
+        if (!(idx[i - 1] < idx[i])) return false;
+    return true;
+}
+
+int pe_on_attester_slashing(pe_engine* h, const pe_attestation* d1, const uint64_t* i1, uint64_t n1,
+                            const pe_attestation* d2, const uint64_t* i2, uint64_t n2)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!d1 || !d2) return PE_ERR_INVALID_ARG;
+    // is_slashable_attestation_data (pe:1134-1143)
+    const bool double_vote = !att_data_equal(*d1, *d2) && d1->target_epoch == d2->target_epoch;
+    const bool surround = d1->source_epoch < d2->source_epoch && d2->target_epoch < d1->target_epoch;
+    if (!(double_vote || surround)) return fail(h, PE_ERR_NOT_SLASHABLE, "attestation data not slashable");
+    // is_valid_indexed_attestation (A.7): structure + injected signature verdict
+    if (!sorted_unique_nonempty(i1, n1) || !(d1->flags & PE_ATT_FLAG_SIGNATURE_VALID) ||
+        !sorted_unique_nonempty(i2, n2) || !(d2->flags & PE_ATT_FLAG_SIGNATURE_VALID))
+        return fail(h, PE_ERR_INVALID_INDEXED, "invalid indexed attestation");
+    std::vector<uint64_t> inter;
+    std::set_intersection(i1, i1 + n1, i2, i2 + n2, std::back_inserter(inter));
+    for (uint64_t v : inter)
+        if (v >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "validator index out of range");
+    return pe_mark_equivocating(h, inter.data(), inter.size());  // pe:1459-1461
+}
+
+int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const uint32_t* offsets,
+                      const uint32_t* members)
+{
+    if (!h || !offsets || (n_committees && offsets[n_committees] && !members)) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n_committees == 0 || n_committees % h->cfg.slots_per_epoch != 0)
+        return fail(h, PE_ERR_INVALID_ARG, "n_committees must be a positive multiple of SLOTS_PER_EPOCH");
+    if (offsets[0] != 0) return fail(h, PE_ERR_INVALID_ARG, "offsets[0] must be 0");
+    for (uint32_t c = 0; c < n_committees; ++c)
+        if (offsets[c + 1] < offsets[c]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
+    const uint32_t total = offsets[n_committees];
+    std::vector<uint8_t> seen(h->n_val, 0);
+    bool partition = true;
+    for (uint32_t i = 0; i < total; ++i) {
+        if (members[i] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "committee member index out of range");
+        if (seen[members[i]]) partition = false;
+        seen[members[i]] = 1;
+    }
+    // within one committee members must be distinct (a committee is a slice of a permutation)
+    if (!partition) {
+        std::vector<uint32_t> tmp;
+        for (uint32_t c = 0; c < n_committees; ++c) {
+            tmp.assign(members + offsets[c], members + offsets[c + 1]);
+            std::sort(tmp.begin(), tmp.end());
+            if (std::adjacent_find(tmp.begin(), tmp.end()) != tmp.end())
+                return fail(h, PE_ERR_INVALID_ARG, "duplicate member inside a committee");
+        }
+    }
+    CommitteeTable* t = find_table(h, epoch);
+    if (!t) {
+        if (h->tables.size() < 4) {
+            h->tables.emplace_back();
+            t = &h->tables.back();
+        } else {
+            t = &*std::min_element(h->tables.begin(), h->tables.end(),
+                                   [](const CommitteeTable& a, const CommitteeTable& b) { return a.stamp < b.stamp; });
+        }
+    }
+    HIP_TRY(h, t->d_members.ensure(std::max<size_t>(64, 4ull * total)));
+    HIP_TRY(h, hipMemcpyAsync(t->d_members.p, members, 4ull * total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    t->epoch = epoch;
+    t->n_committees = n_committees;
+    t->offsets.assign(offsets, offsets + n_committees + 1);
+    t->is_partition = partition;
+    t->stamp = ++h->table_stamp;
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- get_head
+int pe_get_head(pe_engine* h, uint8_t out_root[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!out_root) return PE_ERR_INVALID_ARG;
+    rc = refresh_tree(h);
+    if (rc) return rc;
+    {
+        ProfScope ps(h, PE_KERNEL_VOTES);
+        launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
+                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(),
+                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>());
+    }
+    uint32_t head;
+    rc = run_tree(h, h->d_direct.as<uint64_t>(), 0, 0, 0, &head);
+    if (rc) return rc;
+    memcpy(out_root, h->blocks[head].root.data(), 32);
+    return PE_OK;
+}
+
+int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!out_weights || n != h->blocks.size()) return fail(h, PE_ERR_INVALID_ARG, "n must equal pe_num_blocks");
+    uint8_t root[32];
+    rc = pe_get_head(h, root);  // recompute, then read the per-block weights it left behind
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(out_weights, h->d_weights.p, 8ull * n, hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
+int pe_votes_partial(pe_engine* h, void* dev_weights_u64, uint32_t n_blocks, uint64_t* out_bal, uint64_t* out_num)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!dev_weights_u64 || n_blocks != h->blocks.size()) return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
+    rc = refresh_tree(h);
+    if (rc) return rc;
+    {
+        ProfScope ps(h, PE_KERNEL_VOTES);
+        launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
+                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), n_blocks,
+                     static_cast<uint64_t*>(dev_weights_u64), h->d_totals.as<VoteTotals>());
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, h->h_pin.ensure(64));
+    HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_totals.p, sizeof(VoteTotals), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const VoteTotals* t = h->h_pin.as<VoteTotals>();
+    if (out_bal) *out_bal = t->total_active_balance;
+    if (out_num) *out_num = t->num_active;
+    return PE_OK;
+}
+
+int pe_head_from_weights(pe_engine* h, const void* dev_weights_u64, uint32_t n_blocks, uint64_t total_active_balance,
+                         uint64_t num_active, uint8_t out_root[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!dev_weights_u64 || !out_root || n_blocks != h->blocks.size())
+        return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
+    rc = refresh_tree(h);
+    if (rc) return rc;
+    uint32_t head;
+    rc = run_tree(h, const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_weights_u64)), 1, total_active_balance,
+                  num_active, &head);
+    if (rc) return rc;
+    memcpy(out_root, h->blocks[head].root.data(), 32);
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- on_attestation
+int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
+                            uint64_t arena_len, int32_t* status, uint8_t* out_aggpk96, uint32_t* out_count)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (n && (!atts || !bits_arena || !status)) return PE_ERR_INVALID_ARG;
+    if (out_aggpk96 && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
+    if (n == 0) return PE_OK;
+    // ---- validate everything first (validation reads only time/blocks/tables, never latest_messages) ----
+    std::vector<Resolved> res(n);
+    std::vector<AttRow> rows;
+    rows.reserve(n);
+    std::vector<uint32_t> words;        // re-packed bit arena (u32 words)
+    std::vector<uint32_t> row_of(n, NONE32);
+    std::vector<uint32_t> counts(n, 0);
+    CommitteeTable* table_used = nullptr;
+    bool multi_table = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pe_attestation& a = atts[i];
+        if ((uint64_t)a.bits_offset + (a.n_bits + 7) / 8 > arena_len)
+            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        if (a.target_epoch >= 0xFFFFFFFEull) return fail(h, PE_ERR_INVALID_ARG, "target epoch must fit 32 bits");
+        int32_t st = validate_for_fork_choice(h, a, &res[i]);
+        if (st == PE_ATT_OK) {
+            const uint32_t use = res[i].size;  // bits beyond the committee length are never read (A.6)
+            const size_t w0 = words.size();
+            words.resize(w0 + (use + 31) / 32);
+            counts[i] = use ? pack_bits(bits_arena + a.bits_offset, use, words.data() + w0) : 0;
+            // is_valid_indexed_attestation (A.7): non-empty sorted-unique indices, then the signature verdict
+            if (counts[i] == 0) st = PE_ATT_EMPTY_OR_INVALID_INDICES;
+            else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) st = PE_ATT_BAD_SIGNATURE;
+            if (st != PE_ATT_OK) words.resize(w0);
+            else {
+                AttRow r;
+                r.member_base = res[i].table->offsets[res[i].pos];
+                r.n_bits = use;
+                r.bits_word = (uint32_t)w0;
+                r.block_idx = res[i].block_idx;
+                r.epoch_p1 = (uint32_t)a.target_epoch + 1;
+                r.order = (uint32_t)rows.size();
+                r.flag_mask = 0;
+                r.which = 0;
+                row_of[i] = (uint32_t)rows.size();
+                rows.push_back(r);
+                if (table_used && table_used != res[i].table) multi_table = true;
+                table_used = res[i].table;
+            }
+        }
+        status[i] = st;
+        if (out_count) out_count[i] = st == PE_ATT_OK ? counts[i] : 0;
+    }
+    if (out_aggpk96)
+        for (uint32_t i = 0; i < n; ++i) { memset(out_aggpk96 + 96ull * i, 0, 96); out_aggpk96[96ull * i] = 0x40; }
+    if (rows.empty()) return PE_OK;
+    // Rows of different epochs index different member arrays: run one table at a time, in batch order per table.
+    // (order values stay global, so the first-seen rule across tables still holds: a validator's winner is the
+    // max (epoch, -order) over all rows.)
+    std::vector<CommitteeTable*> tabs;
+    if (!multi_table) tabs.push_back(table_used);
+    else
+        for (uint32_t i = 0; i < n; ++i)
+            if (row_of[i] != NONE32 && std::find(tabs.begin(), tabs.end(), res[i].table) == tabs.end())
+                tabs.push_back(res[i].table);
+    HIP_TRY(h, h->d_arena.ensure(std::max<size_t>(64, words.size() * 4)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_arena.p, words.data(), words.size() * 4, hipMemcpyHostToDevice, h->stream));
+    for (CommitteeTable* t : tabs) {
+        std::vector<AttRow> sub;
+        std::vector<uint32_t> sub_src;  // original attestation index per sub row
+        for (uint32_t i = 0; i < n; ++i)
+            if (row_of[i] != NONE32 && res[i].table == t) { sub.push_back(rows[row_of[i]]); sub_src.push_back(i); }
+        HIP_TRY(h, h->d_rows.ensure(sizeof(AttRow) * sub.size()));
+        HIP_TRY(h, hipMemcpyAsync(h->d_rows.p, sub.data(), sizeof(AttRow) * sub.size(), hipMemcpyHostToDevice,
+                                  h->stream));
+        {
+            ProfScope ps(h, PE_KERNEL_LMD);
+            launch_lmd_update(h->stream, h->d_rows.as<AttRow>(), (uint32_t)sub.size(), t->d_members.as<uint32_t>(),
+                              h->d_arena.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
+                              h->d_vote_block.as<uint32_t>());
+        }
+        HIP_TRY(h, hipGetLastError());
+        if (out_aggpk96) {
+            std::vector<uint32_t> sizes(sub.size());
+            for (size_t k = 0; k < sub.size(); ++k) sizes[k] = sub[k].n_bits;
+            G1Plan plan;
+            plan_g1(sizes, &plan);
+            for (size_t k = 0; k < sub.size(); ++k) {
+                plan.groups[k].member_start = sub[k].member_base;
+                plan.groups[k].bits_word = sub[k].bits_word;
+            }
+            std::vector<uint8_t> tmp(96ull * sub.size());
+            rc = run_g1(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(), h->d_arena.as<uint32_t>(), plan,
+                        tmp.data(), nullptr);
+            if (rc) return rc;
+            for (size_t k = 0; k < sub.size(); ++k) memcpy(out_aggpk96 + 96ull * sub_src[k], tmp.data() + 96 * k, 96);
+        }
+        HIP_TRY(h, hipStreamSynchronize(h->stream));  // sub/words are reused
+        t->stamp = ++h->table_stamp;
+    }
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- aggregation
+int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena, uint64_t arena_len,
+                 const uint8_t* sig_points96, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                 uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_sig96, uint8_t* out_aggpk96,
+                 uint32_t* out_count)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (!out_n_groups || (n && (!atts || !bits_arena || !out_atts || !out_bits_arena))) return PE_ERR_INVALID_ARG;
+    if (out_sig96 && !sig_points96) return fail(h, PE_ERR_INVALID_ARG, "out_sig96 requires sig_points96");
+    if (out_aggpk96 && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
+    *out_n_groups = 0;
+    if (n == 0) return PE_OK;
+    // ---- group by identical AttestationData + n_bits, in order of first appearance ----
+    auto hash_att = [](const pe_attestation& a) {
+        uint64_t hsh = a.slot * 0x9E3779B97F4A7C15ull ^ (a.index + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+        uint64_t t;
+        memcpy(&t, a.beacon_block_root, 8); hsh ^= t * 0x94D049BB133111EBull;
+        memcpy(&t, a.target_root, 8); hsh ^= (t + a.target_epoch) * 0xD6E8FEB86659FD93ull;
+        memcpy(&t, a.source_root, 8); hsh ^= (t + a.source_epoch) * 0xA24BAED4963EE407ull;
+        return (size_t)(hsh ^ a.n_bits);
+    };
+    std::unordered_multimap<size_t, uint32_t> buckets;
+    std::vector<uint32_t> gof(n);
+    std::vector<std::vector<uint32_t>> glist;
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
+            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        const size_t hv = hash_att(atts[i]);
+        uint32_t g = NONE32;
+        auto range = buckets.equal_range(hv);
+        for (auto it = range.first; it != range.second; ++it) {
+            const pe_attestation& rep = atts[glist[it->second][0]];
+            if (rep.n_bits == atts[i].n_bits && att_data_equal(rep, atts[i])) { g = it->second; break; }
+        }
+        if (g == NONE32) {
+            g = (uint32_t)glist.size();
+            glist.emplace_back();
+            buckets.emplace(hv, g);
+        }
+        glist[g].push_back(i);
+        gof[i] = g;
+    }
+    const uint32_t ng = (uint32_t)glist.size();
+    // ---- re-pack input bits, lay out the output arena ----
+    std::vector<uint32_t> words, att_word(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        att_word[i] = (uint32_t)words.size();
+        const uint32_t nb = atts[i].n_bits;
+        words.resize(words.size() + (nb + 31) / 32);
+        if (nb) pack_bits(bits_arena + atts[i].bits_offset, nb, words.data() + att_word[i]);
+    }
+    std::vector<UnionGroup> ug(ng);
+    std::vector<uint32_t> uwords;
+    uint32_t out_words = 0;
+    uint64_t out_bytes = 0;
+    std::vector<uint32_t> out_byte_off(ng);
+    for (uint32_t g = 0; g < ng; ++g) {
+        ug[g].list_start = (uint32_t)uwords.size();
+        ug[g].n_atts = (uint32_t)glist[g].size();
+        ug[g].n_words = (atts[glist[g][0]].n_bits + 31) / 32;
+        ug[g].out_word = out_words;
+        out_words += ug[g].n_words;
+        for (uint32_t i : glist[g]) uwords.push_back(att_word[i]);
+        out_byte_off[g] = (uint32_t)out_bytes;
+        out_bytes += (atts[glist[g][0]].n_bits + 7) / 8;
+    }
+    if (out_bytes > out_arena_cap) return fail(h, PE_ERR_CAPACITY, "output bit arena too small");
+    // ---- aggregate pubkey needs each group's committee ----
+    std::vector<Resolved> gres(ng);
+    CommitteeTable* table = nullptr;
+    if (out_aggpk96) {
+        for (uint32_t g = 0; g < ng; ++g) {
+            const pe_attestation& a = atts[glist[g][0]];
+            CommitteeTable* t = find_table(h, a.target_epoch);
+            if (!t) return fail(h, PE_ERR_NO_COMMITTEES, "no committee table for a group's target epoch");
+            if (table && t != table) return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate: one target epoch per call when aggregate pubkeys are requested");
+            table = t;
+            const uint64_t cps = t->n_committees / h->cfg.slots_per_epoch;
+            const uint64_t pos = (a.slot % h->cfg.slots_per_epoch) * cps + a.index;
+            if (a.index >= cps) return fail(h, PE_ERR_INVALID_ARG, "committee index out of range");
+            const uint32_t size = t->offsets[pos + 1] - t->offsets[pos];
+            if (a.n_bits != size) return fail(h, PE_ERR_INVALID_ARG, "len(aggregation_bits) != len(committee)");  // pe:730
+            gres[g].table = t;
+            gres[g].pos = (uint32_t)pos;
+            gres[g].size = size;
+        }
+    }
+    // ---- device: union ----
+    HIP_TRY(h, h->d_arena.ensure(std::max<size_t>(64, words.size() * 4)));
+    HIP_TRY(h, h->d_ugroups.ensure(sizeof(UnionGroup) * ng));
+    HIP_TRY(h, h->d_uwords.ensure(std::max<size_t>(64, uwords.size() * 4)));
+    HIP_TRY(h, h->d_uarena.ensure(std::max<size_t>(64, out_words * 4ull)));
+    HIP_TRY(h, h->d_ucount.ensure(std::max<size_t>(64, ng * 4ull)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_arena.p, words.data(), words.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ugroups.p, ug.data(), sizeof(UnionGroup) * ng, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_uwords.p, uwords.data(), uwords.size() * 4, hipMemcpyHostToDevice, h->stream));
+    {
+        ProfScope ps(h, PE_KERNEL_BITS_UNION);
+        launch_bits_union(h->stream, h->d_ugroups.as<UnionGroup>(), ng, h->d_uwords.as<uint32_t>(),
+                          h->d_arena.as<uint32_t>(), h->d_uarena.as<uint32_t>(), h->d_ucount.as<uint32_t>());
+    }
+    HIP_TRY(h, hipGetLastError());
+    std::vector<uint32_t> h_out_words(out_words), h_count(ng);
+    HIP_TRY(h, hipMemcpyAsync(h_out_words.data(), h->d_uarena.p, out_words * 4ull, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h_count.data(), h->d_ucount.p, ng * 4ull, hipMemcpyDeviceToHost, h->stream));
+    // ---- device: aggregate pubkey over the OR-ed bits (device-resident: no round trip of the bits) ----
+    if (out_aggpk96) {
+        std::vector<uint32_t> sizes(ng);
+        for (uint32_t g = 0; g < ng; ++g) sizes[g] = gres[g].size;
+        G1Plan plan;
+        plan_g1(sizes, &plan);
+        for (uint32_t g = 0; g < ng; ++g) {
+            plan.groups[g].member_start = table->offsets[gres[g].pos];
+            plan.groups[g].bits_word = ug[g].out_word;
+        }
+        int rc = run_g1(h, h->d_points.as<uint32_t>(), table->d_members.as<uint32_t>(), h->d_uarena.as<uint32_t>(),
+                        plan, out_aggpk96, nullptr);
+        if (rc) return rc;
+        table->stamp = ++h->table_stamp;
+    }
+    // ---- device: signature sum (bls.Aggregate): points indexed by input attestation ----
+    if (out_sig96) {
+        HIP_TRY(h, h->d_tmp_be.ensure(96ull * n));
+        HIP_TRY(h, h->d_tmp_points.ensure(96ull * n));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, h->stream));
+        launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
+        std::vector<uint32_t> idx, sizes(ng);
+        idx.reserve(n);
+        G1Plan plan;
+        for (uint32_t g = 0; g < ng; ++g) sizes[g] = (uint32_t)glist[g].size();
+        plan_g1(sizes, &plan);
+        for (uint32_t g = 0; g < ng; ++g) {
+            plan.groups[g].member_start = (uint32_t)idx.size();
+            for (uint32_t i : glist[g]) idx.push_back(i);
+        }
+        HIP_TRY(h, h->d_idx.ensure(4ull * n));
+        HIP_TRY(h, hipMemcpyAsync(h->d_idx.p, idx.data(), 4ull * n, hipMemcpyHostToDevice, h->stream));
+        int rc = run_g1(h, h->d_tmp_points.as<uint32_t>(), h->d_idx.as<uint32_t>(), nullptr, plan, out_sig96, nullptr);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // ---- outputs ----
+    const uint8_t* ob = reinterpret_cast<const uint8_t*>(h_out_words.data());
+    for (uint32_t g = 0; g < ng; ++g) {
+        out_atts[g] = atts[glist[g][0]];
+        out_atts[g].bits_offset = out_byte_off[g];
+        uint32_t fl = PE_ATT_FLAG_SIGNATURE_VALID;
+        for (uint32_t i : glist[g]) fl &= atts[i].flags | ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID;
+        out_atts[g].flags = (atts[glist[g][0]].flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | (fl & PE_ATT_FLAG_SIGNATURE_VALID);
+        memcpy(out_bits_arena + out_byte_off[g], ob + 4ull * ug[g].out_word, (out_atts[g].n_bits + 7) / 8);
+        if (out_count) out_count[g] = h_count[g];
+    }
+    if (group_of) memcpy(group_of, gof.data(), 4ull * n);
+    *out_n_groups = ng;
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- process_attestation
+int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_attestation* atts, uint32_t n,
+                                 const uint8_t* bits_arena, uint64_t arena_len, int32_t* status,
+                                 uint64_t* out_numerators)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!st || (n && (!atts || !bits_arena || !status || !out_numerators))) return PE_ERR_INVALID_ARG;
+    if (n == 0) return PE_OK;
+    uint32_t tip;
+    if (!find_block(h, to_root(st->chain_tip_root), &tip)) return fail(h, PE_ERR_UNKNOWN_ROOT, "chain tip unknown");
+    const uint64_t spe = h->cfg.slots_per_epoch;
+    const uint64_t cur_epoch = st->slot / spe;
+    const uint64_t prev_epoch = cur_epoch > 0 ? cur_epoch - 1 : 0;
+    const uint64_t sqrt_spe = isqrt64(spe);
+    Checkpoint cj, pj;
+    cj.epoch = st->current_justified_epoch; cj.root = to_root(st->current_justified_root);
+    pj.epoch = st->previous_justified_epoch; pj.root = to_root(st->previous_justified_root);
+
+    struct Acc { AttRow row; uint32_t src; CommitteeTable* table; uint32_t pos; };
+    std::vector<Acc> acc;
+    std::vector<uint32_t> words;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pe_attestation& a = atts[i];
+        out_numerators[i] = 0;
+        if ((uint64_t)a.bits_offset + (a.n_bits + 7) / 8 > arena_len)
+            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        int32_t s = PE_ATT_OK;
+        CommitteeTable* t = nullptr;
+        uint64_t pos = 0;
+        uint32_t size = 0;
+        if (a.target_epoch != prev_epoch && a.target_epoch != cur_epoch) s = PE_ATT_TARGET_EPOCH_NOT_CURRENT_OR_PREVIOUS;  // pe:724
+        else if (a.target_epoch != a.slot / spe) s = PE_ATT_TARGET_EPOCH_SLOT_MISMATCH;                                  // pe:725
+        else if (!(a.slot + h->cfg.min_attestation_inclusion_delay <= st->slot && st->slot <= a.slot + spe))
+            s = PE_ATT_INCLUSION_WINDOW;                                                                                 // pe:726
+        else if (!(t = find_table(h, a.target_epoch))) s = PE_ATT_NO_COMMITTEE_TABLE;
+        else if (a.index >= t->n_committees / spe) s = PE_ATT_COMMITTEE_INDEX_OUT_OF_RANGE;                              // pe:727
+        else {
+            pos = (a.slot % spe) * (t->n_committees / spe) + a.index;
+            size = t->offsets[pos + 1] - t->offsets[pos];
+            if (a.n_bits != size) s = PE_ATT_BITS_LENGTH_MISMATCH;                                                       // pe:730
+        }
+        uint32_t flag_mask = 0;
+        if (s == PE_ATT_OK) {
+            // get_attestation_participation_flag_indices (A.9)
+            const Checkpoint& justified = a.target_epoch == cur_epoch ? cj : pj;
+            Checkpoint src;
+            src.epoch = a.source_epoch; src.root = to_root(a.source_root);
+            const bool matching_source = src == justified;
+            if (!matching_source) s = PE_ATT_SOURCE_MISMATCH;
+            else {
+                // get_block_root(state, epoch) / get_block_root_at_slot(state, slot): the state's chain is the
+                // ancestry of chain_tip_root (both slots are < state.slot by pe:726)
+                const uint32_t tgt_blk = get_ancestor(h, tip, a.target_epoch * spe);
+                const bool matching_target = memcmp(h->blocks[tgt_blk].root.data(), a.target_root, 32) == 0;
+                const uint32_t head_blk = get_ancestor(h, tip, a.slot);
+                const bool matching_head = matching_target && memcmp(h->blocks[head_blk].root.data(), a.beacon_block_root, 32) == 0;
+                const uint64_t delay = st->slot - a.slot;
+                if (delay <= sqrt_spe) flag_mask |= 1u;                                        // TIMELY_SOURCE
+                if (matching_target && delay <= spe) flag_mask |= 2u;                          // TIMELY_TARGET
+                if (matching_head && delay == h->cfg.min_attestation_inclusion_delay) flag_mask |= 4u;  // TIMELY_HEAD
+            }
+        }
+        if (s == PE_ATT_OK) {
+            const size_t w0 = words.size();
+            words.resize(w0 + (size + 31) / 32);
+            const uint32_t cnt = size ? pack_bits(bits_arena + a.bits_offset, size, words.data() + w0) : 0;
+            if (cnt == 0) s = PE_ATT_EMPTY_OR_INVALID_INDICES;                                 // pe:736
+            else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) s = PE_ATT_BAD_SIGNATURE;
+            if (s != PE_ATT_OK) words.resize(w0);
+            else {
+                Acc e;
+                e.row.member_base = t->offsets[pos];
+                e.row.n_bits = size;
+                e.row.bits_word = (uint32_t)w0;
+                e.row.block_idx = 0;
+                e.row.epoch_p1 = 0;
+                e.row.order = 0;
+                e.row.flag_mask = flag_mask;
+                e.row.which = a.target_epoch == cur_epoch ? 0u : 1u;                           // pe:739-742
+                e.src = i;
+                e.table = t;
+                e.pos = (uint32_t)pos;
+                acc.push_back(e);
+            }
+        }
+        status[i] = s;
+    }
+    if (acc.empty()) return PE_OK;
+    // ---- rounds: attestations of one round touch pairwise disjoint validators, so the order inside a
+    // round is irrelevant; rounds run in order, which keeps the sequential semantics of pe:745-749 ----
+    std::vector<uint32_t> round_of(acc.size());
+    uint32_t n_rounds = 0;
+    {
+        std::unordered_map<uint64_t, uint32_t> seen;  // (table, which, committee) -> attestations so far
+        for (size_t k = 0; k < acc.size(); ++k) {
+            uint32_t r;
+            if (acc[k].table->is_partition) {
+                const uint64_t key = ((uint64_t)(acc[k].table - h->tables.data()) << 40) ^ ((uint64_t)acc[k].row.which << 36) ^ acc[k].pos;
+                r = seen[key]++;
+            } else {
+                r = (uint32_t)k;  // committees may overlap: fully sequential
+            }
+            round_of[k] = r;
+            n_rounds = std::max(n_rounds, r + 1);
+        }
+    }
+    HIP_TRY(h, h->d_arena.ensure(std::max<size_t>(64, words.size() * 4)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_arena.p, words.data(), words.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, h->d_numer.ensure(8ull * n));
+    HIP_TRY(h, hipMemsetAsync(h->d_numer.p, 0, 8ull * n, h->stream));
+    // rows sorted by (round, table); one launch per (round, table)
+    std::vector<size_t> ord(acc.size());
+    std::iota(ord.begin(), ord.end(), size_t(0));
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+        if (round_of[a] != round_of[b]) return round_of[a] < round_of[b];
+        return acc[a].table < acc[b].table;
+    });
+    std::vector<AttRow> rows(acc.size());
+    std::vector<uint32_t> nslot(acc.size());
+    for (size_t k = 0; k < ord.size(); ++k) { rows[k] = acc[ord[k]].row; nslot[k] = acc[ord[k]].src; }
+    HIP_TRY(h, h->d_rows.ensure(sizeof(AttRow) * rows.size()));
+    HIP_TRY(h, h->d_nslot.ensure(4ull * rows.size()));
+    HIP_TRY(h, hipMemcpyAsync(h->d_rows.p, rows.data(), sizeof(AttRow) * rows.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_nslot.p, nslot.data(), 4ull * rows.size(), hipMemcpyHostToDevice, h->stream));
+    for (size_t k = 0; k < ord.size();) {
+        size_t e = k + 1;
+        while (e < ord.size() && round_of[ord[e]] == round_of[ord[k]] && acc[ord[e]].table == acc[ord[k]].table) ++e;
+        ProfScope ps(h, PE_KERNEL_PARTICIPATION);
+        launch_participation(h->stream, h->d_rows.as<AttRow>() + k, (uint32_t)(e - k),
+                             acc[ord[k]].table->d_members.as<uint32_t>(), h->d_arena.as<uint32_t>(),
+                             h->d_incr.as<uint16_t>(), st->base_reward_per_increment, h->d_part_cur.as<uint32_t>(),
+                             h->d_part_prev.as<uint32_t>(), h->d_numer.as<uint64_t>(), h->d_nslot.as<uint32_t>() + k);
+        k = e;
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_numerators, h->d_numer.p, 8ull * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PE_OK;
+}
+
+int pe_participation_set(pe_engine* h, int which, const uint8_t* flags, uint64_t n)
+{
+    if (!h || !flags || n != h->n_val || (which != 0 && which != 1)) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    DevBuf& b = which ? h->d_part_prev : h->d_part_cur;
+    HIP_TRY(h, hipMemcpyAsync(b.p, flags, n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PE_OK;
+}
+int pe_participation_get(pe_engine* h, int which, uint8_t* out_flags, uint64_t n)
+{
+    if (!h || !out_flags || n != h->n_val || (which != 0 && which != 1)) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    DevBuf& b = which ? h->d_part_prev : h->d_part_cur;
+    HIP_TRY(h, hipMemcpyAsync(out_flags, b.p, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PE_OK;
+}
+int pe_participation_rotate(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    std::swap(h->d_part_cur, h->d_part_prev);  // previous = current
+    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), h->stream));  // current = 0
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- plain G1 sums
+int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const uint32_t* index, const uint32_t* offsets,
+              uint32_t n_groups, uint8_t* out96)
+{
+    if (!h || !offsets || !out96) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n_groups == 0) return PE_OK;
+    const uint32_t total = offsets[n_groups];
+    const uint32_t* d_pts;
+    uint64_t np;
+    if (points96) {
+        if (n_points >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "too many points");
+        HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(96, 96ull * n_points)));
+        HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(96, 96ull * n_points)));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n_points, hipMemcpyHostToDevice, h->stream));
+        launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
+        d_pts = h->d_tmp_points.as<uint32_t>();
+        np = n_points;
+    } else {
+        if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
+        d_pts = h->d_points.as<uint32_t>();
+        np = h->n_val;
+    }
+    std::vector<uint32_t> sizes(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
+        sizes[g] = offsets[g + 1] - offsets[g];
+    }
+    if (index) {
+        for (uint32_t j = 0; j < total; ++j)
+            if (index[j] >= np) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
+        HIP_TRY(h, h->d_idx.ensure(std::max<size_t>(64, 4ull * total)));
+        HIP_TRY(h, hipMemcpyAsync(h->d_idx.p, index, 4ull * total, hipMemcpyHostToDevice, h->stream));
+    } else if (total > np) {
+        return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
+    }
+    G1Plan plan;
+    plan_g1(sizes, &plan);
+    for (uint32_t g = 0; g < n_groups; ++g) plan.groups[g].member_start = offsets[g];
+    return run_g1(h, d_pts, index ? h->d_idx.as<uint32_t>() : nullptr, nullptr, plan, out96, nullptr);
+}
+
+int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, void* dev_partials)
+{
+    if (!h || !offsets || !dev_partials) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
+    if (n_groups == 0) return PE_OK;
+    const uint32_t total = offsets[n_groups];
+    std::vector<uint32_t> sizes(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) sizes[g] = offsets[g + 1] - offsets[g];
+    if (index) {
+        for (uint32_t j = 0; j < total; ++j)
+            if (index[j] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
+        HIP_TRY(h, h->d_idx.ensure(std::max<size_t>(64, 4ull * total)));
+        HIP_TRY(h, hipMemcpyAsync(h->d_idx.p, index, 4ull * total, hipMemcpyHostToDevice, h->stream));
+    }
+    G1Plan plan;
+    plan_g1(sizes, &plan);
+    for (uint32_t g = 0; g < n_groups; ++g) plan.groups[g].member_start = offsets[g];
+    return run_g1(h, h->d_points.as<uint32_t>(), index ? h->d_idx.as<uint32_t>() : nullptr, nullptr, plan, nullptr,
+                  static_cast<uint32_t*>(dev_partials));
+}
+
+int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups, uint8_t* out96)
+{
+    if (!h || !dev_gathered || !out96 || n_ranks == 0) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n_groups == 0) return PE_OK;
+    HIP_TRY(h, h->d_out96.ensure(96ull * n_groups));
+    {
+        ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
+        launch_g1_finish(h->stream, static_cast<const uint32_t*>(dev_gathered), nullptr, n_groups, n_ranks, n_groups,
+                         h->d_out96.as<uint8_t>(), nullptr);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, h->h_pin.ensure(96ull * n_groups));
+    HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_out96.p, 96ull * n_groups, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out96, h->h_pin.p, 96ull * n_groups);
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- inspection
+uint32_t pe_num_blocks(const pe_engine* h) { return h ? (uint32_t)h->blocks.size() : 0; }
+uint64_t pe_num_validators(const pe_engine* h) { return h ? h->n_val : 0; }
+int pe_block_root_at(const pe_engine* h, uint32_t i, uint8_t out_root[32])
+{
+    if (!h || !out_root || i >= h->blocks.size()) return PE_ERR_INVALID_ARG;
+    memcpy(out_root, h->blocks[i].root.data(), 32);
+    return PE_OK;
+}
+int pe_block_index_of(const pe_engine* h, const uint8_t root[32], uint32_t* out_index)
+{
+    if (!h || !root || !out_index) return PE_ERR_INVALID_ARG;
+    uint32_t i;
+    if (!find_block(h, to_root(root), &i)) return PE_ERR_UNKNOWN_ROOT;
+    *out_index = i;
+    return PE_OK;
+}
+int pe_get_latest_messages(pe_engine* h, uint64_t* out_epoch, uint32_t* out_block_index, uint64_t n)
+{
+    if (!h || !out_epoch || !out_block_index || n != h->n_val) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n == 0) return PE_OK;
+    std::vector<uint64_t> key(n);
+    HIP_TRY(h, hipMemcpyAsync(key.data(), h->d_vote_key.p, 8 * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_block_index, h->d_vote_block.p, 4 * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (key[i] == 0) { out_epoch[i] = 0; out_block_index[i] = NONE32; }
+        else out_epoch[i] = (key[i] >> 32) - 1;
+    }
+    return PE_OK;
+}
+int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_time, uint64_t* je, uint8_t jr[32],
+                         uint64_t* fe, uint8_t fr[32], uint64_t* be, uint8_t br[32], uint8_t boost[32])
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    if (time) *time = h->time;
+    if (genesis_time) *genesis_time = h->genesis_time;
+    if (je) *je = h->justified.epoch;
+    if (jr) memcpy(jr, h->justified.root.data(), 32);
+    if (fe) *fe = h->finalized.epoch;
+    if (fr) memcpy(fr, h->finalized.root.data(), 32);
+    if (be) *be = h->best_justified.epoch;
+    if (br) memcpy(br, h->best_justified.root.data(), 32);
+    if (boost) memcpy(boost, h->boost_root.data(), 32);
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- profiling
+int pe_profile_enable(pe_engine* h, int on)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    h->profiling = on != 0;
+    return PE_OK;
+}
+static void prof_drain(pe_engine* h)
+{
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->prof) {
+        for (auto& ev : p.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { p.total_ms += ms; p.launches += 1; }
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        p.pending.clear();
+    }
+}
+int pe_profile_reset(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    prof_drain(h);
+    for (auto& p : h->prof) { p.launches = 0; p.total_ms = 0; }
+    return PE_OK;
+}
+int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms)
+{
+    if (!h || kernel < 0 || kernel >= PE_KERNEL_COUNT) return PE_ERR_INVALID_ARG;
+    prof_drain(h);
+    if (launches) *launches = h->prof[kernel].launches;
+    if (total_ms) *total_ms = h->prof[kernel].total_ms;
+    return PE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,416 @@
+// fc_kernels.hip -- LMD-GHOST fork-choice and attestation bookkeeping kernels for gfx950.
+//
+//   k_votes          get_latest_attesting_balance's O(V) part (called from
+//                    get_head pe:1116): stream vote/balance/flags (13 B per validator),
+//                    LDS-privatised u64 histogram per workgroup, non-zero bins flushed
+//                    with one global atomic each; also the active-balance totals the
+//                    proposer boost needs.
+//   k_tree           one workgroup, block tree resident in LDS in DFS pre-order:
+//                    subtree weight = prefix-sum difference (pe:322: "B or descendants
+//                    of B"), filter_block_tree viability (A.3) from a second scan,
+//                    best child by (weight, root) (pe:1114-1116), then pointer jumping
+//                    replaces the sequential descent of pe:1107-1116.
+//   k_lmd_*          update_latest_messages (pe:1435-1441) for a whole batch with the
+//                    sequential semantics kept by a 64-bit atomicMax on (epoch+1, ~order).
+//   k_participation  the flag loop of process_attestation (pe:744-749).
+//   k_bits_union     aggregation_bits = OR (validator guide; pe:715, pe:730), popcount by
+//                    wave reduction.
+//
+// All of this is HBM/latency-bound integer work; no MFMA.
+#include "kernels.h"
+
+namespace posevo {
+
+constexpr uint32_t VAL_ACTIVE = 0x01u, VAL_SLASHED = 0x02u, VAL_EQUIVOCATING = 0x04u;
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ votes
+constexpr int VOTES_WG = 512;
+constexpr int VOTES_PER_THREAD = 4;
+
+__global__ void __launch_bounds__(VOTES_WG)
+k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ eff_balance,
+        const uint8_t* __restrict__ flags, uint64_t n_val, uint32_t filter_slashed,
+        const uint32_t* __restrict__ pos_of_idx, uint32_t n_blocks, unsigned long long* __restrict__ direct,
+        VoteTotals* __restrict__ totals)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];  // n_blocks bins, by insertion index
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) hist[b] = 0;
+    __syncthreads();
+
+    unsigned long long act_bal = 0;
+    uint32_t act_num = 0;
+    const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
+    for (uint64_t q = (uint64_t)blockIdx.x * VOTES_WG + threadIdx.x; q < n_quads; q += (uint64_t)gridDim.x * VOTES_WG) {
+        const uint64_t v0 = q * VOTES_PER_THREAD;
+        uint32_t vb[4];
+        unsigned long long bal[4];
+        uint32_t fl[4];
+        if (v0 + 4 <= n_val) {  // arrays are 16-byte aligned and v0 % 4 == 0: 16 + 32 + 4 byte vector loads
+            const uint4 t = *reinterpret_cast<const uint4*>(vote_block + v0);
+            vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
+            const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(eff_balance + v0);
+            const ulonglong2 b23 = *reinterpret_cast<const ulonglong2*>(eff_balance + v0 + 2);
+            bal[0] = b01.x; bal[1] = b01.y; bal[2] = b23.x; bal[3] = b23.y;
+            const uint32_t f = *reinterpret_cast<const uint32_t*>(flags + v0);
+            fl[0] = f & 0xff; fl[1] = (f >> 8) & 0xff; fl[2] = (f >> 16) & 0xff; fl[3] = f >> 24;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = v0 + k < n_val;
+                vb[k] = ok ? vote_block[v0 + k] : NONE32;
+                bal[k] = ok ? eff_balance[v0 + k] : 0ull;
+                fl[k] = ok ? flags[v0 + k] : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(fl[k] & VAL_ACTIVE)) continue;
+            act_bal += bal[k];
+            act_num += 1;
+            if (fl[k] & VAL_EQUIVOCATING) continue;
+            if (filter_slashed && (fl[k] & VAL_SLASHED)) continue;
+            if (vb[k] >= n_blocks) continue;  // NONE32 = no latest message
+            atomicAdd(&hist[vb[k]], bal[k]);  // ds_add_u64
+        }
+    }
+    act_bal = wave_sum_u64(act_bal);
+    act_num = wave_sum_u32(act_num);
+    if ((threadIdx.x & 63) == 0 && act_num) {
+        atomicAdd(&totals->total_active_balance, act_bal);
+        atomicAdd(&totals->num_active, (unsigned long long)act_num);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) {
+        const unsigned long long w = hist[b];
+        if (w) atomicAdd(&direct[pos_of_idx[b]], w);
+    }
+}
+
+void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
+                  uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx, uint32_t n_blocks,
+                  uint64_t* direct, VoteTotals* totals)
+{
+    hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
+    hipMemsetAsync(totals, 0, sizeof(VoteTotals), s);
+    if (n_val == 0) return;
+    const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
+    uint64_t blocks = (n_quads + VOTES_WG - 1) / VOTES_WG;
+    if (blocks > 256) blocks = 256;  // one workgroup per CU, grid-stride the rest: bounds the flush atomics
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(uint64_t) * TREE_MAX_BLOCKS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_votes, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
+                       eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
+                       reinterpret_cast<unsigned long long*>(direct), totals);
+}
+
+// ------------------------------------------------------------------ tree
+constexpr int TREE_WG = 1024;
+constexpr int TREE_PER_THREAD = TREE_MAX_BLOCKS / TREE_WG;  // 8
+
+// Exclusive prefix sum over n <= 8192 values held as 8 consecutive items per thread.
+// out[i] (LDS, n+1 entries) = sum of in[0..i); wave shuffles + one LDS hop across the 16 waves.
+template <typename T>
+__device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_THREAD], T* out, T* wave_tot, uint32_t n)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T local = 0;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) local += item[k];
+    T incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        T o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    T base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    T run = base + incl - local;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        if (i <= n) out[i] = run;
+        run += item[k];
+    }
+    if (tid == TREE_WG - 1 && (uint32_t)(TREE_WG * TREE_PER_THREAD) <= n) out[n] = run;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TREE_WG)
+k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* __restrict__ totals,
+       unsigned long long ov_balance, unsigned long long ov_num, int use_override, uint32_t justified_pos,
+       uint32_t boost_pos, unsigned long long slots_per_epoch, unsigned long long boost_percent,
+       unsigned long long balance_increment, unsigned long long* __restrict__ weights_by_idx,
+       uint32_t* __restrict__ head_idx)
+{
+    // LDS plan (n <= 8192):  S u64[n+1] (later bestW) | L u32[n+1] (later bestRank) | jump u32[n] | scratch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* S = reinterpret_cast<unsigned long long*>(smem);
+    uint32_t* L = reinterpret_cast<uint32_t*>(S + (TREE_MAX_BLOCKS + 2));
+    uint32_t* jump = L + (TREE_MAX_BLOCKS + 2);
+    unsigned long long* wave_tot64 = reinterpret_cast<unsigned long long*>(jump + TREE_MAX_BLOCKS);
+    uint32_t* wave_tot32 = reinterpret_cast<uint32_t*>(wave_tot64 + 16);
+
+    const uint32_t n = tree.n;
+    const int tid = threadIdx.x;
+
+    // proposer boost (A.1): one extra "vote" of proposer_score at the boosted block -- it then
+    // counts for that block and every ancestor, exactly the get_ancestor(...) == root test.
+    unsigned long long boost = 0;
+    if (boost_pos != NONE32) {
+        unsigned long long total = use_override ? ov_balance : totals->total_active_balance;
+        const unsigned long long num = use_override ? ov_num : totals->num_active;
+        if (num > 0) {
+            if (total < balance_increment) total = balance_increment;  // get_total_balance's max()
+            const unsigned long long avg_balance = total / num;
+            const unsigned long long committee_size = num / slots_per_epoch;
+            const unsigned long long committee_weight = committee_size * avg_balance;
+            // committee_weight * boost_percent can exceed 64 bits only beyond 1.8e17 Gwei * percent: split
+            const unsigned long long q = committee_weight / 100, r = committee_weight % 100;
+            boost = q * boost_percent + (r * boost_percent) / 100;
+        }
+    }
+
+    unsigned long long w_item[TREE_PER_THREAD];
+    uint32_t l_item[TREE_PER_THREAD], sz[TREE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        const bool in = i < n;
+        sz[k] = in ? tree.size[i] : 0u;
+        unsigned long long d = in ? direct[i] : 0ull;
+        if (in && i == boost_pos) d += boost;
+        w_item[k] = d;
+        l_item[k] = (in && sz[k] == 1 && tree.leaf_ok[i]) ? 1u : 0u;
+    }
+    block_exclusive_scan<unsigned long long>(w_item, S, wave_tot64, n);
+    block_exclusive_scan<uint32_t>(l_item, L, wave_tot32, n);
+
+    unsigned long long W[TREE_PER_THREAD];
+    uint32_t viable = 0;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        W[k] = 0;
+        if (i < n) {
+            W[k] = S[i + sz[k]] - S[i];
+            if (L[i + sz[k]] - L[i] > 0) viable |= 1u << k;
+            weights_by_idx[tree.idx_of_pos[i]] = W[k];
+        }
+    }
+    __syncthreads();
+    // best child, pass 1: max weight among viable children
+    unsigned long long* bestW = S;
+    uint32_t* bestRank = L;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        if (i < n) { bestW[i] = 0; bestRank[i] = 0; jump[i] = i; }
+    }
+    __syncthreads();
+    uint32_t par[TREE_PER_THREAD], rk[TREE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        par[k] = NONE32; rk[k] = 0;
+        if (i < n && ((viable >> k) & 1u)) {
+            par[k] = tree.parent[i];
+            rk[k] = tree.rank[i] + 1;  // 0 = "no viable child yet"
+            if (par[k] != NONE32) atomicMax(&bestW[par[k]], W[k]);
+        }
+    }
+    __syncthreads();
+    // pass 2: among the heaviest, the lexicographically highest root
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k)
+        if (par[k] != NONE32 && W[k] == bestW[par[k]]) atomicMax(&bestRank[par[k]], rk[k]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k)
+        if (par[k] != NONE32 && W[k] == bestW[par[k]] && rk[k] == bestRank[par[k]])
+            jump[par[k]] = tid * TREE_PER_THREAD + k;
+    __syncthreads();
+    // descent by pointer jumping: after r rounds jump[i] is 2^r best-child steps below i (or the leaf)
+    for (uint32_t span = 1; span < n; span <<= 1) {
+        uint32_t nj[TREE_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < TREE_PER_THREAD; ++k) {
+            const uint32_t i = tid * TREE_PER_THREAD + k;
+            nj[k] = i < n ? jump[jump[i]] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TREE_PER_THREAD; ++k) {
+            const uint32_t i = tid * TREE_PER_THREAD + k;
+            if (i < n) jump[i] = nj[k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) head_idx[0] = tree.idx_of_pos[jump[justified_pos]];
+}
+
+void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
+                 uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
+                 uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
+                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx)
+{
+    const size_t lds = sizeof(uint64_t) * (TREE_MAX_BLOCKS + 2) + sizeof(uint32_t) * (TREE_MAX_BLOCKS + 2) +
+                       sizeof(uint32_t) * TREE_MAX_BLOCKS + sizeof(uint64_t) * 16 + sizeof(uint32_t) * 16;
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_tree, dim3(1), dim3(TREE_WG), lds, s, tree, reinterpret_cast<unsigned long long*>(direct),
+                       totals, (unsigned long long)totals_override_balance, (unsigned long long)totals_override_num,
+                       use_override, justified_pos, boost_pos, (unsigned long long)slots_per_epoch,
+                       (unsigned long long)boost_percent, (unsigned long long)balance_increment,
+                       reinterpret_cast<unsigned long long*>(weights_by_idx), head_idx);
+}
+
+// ------------------------------------------------------------------ LMD update
+// One wave per attestation; lane l walks bit words l, l+64, ...
+__device__ __forceinline__ unsigned long long lmd_key(uint32_t epoch_p1, uint32_t order)
+{
+    return ((unsigned long long)epoch_p1 << 32) | (unsigned long long)(0xFFFFFFFEu - order);
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(256)
+k_lmd(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restrict__ members,
+      const uint32_t* __restrict__ bit_arena, const uint8_t* __restrict__ flags,
+      unsigned long long* __restrict__ vote_key, uint32_t* __restrict__ vote_block)
+{
+    const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const AttRow r = rows[a];
+    const unsigned long long key = lmd_key(r.epoch_p1, r.order);
+    const uint32_t n_words = (r.n_bits + 31) >> 5;
+    for (uint32_t w = lane; w < n_words; w += 64) {
+        uint32_t bits = bit_arena[r.bits_word + w];
+        while (bits) {
+            const uint32_t b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t v = members[r.member_base + (w << 5) + b];
+            if (PHASE == 0) {
+                if (flags[v] & VAL_EQUIVOCATING) continue;  // pe:1438
+                atomicMax(&vote_key[v], key);                // strictly-later epoch wins; first in batch among equals
+            } else {
+                if (vote_key[v] == key) {                    // unique winner: (epoch, order) identifies one attestation
+                    vote_block[v] = r.block_idx;
+                    vote_key[v] = ((unsigned long long)r.epoch_p1 << 32) | 0xFFFFFFFFull;  // settled
+                }
+            }
+        }
+    }
+}
+
+void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
+                       const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block)
+{
+    if (n_rows == 0) return;
+    const unsigned blocks = (n_rows + 3) / 4;
+    hipLaunchKernelGGL(k_lmd<0>, dim3(blocks), dim3(256), 0, s, rows, n_rows, members, bit_arena, flags,
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block);
+    hipLaunchKernelGGL(k_lmd<1>, dim3(blocks), dim3(256), 0, s, rows, n_rows, members, bit_arena, flags,
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block);
+}
+
+// ------------------------------------------------------------------ participation
+__global__ void __launch_bounds__(256)
+k_participation(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restrict__ members,
+                const uint32_t* __restrict__ bit_arena, const uint16_t* __restrict__ eff_increments,
+                unsigned long long base_reward_per_increment, uint32_t* __restrict__ part_cur,
+                uint32_t* __restrict__ part_prev, unsigned long long* __restrict__ numerators,
+                const uint32_t* __restrict__ numerator_slot)
+{
+    const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    const AttRow r = rows[a];
+    uint32_t* part = r.which ? part_prev : part_cur;
+    const uint32_t n_words = (r.n_bits + 31) >> 5;
+    unsigned long long num = 0;
+    for (uint32_t w = lane; w < n_words; w += 64) {
+        uint32_t bits = bit_arena[r.bits_word + w];
+        while (bits) {
+            const uint32_t b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t v = members[r.member_base + (w << 5) + b];
+            const uint32_t sh = 8u * (v & 3u);
+            // attestations of one round touch disjoint validators; the word-wide atomic only guards
+            // the three neighbours sharing the 32-bit word
+            const uint32_t old = atomicOr(&part[v >> 2], r.flag_mask << sh);
+            const uint32_t fresh = r.flag_mask & ~(old >> sh) & 0x7u;
+            if (fresh) {
+                // PARTICIPATION_FLAG_WEIGHTS = [14, 26, 14] (Appendix A.9)
+                const uint32_t wsum = ((fresh & 1u) ? 14u : 0u) + ((fresh & 2u) ? 26u : 0u) + ((fresh & 4u) ? 14u : 0u);
+                num += (unsigned long long)eff_increments[v] * base_reward_per_increment * wsum;
+            }
+        }
+    }
+    num = wave_sum_u64(num);
+    if (lane == 0) numerators[numerator_slot[a]] = num;
+}
+
+void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
+                          const uint32_t* bit_arena, const uint16_t* eff_increments,
+                          uint64_t base_reward_per_increment, uint32_t* part_cur_words, uint32_t* part_prev_words,
+                          uint64_t* numerators, const uint32_t* numerator_slot)
+{
+    if (n_rows == 0) return;
+    hipLaunchKernelGGL(k_participation, dim3((n_rows + 3) / 4), dim3(256), 0, s, rows, n_rows, members, bit_arena,
+                       eff_increments, (unsigned long long)base_reward_per_increment, part_cur_words,
+                       part_prev_words, reinterpret_cast<unsigned long long*>(numerators), numerator_slot);
+}
+
+// ------------------------------------------------------------------ bitfield union
+__global__ void __launch_bounds__(256)
+k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ att_words,
+             const uint32_t* __restrict__ bit_arena, uint32_t* __restrict__ out_arena,
+             uint32_t* __restrict__ out_count)
+{
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const int lane = threadIdx.x & 63;
+    const UnionGroup d = groups[g];
+    uint32_t cnt = 0;
+    for (uint32_t w = lane; w < d.n_words; w += 64) {
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < d.n_atts; ++k) acc |= bit_arena[att_words[d.list_start + k] + w];
+        out_arena[d.out_word + w] = acc;
+        cnt += __builtin_popcount(acc);
+    }
+    cnt = wave_sum_u32(cnt);
+    if (lane == 0 && out_count) out_count[g] = cnt;
+}
+
+void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
+                       const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count)
+{
+    if (n_groups == 0) return;
+    hipLaunchKernelGGL(k_bits_union, dim3((n_groups + 3) / 4), dim3(256), 0, s, groups, n_groups, att_words,
+                       bit_arena, out_arena, out_count);
+}
+
+}  // namespace posevo

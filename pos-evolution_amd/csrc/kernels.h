@@ -1,0 +1,93 @@
+// kernels.h -- host-callable launch wrappers around the HIP kernels (internal interface
+// between engine.cpp and the *.hip translation units; NOT the public ABI -- that is
+// include/posevo.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace posevo {
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr int G1_WG = 256;             // lanes (task slots) per workgroup of the accumulate kernel
+constexpr int TREE_MAX_BLOCKS = 8192;  // LDS-resident block tree capacity (K_tree)
+
+// One summation group of the G1 accumulate kernel (device-resident array, built by the host).
+//   sum over i in [0, n_members), bit i set (if bits_word != NONE32) of
+//   points[ members ? members[member_start + i] : member_start + i ]
+struct G1Group {
+    uint32_t member_start;  // offset into the members array (or first point index when members == null)
+    uint32_t n_members;
+    uint32_t bits_word;     // u32-word offset of the group's bitfield in the device bit arena, or NONE32
+    uint32_t slot_base;     // first lane slot of this group (aligned to its padded block)
+    uint32_t n_tasks;       // ceil(n_members / k)
+    uint32_t k;             // members per lane
+    uint32_t log2_block;    // padded block = 1 << log2_block slots (<= 8); groups wider than 256 tasks use whole WGs
+    uint32_t out_base;      // first slot in the wg-partials buffer; one partial per workgroup the group spans
+};
+
+// ---- G1 ----
+// 96-byte big-endian uncompressed affine -> 24 u32 Montgomery limbs (x | y); infinity -> all zero.
+void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uint64_t n);
+// Per-lane Jacobian accumulation + LDS tree; writes one 36-u32 Jacobian partial per (group, workgroup).
+void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
+                          const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups,
+                          uint32_t n_slots, uint32_t* wg_partials36);
+// Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
+// g when first == null), then either write the Jacobian (36 u32) or normalise to 96-byte affine.
+void launch_g1_finish(hipStream_t s, const uint32_t* partials36, const G1Group* groups, uint32_t n_groups,
+                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_jac36);
+
+// ---- fork choice ----
+struct TreeDev {               // block tree in DFS pre-order (device arrays of n entries)
+    const uint32_t* size;      // subtree size of the block at pre-order position i
+    const uint32_t* parent;    // pre-order position of the parent (NONE32 for the root of the order)
+    const uint32_t* rank;      // rank of the block's root in lexicographic order (tie-break, pe:1114-1116)
+    const uint8_t* leaf_ok;    // filter_block_tree's leaf test (Appendix A.3)
+    const uint32_t* pos_of_idx;  // insertion index -> pre-order position
+    const uint32_t* idx_of_pos;  // pre-order position -> insertion index
+    uint32_t n;
+};
+struct VoteTotals {            // written by K_votes, read by K_tree
+    unsigned long long total_active_balance;
+    unsigned long long num_active;
+};
+// direct[pos] += effective_balance of every counted validator voting for the block at pos.
+void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
+                  uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx,
+                  uint32_t n_blocks, uint64_t* direct, VoteTotals* totals);
+// Subtree sums (prefix scan over pre-order), viability, best child, pointer-jumping descent.
+void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
+                 uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
+                 uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
+                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx);
+
+// One resolved attestation (device row).
+struct AttRow {
+    uint32_t member_base;  // offset of the committee in the device members array
+    uint32_t n_bits;
+    uint32_t bits_word;    // u32-word offset of its (re-packed, zero-padded) bits in the device arena
+    uint32_t block_idx;    // LMD vote: insertion index of beacon_block_root
+    uint32_t epoch_p1;     // target.epoch + 1
+    uint32_t order;        // position in the batch (first-seen wins among equal epochs, pe:1383/1440)
+    uint32_t flag_mask;    // participation flags this attestation earns (process_attestation)
+    uint32_t which;        // 0 current / 1 previous epoch participation
+};
+// update_latest_messages for a batch: phase 1 atomicMax of (epoch+1, ~order), phase 2 winners write.
+void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
+                       const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block);
+// process_attestation flag loop for one round of pairwise-disjoint attestations.
+void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
+                          const uint32_t* bit_arena, const uint16_t* eff_increments,
+                          uint64_t base_reward_per_increment, uint32_t* part_cur_words,
+                          uint32_t* part_prev_words, uint64_t* numerators, const uint32_t* numerator_slot);
+// aggregation_bits = OR over the group's member attestations; count = popcount (wave reduce).
+struct UnionGroup {
+    uint32_t list_start;   // into att_words[]: the member attestations' bit word offsets
+    uint32_t n_atts;
+    uint32_t n_words;
+    uint32_t out_word;     // word offset of the output bitfield
+};
+void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
+                       const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
+
+}  // namespace posevo

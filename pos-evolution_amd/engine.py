@@ -1,0 +1,346 @@
+"""numpy-level wrapper over the C ABI (include/posevo.h).  Thin: no arithmetic here.
+
+Every method maps to exactly one ``pe_*`` entry point and raises ``EngineError``
+(an ``AssertionError`` subclass, so spec-style ``assert``-driven tests behave as
+with the pyspec) on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._abi import pe_attestation, pe_config, pe_state_ctx
+
+ZERO_ROOT = bytes(32)
+
+
+class EngineError(AssertionError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"posevo status {status}: {message}")
+        self.status = status
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _att_ptr(arr):
+    """ctypes array of pe_attestation or numpy structured array (synth.ATT_DTYPE) -> pointer."""
+    if isinstance(arr, np.ndarray):
+        assert arr.dtype.itemsize == 144 and arr.flags["C_CONTIGUOUS"]
+        return arr.ctypes.data_as(C.POINTER(pe_attestation))
+    return arr
+
+
+def _root(b: bytes):
+    assert len(b) == 32, "roots are 32 bytes"
+    return (C.c_uint8 * 32).from_buffer_copy(bytes(b))
+
+
+@dataclass
+class AttRow:
+    """AttestationData (pe:689-697) + aggregation bits + the injected signature verdict."""
+    slot: int
+    index: int
+    beacon_block_root: bytes
+    source_epoch: int
+    source_root: bytes
+    target_epoch: int
+    target_root: bytes
+    bits: np.ndarray  # bool or 0/1, one entry per committee position
+    signature_valid: bool = True
+    is_from_block: bool = False
+
+
+def pack_attestations(rows: Sequence[AttRow]):
+    """-> (ctypes array of pe_attestation, uint8 arena).  Bits are packed LSB-first (SSZ order)."""
+    n = len(rows)
+    arr = (pe_attestation * max(n, 1))()
+    chunks = []
+    off = 0
+    for i, r in enumerate(rows):
+        a = arr[i]
+        a.slot, a.index = int(r.slot), int(r.index)
+        C.memmove(a.beacon_block_root, bytes(r.beacon_block_root), 32)
+        a.source_epoch = int(r.source_epoch)
+        C.memmove(a.source_root, bytes(r.source_root), 32)
+        a.target_epoch = int(r.target_epoch)
+        C.memmove(a.target_root, bytes(r.target_root), 32)
+        bits = np.asarray(r.bits).astype(np.uint8)
+        packed = np.packbits(bits, bitorder="little") if bits.size else np.zeros(0, dtype=np.uint8)
+        a.bits_offset, a.n_bits = off, int(bits.size)
+        a.flags = (_abi.PE_ATT_FLAG_SIGNATURE_VALID if r.signature_valid else 0) | (
+            _abi.PE_ATT_FLAG_FROM_BLOCK if r.is_from_block else 0)
+        chunks.append(packed)
+        off += packed.size
+    arena = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+    if arena.size == 0:
+        arena = np.zeros(1, dtype=np.uint8)
+    return arr, np.ascontiguousarray(arena)
+
+
+class Engine:
+    """One engine handle = one fork-choice store + validator registry on one GPU."""
+
+    def __init__(self, device: int = -1, **config):
+        self._lib = _abi.load()
+        cfg = pe_config()
+        self._lib.pe_config_default(C.byref(cfg))
+        cfg.device = device
+        for k, v in config.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown config field {k}")
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self._lib.pe_engine_create(C.byref(cfg), C.byref(h))
+        if rc != _abi.PE_OK:
+            raise EngineError(rc, self._lib.pe_strerror(rc).decode() +
+                              " (the engine needs a HIP device; there is no CPU fallback)")
+        self._h = h
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pe_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != _abi.PE_OK:
+            detail = self._lib.pe_last_error(self._h).decode()
+            raise EngineError(rc, f"{self._lib.pe_strerror(rc).decode()}: {detail}")
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.pe_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # -- store ------------------------------------------------------------
+    def store_init(self, genesis_time: int, anchor_slot: int, anchor_root: bytes):
+        self._check(self._lib.pe_store_init(self._h, genesis_time, anchor_slot, _root(anchor_root)))
+
+    def set_validators(self, effective_balance, flags, pubkeys96=None):
+        bal = np.ascontiguousarray(effective_balance, dtype=np.uint64)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert bal.shape == fl.shape
+        pk = None
+        if pubkeys96 is not None:
+            pk = np.ascontiguousarray(pubkeys96, dtype=np.uint8)
+            assert pk.size == 96 * bal.size
+        self._check(self._lib.pe_set_validators(self._h, bal.size, _ptr(pk, C.c_uint8), _ptr(bal, C.c_uint64),
+                                                _ptr(fl, C.c_uint8)))
+
+    def set_balances(self, effective_balance, flags):
+        bal = np.ascontiguousarray(effective_balance, dtype=np.uint64)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(self._lib.pe_set_balances(self._h, bal.size, _ptr(bal, C.c_uint64), _ptr(fl, C.c_uint8)))
+
+    def on_tick(self, time: int):
+        self._check(self._lib.pe_on_tick(self._h, time))
+
+    def on_block(self, root, parent_root, slot, post_justified=(0, ZERO_ROOT), post_finalized=(0, ZERO_ROOT)):
+        self._check(self._lib.pe_on_block(self._h, _root(root), _root(parent_root), slot, post_justified[0],
+                                          _root(post_justified[1]), post_finalized[0], _root(post_finalized[1])))
+
+    def add_block(self, root, parent_root, slot, post_justified=(0, ZERO_ROOT), post_finalized=(0, ZERO_ROOT)):
+        self._check(self._lib.pe_add_block(self._h, _root(root), _root(parent_root), slot, post_justified[0],
+                                           _root(post_justified[1]), post_finalized[0], _root(post_finalized[1])))
+
+    def set_checkpoints(self, justified: Tuple[int, bytes], finalized: Tuple[int, bytes]):
+        self._check(self._lib.pe_set_checkpoints(self._h, justified[0], _root(justified[1]), finalized[0],
+                                                 _root(finalized[1])))
+
+    def set_proposer_boost(self, root: bytes):
+        self._check(self._lib.pe_set_proposer_boost(self._h, _root(root)))
+
+    def mark_equivocating(self, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        self._check(self._lib.pe_mark_equivocating(self._h, _ptr(idx, C.c_uint64), idx.size))
+
+    def on_attester_slashing(self, row1: AttRow, indices1, row2: AttRow, indices2):
+        a1, _ = pack_attestations([row1])
+        a2, _ = pack_attestations([row2])
+        i1 = np.ascontiguousarray(indices1, dtype=np.uint64)
+        i2 = np.ascontiguousarray(indices2, dtype=np.uint64)
+        self._check(self._lib.pe_on_attester_slashing(self._h, a1, _ptr(i1, C.c_uint64), i1.size, a2,
+                                                      _ptr(i2, C.c_uint64), i2.size))
+
+    def set_committees(self, epoch: int, offsets, members):
+        off = np.ascontiguousarray(offsets, dtype=np.uint32)
+        mem = np.ascontiguousarray(members, dtype=np.uint32)
+        assert off[-1] == mem.size
+        if mem.size == 0:
+            mem = np.zeros(1, dtype=np.uint32)
+        self._check(self._lib.pe_set_committees(self._h, epoch, off.size - 1, _ptr(off, C.c_uint32),
+                                                _ptr(mem, C.c_uint32)))
+
+    # -- hot path ---------------------------------------------------------
+    def get_head(self) -> bytes:
+        out = (C.c_uint8 * 32)()
+        self._check(self._lib.pe_get_head(self._h, out))
+        return bytes(out)
+
+    def get_weights(self) -> np.ndarray:
+        n = self.num_blocks
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.pe_get_weights(self._h, _ptr(out, C.c_uint64), n))
+        return out
+
+    def on_attestation_batch(self, rows=None, packed=None, want_aggregate_pubkeys=False):
+        """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n])."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        count = np.zeros(max(n, 1), dtype=np.uint32)
+        agg = np.zeros((max(n, 1), 96), dtype=np.uint8) if want_aggregate_pubkeys else None
+        self._check(self._lib.pe_on_attestation_batch(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
+                                                      _ptr(status, C.c_int32), _ptr(agg, C.c_uint8),
+                                                      _ptr(count, C.c_uint32)))
+        return status[:n], (agg[:n] if agg is not None else None), count[:n]
+
+    def aggregate(self, rows=None, packed=None, sig_points96=None, want_aggregate_pubkeys=False):
+        """-> dict(groups=[AttRow-like tuples], group_of, bits (list of bool arrays), sig96, aggpk96, count)."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        out_atts = (pe_attestation * max(n, 1))()
+        n_groups = C.c_uint32(0)
+        group_of = np.zeros(max(n, 1), dtype=np.uint32)
+        out_arena = np.zeros(max(arena.size, 1), dtype=np.uint8)
+        sig = None
+        if sig_points96 is not None:
+            sig = np.ascontiguousarray(sig_points96, dtype=np.uint8)
+            assert sig.size == 96 * n
+        out_sig = np.zeros((max(n, 1), 96), dtype=np.uint8) if sig is not None else None
+        out_pk = np.zeros((max(n, 1), 96), dtype=np.uint8) if want_aggregate_pubkeys else None
+        count = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(self._lib.pe_aggregate(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size, _ptr(sig, C.c_uint8),
+                                           out_atts, C.byref(n_groups), _ptr(group_of, C.c_uint32),
+                                           _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
+                                           _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
+        g = n_groups.value
+        bits = []
+        for k in range(g):
+            a = out_atts[k]
+            nb = (a.n_bits + 7) // 8
+            bits.append(np.unpackbits(out_arena[a.bits_offset:a.bits_offset + nb], bitorder="little")[:a.n_bits]
+                        .astype(bool))
+        return dict(n_groups=g, atts=out_atts, group_of=group_of[:n], bits=bits, out_arena=out_arena,
+                    sig96=None if out_sig is None else out_sig[:g], aggpk96=None if out_pk is None else out_pk[:g],
+                    count=count[:g])
+
+    def process_attestation_batch(self, state_ctx: pe_state_ctx, rows=None, packed=None):
+        """-> (status int32[n], proposer_reward_numerator uint64[n])."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        num = np.zeros(max(n, 1), dtype=np.uint64)
+        self._check(self._lib.pe_process_attestation_batch(self._h, C.byref(state_ctx), _att_ptr(arr), n,
+                                                           _ptr(arena, C.c_uint8), arena.size,
+                                                           _ptr(status, C.c_int32), _ptr(num, C.c_uint64)))
+        return status[:n], num[:n]
+
+    def participation_set(self, which: int, flags):
+        f = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(self._lib.pe_participation_set(self._h, which, _ptr(f, C.c_uint8), f.size))
+
+    def participation_get(self, which: int) -> np.ndarray:
+        out = np.zeros(self.num_validators, dtype=np.uint8)
+        self._check(self._lib.pe_participation_get(self._h, which, _ptr(out, C.c_uint8), out.size))
+        return out
+
+    def participation_rotate(self):
+        self._check(self._lib.pe_participation_rotate(self._h))
+
+    def g1_sum(self, offsets, index=None, points96=None) -> np.ndarray:
+        off = np.ascontiguousarray(offsets, dtype=np.uint32)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint32)
+        pts = None if points96 is None else np.ascontiguousarray(points96, dtype=np.uint8)
+        n_points = 0 if pts is None else pts.size // 96
+        n_groups = off.size - 1
+        out = np.zeros((max(n_groups, 1), 96), dtype=np.uint8)
+        self._check(self._lib.pe_g1_sum(self._h, _ptr(pts, C.c_uint8), n_points, _ptr(idx, C.c_uint32),
+                                        _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
+        return out[:n_groups]
+
+    # -- multi-GPU exchange -------------------------------------------------
+    def votes_partial(self, dev_ptr: int) -> Tuple[int, int]:
+        bal, num = C.c_uint64(0), C.c_uint64(0)
+        self._check(self._lib.pe_votes_partial(self._h, C.c_void_p(dev_ptr), self.num_blocks, C.byref(bal),
+                                               C.byref(num)))
+        return bal.value, num.value
+
+    def head_from_weights(self, dev_ptr: int, total_active_balance: int, num_active: int) -> bytes:
+        out = (C.c_uint8 * 32)()
+        self._check(self._lib.pe_head_from_weights(self._h, C.c_void_p(dev_ptr), self.num_blocks,
+                                                   total_active_balance, num_active, out))
+        return bytes(out)
+
+    def g1_partial(self, offsets, index, dev_ptr: int):
+        off = np.ascontiguousarray(offsets, dtype=np.uint32)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint32)
+        self._check(self._lib.pe_g1_partial(self._h, _ptr(idx, C.c_uint32), _ptr(off, C.c_uint32), off.size - 1,
+                                            C.c_void_p(dev_ptr)))
+
+    def g1_finish(self, dev_ptr: int, n_ranks: int, n_groups: int) -> np.ndarray:
+        out = np.zeros((max(n_groups, 1), 96), dtype=np.uint8)
+        self._check(self._lib.pe_g1_finish(self._h, C.c_void_p(dev_ptr), n_ranks, n_groups, _ptr(out, C.c_uint8)))
+        return out[:n_groups]
+
+    # -- inspection -------------------------------------------------------
+    @property
+    def num_blocks(self) -> int:
+        return int(self._lib.pe_num_blocks(self._h))
+
+    @property
+    def num_validators(self) -> int:
+        return int(self._lib.pe_num_validators(self._h))
+
+    def block_root_at(self, i: int) -> bytes:
+        out = (C.c_uint8 * 32)()
+        self._check(self._lib.pe_block_root_at(self._h, i, out))
+        return bytes(out)
+
+    def block_index_of(self, root: bytes) -> int:
+        out = C.c_uint32(0)
+        self._check(self._lib.pe_block_index_of(self._h, _root(root), C.byref(out)))
+        return out.value
+
+    def latest_messages(self):
+        """-> (epoch uint64[V], block_index uint32[V]); block_index 0xFFFFFFFF = no message."""
+        n = self.num_validators
+        ep = np.zeros(max(n, 1), dtype=np.uint64)
+        bi = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(self._lib.pe_get_latest_messages(self._h, _ptr(ep, C.c_uint64), _ptr(bi, C.c_uint32), n))
+        return ep[:n], bi[:n]
+
+    def store_scalars(self) -> dict:
+        t, g, je, fe, be = (C.c_uint64(0) for _ in range(5))
+        jr, fr, br, boost = ((C.c_uint8 * 32)() for _ in range(4))
+        self._check(self._lib.pe_get_store_scalars(self._h, C.byref(t), C.byref(g), C.byref(je), jr, C.byref(fe), fr,
+                                                   C.byref(be), br, boost))
+        return dict(time=t.value, genesis_time=g.value, justified=(je.value, bytes(jr)),
+                    finalized=(fe.value, bytes(fr)), best_justified=(be.value, bytes(br)),
+                    proposer_boost_root=bytes(boost))
+
+    # -- profiling --------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.pe_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.pe_profile_reset(self._h))
+
+    def profile(self) -> dict:
+        out = {}
+        for k, name in enumerate(_abi.KERNEL_NAMES):
+            n, ms = C.c_uint64(0), C.c_double(0)
+            self._check(self._lib.pe_profile_get(self._h, k, C.byref(n), C.byref(ms)))
+            out[name] = dict(launches=n.value, total_ms=ms.value)
+        return out

@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference's fork-choice / attestation interface, backed by the
+MI355X engine through the C ABI.
+
+Same names, argument meaning and error behaviour as the pyspec excerpts in
+pos-evolution.md (``pe:N``):
+
+    get_forkchoice_store(anchor_state, anchor_block)        pe:1077-1095
+    on_tick(store, time)                                    pe:934-955
+    on_block(store, signed_block, post_state)               pe:986-1036   (state_transition is the caller's)
+    on_attestation(store, attestation, is_from_block=False) pe:963-979, pe:1423-1428
+    on_attester_slashing(store, attester_slashing)          pe:1447-1461
+    get_head(store) -> Root                                 pe:1102-1116
+    process_attestation(state, attestation)                 pe:722-754    (state bound with bind_state)
+
+Objects are duck-typed: anything exposing the pyspec's field names works
+(``attestation.data.beacon_block_root``, ``attestation.aggregation_bits``,
+``state.validators[i].effective_balance`` ...).  A failed handler raises
+``AssertionError`` (``EngineError``) and leaves the store unmodified (pe:1041).
+
+Out of scope and therefore supplied by the caller: SSZ
+``hash_tree_root`` (pass the function), ``state_transition`` (pass the post-state),
+committee shuffling (pass the committees), the pairing check (its boolean rides on
+``attestation.signature_valid``, default True).
+
+This module performs no arithmetic of the hot path itself and never imports the
+oracle: without libposevo.so + a HIP device it raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .engine import AttRow, Engine, EngineError, ZERO_ROOT
+from ._abi import pe_state_ctx
+
+GENESIS_EPOCH = 0
+PARTICIPATION_FLAG_WEIGHTS = [14, 26, 14]
+PROPOSER_WEIGHT = 8
+WEIGHT_DENOMINATOR = 64
+
+
+@dataclass(eq=True, frozen=True)
+class Checkpoint:
+    """pe:219-221"""
+    epoch: int = 0
+    root: bytes = ZERO_ROOT
+
+
+@dataclass(eq=True, frozen=True)
+class LatestMessage:
+    """pe:286-289"""
+    epoch: int
+    root: bytes
+
+
+def _att_row(attestation, is_from_block: bool = False) -> AttRow:
+    d = attestation.data
+    return AttRow(
+        slot=int(d.slot), index=int(d.index), beacon_block_root=bytes(d.beacon_block_root),
+        source_epoch=int(d.source.epoch), source_root=bytes(d.source.root),
+        target_epoch=int(d.target.epoch), target_root=bytes(d.target.root),
+        bits=np.asarray(attestation.aggregation_bits, dtype=np.uint8),
+        signature_valid=bool(getattr(attestation, "signature_valid", True)),
+        is_from_block=is_from_block,
+    )
+
+
+class Store:
+    """Engine-backed ``Store`` (pe:889-901).  Scalars live in the engine; this object exposes them
+    under the pyspec's attribute names."""
+
+    def __init__(self, engine: Engine, hash_tree_root: Optional[Callable] = None):
+        self.engine = engine
+        self.hash_tree_root = hash_tree_root
+        self.equivocating_indices = set()   # host mirror of pe:897 (the engine holds the per-validator bit)
+        self.blocks: Dict[bytes, object] = {}  # root -> the caller's block object (pe:898)
+
+    # -- the spec's fields ---------------------------------------------------
+    @property
+    def time(self) -> int:
+        return self.engine.store_scalars()["time"]
+
+    @property
+    def genesis_time(self) -> int:
+        return self.engine.store_scalars()["genesis_time"]
+
+    @property
+    def justified_checkpoint(self) -> Checkpoint:
+        return Checkpoint(*self.engine.store_scalars()["justified"])
+
+    @property
+    def finalized_checkpoint(self) -> Checkpoint:
+        return Checkpoint(*self.engine.store_scalars()["finalized"])
+
+    @property
+    def best_justified_checkpoint(self) -> Checkpoint:
+        return Checkpoint(*self.engine.store_scalars()["best_justified"])
+
+    @property
+    def proposer_boost_root(self) -> bytes:
+        return self.engine.store_scalars()["proposer_boost_root"]
+
+    @proposer_boost_root.setter
+    def proposer_boost_root(self, root: bytes):
+        self.engine.set_proposer_boost(bytes(root))
+
+    @property
+    def latest_messages(self) -> Dict[int, LatestMessage]:
+        epoch, block = self.engine.latest_messages()
+        roots = [self.engine.block_root_at(i) for i in range(self.engine.num_blocks)]
+        return {int(i): LatestMessage(int(epoch[i]), roots[int(block[i])])
+                for i in np.nonzero(block != _abi.NONE32)[0]}
+
+    # -- inputs the pyspec derives from states the engine does not hold -----------
+    def set_justified_state(self, state, slots_per_epoch: Optional[int] = None):
+        """checkpoint_states[justified_checkpoint] (Appendix A.1): balances/activity feeding the weights,
+        and the pubkeys feeding the G1 sums."""
+        spe = slots_per_epoch or int(self.engine.cfg.slots_per_epoch)
+        epoch = int(state.slot) // spe
+        n = len(state.validators)
+        bal = np.fromiter((int(v.effective_balance) for v in state.validators), dtype=np.uint64, count=n)
+        flags = np.fromiter(
+            ((_abi.PE_VAL_ACTIVE if int(v.activation_epoch) <= epoch < int(v.exit_epoch) else 0)
+             | (_abi.PE_VAL_SLASHED if v.slashed else 0) for v in state.validators), dtype=np.uint8, count=n)
+        pk = None
+        if n and all(getattr(v, "pubkey", None) is not None for v in state.validators):
+            pk = np.frombuffer(b"".join(_point96(v.pubkey) for v in state.validators), dtype=np.uint8)
+        if self.engine.num_validators == n and pk is None:
+            self.engine.set_balances(bal, flags)
+        else:
+            self.engine.set_validators(bal, flags, pk)
+
+    def set_committees(self, epoch: int, committees: Sequence[Sequence[int]]):
+        """get_beacon_committee(state, slot, index) for every (slot, index) of ``epoch``, in committee-id
+        order (slot-major): the L2 feeder's output (compute_committee, pe:495-504)."""
+        sizes = np.fromiter((len(c) for c in committees), dtype=np.uint32, count=len(committees))
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+        members = (np.concatenate([np.asarray(c, dtype=np.uint32) for c in committees])
+                   if len(committees) else np.zeros(0, dtype=np.uint32))
+        self.engine.set_committees(epoch, offsets, members)
+
+
+def _point96(pt) -> bytes:
+    """Affine (x, y) int tuple / None / 96 raw bytes -> 96-byte uncompressed encoding."""
+    if isinstance(pt, (bytes, bytearray)):
+        assert len(pt) == 96
+        return bytes(pt)
+    if pt is None:
+        return bytes([0x40]) + bytes(95)
+    x, y = pt
+    return int(x).to_bytes(48, "big") + int(y).to_bytes(48, "big")
+
+
+# ----------------------------------------------------------------------------- handlers
+def get_forkchoice_store(anchor_state, anchor_block, *, hash_tree_root: Callable, engine: Optional[Engine] = None,
+                         **engine_config) -> Store:
+    """pe:1077-1095"""
+    assert bytes(anchor_block.state_root) == bytes(hash_tree_root(anchor_state))
+    anchor_root = bytes(hash_tree_root(anchor_block))
+    eng = engine or Engine(**engine_config)
+    eng.store_init(int(anchor_state.genesis_time), int(anchor_state.slot), anchor_root)
+    store = Store(eng, hash_tree_root)
+    store.blocks[anchor_root] = anchor_block
+    store.set_justified_state(anchor_state)  # checkpoint_states = {justified_checkpoint: anchor_state}
+    return store
+
+
+def on_tick(store: Store, time: int) -> None:
+    """pe:934-955"""
+    store.engine.on_tick(int(time))
+
+
+def on_block(store: Store, signed_block, post_state) -> None:
+    """pe:986-1036.  ``post_state`` = the block's post-state as computed by the caller's
+    ``state_transition`` (pe:1009); only its two checkpoints are read."""
+    block = signed_block.message
+    root = bytes(store.hash_tree_root(block))
+    j, f = post_state.current_justified_checkpoint, post_state.finalized_checkpoint
+    store.engine.on_block(root, bytes(block.parent_root), int(block.slot), (int(j.epoch), bytes(j.root)),
+                          (int(f.epoch), bytes(f.root)))
+    store.blocks[root] = block
+
+
+def on_attestation(store: Store, attestation, is_from_block: bool = False) -> None:
+    """pe:963-979 with the ``is_from_block`` form of pe:1423-1428."""
+    status, _, _ = store.engine.on_attestation_batch([_att_row(attestation, is_from_block)])
+    if status[0] != 0:
+        raise EngineError(int(status[0]), "on_attestation: " + _abi.ATT_STATUS_NAMES.get(int(status[0]), "?"))
+
+
+def on_attestations(store: Store, attestations: Iterable, is_from_block: bool = False) -> np.ndarray:
+    """Batch form: ``on_attestation`` x n applied as if sequentially; returns the per-attestation status
+    (0 = applied) instead of raising on the first invalid one."""
+    rows = [_att_row(a, is_from_block) for a in attestations]
+    status, _, _ = store.engine.on_attestation_batch(rows)
+    return status
+
+
+def on_attester_slashing(store: Store, attester_slashing) -> None:
+    """pe:1447-1461"""
+    a1, a2 = attester_slashing.attestation_1, attester_slashing.attestation_2
+
+    def row(ia):
+        d = ia.data
+        return AttRow(int(d.slot), int(d.index), bytes(d.beacon_block_root), int(d.source.epoch), bytes(d.source.root),
+                      int(d.target.epoch), bytes(d.target.root), np.zeros(0, dtype=np.uint8),
+                      bool(getattr(ia, "signature_valid", True)))
+
+    store.engine.on_attester_slashing(row(a1), list(a1.attesting_indices), row(a2), list(a2.attesting_indices))
+    store.equivocating_indices |= set(a1.attesting_indices).intersection(a2.attesting_indices)
+
+
+def get_head(store: Store) -> bytes:
+    """pe:1102-1116"""
+    return store.engine.get_head()
+
+
+# ----------------------------------------------------------------------------- process_attestation
+class StateBinding:
+    """Binds a BeaconState-like object to the engine's working participation arrays so that
+    ``process_attestation(state, attestation)`` can mutate it as the pyspec does."""
+
+    def __init__(self, engine: Engine, state, chain_tip_root: bytes, base_reward_per_increment: int):
+        self.engine = engine
+        self.state = state
+        self.chain_tip_root = bytes(chain_tip_root)
+        self.base_reward_per_increment = int(base_reward_per_increment)
+        engine.participation_set(0, np.asarray(state.current_epoch_participation, dtype=np.uint8))
+        engine.participation_set(1, np.asarray(state.previous_epoch_participation, dtype=np.uint8))
+
+    def ctx(self) -> pe_state_ctx:
+        s = self.state
+        c = pe_state_ctx()
+        c.slot = int(s.slot)
+        c.chain_tip_root[:] = self.chain_tip_root
+        c.current_justified_epoch = int(s.current_justified_checkpoint.epoch)
+        c.current_justified_root[:] = bytes(s.current_justified_checkpoint.root)
+        c.previous_justified_epoch = int(s.previous_justified_checkpoint.epoch)
+        c.previous_justified_root[:] = bytes(s.previous_justified_checkpoint.root)
+        c.base_reward_per_increment = self.base_reward_per_increment
+        return c
+
+    def sync_back(self):
+        self.state.current_epoch_participation[:] = [int(x) for x in self.engine.participation_get(0)]
+        self.state.previous_epoch_participation[:] = [int(x) for x in self.engine.participation_get(1)]
+
+
+_bindings: Dict[int, StateBinding] = {}
+
+
+def bind_state(engine: Engine, state, chain_tip_root: bytes, base_reward_per_increment: int) -> StateBinding:
+    b = StateBinding(engine, state, chain_tip_root, base_reward_per_increment)
+    _bindings[id(state)] = b
+    return b
+
+
+def process_attestation(state, attestation, *, get_beacon_proposer_index: Optional[Callable] = None) -> None:
+    """pe:722-754.  ``state`` must have been bound with ``bind_state``."""
+    b = _bindings.get(id(state))
+    assert b is not None, "process_attestation: bind_state(engine, state, ...) first"
+    status, numerators = b.engine.process_attestation_batch(b.ctx(), [_att_row(attestation)])
+    if status[0] != 0:
+        raise EngineError(int(status[0]), "process_attestation: " + _abi.ATT_STATUS_NAMES.get(int(status[0]), "?"))
+    b.sync_back()
+    # Reward proposer (pe:752-754)
+    proposer_reward_denominator = (WEIGHT_DENOMINATOR - PROPOSER_WEIGHT) * WEIGHT_DENOMINATOR // PROPOSER_WEIGHT
+    proposer_reward = int(numerators[0]) // proposer_reward_denominator
+    proposer = get_beacon_proposer_index(state) if get_beacon_proposer_index else 0
+    state.balances[proposer] += proposer_reward
+    state._last_proposer_reward_numerator = int(numerators[0])

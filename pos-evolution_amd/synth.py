@@ -1,0 +1,181 @@
+"""Seeded synthetic workloads of the BASELINE.json shapes (numpy only; no oracle, no engine).
+
+Used by bench.py, __graft_entry__.smoke() and the tests to build identical inputs for the engine
+and for the checker.  Shapes follow SURVEY.md 8(d):
+
+    validators  effective balances (Gwei, multiples of the increment), activity/slashed flags
+    block tree  roots (sha256 of a counter), parent index < child index, strictly increasing slots
+    committees  a random partition of the validators into C committees (slot-major ids)
+    votes       latest-message block per validator, Zipf over the most recent blocks
+    batches     pe_attestation rows + LSB-first bit arena as numpy structured arrays
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+ATT_DTYPE = np.dtype([
+    ("slot", "<u8"), ("index", "<u8"), ("beacon_block_root", "u1", (32,)),
+    ("source_epoch", "<u8"), ("source_root", "u1", (32,)),
+    ("target_epoch", "<u8"), ("target_root", "u1", (32,)),
+    ("bits_offset", "<u4"), ("n_bits", "<u4"), ("flags", "<u4"), ("reserved0", "<u4"),
+])
+assert ATT_DTYPE.itemsize == 144
+
+GWEI_PER_ETH = 10**9
+NONE32 = 0xFFFFFFFF
+
+
+def make_roots(n: int, salt: bytes = b"posevo") -> np.ndarray:
+    """(n, 32) uint8: sha256(salt || counter) -- opaque block ids."""
+    out = np.empty((n, 32), dtype=np.uint8)
+    for i in range(n):
+        out[i] = np.frombuffer(hashlib.sha256(salt + i.to_bytes(8, "little")).digest(), dtype=np.uint8)
+    return out
+
+
+@dataclass
+class Tree:
+    roots: np.ndarray    # (B, 32) u8
+    parent: np.ndarray   # (B,) u32, parent[0] = NONE32
+    slot: np.ndarray     # (B,) u64, strictly increasing along parent links
+
+
+def random_tree(n_blocks: int, seed: int, kind: str = "branchy", anchor_slot: int = 0) -> Tree:
+    """kind: 'chain' (depth = B: the LDS scan stress of config 3), 'branchy' (main chain with
+    geometric side branches, config 2), 'bushy' (uniform random parent among the last 64 blocks)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    parent = np.full(n_blocks, NONE32, dtype=np.uint32)
+    slot = np.zeros(n_blocks, dtype=np.uint64)
+    slot[0] = anchor_slot
+    if kind == "chain":
+        parent[1:] = np.arange(n_blocks - 1, dtype=np.uint32)
+        slot[1:] = anchor_slot + np.arange(1, n_blocks, dtype=np.uint64)
+    else:
+        tip = 0
+        for i in range(1, n_blocks):
+            if kind == "branchy":
+                p = tip if rng.random() > 0.1 else int(rng.integers(max(0, i - 16), i))
+            else:
+                p = int(rng.integers(max(0, i - 64), i))
+            parent[i] = p
+            slot[i] = slot[p] + 1 + (1 if rng.random() < 0.05 else 0)  # occasional skipped slot
+            if kind == "branchy" and p == tip:
+                tip = i
+    return Tree(make_roots(n_blocks, b"blk%d" % seed), parent, slot)
+
+
+def balances(n: int, seed: int, mixed: bool = False, increment: int = GWEI_PER_ETH) -> np.ndarray:
+    """32 ETH flat, or the config-5 mix: 70 % at 32 ETH, 30 % uniform integer ETH in [32, 2048]."""
+    if not mixed:
+        return np.full(n, 32 * increment, dtype=np.uint64)
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    eth = np.where(rng.random(n) < 0.7, 32, rng.integers(32, 2049, size=n)).astype(np.uint64)
+    return eth * np.uint64(increment)
+
+
+def validator_flags(n: int, seed: int, inactive_frac: float = 0.0, slashed_frac: float = 0.0) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed + 2000))
+    f = np.full(n, 0x01, dtype=np.uint8)
+    if inactive_frac:
+        f[rng.random(n) < inactive_frac] &= 0xFE
+    if slashed_frac:
+        f[rng.random(n) < slashed_frac] |= 0x02
+    return f
+
+
+def zipf_votes(n_val: int, n_blocks: int, seed: int, participation: float = 0.99, recent: int = 64) -> np.ndarray:
+    """Latest-message block index per validator (NONE32 = none): Zipf(1.2) rank over the `recent`
+    most recently inserted blocks."""
+    rng = np.random.Generator(np.random.PCG64(seed + 3000))
+    r = min(recent, n_blocks)
+    rank = np.minimum(rng.zipf(1.2, size=n_val) - 1, r - 1)
+    vote = (n_blocks - 1 - rank).astype(np.uint32)
+    vote[rng.random(n_val) >= participation] = NONE32
+    return vote
+
+
+@dataclass
+class Committees:
+    offsets: np.ndarray  # (C+1,) u32
+    members: np.ndarray  # (V,) u32: committee c = members[offsets[c]:offsets[c+1]]
+
+
+def random_committees(n_val: int, n_committees: int, seed: int, lo: int = 0) -> Committees:
+    """Random partition of validators [lo, lo + n_val) into n_committees near-equal committees
+    (compute_committee's slicing rule, pe:502-503)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 4000))
+    perm = (rng.permutation(n_val) + lo).astype(np.uint32)
+    idx = np.arange(n_committees + 1, dtype=np.uint64)
+    offsets = ((np.uint64(n_val) * idx) // np.uint64(n_committees)).astype(np.uint32)
+    return Committees(offsets, perm)
+
+
+def ancestor_at(tree: Tree, idx: int, slot: int) -> int:
+    """get_ancestor on the synthetic tree."""
+    while tree.slot[idx] > slot and tree.parent[idx] != NONE32:
+        idx = int(tree.parent[idx])
+    return idx
+
+
+def pack_bit_rows(bit_rows) -> tuple:
+    """list of bool arrays -> (arena u8, byte offsets u32, n_bits u32); LSB-first, byte aligned per row."""
+    offs, nb, chunks, off = [], [], [], 0
+    for b in bit_rows:
+        b = np.asarray(b, dtype=np.uint8)
+        p = np.packbits(b, bitorder="little") if b.size else np.zeros(0, dtype=np.uint8)
+        offs.append(off)
+        nb.append(b.size)
+        chunks.append(p)
+        off += p.size
+    arena = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+    if arena.size == 0:
+        arena = np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(arena), np.asarray(offs, dtype=np.uint32), np.asarray(nb, dtype=np.uint32)
+
+
+def epoch_attestations(comm: Committees, tree: Tree, epoch: int, slots_per_epoch: int, seed: int,
+                       density: float = 0.99, parts: int = 1, source=(0, None), vote_recent: int = 8,
+                       from_block: bool = False):
+    """One epoch's attestations: committee c attests in slot epoch*SPE + c // cps with index c % cps,
+    voting for one of the `vote_recent` most recent blocks whose slot is <= its slot.  Each committee
+    contributes `parts` partial aggregates with disjoint random bit subsets (union density `density`).
+
+    Returns (atts ATT_DTYPE[n], arena u8, bit_rows list) with n = C * parts."""
+    rng = np.random.Generator(np.random.PCG64(seed + 5000 + epoch))
+    n_comm = comm.offsets.size - 1
+    cps = n_comm // slots_per_epoch
+    assert cps * slots_per_epoch == n_comm
+    n = n_comm * parts
+    atts = np.zeros(n, dtype=ATT_DTYPE)
+    src_root = tree.roots[0] if source[1] is None else np.frombuffer(source[1], dtype=np.uint8)
+    bit_rows = []
+    order = np.argsort(tree.slot, kind="stable")
+    sorted_slots = tree.slot[order]
+    k = 0
+    for c in range(n_comm):
+        size = int(comm.offsets[c + 1] - comm.offsets[c])
+        slot = epoch * slots_per_epoch + c // cps
+        # candidate head votes: blocks with slot <= attestation slot, among the most recent
+        hi = int(np.searchsorted(sorted_slots, slot, side="right"))
+        cand = order[max(0, hi - vote_recent):hi]
+        on = rng.random(size) < density
+        part_of = rng.integers(0, parts, size=size)
+        blk = int(cand[rng.integers(0, cand.size)]) if cand.size else 0
+        target_idx = ancestor_at(tree, blk, epoch * slots_per_epoch)  # FFG target consistent with the LMD vote
+        for p in range(parts):
+            bits = on & (part_of == p)
+            a = atts[k]
+            a["slot"], a["index"] = slot, c % cps
+            a["beacon_block_root"] = tree.roots[blk]
+            a["source_epoch"], a["source_root"] = source[0], src_root
+            a["target_epoch"], a["target_root"] = epoch, tree.roots[target_idx]
+            a["flags"] = 3 if from_block else 1
+            bit_rows.append(bits)
+            k += 1
+    arena, offs, nb = pack_bit_rows(bit_rows)
+    atts["bits_offset"], atts["n_bits"] = offs, nb
+    return atts, arena, bit_rows

@@ -1,0 +1,291 @@
+"""-m gpu: the HIP engine through the C ABI vs the L1 C oracle on identical seeded inputs (bit-exact)."""
+import numpy as np
+import pytest
+
+import pos_evolution_amd.synth as synth
+from oracle import cport, g1
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+NONE32 = 0xFFFFFFFF
+
+
+# ---------------------------------------------------------------- G1
+def test_g1_known_answers(engine_factory):
+    e = engine_factory()
+    G96 = np.frombuffer(g1.to_bytes96(g1.G), dtype=np.uint8)
+    # (i+1)*G: 1G + 2G = 3G, then + 3G forces the doubling branch
+    pts = cport.g1_arith_progression(G96.tobytes(), G96.tobytes(), 64)
+    out = e.g1_sum([0, 64, 64, 65], index=[*range(64), 0], points96=pts)
+    assert out[0].tobytes() == g1.to_bytes96(g1.mul(64 * 65 // 2, g1.G))
+    assert out[1].tobytes()[0] == 0x40 and not any(out[1][1:])          # empty group = infinity
+    assert out[2].tobytes() == g1.to_bytes96(g1.G)
+    # external known answers (compressed 2G, 3G)
+    two = e.g1_sum([0, 2], index=[0, 0], points96=pts)[0].tobytes()
+    assert g1.compress(g1.from_bytes96(two)).hex().startswith("a572cbea904d6746")
+    # P + (-P) = infinity, infinity inputs are skipped
+    A = g1.mul(7, g1.G)
+    trio = np.stack([np.frombuffer(g1.to_bytes96(p), dtype=np.uint8) for p in (A, g1.neg(A), None, A)])
+    out = e.g1_sum([0, 2, 4, 4], points96=trio)
+    assert out[0][0] == 0x40
+    assert out[1].tobytes() == g1.to_bytes96(A)
+    assert out[2][0] == 0x40
+
+
+@pytest.mark.parametrize("n,groups", [(1000, 7), (5000, 300), (70000, 3), (300000, 2048)])
+def test_g1_sum_vs_oracle(engine_factory, n, groups):
+    e = engine_factory()
+    pts, (a, b) = H.oracle_points(n)
+    rng = np.random.default_rng(n)
+    index = rng.integers(0, n, size=n, dtype=np.uint32)
+    cuts = np.sort(rng.integers(0, n + 1, size=groups - 1))
+    offsets = np.concatenate([[0], cuts, [n]]).astype(np.uint32)
+    got = e.g1_sum(offsets, index=index, points96=pts)
+    want = cport.g1_sum_groups(pts, index, offsets)
+    assert np.array_equal(got, want)
+    # closed form on one group (independent of the C oracle's adder)
+    g = int(np.argmax(np.diff(offsets.astype(np.int64))))
+    assert got[g].tobytes() == H.closed_form_sum(index[offsets[g]:offsets[g + 1]], a, b)
+
+
+def test_g1_single_huge_group(engine_factory):
+    e = engine_factory()
+    n = 200000
+    pts, (a, b) = H.oracle_points(n)
+    got = e.g1_sum([0, n], points96=pts)
+    assert got[0].tobytes() == H.closed_form_sum(range(n), a, b)
+
+
+# ---------------------------------------------------------------- get_head
+@pytest.mark.parametrize("n_val,n_blocks,kind,boost,mixed", [
+    (1024, 40, "branchy", False, False),
+    (65536, 2048, "branchy", True, False),
+    (262144, 4096, "chain", True, False),
+    (262144, 4096, "bushy", False, True),
+    (100003, 8192, "bushy", True, True),
+])
+def test_get_head_vs_oracle(engine_factory, n_val, n_blocks, kind, boost, mixed):
+    e = engine_factory()
+    seed = n_val + n_blocks
+    tree = synth.random_tree(n_blocks, seed, kind)
+    rng = np.random.default_rng(seed)
+    # leaf checkpoints: ~10 % of blocks carry a non-matching justified checkpoint (filter_block_tree)
+    good = (1, tree.roots[0].tobytes())
+    bad = (1, tree.roots[min(1, n_blocks - 1)].tobytes())
+    leaf_ok = rng.random(n_blocks) > 0.1
+    leaf_ok[0] = True
+    leaf_cp = [((good if leaf_ok[i] else bad), good) for i in range(n_blocks)]
+    H.load_tree(e, tree, leaf_cp)
+    e.set_checkpoints(good, good)            # epoch 1 != GENESIS: the leaf test is live
+    bal = synth.balances(n_val, seed, mixed)
+    flags = synth.validator_flags(n_val, seed, inactive_frac=0.005, slashed_frac=0.01)
+    e.set_validators(bal, flags)
+    # latest messages are installed through on_attestation (the ABI has no back door)
+    comm = synth.random_committees(n_val, 64, seed)
+    vote = synth.zipf_votes(n_val, n_blocks, seed)
+    rng2 = np.random.default_rng(seed + 1)
+    equiv = rng2.choice(n_val, size=max(1, n_val // 100), replace=False)
+    e.mark_equivocating(equiv)
+    flags_o = flags.copy()
+    flags_o[equiv] |= 0x04
+    votes_dev = _install_votes(e, tree, comm, vote)
+    boost_idx = NONE32
+    if boost:
+        boost_idx = n_blocks - 1
+        e.set_proposer_boost(tree.roots[boost_idx].tobytes())
+    parent = tree.parent.copy()
+    head_o, w_o = cport.get_head(parent, leaf_ok.astype(np.uint8), tree.roots, votes_dev, bal, flags_o, 0, boost_idx)
+    w_e = e.get_weights()
+    assert np.array_equal(w_e, w_o)
+    assert e.get_head() == tree.roots[head_o].tobytes()
+
+
+def _install_votes(e, tree, comm, vote):
+    """Drive `vote` into the engine through on_attestation batches; returns the vote table actually installed
+    (validators whose Zipf block fails validate_on_attestation keep no message)."""
+    n_comm = comm.offsets.size - 1
+    spe = 32
+    cps = n_comm // spe
+    n_blocks = tree.roots.shape[0]
+    # every attestation: slot = 31 of the block's epoch or later so block.slot <= slot; use a single far epoch
+    E = int(tree.slot.max()) // spe + 1
+    e.set_committees(E, comm.offsets, comm.members)
+    e.on_tick((E + 2) * spe * 12)
+    # equivocators' votes are dropped by update_latest_messages (pe:1438): the caller accounts for that
+    atts_list, bits_list = [], []
+    installed = np.full(vote.shape[0], NONE32, dtype=np.uint32)
+    for c in range(n_comm):
+        mem = comm.members[comm.offsets[c]:comm.offsets[c + 1]]
+        v = vote[mem]
+        for blk in np.unique(v[v != NONE32]):
+            blk = int(blk)
+            a = np.zeros(1, dtype=synth.ATT_DTYPE)[0]
+            a["slot"], a["index"] = E * spe + c // cps, c % cps
+            a["beacon_block_root"] = tree.roots[blk]
+            a["target_epoch"] = E
+            a["target_root"] = tree.roots[synth.ancestor_at(tree, blk, E * spe)]
+            a["source_root"] = tree.roots[0]
+            a["flags"] = 3   # signature valid | is_from_block (no wall-clock epoch check, pe:1423)
+            atts_list.append(a)
+            bits_list.append(v == blk)
+            installed[mem[v == blk]] = blk
+    atts = np.array(atts_list, dtype=synth.ATT_DTYPE)
+    arena, offs, nb = synth.pack_bit_rows(bits_list)
+    atts["bits_offset"], atts["n_bits"] = offs, nb
+    status, _, _ = e.on_attestation_batch(packed=(atts, arena))
+    assert (status == 0).all(), np.unique(status)
+    return installed
+
+
+# ---------------------------------------------------------------- LMD update (ordering rule)
+def test_lmd_update_vs_oracle(engine_factory):
+    e = engine_factory()
+    n_val, n_blocks, spe = 50000, 300, 32
+    tree = synth.random_tree(n_blocks, 5, "branchy")
+    H.load_tree(e, tree)
+    bal = synth.balances(n_val, 5)
+    flags = synth.validator_flags(n_val, 5)
+    e.set_validators(bal, flags)
+    rng = np.random.default_rng(5)
+    equiv = rng.choice(n_val, size=500, replace=False)
+    e.mark_equivocating(equiv)
+    flags_o = flags.copy()
+    flags_o[equiv] |= 0x04
+    vote_epoch = np.zeros(n_val, dtype=np.uint64)
+    vote_block = np.full(n_val, NONE32, dtype=np.uint32)
+    last_epoch = int(tree.slot.max()) // spe + 1
+    e.on_tick((last_epoch + 3) * spe * 12)
+    # three batches; epochs go up and DOWN so that stale votes must lose, duplicates inside a batch so
+    # that first-seen must win (pe:1383, pe:1440)
+    for batch, epochs in enumerate([(last_epoch + 1,), (last_epoch,), (last_epoch + 2, last_epoch + 1)]):
+        all_atts, all_bits, all_comm = [], [], []
+        for ep in epochs:
+            comm = synth.random_committees(n_val, 64, 100 * batch + ep)
+            e.set_committees(ep, comm.offsets, comm.members)
+            atts, arena, bit_rows = synth.epoch_attestations(comm, tree, ep, spe, seed=batch, density=0.6, parts=3)
+            # overlapping duplicates: re-emit the first 20 rows with different head votes
+            atts["flags"] = 3
+            dup = atts[:20].copy()
+            dup["beacon_block_root"] = tree.roots[0]
+            dup["target_root"] = tree.roots[0]
+            all_atts += [atts, dup]
+            all_bits += bit_rows + bit_rows[:20]
+            all_comm += [comm] * (len(atts) + 20)
+        atts = np.concatenate(all_atts)
+        arena, offs, nb = synth.pack_bit_rows(all_bits)
+        atts["bits_offset"], atts["n_bits"] = offs, nb
+        status, _, count = e.on_attestation_batch(packed=(atts, arena))
+        ok = status == 0
+        assert ok.sum() > 0
+        # oracle: sequential over the accepted rows, each against its own committee table
+        for i in np.nonzero(ok)[0]:
+            comm = all_comm[i]
+            mo, nbits, bo = H.att_device_rows(atts[i:i + 1], comm, spe)
+            blk = e.block_index_of(atts[i]["beacon_block_root"].tobytes())
+            cport.update_latest_messages(mo, nbits, bo, atts[i:i + 1]["target_epoch"], [blk], arena, comm.members,
+                                         flags_o, vote_epoch, vote_block)
+        ep_e, blk_e = e.latest_messages()
+        assert np.array_equal(blk_e, vote_block)
+        has = vote_block != NONE32
+        assert np.array_equal(ep_e[has], vote_epoch[has])
+
+
+# ---------------------------------------------------------------- aggregation
+def test_aggregate_vs_oracle(engine_factory):
+    e = engine_factory()
+    n_val, spe = 40000, 32
+    tree = synth.random_tree(64, 9, "branchy")
+    H.load_tree(e, tree)
+    pts, (a, b) = H.oracle_points(n_val)
+    e.set_validators(synth.balances(n_val, 9), synth.validator_flags(n_val, 9), pts)
+    comm = synth.random_committees(n_val, 128, 9)
+    e.set_committees(1, comm.offsets, comm.members)
+    atts, arena, bit_rows = synth.epoch_attestations(comm, tree, 1, spe, seed=9, density=0.9, parts=4)
+    perm = np.random.default_rng(9).permutation(len(atts))     # shuffle: grouping must not rely on adjacency
+    atts, bit_rows = atts[perm], [bit_rows[i] for i in perm]
+    arena, offs, nb = synth.pack_bit_rows(bit_rows)
+    atts["bits_offset"], atts["n_bits"] = offs, nb
+    sigs = pts[np.random.default_rng(10).integers(0, n_val, size=len(atts))]
+    res = e.aggregate(packed=(atts, arena), sig_points96=sigs, want_aggregate_pubkeys=True)
+    assert res["n_groups"] == 128
+    for g in range(res["n_groups"]):
+        members_i = np.nonzero(res["group_of"] == g)[0]
+        want_bits = np.zeros_like(bit_rows[members_i[0]], dtype=bool)
+        for i in members_i:
+            want_bits |= np.asarray(bit_rows[i], dtype=bool)
+        assert np.array_equal(res["bits"][g], want_bits)
+        assert res["count"][g] == want_bits.sum()
+        out = res["atts"][g]
+        cps = 128 // spe
+        c = (out.slot % spe) * cps + out.index
+        mem = comm.members[comm.offsets[c]:comm.offsets[c + 1]]
+        assert res["aggpk96"][g].tobytes() == H.closed_form_sum(mem[want_bits], a, b)
+    want_sig = cport.g1_sum_groups(sigs, np.argsort(res["group_of"], kind="stable").astype(np.uint32),
+                                   np.concatenate([[0], np.cumsum(np.bincount(res["group_of"], minlength=128))]))
+    assert np.array_equal(res["sig96"], want_sig)
+
+
+# ---------------------------------------------------------------- process_attestation flags
+def test_process_attestation_vs_oracle(engine_factory):
+    from pos_evolution_amd._abi import pe_state_ctx
+    e = engine_factory()
+    n_val = 30000
+    tree = synth.random_tree(80, 11, "chain")
+    H.load_tree(e, tree)
+    bal = synth.balances(n_val, 11, mixed=True)
+    e.set_validators(bal, synth.validator_flags(n_val, 11))
+    spe = 32
+    comms = {ep: synth.random_committees(n_val, 64, 11 + ep) for ep in (1, 2)}
+    parts, rows_comm = [], []
+    bit_rows = []
+    for ep, seed, dens, np_ in ((1, 11, 0.7, 2), (2, 13, 0.6, 1), (1, 12, 0.95, 1), (2, 14, 0.9, 1)):
+        e.set_committees(ep, comms[ep].offsets, comms[ep].members)
+        a, _, br = synth.epoch_attestations(comms[ep], tree, ep, spe, seed=seed, density=dens, parts=np_,
+                                            source=(0, tree.roots[0].tobytes()))
+        parts.append(a)
+        bit_rows += br
+        rows_comm += [ep] * len(a)
+    all_atts = np.concatenate(parts)
+    arena, offs, nb = synth.pack_bit_rows(bit_rows)
+    all_atts["bits_offset"], all_atts["n_bits"] = offs, nb
+    ctx = pe_state_ctx()
+    state_slot = 70   # epoch 2; epoch-1 rows with slot < 38 and epoch-2 rows with slot >= 70 fall outside pe:726
+    ctx.slot = state_slot
+    tip = 69
+    ctx.chain_tip_root[:] = tree.roots[tip].tobytes()
+    ctx.current_justified_epoch, ctx.previous_justified_epoch = 0, 0
+    ctx.current_justified_root[:] = tree.roots[0].tobytes()
+    ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+    ctx.base_reward_per_increment = 357
+    status, num = e.process_attestation_batch(ctx, packed=(all_atts, arena))
+    ok = status == 0
+    assert ok.sum() > len(all_atts) // 3 and (status == 13).sum() > 0
+    # oracle: flag masks recomputed independently in Python from the spec text (A.9)
+    cur_epoch = state_slot // spe
+    # one members array per epoch table: concatenate both and offset epoch-2 rows
+    members = np.concatenate([comms[1].members, comms[2].members])
+    mo = np.zeros(len(all_atts), dtype=np.uint32)
+    for i, a in enumerate(all_atts):
+        ep = rows_comm[i]
+        m, _, _ = H.att_device_rows(all_atts[i:i + 1], comms[ep], spe)
+        mo[i] = m[0] + (0 if ep == 1 else comms[1].members.size)
+    nbits, bo = all_atts["n_bits"].astype(np.uint32), all_atts["bits_offset"].astype(np.uint32)
+    masks, which = [], []
+    for a in all_atts:
+        delay = state_slot - int(a["slot"])
+        tgt = synth.ancestor_at(tree, tip, int(a["target_epoch"]) * spe)
+        head = synth.ancestor_at(tree, tip, int(a["slot"]))
+        mt = a["target_root"].tobytes() == tree.roots[tgt].tobytes()
+        mh = mt and a["beacon_block_root"].tobytes() == tree.roots[head].tobytes()
+        m = (1 if delay <= 5 else 0) | (2 if mt and delay <= spe else 0) | (4 if mh and delay == 1 else 0)
+        masks.append(m)
+        which.append(0 if int(a["target_epoch"]) == cur_epoch else 1)
+    pc = np.zeros(n_val, dtype=np.uint8)
+    pp = np.zeros(n_val, dtype=np.uint8)
+    sel = np.nonzero(ok)[0]
+    want = cport.process_attestation_flags(mo[sel], nbits[sel], bo[sel], np.array(masks, dtype=np.uint8)[sel],
+                                           np.array(which, dtype=np.uint8)[sel], arena, members, bal,
+                                           10**9, 357, pc, pp)
+    assert np.array_equal(num[sel], want)
+    assert np.array_equal(e.participation_get(0), pc)
+    assert np.array_equal(e.participation_get(1), pp)
