@@ -1,0 +1,354 @@
+#!/usr/bin/env python
+"""bench.py -- attestations aggregated/sec + get_head() p50 latency at 1M validators (BASELINE.json metric).
+
+A "step" = one epoch's pass of the hot path over one batch of synthetic input, per GPU:
+    4 partial aggregates per committee (8192 rows) --pe_aggregate--> 2048 aggregates: bitfield union +
+    aggregate pubkey (BLS12-381 G1 sum of ~1M validator points)        [A1, A2, A3]
+    --pe_on_attestation_batch--> LMD latest-message update (~1M)       [A4, A5]
+    --pe_process_attestation_batch--> participation flags + numerators [A6]
+    --pe_get_head--> weights from the 1M-entry vote table + descent    [H1-H6]
+Every step targets a new epoch (fresh committee table, fresh votes, rotated participation), so no work is
+cached or skipped.  Inputs (registry, tree, committee tables) are resident in HBM before the timed region;
+the per-step attestation rows + bits (~1.7 MB) cross PCIe inside it, as the C ABI hands over host buffers.
+
+N > 1 (launched by torch.distributed.run): validators are range-sharded (weak scaling: 1M per GPU); the
+exchange steps are one RCCL all-gather of G1 Jacobian partials and one all-reduce of per-block weights.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guide: ~6290 GB/s achievable)
+
+
+def build_workload(e, args, rank, n_steps_total):
+    import pos_evolution_amd.synth as synth
+
+    V, B, C, spe = args.validators, args.blocks, args.committees, 32
+    seed = 4 + rank  # config 4 of BASELINE.json, per-rank registry
+    tree = synth.random_tree(B, 4, "bushy")  # the tree is global: same on every rank
+    e.store_init(0, 0, tree.roots[0].tobytes())
+    for i in range(1, B):
+        e.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+    bal = synth.balances(V, seed, mixed=args.mixed_balances)
+    flags = synth.validator_flags(V, seed, inactive_frac=0.005)
+    pts = synth.registry_points(e, V, lo=rank * V)
+    e.set_validators(bal, flags, pts)
+    epoch0 = int(tree.slot.max()) // spe + 1
+    steps = []
+    for s in range(n_steps_total):
+        ep = epoch0 + s
+        comm = synth.random_committees(V, C, 100 * seed + s)
+        e.set_committees(ep, comm.offsets, comm.members)
+        atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=seed, density=0.99, parts=args.parts,
+                                                  source=(0, tree.roots[0].tobytes()), vote_recent=64)
+        steps.append(dict(epoch=ep, comm=comm, atts=atts, arena=arena))
+    return dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe)
+
+
+def state_ctx(w, ep):
+    from pos_evolution_amd._abi import pe_state_ctx
+
+    tree = w["tree"]
+    c = pe_state_ctx()
+    c.slot = (ep + 1) * w["spe"]
+    c.chain_tip_root[:] = tree.roots[tree.roots.shape[0] - 1].tobytes()
+    c.current_justified_root[:] = tree.roots[0].tobytes()
+    c.previous_justified_root[:] = tree.roots[0].tobytes()
+    c.base_reward_per_increment = 2264  # 1e9 * 64 // isqrt(32e9 * 2^20 * 0.995) for the 1M x 32 ETH registry
+    return c
+
+
+def run_step_single(e, w, st):
+    import pos_evolution_amd.synth as synth
+
+    ep = st["epoch"]
+    e.on_tick((ep + 1) * w["spe"] * 12)
+    e.participation_rotate()
+    agg = e.aggregate(packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
+    g = agg["n_groups"]
+    rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
+    status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
+    st2, num = e.process_attestation_batch(state_ctx(w, ep), packed=(rows, agg["out_arena"]))
+    head = e.get_head()
+    return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
+
+
+class Exchange:
+    """The two collectives of the sharded path on torch.distributed (backend nccl = RCCL over xGMI)."""
+
+    def __init__(self, e, n_blocks, n_groups, world):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.world = torch, dist, world
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.wbuf = torch.zeros(n_blocks + 2, dtype=torch.int64, device=dev)
+        self.partial = torch.zeros(n_groups * 36, dtype=torch.int32, device=dev)
+        self.gathered = torch.zeros(world * n_groups * 36, dtype=torch.int32, device=dev)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)  # engine kernels and RCCL ordered in-stream
+
+
+def run_step_sharded(e, w, st, ex):
+    import pos_evolution_amd.synth as synth
+
+    ep = st["epoch"]
+    e.on_tick((ep + 1) * w["spe"] * 12)
+    e.participation_rotate()
+    agg = e.aggregate_partial(ex.partial.data_ptr(), packed=(st["atts"], st["arena"]))
+    g = agg["n_groups"]
+    ex.dist.all_gather_into_tensor(ex.gathered, ex.partial)          # C x 144 B per rank
+    aggpk = e.g1_finish(ex.gathered.data_ptr(), ex.world, g)
+    rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
+    status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
+    st2, num = e.process_attestation_batch(state_ctx(w, ep), packed=(rows, agg["out_arena"]))
+    e.votes_partial(ex.wbuf.data_ptr())
+    ex.dist.all_reduce(ex.wbuf)                                      # (B + 2) x 8 B, integer sum: bit-exact
+    head = e.head_from_weights(ex.wbuf.data_ptr())
+    return dict(agg=agg, aggpk=aggpk, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
+
+
+def cpu_baseline(w, st, target_seconds=12.0):
+    """The L1 C oracle ("port") timed on one host core over whole steps of the same workload."""
+    from oracle import cport
+    import pos_evolution_amd.synth as synth
+
+    tree, comm, atts, arena = w["tree"], st["comm"], st["atts"], st["arena"]
+    spe = w["spe"]
+    n_comm = comm.offsets.size - 1
+    cps = n_comm // spe
+    V = w["bal"].size
+    pos = ((atts["slot"] % spe) * cps + atts["index"]).astype(np.int64)
+    order = np.argsort(pos, kind="stable")
+    group_start = np.concatenate([[0], np.cumsum(np.bincount(pos, minlength=n_comm))]).astype(np.uint32)
+    sizes = (comm.offsets[1:] - comm.offsets[:-1]).astype(np.uint32)
+    out_off = np.concatenate([[0], np.cumsum((sizes + 7) // 8)]).astype(np.uint32)
+    first = order[group_start[:-1]]
+    blk = np.array([int(np.nonzero((tree.roots == atts[i]["beacon_block_root"]).all(axis=1))[0][0]) for i in first],
+                   dtype=np.uint32)
+    vote_epoch = np.zeros(V, dtype=np.uint64)
+    vote_block = np.full(V, 0xFFFFFFFF, dtype=np.uint32)
+    pc, pp = np.zeros(V, dtype=np.uint8), np.zeros(V, dtype=np.uint8)
+    n_att = 0
+    t0 = time.perf_counter()
+    reps = 0
+    result = None
+    while True:
+        union, count = cport.bits_union(group_start, order.astype(np.uint32), atts["bits_offset"], arena, sizes,
+                                        out_off[:-1], int(out_off[-1]))
+        bits = np.unpackbits(union, bitorder="little")
+        idx_parts, offs = [], [0]
+        for c in range(n_comm):
+            sel = bits[8 * out_off[c]: 8 * out_off[c] + sizes[c]].astype(bool)
+            idx_parts.append(comm.members[comm.offsets[c]:comm.offsets[c + 1]][sel])
+            offs.append(offs[-1] + int(sel.sum()))
+        aggpk = cport.g1_sum_groups(w["pts"], np.concatenate(idx_parts), np.array(offs, dtype=np.uint32))
+        te = atts["target_epoch"][first] + reps
+        cport.update_latest_messages(comm.offsets[:-1], sizes, out_off[:-1], te, blk, union, comm.members, w["flags"],
+                                     vote_epoch, vote_block)
+        pp[:] = 0
+        num = cport.process_attestation_flags(comm.offsets[:-1], sizes, out_off[:-1], np.full(n_comm, 1, np.uint8),
+                                              np.ones(n_comm, np.uint8), union, comm.members, w["bal"], 10**9, 2264,
+                                              pc, pp)
+        head, weights = cport.get_head(tree.parent, np.ones(tree.parent.size, np.uint8), tree.roots, vote_block,
+                                       w["bal"], w["flags"], 0)
+        n_att += int(count.sum())
+        reps += 1
+        if result is None:
+            result = dict(aggpk=aggpk, count=count, head=tree.roots[head].tobytes(), weights=weights,
+                          vote_block=vote_block.copy())
+        if time.perf_counter() - t0 > target_seconds:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=n_att / dt, unit="attestations/s", cores=1, kind="port",
+                sample=f"{reps} full steps ({n_att} attestations: union + G1 sums + LMD + flags + get_head) of the "
+                       f"timed workload, oracle/posevo_oracle.c, single thread, {dt:.1f} s"), result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--validators", type=int, default=1 << 20, help="per GPU")
+    ap.add_argument("--blocks", type=int, default=4096)
+    ap.add_argument("--committees", type=int, default=2048)
+    ap.add_argument("--parts", type=int, default=4, help="partial aggregates per committee")
+    ap.add_argument("--mixed-balances", action="store_true")
+    ap.add_argument("--head-calls", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # a non-null stream shared by the engine's kernels and the RCCL collectives (torch orders collectives
+        # against the CURRENT stream; the engine treats a null handle as "use your own stream")
+        torch.cuda.set_stream(torch.cuda.Stream())
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run --nproc-per-node N"
+
+    import pos_evolution_amd as pea
+
+    total = args.warmup + args.steps
+    e = pea.Engine(device=local_rank, max_committee_tables=total + 1)
+    w = build_workload(e, args, rank, total)
+    ex = Exchange(e, args.blocks, args.committees, world) if world > 1 else None
+
+    def step(st):
+        return run_step_sharded(e, w, st, ex) if ex else run_step_single(e, w, st)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step(w["steps"][s])
+    e.profile_enable(True)
+    e.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    n_att_local = 0
+    for s in range(args.warmup, total):
+        last = step(w["steps"][s])
+        n_att_local += int(last["count"].sum())
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = e.profile()
+    e.profile_enable(False)
+    assert (last["status"] == 0).all() and (last["pstatus"] == 0).all(), "synthetic attestations were rejected"
+
+    # get_head latency: full recomputation from the vote table, after the timed region
+    lat = []
+    for _ in range(20):
+        e.get_head() if ex is None else (e.votes_partial(ex.wbuf.data_ptr()), dist.all_reduce(ex.wbuf), e.head_from_weights(ex.wbuf.data_ptr()))
+    for _ in range(args.head_calls):
+        t = time.perf_counter()
+        if ex is None:
+            e.get_head()
+        else:
+            e.votes_partial(ex.wbuf.data_ptr())
+            dist.all_reduce(ex.wbuf)
+            e.head_from_weights(ex.wbuf.data_ptr())
+        lat.append((time.perf_counter() - t) * 1e6)
+    lat = np.sort(np.array(lat))
+
+    if dist is not None:
+        t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, n_att = float(tmax[0]), float(t[1])
+        heads = [None] * world
+        dist.all_gather_object(heads, last["head"])
+        assert all(h == heads[0] for h in heads), "ranks disagree on the head"
+    else:
+        n_att = float(n_att_local)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: k_g1_accumulate, algorithmic bytes per launch ----
+    C = args.committees
+    att_per_launch = n_att_local / args.steps
+    alg_bytes = 100.125 * att_per_launch + C * (96 + (args.validators / C) / 8)
+    acc = prof["g1_accumulate"]
+    acc_ms = acc["total_ms"] / max(acc["launches"], 1)
+    achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_g1_accumulate_bytes_per_launch")
+        except Exception:
+            traffic = None
+    votes = prof["votes"]
+    votes_ms = votes["total_ms"] / max(votes["launches"], 1)
+    votes_bytes = 13.0 * args.validators + 32.0 * args.blocks
+    kernel_ms = {k: (v["total_ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()}
+
+    out = {
+        "metric": "attestations aggregated/sec + get_head() p50 latency at 1M validators",
+        "value": n_att / dt,
+        "unit": "attestations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 limbs (381-bit Fp, integer) + u64 Gwei",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[3] shape on {world} GPU(s): {args.validators} validators/GPU, "
+                        f"{C} committees x {args.validators // C}, {args.parts} partial aggregates/committee, "
+                        f"99% participation, {args.blocks}-block tree, one epoch per step",
+            "validators_per_gpu": args.validators, "blocks": args.blocks, "committees": C,
+            "parallelism": f"validator-range shards x{world}" if world > 1 else "single GPU",
+        },
+        "get_head_p50_us": float(lat[len(lat) // 2]),
+        "get_head_p99_us": float(lat[min(len(lat) - 1, int(len(lat) * 0.99))]),
+        "roofline": {
+            "kernel": "k_g1_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms, "launches": acc["launches"],
+            "note": "integer-VALU bound (about 11 Montgomery products per 100 B gathered), not HBM bound: "
+                    "see DESIGN.md; votes kernel below is the HBM-streaming one",
+        },
+        "roofline_votes": {
+            "kernel": "k_votes", "bound": "hbm", "achieved": votes_bytes / (votes_ms * 1e-3) / 1e9 if votes_ms else 0.0,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (votes_bytes / (votes_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if votes_ms else 0.0,
+            "avg_launch_ms": votes_ms, "launches": votes["launches"],
+        },
+        "kernel_avg_ms": kernel_ms,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        base, chk = cpu_baseline(w, w["steps"][0])
+        out["cpu_baseline"] = base
+        out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        # same-input cross-check of step 0's G1 aggregates against the oracle (not timed)
+        e2 = pea.Engine(device=local_rank)
+        st0 = w["steps"][0]
+        e2.store_init(0, 0, w["tree"].roots[0].tobytes())
+        e2.set_validators(w["bal"], w["flags"], w["pts"])
+        e2.set_committees(st0["epoch"], st0["comm"].offsets, st0["comm"].members)
+        agg = e2.aggregate(packed=(st0["atts"], st0["arena"]), want_aggregate_pubkeys=True)
+        import pos_evolution_amd.synth as synth
+        rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=agg["n_groups"])
+        cps = C // 32
+        pos = ((rows["slot"] % 32) * cps + rows["index"]).astype(np.int64)
+        out["checked_against_oracle"] = bool(np.array_equal(agg["aggpk96"], chk["aggpk"][pos]))
+        assert out["checked_against_oracle"], "GPU aggregate pubkeys differ from the oracle"
+        e2.close()
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,7 +95,7 @@ typedef struct pe_config {
     int32_t  device;                          /* HIP device ordinal; -1 = current device */
     uint64_t reserve_validators;              /* capacity hints (0 = grow on demand) */
     uint32_t reserve_blocks;
-    uint32_t reserved0;
+    uint32_t max_committee_tables;            /* epochs of committee tables kept resident (0 = 4) */
 } pe_config;
 
 /* Validator flag bits (T1: the per-validator byte the vote kernel streams). */
@@ -191,7 +191,7 @@ int pe_on_attester_slashing(pe_engine* h,
  * (slot, index) of that epoch (Appendix A.6 / compute_committee pe:495-504), as CSR:
  * committee id = (slot % SLOTS_PER_EPOCH) * committees_per_slot + index,
  * members[offsets[id] .. offsets[id+1]).  n_committees must be a multiple of
- * SLOTS_PER_EPOCH.  The engine keeps the four most recent epochs. */
+ * SLOTS_PER_EPOCH.  The engine keeps the cfg.max_committee_tables most recently used epochs. */
 int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees,
                       const uint32_t* offsets, const uint32_t* members);
 
@@ -269,16 +269,16 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
 /* ---- multi-GPU exchange (validator-range shards) ----------- */
 /* Each rank owns a contiguous validator range and the whole (small) block table.
  * get_head splits at the one exchange point:
- *   pe_votes_partial  : this shard's direct vote weight per block (tree order),
- *                       written to a caller-owned DEVICE buffer of pe_num_blocks u64
- *   <host framework: all-reduce(sum, u64) over ranks -- RCCL via torch.distributed>
- *   pe_head_from_weights : subtree sums + descent from the reduced DEVICE buffer
- * total_active_balance / num_active feed the proposer boost (Appendix A.1) and
- * must be the global (all-shard) values. */
-int pe_votes_partial(pe_engine* h, void* dev_weights_u64, uint32_t n_blocks,
-                     uint64_t* out_local_active_balance, uint64_t* out_local_num_active);
-int pe_head_from_weights(pe_engine* h, const void* dev_weights_u64, uint32_t n_blocks,
-                         uint64_t total_active_balance, uint64_t num_active, uint8_t out_root[32]);
+ *   pe_votes_partial  : this shard's direct vote weight per block (tree order) into a
+ *                       caller-owned DEVICE buffer of n_blocks + 2 u64; entries
+ *                       [n_blocks] / [n_blocks+1] receive the shard's active balance /
+ *                       active validator count (the proposer boost needs the global
+ *                       values, Appendix A.1).  Asynchronous on the engine's stream.
+ *   <host framework: ONE all-reduce(sum, u64) of the buffer -- RCCL via torch.distributed>
+ *   pe_head_from_weights : subtree sums + descent from the reduced DEVICE buffer.
+ * Integer sums: bit-exact for any reduction order. */
+int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks);
+int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32]);
 /* G1: per-group Jacobian partial sums (144 B each, Montgomery form) of this shard's
  * points into a caller-owned DEVICE buffer; after an all-gather over ranks,
  * pe_g1_finish adds the n_ranks partials per group and normalises to affine. */
@@ -287,6 +287,15 @@ int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, 
                   void* dev_partials);
 int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups,
                  uint8_t* out96);
+/* pe_aggregate whose aggregate pubkeys stay Jacobian partials of THIS shard's committee
+ * members, written to a caller-owned DEVICE buffer (PE_G1_PARTIAL_BYTES per group, group
+ * order as in out_atts); all-gather them and call pe_g1_finish.  Asynchronous w.r.t. the
+ * partials; everything else as pe_aggregate. */
+int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
+                         const uint8_t* bits_arena, uint64_t arena_len,
+                         pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                         uint8_t* out_bits_arena, uint64_t out_arena_cap, uint32_t* out_count,
+                         void* dev_partials);
 
 /* ---- profiling hooks (bench.py roofline leg) ----------------------------- */
 /* When enabled, the engine brackets each launch of its kernels with HIP events on

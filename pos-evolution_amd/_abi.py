@@ -37,7 +37,7 @@ class pe_config(C.Structure):
         ("safe_slots_to_update_justified", C.c_uint64), ("proposer_score_boost", C.c_uint64),
         ("effective_balance_increment", C.c_uint64), ("min_attestation_inclusion_delay", C.c_uint64),
         ("max_validators_per_committee", C.c_uint64), ("filter_slashed", C.c_uint32), ("device", C.c_int32),
-        ("reserve_validators", C.c_uint64), ("reserve_blocks", C.c_uint32), ("reserved0", C.c_uint32),
+        ("reserve_validators", C.c_uint64), ("reserve_blocks", C.c_uint32), ("max_committee_tables", C.c_uint32),
     ]
 
 
@@ -104,8 +104,10 @@ SIGNATURES = {
     "pe_block_index_of": (C.c_int, [_H, _u8p, _u32p]),
     "pe_get_latest_messages": (C.c_int, [_H, _u64p, _u32p, C.c_uint64]),
     "pe_get_store_scalars": (C.c_int, [_H, _u64p, _u64p, _u64p, _u8p, _u64p, _u8p, _u64p, _u8p, _u8p]),
-    "pe_votes_partial": (C.c_int, [_H, C.c_void_p, C.c_uint32, _u64p, _u64p]),
-    "pe_head_from_weights": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, _u8p]),
+    "pe_votes_partial": (C.c_int, [_H, C.c_void_p, C.c_uint32]),
+    "pe_head_from_weights": (C.c_int, [_H, C.c_void_p, C.c_uint32, _u8p]),
+    "pe_aggregate_partial": (C.c_int, [_H, _P(pe_attestation), C.c_uint32, _u8p, C.c_uint64, _P(pe_attestation),
+                                       _u32p, _u32p, _u8p, C.c_uint64, _u32p, C.c_void_p]),
     "pe_g1_partial": (C.c_int, [_H, _u32p, _u32p, C.c_uint32, C.c_void_p]),
     "pe_g1_finish": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, _u8p]),
     "pe_profile_enable": (C.c_int, [_H, C.c_int]),

@@ -555,7 +555,7 @@ int need_init(pe_engine* h)
 }
 
 // get_head's device part on arbitrary weight buffer.
-int run_tree(pe_engine* h, uint64_t* d_direct, int use_override, uint64_t ov_bal, uint64_t ov_num, uint32_t* head_out)
+int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, uint32_t* head_out)
 {
     uint32_t just_idx;
     if (!find_block(h, h->justified.root, &just_idx))
@@ -567,7 +567,7 @@ int run_tree(pe_engine* h, uint64_t* d_direct, int use_override, uint64_t ov_bal
     }
     {
         ProfScope ps(h, PE_KERNEL_TREE);
-        launch_tree(h->stream, tree_dev(h), d_direct, h->d_totals.as<VoteTotals>(), ov_bal, ov_num, use_override,
+        launch_tree(h->stream, tree_dev(h), d_direct, d_totals, 0, 0, 0,
                     h->h_pos_of_idx[just_idx], boost_pos, h->cfg.slots_per_epoch, h->cfg.proposer_score_boost,
                     h->cfg.effective_balance_increment, h->d_weights.as<uint64_t>(), h->d_head.as<uint32_t>());
     }
@@ -652,6 +652,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
         return PE_ERR_NO_DEVICE;
     }
     h->stream = h->own_stream;
+    h->tables.reserve(c.max_committee_tables ? c.max_committee_tables : 4u);
     *out = h;
     return PE_OK;
 }
@@ -954,7 +955,7 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const
     }
     CommitteeTable* t = find_table(h, epoch);
     if (!t) {
-        if (h->tables.size() < 4) {
+        if (h->tables.size() < (h->cfg.max_committee_tables ? h->cfg.max_committee_tables : 4u)) {
             h->tables.emplace_back();
             t = &h->tables.back();
         } else {
@@ -988,7 +989,7 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
                      h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>());
     }
     uint32_t head;
-    rc = run_tree(h, h->d_direct.as<uint64_t>(), 0, 0, 0, &head);
+    rc = run_tree(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), &head);
     if (rc) return rc;
     memcpy(out_root, h->blocks[head].root.data(), 32);
     return PE_OK;
@@ -1006,41 +1007,35 @@ int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)
     return PE_OK;
 }
 
-int pe_votes_partial(pe_engine* h, void* dev_weights_u64, uint32_t n_blocks, uint64_t* out_bal, uint64_t* out_num)
+int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
 {
     int rc = need_init(h);
     if (rc) return rc;
-    if (!dev_weights_u64 || n_blocks != h->blocks.size()) return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
+    if (!dev_buf_u64 || n_blocks != h->blocks.size()) return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
     rc = refresh_tree(h);
     if (rc) return rc;
+    uint64_t* buf = static_cast<uint64_t*>(dev_buf_u64);
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
-                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), n_blocks,
-                     static_cast<uint64_t*>(dev_weights_u64), h->d_totals.as<VoteTotals>());
+                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), n_blocks, buf,
+                     reinterpret_cast<VoteTotals*>(buf + n_blocks));
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, h->h_pin.ensure(64));
-    HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_totals.p, sizeof(VoteTotals), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const VoteTotals* t = h->h_pin.as<VoteTotals>();
-    if (out_bal) *out_bal = t->total_active_balance;
-    if (out_num) *out_num = t->num_active;
     return PE_OK;
 }
 
-int pe_head_from_weights(pe_engine* h, const void* dev_weights_u64, uint32_t n_blocks, uint64_t total_active_balance,
-                         uint64_t num_active, uint8_t out_root[32])
+int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32])
 {
     int rc = need_init(h);
     if (rc) return rc;
-    if (!dev_weights_u64 || !out_root || n_blocks != h->blocks.size())
+    if (!dev_buf_u64 || !out_root || n_blocks != h->blocks.size())
         return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
     rc = refresh_tree(h);
     if (rc) return rc;
+    uint64_t* buf = const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_buf_u64));
     uint32_t head;
-    rc = run_tree(h, const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_weights_u64)), 1, total_active_balance,
-                  num_active, &head);
+    rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + n_blocks), &head);
     if (rc) return rc;
     memcpy(out_root, h->blocks[head].root.data(), 32);
     return PE_OK;
@@ -1149,16 +1144,17 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
 }
 
 // ---------------------------------------------------------------- aggregation
-int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena, uint64_t arena_len,
-                 const uint8_t* sig_points96, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
-                 uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_sig96, uint8_t* out_aggpk96,
-                 uint32_t* out_count)
+static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
+                          uint64_t arena_len, const uint8_t* sig_points96, pe_attestation* out_atts,
+                          uint32_t* out_n_groups, uint32_t* group_of, uint8_t* out_bits_arena, uint64_t out_arena_cap,
+                          uint8_t* out_sig96, uint8_t* out_aggpk96, uint32_t* out_count, void* dev_partials)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     if (!out_n_groups || (n && (!atts || !bits_arena || !out_atts || !out_bits_arena))) return PE_ERR_INVALID_ARG;
     if (out_sig96 && !sig_points96) return fail(h, PE_ERR_INVALID_ARG, "out_sig96 requires sig_points96");
-    if (out_aggpk96 && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
+    const bool want_pk = out_aggpk96 || dev_partials;
+    if (want_pk && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     *out_n_groups = 0;
     if (n == 0) return PE_OK;
     // ---- group by identical AttestationData + n_bits, in order of first appearance ----
@@ -1219,7 +1215,7 @@ int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uin
     // ---- aggregate pubkey needs each group's committee ----
     std::vector<Resolved> gres(ng);
     CommitteeTable* table = nullptr;
-    if (out_aggpk96) {
+    if (want_pk) {
         for (uint32_t g = 0; g < ng; ++g) {
             const pe_attestation& a = atts[glist[g][0]];
             CommitteeTable* t = find_table(h, a.target_epoch);
@@ -1255,7 +1251,7 @@ int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uin
     HIP_TRY(h, hipMemcpyAsync(h_out_words.data(), h->d_uarena.p, out_words * 4ull, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h_count.data(), h->d_ucount.p, ng * 4ull, hipMemcpyDeviceToHost, h->stream));
     // ---- device: aggregate pubkey over the OR-ed bits (device-resident: no round trip of the bits) ----
-    if (out_aggpk96) {
+    if (want_pk) {
         std::vector<uint32_t> sizes(ng);
         for (uint32_t g = 0; g < ng; ++g) sizes[g] = gres[g].size;
         G1Plan plan;
@@ -1265,7 +1261,7 @@ int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uin
             plan.groups[g].bits_word = ug[g].out_word;
         }
         int rc = run_g1(h, h->d_points.as<uint32_t>(), table->d_members.as<uint32_t>(), h->d_uarena.as<uint32_t>(),
-                        plan, out_aggpk96, nullptr);
+                        plan, out_aggpk96, static_cast<uint32_t*>(dev_partials));
         if (rc) return rc;
         table->stamp = ++h->table_stamp;
     }
@@ -1304,6 +1300,24 @@ int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uin
     if (group_of) memcpy(group_of, gof.data(), 4ull * n);
     *out_n_groups = ng;
     return PE_OK;
+}
+
+int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena, uint64_t arena_len,
+                 const uint8_t* sig_points96, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                 uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_sig96, uint8_t* out_aggpk96,
+                 uint32_t* out_count)
+{
+    return aggregate_impl(h, atts, n, bits_arena, arena_len, sig_points96, out_atts, out_n_groups, group_of,
+                          out_bits_arena, out_arena_cap, out_sig96, out_aggpk96, out_count, nullptr);
+}
+
+int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
+                         uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                         uint8_t* out_bits_arena, uint64_t out_arena_cap, uint32_t* out_count, void* dev_partials)
+{
+    if (!dev_partials) return PE_ERR_INVALID_ARG;
+    return aggregate_impl(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of,
+                          out_bits_arena, out_arena_cap, nullptr, nullptr, out_count, dev_partials);
 }
 
 // ---------------------------------------------------------------- process_attestation

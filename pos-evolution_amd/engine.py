@@ -271,17 +271,30 @@ class Engine:
         return out[:n_groups]
 
     # -- multi-GPU exchange -------------------------------------------------
-    def votes_partial(self, dev_ptr: int) -> Tuple[int, int]:
-        bal, num = C.c_uint64(0), C.c_uint64(0)
-        self._check(self._lib.pe_votes_partial(self._h, C.c_void_p(dev_ptr), self.num_blocks, C.byref(bal),
-                                               C.byref(num)))
-        return bal.value, num.value
+    def votes_partial(self, dev_ptr: int):
+        """dev_ptr: device buffer of num_blocks + 2 u64 (weights | active balance | active count)."""
+        self._check(self._lib.pe_votes_partial(self._h, C.c_void_p(dev_ptr), self.num_blocks))
 
-    def head_from_weights(self, dev_ptr: int, total_active_balance: int, num_active: int) -> bytes:
+    def head_from_weights(self, dev_ptr: int) -> bytes:
         out = (C.c_uint8 * 32)()
-        self._check(self._lib.pe_head_from_weights(self._h, C.c_void_p(dev_ptr), self.num_blocks,
-                                                   total_active_balance, num_active, out))
+        self._check(self._lib.pe_head_from_weights(self._h, C.c_void_p(dev_ptr), self.num_blocks, out))
         return bytes(out)
+
+    def aggregate_partial(self, dev_ptr: int, rows=None, packed=None):
+        """pe_aggregate with the aggregate pubkeys left as this shard's Jacobian partials at dev_ptr."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        out_atts = (pe_attestation * max(n, 1))()
+        n_groups = C.c_uint32(0)
+        group_of = np.zeros(max(n, 1), dtype=np.uint32)
+        out_arena = np.zeros(max(arena.size, 1), dtype=np.uint8)
+        count = np.zeros(max(n, 1), dtype=np.uint32)
+        self._check(self._lib.pe_aggregate_partial(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
+                                                   out_atts, C.byref(n_groups), _ptr(group_of, C.c_uint32),
+                                                   _ptr(out_arena, C.c_uint8), out_arena.size,
+                                                   _ptr(count, C.c_uint32), C.c_void_p(dev_ptr)))
+        g = n_groups.value
+        return dict(n_groups=g, atts=out_atts, group_of=group_of[:n], out_arena=out_arena, count=count[:g])
 
     def g1_partial(self, offsets, index, dev_ptr: int):
         off = np.ascontiguousarray(offsets, dtype=np.uint32)

@@ -179,3 +179,83 @@ def epoch_attestations(comm: Committees, tree: Tree, epoch: int, slots_per_epoch
     arena, offs, nb = pack_bit_rows(bit_rows)
     atts["bits_offset"], atts["n_bits"] = offs, nb
     return atts, arena, bit_rows
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic pubkey registry P_v = A + v*B, built WITHOUT the oracle: a few hundred pure-Python
+# affine additions seed three small tables, the engine's own G1 kernel does the bulk pair sums.
+# (Subset sums of such a registry have the closed form |S|*A + (sum v)*B -- SURVEY.md 8c.)
+# ---------------------------------------------------------------------------------------------
+_P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_G = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+      0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+
+
+def _ec_add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        if (y1 + y2) % _P == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, _P) % _P
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, _P) % _P
+    x3 = (lam * lam - x1 - x2) % _P
+    return (x3, (lam * (x1 - x3) - y1) % _P)
+
+
+def _ec_mul(k, p):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _ec_add(acc, p)
+        p = _ec_add(p, p)
+        k >>= 1
+    return acc
+
+
+def _enc96(p) -> bytes:
+    if p is None:
+        return bytes([0x40]) + bytes(95)
+    return p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+
+
+def _progression(start, step, n):
+    out, cur = [], start
+    for _ in range(n):
+        out.append(cur)
+        cur = _ec_add(cur, step)
+    return out
+
+
+def registry_points(engine, n: int, a: int = 0x1234567, b: int = 0x89ABCDE, lo: int = 0) -> np.ndarray:
+    """(n, 96) uint8, row v = A + (lo + v)*B with A = a*G, B = b*G.
+    v = v0 + 256*v1 + 65536*v2  ->  P_v = (A + v0*B) + (v1*256*B) + (v2*65536*B)."""
+    A, B = _ec_mul(a, _G), _ec_mul(b, _G)
+    hi_n = (lo + n + 65535) // 65536
+    t0 = _progression(A, B, 256)
+    t1 = _progression(None, _ec_mul(256, B), 256)
+    t2 = _progression(None, _ec_mul(65536, B), hi_n)
+    table = np.frombuffer(b"".join(_enc96(p) for p in t0 + t1 + t2), dtype=np.uint8).reshape(-1, 96)
+    out = np.empty((n, 96), dtype=np.uint8)
+    chunk = 1 << 20
+    for base in range(0, n, chunk):
+        m = min(chunk, n - base)
+        v = np.arange(lo + base, lo + base + m, dtype=np.uint64)
+        idx = np.empty((m, 3), dtype=np.uint32)
+        idx[:, 0] = v & 255
+        idx[:, 1] = 256 + ((v >> 8) & 255)
+        idx[:, 2] = 512 + (v >> 16)
+        offsets = np.arange(0, 3 * m + 1, 3, dtype=np.uint32)
+        out[base:base + m] = engine.g1_sum(offsets, index=idx.reshape(-1), points96=table)
+    return out
+
+
+def registry_closed_form(indices, a: int = 0x1234567, b: int = 0x89ABCDE) -> bytes:
+    """96-byte encoding of sum_{v in indices} (A + v*B) by one double-and-add (pure Python)."""
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    idx = [int(i) for i in indices]
+    return _enc96(_ec_mul((len(idx) * a + sum(idx) * b) % r, _G))
