@@ -68,18 +68,31 @@ def state_ctx(w, ep):
     return c
 
 
+_BREAKDOWN = {} if os.environ.get("POSEVO_BREAKDOWN") else None
+
+
+def _timed(name, fn, *a, **k):
+    if _BREAKDOWN is None:
+        return fn(*a, **k)
+    t = time.perf_counter()
+    r = fn(*a, **k)
+    _BREAKDOWN[name] = _BREAKDOWN.get(name, 0.0) + time.perf_counter() - t
+    return r
+
+
 def run_step_single(e, w, st):
     import pos_evolution_amd.synth as synth
 
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
-    agg = e.aggregate(packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
+    agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
     g = agg["n_groups"]
     rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
-    status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
-    st2, num = e.process_attestation_batch(state_ctx(w, ep), packed=(rows, agg["out_arena"]))
-    head = e.get_head()
+    status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, agg["out_arena"]))
+    st2, num = _timed("process_attestation", e.process_attestation_batch, state_ctx(w, ep),
+                      packed=(rows, agg["out_arena"]))
+    head = _timed("get_head", e.get_head)
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
@@ -92,7 +105,7 @@ class Exchange:
 
         self.torch, self.dist, self.world = torch, dist, world
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.wbuf = torch.zeros(n_blocks + 2, dtype=torch.int64, device=dev)
+        self.wbuf = torch.zeros(n_blocks + 512, dtype=torch.int64, device=dev)  # + PE_EXCHANGE_EXTRA
         self.partial = torch.zeros(n_groups * 36, dtype=torch.int32, device=dev)
         self.gathered = torch.zeros(world * n_groups * 36, dtype=torch.int32, device=dev)
         e.set_stream(torch.cuda.current_stream().cuda_stream)  # engine kernels and RCCL ordered in-stream
@@ -345,6 +358,8 @@ def main():
         out["checked_against_oracle"] = bool(np.array_equal(agg["aggpk96"], chk["aggpk"][pos]))
         assert out["checked_against_oracle"], "GPU aggregate pubkeys differ from the oracle"
         e2.close()
+    if _BREAKDOWN is not None:
+        out["host_breakdown_ms_per_step"] = {k: v / total * 1e3 for k, v in _BREAKDOWN.items()}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -270,13 +270,15 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
 /* Each rank owns a contiguous validator range and the whole (small) block table.
  * get_head splits at the one exchange point:
  *   pe_votes_partial  : this shard's direct vote weight per block (tree order) into a
- *                       caller-owned DEVICE buffer of n_blocks + 2 u64; entries
- *                       [n_blocks] / [n_blocks+1] receive the shard's active balance /
- *                       active validator count (the proposer boost needs the global
- *                       values, Appendix A.1).  Asynchronous on the engine's stream.
+ *                       caller-owned DEVICE buffer of n_blocks + PE_EXCHANGE_EXTRA u64;
+ *                       the extra entries carry the shard's active balance / active
+ *                       validator count as per-workgroup partials (the proposer boost
+ *                       needs the global values, Appendix A.1).  Asynchronous on the
+ *                       engine's stream.
  *   <host framework: ONE all-reduce(sum, u64) of the buffer -- RCCL via torch.distributed>
  *   pe_head_from_weights : subtree sums + descent from the reduced DEVICE buffer.
  * Integer sums: bit-exact for any reduction order. */
+#define PE_EXCHANGE_EXTRA 512
 int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks);
 int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32]);
 /* G1: per-group Jacobian partial sums (144 B each, Montgomery form) of this shard's

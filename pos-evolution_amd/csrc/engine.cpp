@@ -305,7 +305,7 @@ int refresh_tree(pe_engine* h)
     HIP_TRY(h, h->d_tidx.ensure(cap * 4));
     HIP_TRY(h, h->d_direct.ensure(cap * 8));
     HIP_TRY(h, h->d_weights.ensure(cap * 8));
-    HIP_TRY(h, h->d_totals.ensure(sizeof(VoteTotals)));
+    HIP_TRY(h, h->d_totals.ensure(sizeof(VoteTotals) * VOTES_MAX_WG));
     HIP_TRY(h, h->d_head.ensure(64));
     hipStream_t s = h->stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_tsize.p, sz_pos.data(), n * 4, hipMemcpyHostToDevice, s));
@@ -360,17 +360,12 @@ uint32_t pack_bits(const uint8_t* src, uint32_t n_use, uint32_t* dst_words)
 {
     const uint32_t n_words = (n_use + 31) / 32;
     const uint32_t n_bytes = (n_use + 7) / 8;
+    if (n_words == 0) return 0;
+    dst_words[n_words - 1] = 0;
+    memcpy(dst_words, src, n_bytes);  // little-endian host: byte k of the arena is byte k of the word stream
+    if (n_use & 31) dst_words[n_words - 1] &= (1u << (n_use & 31)) - 1u;
     uint32_t cnt = 0;
-    for (uint32_t w = 0; w < n_words; ++w) {
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < 4; ++k) {
-            const uint32_t byte = 4 * w + k;
-            if (byte < n_bytes) v |= (uint32_t)src[byte] << (8 * k);
-        }
-        if (w == n_words - 1 && (n_use & 31)) v &= (1u << (n_use & 31)) - 1u;
-        dst_words[w] = v;
-        cnt += (uint32_t)__builtin_popcount(v);
-    }
+    for (uint32_t w = 0; w < n_words; ++w) cnt += (uint32_t)__builtin_popcount(dst_words[w]);
     return cnt;
 }
 

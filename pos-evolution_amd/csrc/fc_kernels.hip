@@ -86,11 +86,21 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
             atomicAdd(&hist[vb[k]], bal[k]);  // ds_add_u64
         }
     }
+    // active-balance totals: wave reduce -> LDS -> ONE plain store per workgroup into its own slot
+    // (same-address device-scope atomics cost ~12 ns each and serialise: 4096 of them were 50 us)
+    __shared__ unsigned long long wg_tot[2];
+    if (threadIdx.x == 0) { wg_tot[0] = 0; wg_tot[1] = 0; }
     act_bal = wave_sum_u64(act_bal);
     act_num = wave_sum_u32(act_num);
+    __syncthreads();
     if ((threadIdx.x & 63) == 0 && act_num) {
-        atomicAdd(&totals->total_active_balance, act_bal);
-        atomicAdd(&totals->num_active, (unsigned long long)act_num);
+        atomicAdd(&wg_tot[0], act_bal);
+        atomicAdd(&wg_tot[1], (unsigned long long)act_num);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        totals[blockIdx.x].total_active_balance = wg_tot[0];
+        totals[blockIdx.x].num_active = wg_tot[1];
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) {
@@ -103,12 +113,12 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx, uint32_t n_blocks,
                   uint64_t* direct, VoteTotals* totals)
 {
-    hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
-    hipMemsetAsync(totals, 0, sizeof(VoteTotals), s);
+    (void)hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
+    (void)hipMemsetAsync(totals, 0, sizeof(VoteTotals) * VOTES_MAX_WG, s);
     if (n_val == 0) return;
     const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
     uint64_t blocks = (n_quads + VOTES_WG - 1) / VOTES_WG;
-    if (blocks > 256) blocks = 256;  // one workgroup per CU, grid-stride the rest: bounds the flush atomics
+    if (blocks > (uint64_t)VOTES_MAX_WG) blocks = VOTES_MAX_WG;  // one workgroup per CU, grid-stride the rest: bounds the flush atomics
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -176,8 +186,17 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
     // counts for that block and every ancestor, exactly the get_ancestor(...) == root test.
     unsigned long long boost = 0;
     if (boost_pos != NONE32) {
-        unsigned long long total = use_override ? ov_balance : totals->total_active_balance;
-        const unsigned long long num = use_override ? ov_num : totals->num_active;
+        // sum the votes kernel's per-workgroup partial totals (all ranks' partials after the all-reduce)
+        __shared__ unsigned long long tot[2];
+        if (tid == 0) { tot[0] = 0; tot[1] = 0; }
+        __syncthreads();
+        if (tid < VOTES_MAX_WG && !use_override) {
+            const unsigned long long b = totals[tid].total_active_balance, c = totals[tid].num_active;
+            if (c) { atomicAdd(&tot[0], b); atomicAdd(&tot[1], c); }
+        }
+        __syncthreads();
+        unsigned long long total = use_override ? ov_balance : tot[0];
+        const unsigned long long num = use_override ? ov_num : tot[1];
         if (num > 0) {
             if (total < balance_increment) total = balance_increment;  // get_total_balance's max()
             const unsigned long long avg_balance = total / num;

@@ -12,6 +12,7 @@
 // arithmetic, see oracle/g1.py header).
 #pragma once
 #include "fp381.cuh"
+#include "fp_inv_safegcd.h"
 
 namespace posevo {
 
@@ -183,6 +184,28 @@ __device__ __noinline__ void fp_inv_fermat(fp& r, const fp& a)
         }
     }
     r = acc;
+}
+
+// R^3 mod p: fp_mul(t, R^3) = t * R^2, lifting (xR)^-1 = x^-1 R^-1 back to Montgomery form x^-1 R
+__device__ __forceinline__ constexpr uint32_t fp_r3_limb(int j)
+{
+    return j == 0 ? 0xd94ca1e0u : j == 1 ? 0xed48ac6bu : j == 2 ? 0x03a7adf8u : j == 3 ? 0x315f831eu
+         : j == 4 ? 0x615e29ddu : j == 5 ? 0x9a53352au : j == 6 ? 0x921e1761u : j == 7 ? 0x34c04e5eu
+         : j == 8 ? 0x65724728u : j == 9 ? 0x2512d435u : j == 10 ? 0x91755d4du : 0x0aa63460u;
+}
+
+// r = a^-1 (Montgomery in, Montgomery out) by safegcd divsteps; a == 0 yields 0.
+__device__ __noinline__ void fp_inv(fp& r, const fp& a)
+{
+    uint32_t plain[12];
+    sg_modinv(plain, a.l, SG_PINV30);  // (aR)^-1 as a plain integer = a^-1 R^-1
+    fp t, r3;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        t.l[j] = plain[j];
+        r3.l[j] = fp_r3_limb(j);
+    }
+    fp_mul(r, t, r3);
 }
 
 }  // namespace posevo

@@ -266,7 +266,7 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
         return;
     }
     fp zi, zi2, zi3, x, y;
-    fp_inv_fermat(zi, acc.z);
+    fp_inv(zi, acc.z);
     fp_sqr(zi2, zi);
     fp_mul(zi3, zi2, zi);
     fp_mul(x, acc.x, zi2);

@@ -10,6 +10,7 @@ namespace posevo {
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr int G1_WG = 256;             // lanes (task slots) per workgroup of the accumulate kernel
 constexpr int TREE_MAX_BLOCKS = 8192;  // LDS-resident block tree capacity (K_tree)
+constexpr int VOTES_MAX_WG = 256;      // workgroups of K_votes = slots of per-workgroup partial totals
 
 // One summation group of the G1 accumulate kernel (device-resident array, built by the host).
 //   sum over i in [0, n_members), bit i set (if bits_word != NONE32) of
@@ -47,7 +48,7 @@ struct TreeDev {               // block tree in DFS pre-order (device arrays of 
     const uint32_t* idx_of_pos;  // pre-order position -> insertion index
     uint32_t n;
 };
-struct VoteTotals {            // written by K_votes, read by K_tree
+struct VoteTotals {            // one per K_votes workgroup (VOTES_MAX_WG slots), summed by K_tree
     unsigned long long total_active_balance;
     unsigned long long num_active;
 };

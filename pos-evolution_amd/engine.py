@@ -83,6 +83,21 @@ def pack_attestations(rows: Sequence[AttRow]):
     return arr, np.ascontiguousarray(arena)
 
 
+class AggregateResult(dict):
+    """Result of Engine.aggregate; ``res["bits"]`` decodes the OR-ed bitfields on demand."""
+
+    def __getitem__(self, key):
+        if key == "bits" and "bits" not in self:
+            out, arena = [], dict.__getitem__(self, "out_arena")
+            for k in range(dict.__getitem__(self, "n_groups")):
+                a = dict.__getitem__(self, "atts")[k]
+                nb = (a.n_bits + 7) // 8
+                out.append(np.unpackbits(arena[a.bits_offset:a.bits_offset + nb], bitorder="little")[:a.n_bits]
+                           .astype(bool))
+            self["bits"] = out
+        return dict.__getitem__(self, key)
+
+
 class Engine:
     """One engine handle = one fork-choice store + validator registry on one GPU."""
 
@@ -226,15 +241,9 @@ class Engine:
                                            _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
                                            _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
         g = n_groups.value
-        bits = []
-        for k in range(g):
-            a = out_atts[k]
-            nb = (a.n_bits + 7) // 8
-            bits.append(np.unpackbits(out_arena[a.bits_offset:a.bits_offset + nb], bitorder="little")[:a.n_bits]
-                        .astype(bool))
-        return dict(n_groups=g, atts=out_atts, group_of=group_of[:n], bits=bits, out_arena=out_arena,
-                    sig96=None if out_sig is None else out_sig[:g], aggpk96=None if out_pk is None else out_pk[:g],
-                    count=count[:g])
+        return AggregateResult(n_groups=g, atts=out_atts, group_of=group_of[:n], out_arena=out_arena,
+                               sig96=None if out_sig is None else out_sig[:g],
+                               aggpk96=None if out_pk is None else out_pk[:g], count=count[:g])
 
     def process_attestation_batch(self, state_ctx: pe_state_ctx, rows=None, packed=None):
         """-> (status int32[n], proposer_reward_numerator uint64[n])."""
@@ -272,7 +281,7 @@ class Engine:
 
     # -- multi-GPU exchange -------------------------------------------------
     def votes_partial(self, dev_ptr: int):
-        """dev_ptr: device buffer of num_blocks + 2 u64 (weights | active balance | active count)."""
+        """dev_ptr: device buffer of num_blocks + PE_EXCHANGE_EXTRA u64 (weights | per-workgroup active totals)."""
         self._check(self._lib.pe_votes_partial(self._h, C.c_void_p(dev_ptr), self.num_blocks))
 
     def head_from_weights(self, dev_ptr: int) -> bytes:
