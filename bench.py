@@ -96,38 +96,19 @@ def run_step_single(e, w, st):
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
-class Exchange:
-    """The two collectives of the sharded path on torch.distributed (backend nccl = RCCL over xGMI)."""
-
-    def __init__(self, e, n_blocks, n_groups, world):
-        import torch
-        import torch.distributed as dist
-
-        self.torch, self.dist, self.world = torch, dist, world
-        dev = torch.device("cuda", torch.cuda.current_device())
-        self.wbuf = torch.zeros(n_blocks + 512, dtype=torch.int64, device=dev)  # + PE_EXCHANGE_EXTRA
-        self.partial = torch.zeros(n_groups * 36, dtype=torch.int32, device=dev)
-        self.gathered = torch.zeros(world * n_groups * 36, dtype=torch.int32, device=dev)
-        e.set_stream(torch.cuda.current_stream().cuda_stream)  # engine kernels and RCCL ordered in-stream
-
-
-def run_step_sharded(e, w, st, ex):
+def run_step_sharded(e, w, st, sh):
     import pos_evolution_amd.synth as synth
 
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
-    agg = e.aggregate_partial(ex.partial.data_ptr(), packed=(st["atts"], st["arena"]))
+    agg = sh.aggregate(packed=(st["atts"], st["arena"]))    # all-gather of C x 144 B Jacobian partials inside
     g = agg["n_groups"]
-    ex.dist.all_gather_into_tensor(ex.gathered, ex.partial)          # C x 144 B per rank
-    aggpk = e.g1_finish(ex.gathered.data_ptr(), ex.world, g)
     rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
     status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
     st2, num = e.process_attestation_batch(state_ctx(w, ep), packed=(rows, agg["out_arena"]))
-    e.votes_partial(ex.wbuf.data_ptr())
-    ex.dist.all_reduce(ex.wbuf)                                      # (B + 2) x 8 B, integer sum: bit-exact
-    head = e.head_from_weights(ex.wbuf.data_ptr())
-    return dict(agg=agg, aggpk=aggpk, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
+    head = sh.get_head()                                    # all-reduce of (B + 512) x 8 B inside
+    return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
 def cpu_baseline(w, st, target_seconds=12.0):
@@ -210,21 +191,21 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("POSEVO_FORCE_DIST"):
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        # a non-null stream shared by the engine's kernels and the RCCL collectives (torch orders collectives
-        # against the CURRENT stream; the engine treats a null handle as "use your own stream")
-        torch.cuda.set_stream(torch.cuda.Stream())
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run --nproc-per-node N"
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
 
     import pos_evolution_amd as pea
 
     total = args.warmup + args.steps
     e = pea.Engine(device=local_rank, max_committee_tables=total + 1)
     w = build_workload(e, args, rank, total)
-    ex = Exchange(e, args.blocks, args.committees, world) if world > 1 else None
+    ex = None
+    if dist is not None:
+        from pos_evolution_amd.sharded import ShardedForkChoice
+        ex = ShardedForkChoice(e, n_groups_max=args.committees)
 
     def step(st):
         return run_step_sharded(e, w, st, ex) if ex else run_step_single(e, w, st)
@@ -255,15 +236,10 @@ def main():
     # get_head latency: full recomputation from the vote table, after the timed region
     lat = []
     for _ in range(20):
-        e.get_head() if ex is None else (e.votes_partial(ex.wbuf.data_ptr()), dist.all_reduce(ex.wbuf), e.head_from_weights(ex.wbuf.data_ptr()))
+        e.get_head() if ex is None else ex.get_head()
     for _ in range(args.head_calls):
         t = time.perf_counter()
-        if ex is None:
-            e.get_head()
-        else:
-            e.votes_partial(ex.wbuf.data_ptr())
-            dist.all_reduce(ex.wbuf)
-            e.head_from_weights(ex.wbuf.data_ptr())
+        e.get_head() if ex is None else ex.get_head()
         lat.append((time.perf_counter() - t) * 1e6)
     lat = np.sort(np.array(lat))
 

@@ -96,7 +96,9 @@ class Root(bytes):
 ZERO_ROOT = Root()
 
 
-def hash(data: bytes) -> Root:  # noqa: A001 - the pyspec's own name (pe:486)
+def sha256(data: bytes) -> Root:
+    """The pyspec's ``hash`` (pe:486, 522, 525).  Not named ``hash`` here: a module-level ``hash`` would
+    shadow the builtin that the frozen dataclasses' generated ``__hash__`` calls."""
     return Root(hashlib.sha256(data).digest())
 
 
@@ -245,14 +247,14 @@ def hash_tree_root(obj) -> Root:
         body = hashlib.sha256(
             repr([(a.aggregation_bits, a.data) for a in obj.body.attestations]).encode() + obj.body.graffiti
         ).digest()
-        return hash(
+        return sha256(
             b"blk" + uint_to_bytes(obj.slot) + uint_to_bytes(obj.proposer_index)
             + obj.parent_root + obj.state_root + body
         )
     if isinstance(obj, BeaconState):
-        return hash(
+        return sha256(
             b"st" + uint_to_bytes(obj.genesis_time) + uint_to_bytes(obj.slot)
-            + uint_to_bytes(len(obj.validators)) + obj.latest_block_root
+            + uint_to_bytes(len(obj.validators))
         )
     raise TypeError(type(obj))
 
@@ -321,7 +323,7 @@ def get_committee_count_per_slot(state: BeaconState, epoch: int) -> int:
 def get_seed(state: BeaconState, epoch: int, domain_type: bytes) -> bytes:
     """[REF pe:481-486]"""
     mix = get_randao_mix(state, epoch + EPOCHS_PER_HISTORICAL_VECTOR - MIN_SEED_LOOKAHEAD - 1)  # Avoid underflow
-    return hash(domain_type + uint_to_bytes(epoch) + mix)
+    return sha256(domain_type + uint_to_bytes(epoch) + mix)
 
 
 def compute_shuffled_index(index: int, index_count: int, seed: bytes) -> int:
@@ -329,10 +331,10 @@ def compute_shuffled_index(index: int, index_count: int, seed: bytes) -> int:
     assert index < index_count
 
     for current_round in range(SHUFFLE_ROUND_COUNT):
-        pivot = bytes_to_uint64(hash(seed + uint_to_bytes(current_round, 1))[0:8]) % index_count
+        pivot = bytes_to_uint64(sha256(seed + uint_to_bytes(current_round, 1))[0:8]) % index_count
         flip = (pivot + index_count - index) % index_count
         position = max(index, flip)
-        source = hash(
+        source = sha256(
             seed
             + uint_to_bytes(current_round, 1)
             + uint_to_bytes(position // 256, 4)
@@ -363,7 +365,7 @@ def get_beacon_committee(state: BeaconState, slot: int, index: int) -> List[int]
     seed = get_seed(state, epoch, DOMAIN_BEACON_ATTESTER)
     pos = (slot % SLOTS_PER_EPOCH) * committees_per_slot + index
     count = committees_per_slot * SLOTS_PER_EPOCH
-    key = (seed, hash(repr(indices).encode()), pos, count, SHUFFLE_ROUND_COUNT)
+    key = (seed, sha256(repr(indices).encode()), pos, count, SHUFFLE_ROUND_COUNT)
     if key not in _committee_cache:
         _committee_cache[key] = compute_committee(indices=indices, seed=seed, index=pos, count=count)
     return list(_committee_cache[key])

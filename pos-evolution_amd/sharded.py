@@ -1,0 +1,77 @@
+"""Validator-range sharding over N GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) for the two exchange steps.
+
+Every rank owns a contiguous range of validators (records, latest messages, participation, pubkeys) and a full copy
+of the (small) block table.  Only two things ever cross ranks:
+
+  * get_head:   ONE all-reduce(sum) of (B + PE_EXCHANGE_EXTRA) u64 -- per-block direct vote weight plus the
+                active-balance partials the proposer boost needs.  Integer sums: bit-exact for any order.
+  * aggregate:  ONE all-gather of C x 144 B Jacobian G1 partials (RCCL has no EC-add reduction op), then every rank
+                runs the finishing add + normalisation locally.
+
+Messages are tens of KiB: latency-bound, so ring-vs-tree and per-link bandwidth are irrelevant here.
+LMD updates and participation flags are local to the shard that owns the validator.
+
+The exchange buffers are torch tensors (plumbing: device memory + collectives); the engine reads and writes them
+through raw device pointers on the SAME stream torch issues the collectives on, so no host synchronisation sits
+between kernels and collectives.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+
+
+class ShardedForkChoice:
+    def __init__(self, engine, n_groups_max: int = 2048, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.engine = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = device
+        self._wbuf = None
+        self._partial = torch.zeros(n_groups_max * 36, dtype=torch.int32, device=device)
+        self._gathered = torch.zeros(self.world * n_groups_max * 36, dtype=torch.int32, device=device)
+        self.n_groups_max = n_groups_max
+        if device.type == "cuda":
+            # engine kernels and RCCL ordered on one (non-null) stream
+            if torch.cuda.current_stream().cuda_stream == 0:
+                torch.cuda.set_stream(torch.cuda.Stream())
+            engine.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def _weights_buffer(self):
+        n = self.engine.num_blocks + _abi.PE_EXCHANGE_EXTRA
+        if self._wbuf is None or self._wbuf.numel() != n:
+            self._wbuf = self.torch.zeros(n, dtype=self.torch.int64, device=self.device)
+        return self._wbuf
+
+    def get_head(self) -> bytes:
+        """get_head (pe:1102-1116) over all shards; every rank returns the same root."""
+        buf = self._weights_buffer()
+        self.engine.votes_partial(buf.data_ptr())
+        if self.dist.is_initialized():  # also with world == 1: keeps the RCCL path exercised on one GPU
+            self.dist.all_reduce(buf, group=self.group)
+        return self.engine.head_from_weights(buf.data_ptr())
+
+    def aggregate(self, rows=None, packed=None):
+        """pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.
+        Every rank must pass attestations that form the SAME groups in the SAME order (group g of every rank =
+        that rank's members of committee g)."""
+        res = self.engine.aggregate_partial(self._partial.data_ptr(), rows=rows, packed=packed)
+        g = res["n_groups"]
+        assert g <= self.n_groups_max
+        part = self._partial[: g * 36]
+        gathered = self._gathered[: self.world * g * 36]
+        if self.dist.is_initialized():
+            self.dist.all_gather(list(gathered.chunk(self.world)), part, group=self.group)
+        else:
+            gathered.copy_(part)
+        res["aggpk96"] = self.engine.g1_finish(gathered.data_ptr(), self.world, g)
+        return res

@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/posevo.h declares; no compute without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "posevo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from pos_evolution_amd import _abi
+    assert header_symbols() == sorted(_abi.SIGNATURES), "include/posevo.h and _abi.SIGNATURES list different entry points"
+
+
+def test_library_exports_every_symbol():
+    from pos_evolution_amd import _abi
+    lib = _abi.load()
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    assert lib.pe_abi_version() == 1
+
+
+def test_struct_layouts():
+    from pos_evolution_amd import _abi, synth
+    assert C.sizeof(_abi.pe_attestation) == 144 == synth.ATT_DTYPE.itemsize
+    assert C.sizeof(_abi.pe_state_ctx) == 8 + 32 + 8 + 32 + 8 + 32 + 8
+    for name in synth.ATT_DTYPE.names:
+        assert synth.ATT_DTYPE.fields[name][1] == getattr(_abi.pe_attestation, name).offset
+
+
+def test_config_defaults_are_the_mainnet_preset():
+    from pos_evolution_amd import _abi
+    lib = _abi.load()
+    cfg = _abi.pe_config()
+    lib.pe_config_default(C.byref(cfg))
+    assert (cfg.slots_per_epoch, cfg.seconds_per_slot, cfg.intervals_per_slot) == (32, 12, 3)
+    assert cfg.proposer_score_boost == 40 and cfg.effective_balance_increment == 10**9
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import pos_evolution_amd as pea
+    with pytest.raises(pea.EngineError) as e:
+        pea.Engine()
+    assert e.value.status == _abi_no_device()
+
+
+def _abi_no_device():
+    from pos_evolution_amd import _abi
+    return _abi.PE_ERR_NO_DEVICE
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pos-evolution_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".cuh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "posevo_oracle" not in text, f

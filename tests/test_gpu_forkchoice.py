@@ -1,0 +1,118 @@
+"""-m gpu: the reference-shaped interface (pos_evolution_amd.forkchoice) on the MI355X engine, run in lockstep
+with the L0 literal oracle: after EVERY handler call the head, the checkpoints, the boost root and the whole
+latest-message table must agree, and accept/reject decisions must match (tests/scenario.py)."""
+import numpy as np
+import pytest
+
+from oracle import spec
+from tests import fc_scenarios
+from tests.scenario import new_world, slot_committee_members
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scenario", fc_scenarios.ALL, ids=lambda f: f.__name__)
+def test_scenario_engine_vs_literal_oracle(scenario, engine_factory):
+    scenario(lambda n, **kw: new_world(n, "minimal", engine_factory=engine_factory, **kw))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_event_stream(engine_factory, seed):
+    """Random ticks / forks / attestations (wire + from-block, valid + stale) / slashings on the minimal preset."""
+    rng = np.random.default_rng(seed)
+    w = new_world(96, "minimal", engine_factory=engine_factory)
+    roots = [w.store.justified_checkpoint.root]
+    slot = 0
+    for step in range(60):
+        slot += int(rng.integers(1, 3))
+        w.tick_to_slot(slot, offset=int(rng.integers(0, spec.SECONDS_PER_SLOT)))
+        parent = roots[int(rng.integers(max(0, len(roots) - 4), len(roots)))]
+        if w.store.blocks[parent].slot < slot:
+            roots.append(w.block(parent, slot, graffiti=bytes([step])))
+        # attest for an earlier slot (in the past), to a random recent block not newer than that slot
+        a_slot = slot - 1
+        cand = [r for r in roots[-6:] if w.store.blocks[r].slot <= a_slot]
+        if cand and a_slot >= 0:
+            target_block = cand[int(rng.integers(0, len(cand)))]
+            voters = slot_committee_members(w.store, a_slot)
+            rng.shuffle(voters)
+            for att in w.attestation_for(voters[: max(1, len(voters) // 2)], target_block, a_slot):
+                w.attest(att, is_from_block=bool(rng.integers(0, 2)))
+        if step % 17 == 16:
+            members = slot_committee_members(w.store, a_slot)
+            eq = sorted(members[:3])
+            tgt = spec.Checkpoint(spec.compute_epoch_at_slot(a_slot), roots[0])
+            d1 = spec.AttestationData(slot=a_slot, index=0, beacon_block_root=roots[-1], target=tgt)
+            d2 = spec.AttestationData(slot=a_slot, index=0, beacon_block_root=roots[0], target=tgt)
+            w.slash(spec.IndexedAttestation(eq, d1), spec.IndexedAttestation(eq, d2))
+    assert len(w.store.latest_messages) > 0
+
+
+def test_on_attestation_aggregate_pubkey_matches_bls_oracle(engine_factory):
+    """The G1 sum FastAggregateVerify consumes (A.7): engine vs exact Python ints, on the (i+1)*G key set whose
+    first additions hit the doubling branch."""
+    from oracle import g1
+    from pos_evolution_amd.forkchoice import _att_row
+    w = new_world(64, "minimal", engine_factory=engine_factory, with_pubkeys=True)
+    anchor = w.store.justified_checkpoint.root
+    w.tick_to_slot(1)
+    b1 = w.block(anchor, 1)
+    w.tick_to_slot(3)
+    state = w.store.block_states[anchor]
+    for s in (1, 2):
+        voters = slot_committee_members(w.store, s)
+        for att in w.attestation_for(voters, b1, s):
+            status, aggpk, count = w.mirror.engine.on_attestation_batch([_att_row(att)], want_aggregate_pubkeys=True)
+            idx = spec.get_indexed_attestation(state, att).attesting_indices
+            assert status[0] == 0 and count[0] == len(idx)
+            assert aggpk[0].tobytes() == g1.to_bytes96(spec.aggregate_pubkeys(state, idx))
+
+
+def test_process_attestation_vs_literal_oracle(engine_factory):
+    """process_attestation (pe:722-754) through the mirror: participation flags, proposer reward, asserts."""
+    import copy
+    import pos_evolution_amd.forkchoice as fc
+    w = new_world(128, "minimal", engine_factory=engine_factory)
+    anchor = w.store.justified_checkpoint.root
+    roots = [anchor]
+    for s in range(1, 7):
+        w.tick_to_slot(s)
+        roots.append(w.block(roots[-1], s))
+    w.tick_to_slot(8)
+    tip = roots[-1]
+    # the state process_attestation runs on: post-state of the tip advanced to slot 7 (a block is being built)
+    state = w.store.block_states[tip].copy()
+    spec.process_slots(state, 7)
+    state.proposer_index_override = 5
+    mstate = state.copy()
+    eng = w.mirror.engine
+    w._ensure_committees(0, state)
+    fc.bind_state(eng, mstate, tip, spec.get_base_reward_per_increment(state))
+    atts = []
+    for s in (3, 5, 6, 6):   # slot 6 twice: the second inclusion must earn nothing new
+        voters = slot_committee_members(w.store, s)
+        head_at_s = spec.get_block_root_at_slot(state, s)
+        atts += w.attestation_for(voters, head_at_s, s)
+    wrong_head = w.attestation_for(slot_committee_members(w.store, 4), roots[1], 4)
+    atts += wrong_head
+    import dataclasses
+    bad_source = dataclasses.replace(atts[0], data=dataclasses.replace(atts[0].data, source=spec.Checkpoint(3, tip)))
+    too_new = w.attestation_for(slot_committee_members(w.store, 7), tip, 7)   # slot + 1 > state.slot
+    for att in atts + [bad_source] + too_new:
+        ok = True
+        try:
+            spec.process_attestation(state, att)
+        except (AssertionError, KeyError):
+            ok = False
+        m_ok = True
+        try:
+            fc.process_attestation(mstate, att, get_beacon_proposer_index=spec.get_beacon_proposer_index)
+        except AssertionError:
+            m_ok = False
+        assert ok == m_ok
+        if ok:
+            assert mstate._last_proposer_reward_numerator == state._last_proposer_reward_numerator
+        assert mstate.current_epoch_participation == state.current_epoch_participation
+        assert mstate.previous_epoch_participation == state.previous_epoch_participation
+        assert mstate.balances == state.balances
+    assert sum(state.current_epoch_participation) > 0
