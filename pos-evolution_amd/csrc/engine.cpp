@@ -17,6 +17,9 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
+#include <cstdlib>
+#include <map>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -128,6 +131,46 @@ struct CommitteeTable {
     uint64_t stamp = 0;
 };
 
+// Diagnostic only (POSEVO_HOST_TRACE=1): wall time of host phases, printed at pe_engine_destroy.
+struct HostTrace {
+    bool on = std::getenv("POSEVO_HOST_TRACE") != nullptr;
+    std::map<std::string, std::pair<double, uint64_t>> acc;
+};
+struct HostScope {
+    HostTrace* t;
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    HostScope(HostTrace* t_, const char* n) : t(t_), name(n)
+    {
+        if (t->on) t0 = std::chrono::steady_clock::now();
+    }
+    ~HostScope()
+    {
+        if (!t->on) return;
+        auto& a = t->acc[name];
+        a.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        a.second += 1;
+    }
+};
+
+struct HostLap {  // lap timer: mark(name) charges the time since the previous mark to `name`
+    HostTrace* t;
+    std::chrono::steady_clock::time_point last;
+    explicit HostLap(HostTrace* t_) : t(t_)
+    {
+        if (t->on) last = std::chrono::steady_clock::now();
+    }
+    void mark(const char* name)
+    {
+        if (!t->on) return;
+        auto now = std::chrono::steady_clock::now();
+        auto& a = t->acc[name];
+        a.first += std::chrono::duration<double, std::micro>(now - last).count();
+        a.second += 1;
+        last = now;
+    }
+};
+
 struct KernelProfile {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     uint64_t launches = 0;
@@ -160,20 +203,22 @@ struct pe_engine {
     bool tree_dirty = true;
     DevBuf d_tsize, d_tparent, d_trank, d_tleaf, d_tpos, d_tidx, d_direct, d_weights, d_totals, d_head;
     std::vector<uint32_t> h_pos_of_idx;
-    PinBuf h_pin;  // small D2H landing zone
+    PinBuf h_pin;   // D2H landing zone (mirrors d_outblk)
+    PinBuf h_head;  // 64 B of host-coherent pinned memory the tree kernel writes the head index into
+    uint32_t votes_grid = 0;  // workgroups of the last k_votes launch on the engine's own buffers
 
     // ---- committees ----
     std::vector<CommitteeTable> tables;
     uint64_t table_stamp = 0;
 
     // ---- scratch ----
-    DevBuf d_rows, d_arena, d_groups, d_partials, d_out96, d_jac, d_idx, d_tmp_points, d_tmp_be, d_numer, d_nslot,
-        d_ugroups, d_uwords, d_uarena, d_ucount;
-    PinBuf h_stage;  // H2D staging
+    DevBuf d_stage, d_outblk, d_partials, d_out96, d_tmp_points, d_tmp_be;
+    PinBuf h_stage;  // H2D staging (mirrors d_stage)
 
     // ---- profiling ----
     bool profiling = false;
     KernelProfile prof[PE_KERNEL_COUNT];
+    HostTrace trace;
 };
 
 namespace {
@@ -303,10 +348,17 @@ int refresh_tree(pe_engine* h)
     HIP_TRY(h, h->d_tleaf.ensure(cap));
     HIP_TRY(h, h->d_tpos.ensure(cap * 4));
     HIP_TRY(h, h->d_tidx.ensure(cap * 4));
-    HIP_TRY(h, h->d_direct.ensure(cap * 8));
     HIP_TRY(h, h->d_weights.ensure(cap * 8));
-    HIP_TRY(h, h->d_totals.ensure(sizeof(VoteTotals) * VOTES_MAX_WG));
+    {
+        const size_t before_d = h->d_direct.cap, before_t = h->d_totals.cap;
+        HIP_TRY(h, h->d_direct.ensure(cap * 8));
+        HIP_TRY(h, h->d_totals.ensure(sizeof(VoteTotals) * VOTES_MAX_WG));
+        // the engine's own weight buffer is zero between get_head calls: k_votes adds, k_tree clears
+        if (h->d_direct.cap != before_d) HIP_TRY(h, hipMemsetAsync(h->d_direct.p, 0, h->d_direct.cap, h->stream));
+        if (h->d_totals.cap != before_t) HIP_TRY(h, hipMemsetAsync(h->d_totals.p, 0, h->d_totals.cap, h->stream));
+    }
     HIP_TRY(h, h->d_head.ensure(64));
+    HIP_TRY(h, h->h_head.ensure(64));
     hipStream_t s = h->stream;
     HIP_TRY(h, hipMemcpyAsync(h->d_tsize.p, sz_pos.data(), n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_tparent.p, parent_pos.data(), n * 4, hipMemcpyHostToDevice, s));
@@ -369,31 +421,86 @@ uint32_t pack_bits(const uint8_t* src, uint32_t n_use, uint32_t* dst_words)
     return cnt;
 }
 
+// ------------------------------------------------------------------ staging
+// One pinned host block mirrored by one device block: a call lays out everything the kernels need (bit words,
+// rows, group descriptors) in the pinned block, uploads it with ONE hipMemcpyAsync, and reads results back
+// from one device output block with ONE copy.  (Separate pageable copies cost 30-50 us each on this box.)
+struct Stage {
+    pe_engine* h;
+    size_t used = 0;
+    explicit Stage(pe_engine* h_) : h(h_) {}
+    hipError_t reserve(size_t bytes)
+    {
+        bytes += 4096;
+        hipError_t e = h->h_stage.ensure(bytes);
+        if (e != hipSuccess) return e;
+        return h->d_stage.ensure(bytes);
+    }
+    size_t alloc(size_t bytes)
+    {
+        const size_t off = (used + 255) & ~size_t(255);
+        used = off + bytes;
+        return off;
+    }
+    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(h->h_stage.as<uint8_t>() + off); }
+    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(h->d_stage.as<uint8_t>() + off); }
+    hipError_t upload() const
+    {
+        if (used == 0) return hipSuccess;
+        return hipMemcpyAsync(h->d_stage.p, h->h_stage.p, used, hipMemcpyHostToDevice, h->stream);
+    }
+};
+struct OutBlock {  // device output block + pinned landing zone with the same layout
+    pe_engine* h;
+    size_t used = 0;
+    explicit OutBlock(pe_engine* h_) : h(h_) {}
+    size_t alloc(size_t bytes)
+    {
+        const size_t off = (used + 255) & ~size_t(255);
+        used = off + bytes;
+        return off;
+    }
+    hipError_t ensure()
+    {
+        hipError_t e = h->d_outblk.ensure(used + 256);
+        if (e != hipSuccess) return e;
+        return h->h_pin.ensure(used + 256);
+    }
+    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(h->d_outblk.as<uint8_t>() + off); }
+    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(h->h_pin.as<uint8_t>() + off); }
+    hipError_t download() const
+    {
+        if (used == 0) return hipSuccess;
+        return hipMemcpyAsync(h->h_pin.p, h->d_outblk.p, used, hipMemcpyDeviceToHost, h->stream);
+    }
+};
+
 // ------------------------------------------------------------------ G1 plan
 constexpr uint32_t G1_TARGET_LANES = 131072;  // 2 waves per SIMD on 256 CUs
 struct G1Plan {
-    std::vector<G1Group> groups;
-    uint32_t n_slots = 0, n_partials = 0;
+    uint32_t n_groups = 0, n_slots = 0, n_partials = 0;
 };
-// sizes[g] = members of group g; member_start/bits_word filled by the caller afterwards.
-void plan_g1(const std::vector<uint32_t>& sizes, G1Plan* plan)
+// sizes[g] = members of group g; writes descriptors into `out` (member_start = 0, bits_word = NONE32: the caller
+// fills them in afterwards).
+template <typename SizeFn>
+void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan)
 {
     uint64_t total = 0;
-    for (uint32_t s : sizes) total += s;
-    uint32_t k = (uint32_t)std::max<uint64_t>(4, (total + G1_TARGET_LANES - 1) / G1_TARGET_LANES);
-    plan->groups.resize(sizes.size());
-    uint32_t cursor = 0, out = 0;
-    for (size_t g = 0; g < sizes.size(); ++g) {
-        G1Group& d = plan->groups[g];
+    for (uint32_t g = 0; g < n_groups; ++g) total += size_of(g);
+    const uint32_t k = (uint32_t)std::max<uint64_t>(4, (total + G1_TARGET_LANES - 1) / G1_TARGET_LANES);
+    uint32_t cursor = 0, outp = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        G1Group& d = out[g];
+        const uint32_t sz = size_of(g);
         d.member_start = 0;
         d.bits_word = NONE32;
-        d.n_members = sizes[g];
+        d.n_members = sz;
         d.k = k;
-        d.n_tasks = (sizes[g] + k - 1) / k;
+        d.n_tasks = (sz + k - 1) / k;
         if (d.n_tasks == 0) {
             d.log2_block = 0;
             d.slot_base = cursor;
-            d.out_base = out;
+            d.out_base = outp;
             continue;
         }
         if (d.n_tasks <= (uint32_t)G1_WG) {
@@ -404,57 +511,39 @@ void plan_g1(const std::vector<uint32_t>& sizes, G1Plan* plan)
             cursor = (cursor + blk - 1) & ~(blk - 1);
             d.slot_base = cursor;
             cursor += blk;
-            d.out_base = out;
-            out += 1;
+            d.out_base = outp;
+            outp += 1;
         } else {
             d.log2_block = 9;  // wide: whole workgroups
             cursor = (cursor + G1_WG - 1) & ~(uint32_t)(G1_WG - 1);
             d.slot_base = cursor;
             const uint32_t wgs = (d.n_tasks + G1_WG - 1) / G1_WG;
             cursor += wgs * G1_WG;
-            d.out_base = out;
-            out += wgs;
+            d.out_base = outp;
+            outp += wgs;
         }
     }
+    plan->n_groups = n_groups;
     plan->n_slots = cursor;
-    plan->n_partials = out;
+    plan->n_partials = outp;
 }
 
-// Run accumulate + finish for a plan whose groups are already complete.  points/members/bit arena are device
-// pointers; out96_host (nullable) receives the affine sums, dev_jac (nullable) the Jacobian sums on device.
-int run_g1(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
-           const G1Plan& plan, uint8_t* out96_host, uint32_t* dev_jac)
+// Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
+int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
+                      const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac)
 {
-    const uint32_t ng = (uint32_t)plan.groups.size();
-    if (ng == 0) return PE_OK;
-    HIP_TRY(h, h->d_groups.ensure(sizeof(G1Group) * ng));
+    if (plan.n_groups == 0) return PE_OK;
     HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(144, 144ull * plan.n_partials)));
-    HIP_TRY(h, hipMemcpyAsync(h->d_groups.p, plan.groups.data(), sizeof(G1Group) * ng, hipMemcpyHostToDevice,
-                              h->stream));
     {
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE);
-        launch_g1_accumulate(h->stream, d_points, d_members, d_bits, h->d_groups.as<G1Group>(), ng, plan.n_slots,
+        launch_g1_accumulate(h->stream, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
                              h->d_partials.as<uint32_t>());
-    }
-    uint8_t* d_out = nullptr;
-    if (out96_host) {
-        HIP_TRY(h, h->d_out96.ensure(96ull * ng));
-        d_out = h->d_out96.as<uint8_t>();
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
-        launch_g1_finish(h->stream, h->d_partials.as<uint32_t>(), h->d_groups.as<G1Group>(), ng, 0, 0, d_out,
-                         dev_jac);
+        launch_g1_finish(h->stream, h->d_partials.as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac);
     }
     HIP_TRY(h, hipGetLastError());
-    if (out96_host) {
-        HIP_TRY(h, h->h_pin.ensure(96ull * ng));
-        HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, d_out, 96ull * ng, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        memcpy(out96_host, h->h_pin.p, 96ull * ng);
-    } else {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));  // plan.groups (host) was the async copy source
-    }
     return PE_OK;
 }
 
@@ -550,7 +639,7 @@ int need_init(pe_engine* h)
 }
 
 // get_head's device part on arbitrary weight buffer.
-int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, uint32_t* head_out)
+int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out)
 {
     uint32_t just_idx;
     if (!find_block(h, h->justified.root, &just_idx))
@@ -560,17 +649,18 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, uint3
         uint32_t bi;
         if (find_block(h, h->boost_root, &bi)) boost_pos = h->h_pos_of_idx[bi];
     }
+    volatile uint32_t* head_word = h->h_head.as<uint32_t>();
+    *head_word = NONE32;
     {
         ProfScope ps(h, PE_KERNEL_TREE);
-        launch_tree(h->stream, tree_dev(h), d_direct, d_totals, 0, 0, 0,
-                    h->h_pos_of_idx[just_idx], boost_pos, h->cfg.slots_per_epoch, h->cfg.proposer_score_boost,
-                    h->cfg.effective_balance_increment, h->d_weights.as<uint64_t>(), h->d_head.as<uint32_t>());
+        // the head index lands directly in host-coherent pinned memory: no D2H copy, just the stream sync
+        launch_tree(h->stream, tree_dev(h), d_direct, d_totals, 0, 0, 0, h->h_pos_of_idx[just_idx], boost_pos,
+                    h->cfg.slots_per_epoch, h->cfg.proposer_score_boost, h->cfg.effective_balance_increment,
+                    h->d_weights.as<uint64_t>(), h->h_head.as<uint32_t>(), clear_direct);
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, h->h_pin.ensure(64));
-    HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_head.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    *head_out = *h->h_pin.as<uint32_t>();
+    *head_out = *head_word;
     if (*head_out >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
     return PE_OK;
 }
@@ -659,17 +749,20 @@ void pe_engine_destroy(pe_engine* h)
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_vote_key, &h->d_vote_block,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
-                      &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_rows,
-                      &h->d_arena, &h->d_groups, &h->d_partials, &h->d_out96, &h->d_jac, &h->d_idx,
-                      &h->d_tmp_points, &h->d_tmp_be, &h->d_numer, &h->d_nslot, &h->d_ugroups, &h->d_uwords,
-                      &h->d_uarena, &h->d_ucount})
+                      &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_stage,
+                      &h->d_outblk, &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
         b->release();
     for (auto& t : h->tables) t.d_members.release();
     h->h_pin.release();
+    h->h_head.release();
     h->h_stage.release();
     for (auto& p : h->prof)
         for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->trace.on)
+        for (auto& kv : h->trace.acc)
+            fprintf(stderr, "[posevo host] %-28s calls %6llu  avg %9.1f us\n", kv.first.c_str(),
+                    (unsigned long long)kv.second.second, kv.second.first / kv.second.second);
     delete h;
 }
 
@@ -747,6 +840,7 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
     } else if (!pubkeys96) {
         h->have_points = h->have_points && n <= old_n;
     }
+    if (h->d_totals.p) HIP_TRY(h, hipMemsetAsync(h->d_totals.p, 0, h->d_totals.cap, h->stream));  // grid may shrink
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_val = n;
     return PE_OK;
@@ -975,16 +1069,24 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
     int rc = need_init(h);
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
+    HostLap lap(&h->trace);
     rc = refresh_tree(h);
     if (rc) return rc;
+    {
+        uint32_t tmp;  // fail before anything is launched: k_votes adds into a buffer only k_tree clears
+        if (!find_block(h, h->justified.root, &tmp))
+            return fail(h, PE_ERR_UNKNOWN_ROOT, "justified checkpoint root is not in the store");
+    }
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
                      h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(),
-                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>());
+                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 0);
     }
+    lap.mark("head.1_launch_votes");
     uint32_t head;
-    rc = run_tree(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), &head);
+    rc = run_tree(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 1, &head);
+    lap.mark("head.2_tree_wait");
     if (rc) return rc;
     memcpy(out_root, h->blocks[head].root.data(), 32);
     return PE_OK;
@@ -1014,7 +1116,7 @@ int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
                      h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), n_blocks, buf,
-                     reinterpret_cast<VoteTotals*>(buf + n_blocks));
+                     reinterpret_cast<VoteTotals*>(buf + n_blocks), 1);
     }
     HIP_TRY(h, hipGetLastError());
     return PE_OK;
@@ -1030,7 +1132,7 @@ int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_block
     if (rc) return rc;
     uint64_t* buf = const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_buf_u64));
     uint32_t head;
-    rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + n_blocks), &head);
+    rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + n_blocks), 0, &head);
     if (rc) return rc;
     memcpy(out_root, h->blocks[head].root.data(), 32);
     return PE_OK;
@@ -1045,96 +1147,128 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
     if (n && (!atts || !bits_arena || !status)) return PE_ERR_INVALID_ARG;
     if (out_aggpk96 && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     if (n == 0) return PE_OK;
-    // ---- validate everything first (validation reads only time/blocks/tables, never latest_messages) ----
-    std::vector<Resolved> res(n);
-    std::vector<AttRow> rows;
-    rows.reserve(n);
-    std::vector<uint32_t> words;        // re-packed bit arena (u32 words)
-    std::vector<uint32_t> row_of(n, NONE32);
-    std::vector<uint32_t> counts(n, 0);
-    CommitteeTable* table_used = nullptr;
-    bool multi_table = false;
+    HostLap lap(&h->trace);
+    // ---- sizes first: the staging block must not move once pointers into it exist ----
+    uint64_t word_bound = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const pe_attestation& a = atts[i];
         if ((uint64_t)a.bits_offset + (a.n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
         if (a.target_epoch >= 0xFFFFFFFEull) return fail(h, PE_ERR_INVALID_ARG, "target epoch must fit 32 bits");
-        int32_t st = validate_for_fork_choice(h, a, &res[i]);
-        if (st == PE_ATT_OK) {
+        word_bound += (a.n_bits + 31) / 32 + 1;
+    }
+    Stage st(h);
+    HIP_TRY(h, st.reserve(word_bound * 4 + (sizeof(AttRow) + sizeof(G1Group)) * (size_t)n + 4096));
+    const size_t off_words = st.alloc(word_bound * 4);
+    const size_t off_rows = st.alloc(sizeof(AttRow) * (size_t)n);
+    const size_t off_groups = st.alloc(sizeof(G1Group) * (size_t)n);
+    uint32_t* words = st.host<uint32_t>(off_words);
+    AttRow* rows = st.host<AttRow>(off_rows);
+    // ---- validate everything (validation reads only time/blocks/tables, never latest_messages) ----
+    std::vector<Resolved> res(n);
+    std::vector<uint32_t> row_src;  // accepted row -> attestation index
+    row_src.reserve(n);
+    uint32_t n_words = 0, n_rows = 0;
+    CommitteeTable* first_table = nullptr;
+    bool multi_table = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pe_attestation& a = atts[i];
+        int32_t stt = validate_for_fork_choice(h, a, &res[i]);
+        uint32_t cnt = 0;
+        if (stt == PE_ATT_OK) {
             const uint32_t use = res[i].size;  // bits beyond the committee length are never read (A.6)
-            const size_t w0 = words.size();
-            words.resize(w0 + (use + 31) / 32);
-            counts[i] = use ? pack_bits(bits_arena + a.bits_offset, use, words.data() + w0) : 0;
+            cnt = use ? pack_bits(bits_arena + a.bits_offset, use, words + n_words) : 0;
             // is_valid_indexed_attestation (A.7): non-empty sorted-unique indices, then the signature verdict
-            if (counts[i] == 0) st = PE_ATT_EMPTY_OR_INVALID_INDICES;
-            else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) st = PE_ATT_BAD_SIGNATURE;
-            if (st != PE_ATT_OK) words.resize(w0);
-            else {
-                AttRow r;
+            if (cnt == 0) stt = PE_ATT_EMPTY_OR_INVALID_INDICES;
+            else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) stt = PE_ATT_BAD_SIGNATURE;
+            if (stt == PE_ATT_OK) {
+                AttRow& r = rows[n_rows];
                 r.member_base = res[i].table->offsets[res[i].pos];
                 r.n_bits = use;
-                r.bits_word = (uint32_t)w0;
+                r.bits_word = n_words;
                 r.block_idx = res[i].block_idx;
                 r.epoch_p1 = (uint32_t)a.target_epoch + 1;
-                r.order = (uint32_t)rows.size();
+                r.order = n_rows;
                 r.flag_mask = 0;
                 r.which = 0;
-                row_of[i] = (uint32_t)rows.size();
-                rows.push_back(r);
-                if (table_used && table_used != res[i].table) multi_table = true;
-                table_used = res[i].table;
+                n_words += (use + 31) / 32;
+                row_src.push_back(i);
+                ++n_rows;
+                if (first_table && first_table != res[i].table) multi_table = true;
+                if (!first_table) first_table = res[i].table;
             }
         }
-        status[i] = st;
-        if (out_count) out_count[i] = st == PE_ATT_OK ? counts[i] : 0;
+        status[i] = stt;
+        if (out_count) out_count[i] = stt == PE_ATT_OK ? cnt : 0;
     }
     if (out_aggpk96)
         for (uint32_t i = 0; i < n; ++i) { memset(out_aggpk96 + 96ull * i, 0, 96); out_aggpk96[96ull * i] = 0x40; }
-    if (rows.empty()) return PE_OK;
-    // Rows of different epochs index different member arrays: run one table at a time, in batch order per table.
-    // (order values stay global, so the first-seen rule across tables still holds: a validator's winner is the
-    // max (epoch, -order) over all rows.)
-    std::vector<CommitteeTable*> tabs;
-    if (!multi_table) tabs.push_back(table_used);
-    else
-        for (uint32_t i = 0; i < n; ++i)
-            if (row_of[i] != NONE32 && std::find(tabs.begin(), tabs.end(), res[i].table) == tabs.end())
-                tabs.push_back(res[i].table);
-    HIP_TRY(h, h->d_arena.ensure(std::max<size_t>(64, words.size() * 4)));
-    HIP_TRY(h, hipMemcpyAsync(h->d_arena.p, words.data(), words.size() * 4, hipMemcpyHostToDevice, h->stream));
-    for (CommitteeTable* t : tabs) {
-        std::vector<AttRow> sub;
-        std::vector<uint32_t> sub_src;  // original attestation index per sub row
-        for (uint32_t i = 0; i < n; ++i)
-            if (row_of[i] != NONE32 && res[i].table == t) { sub.push_back(rows[row_of[i]]); sub_src.push_back(i); }
-        HIP_TRY(h, h->d_rows.ensure(sizeof(AttRow) * sub.size()));
-        HIP_TRY(h, hipMemcpyAsync(h->d_rows.p, sub.data(), sizeof(AttRow) * sub.size(), hipMemcpyHostToDevice,
-                                  h->stream));
+    if (n_rows == 0) return PE_OK;
+    // Rows of different target epochs index different member arrays: make each table's rows contiguous (stable, so
+    // the batch order inside a table is kept; `order` stays global).  Different tables = different epochs, where
+    // the later epoch wins regardless of order, so per-table passes equal the sequential result.
+    std::vector<std::pair<CommitteeTable*, std::pair<uint32_t, uint32_t>>> segs;  // table, [begin, end)
+    if (multi_table) {
+        std::vector<uint32_t> perm(n_rows);
+        std::iota(perm.begin(), perm.end(), 0u);
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) {
+            return res[row_src[x]].table < res[row_src[y]].table;
+        });
+        std::vector<AttRow> tmp(rows, rows + n_rows);
+        std::vector<uint32_t> src2(n_rows);
+        for (uint32_t k = 0; k < n_rows; ++k) { rows[k] = tmp[perm[k]]; src2[k] = row_src[perm[k]]; }
+        row_src.swap(src2);
+    }
+    for (uint32_t k = 0; k < n_rows;) {
+        uint32_t e = k + 1;
+        while (e < n_rows && res[row_src[e]].table == res[row_src[k]].table) ++e;
+        segs.push_back({res[row_src[k]].table, {k, e}});
+        k = e;
+    }
+    // aggregate pubkeys: one G1 plan over all accepted rows (groups in row order); members differ per table, so
+    // one launch per segment over its slice of the descriptors
+    OutBlock ob(h);
+    size_t off_out96 = 0;
+    std::vector<G1Plan> plans(segs.size());
+    if (out_aggpk96) {
+        off_out96 = ob.alloc(96ull * n_rows);
+        HIP_TRY(h, ob.ensure());
+        G1Group* groups = st.host<G1Group>(off_groups);
+        for (size_t sg = 0; sg < segs.size(); ++sg) {
+            const uint32_t b0 = segs[sg].second.first, e0 = segs[sg].second.second;
+            plan_g1(e0 - b0, [&](uint32_t g) { return rows[b0 + g].n_bits; }, groups + b0, &plans[sg]);
+            for (uint32_t k = b0; k < e0; ++k) {
+                groups[k].member_start = rows[k].member_base;
+                groups[k].bits_word = rows[k].bits_word;
+            }
+        }
+    }
+    lap.mark("att.1_validate_pack");
+    HIP_TRY(h, st.upload());
+    for (size_t sg = 0; sg < segs.size(); ++sg) {
+        CommitteeTable* t = segs[sg].first;
+        const uint32_t b0 = segs[sg].second.first, e0 = segs[sg].second.second;
         {
             ProfScope ps(h, PE_KERNEL_LMD);
-            launch_lmd_update(h->stream, h->d_rows.as<AttRow>(), (uint32_t)sub.size(), t->d_members.as<uint32_t>(),
-                              h->d_arena.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
+            launch_lmd_update(h->stream, st.dev<AttRow>(off_rows) + b0, e0 - b0, t->d_members.as<uint32_t>(),
+                              st.dev<uint32_t>(off_words), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
                               h->d_vote_block.as<uint32_t>());
         }
-        HIP_TRY(h, hipGetLastError());
         if (out_aggpk96) {
-            std::vector<uint32_t> sizes(sub.size());
-            for (size_t k = 0; k < sub.size(); ++k) sizes[k] = sub[k].n_bits;
-            G1Plan plan;
-            plan_g1(sizes, &plan);
-            for (size_t k = 0; k < sub.size(); ++k) {
-                plan.groups[k].member_start = sub[k].member_base;
-                plan.groups[k].bits_word = sub[k].bits_word;
-            }
-            std::vector<uint8_t> tmp(96ull * sub.size());
-            rc = run_g1(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(), h->d_arena.as<uint32_t>(), plan,
-                        tmp.data(), nullptr);
+            rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(),
+                                   st.dev<uint32_t>(off_words), st.dev<G1Group>(off_groups) + b0, plans[sg],
+                                   ob.dev<uint8_t>(off_out96) + 96ull * b0, nullptr);
             if (rc) return rc;
-            for (size_t k = 0; k < sub.size(); ++k) memcpy(out_aggpk96 + 96ull * sub_src[k], tmp.data() + 96 * k, 96);
         }
-        HIP_TRY(h, hipStreamSynchronize(h->stream));  // sub/words are reused
         t->stamp = ++h->table_stamp;
     }
+    HIP_TRY(h, hipGetLastError());
+    if (out_aggpk96) HIP_TRY(h, ob.download());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_aggpk96)
+        for (uint32_t k = 0; k < n_rows; ++k)
+            memcpy(out_aggpk96 + 96ull * row_src[k], ob.host<uint8_t>(off_out96) + 96ull * k, 96);
+    lap.mark("att.2_device");
     return PE_OK;
 }
 
@@ -1152,74 +1286,66 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     if (want_pk && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     *out_n_groups = 0;
     if (n == 0) return PE_OK;
-    // ---- group by identical AttestationData + n_bits, in order of first appearance ----
+    HostLap lap(&h->trace);
+    // ---- group by identical AttestationData + n_bits, in order of first appearance (flat open addressing) ----
     auto hash_att = [](const pe_attestation& a) {
         uint64_t hsh = a.slot * 0x9E3779B97F4A7C15ull ^ (a.index + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
         uint64_t t;
         memcpy(&t, a.beacon_block_root, 8); hsh ^= t * 0x94D049BB133111EBull;
         memcpy(&t, a.target_root, 8); hsh ^= (t + a.target_epoch) * 0xD6E8FEB86659FD93ull;
         memcpy(&t, a.source_root, 8); hsh ^= (t + a.source_epoch) * 0xA24BAED4963EE407ull;
-        return (size_t)(hsh ^ a.n_bits);
+        hsh ^= a.n_bits;
+        return hsh ^ (hsh >> 29);
     };
-    std::unordered_multimap<size_t, uint32_t> buckets;
-    std::vector<uint32_t> gof(n);
-    std::vector<std::vector<uint32_t>> glist;
+    uint32_t tab_size = 16;
+    while (tab_size < 2 * n) tab_size <<= 1;
+    std::vector<uint32_t> table(tab_size, NONE32);  // slot -> group id
+    std::vector<uint32_t> gof(n), rep, gcount;      // rep[g] = first attestation of group g
+    uint64_t word_total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
-        const size_t hv = hash_att(atts[i]);
-        uint32_t g = NONE32;
-        auto range = buckets.equal_range(hv);
-        for (auto it = range.first; it != range.second; ++it) {
-            const pe_attestation& rep = atts[glist[it->second][0]];
-            if (rep.n_bits == atts[i].n_bits && att_data_equal(rep, atts[i])) { g = it->second; break; }
+        word_total += (atts[i].n_bits + 31) / 32;
+        uint32_t slot = (uint32_t)hash_att(atts[i]) & (tab_size - 1);
+        uint32_t g;
+        for (;;) {
+            g = table[slot];
+            if (g == NONE32) {
+                g = (uint32_t)rep.size();
+                table[slot] = g;
+                rep.push_back(i);
+                gcount.push_back(0);
+                break;
+            }
+            const pe_attestation& r = atts[rep[g]];
+            if (r.n_bits == atts[i].n_bits && att_data_equal(r, atts[i])) break;
+            slot = (slot + 1) & (tab_size - 1);
         }
-        if (g == NONE32) {
-            g = (uint32_t)glist.size();
-            glist.emplace_back();
-            buckets.emplace(hv, g);
-        }
-        glist[g].push_back(i);
         gof[i] = g;
+        gcount[g] += 1;
     }
-    const uint32_t ng = (uint32_t)glist.size();
-    // ---- re-pack input bits, lay out the output arena ----
-    std::vector<uint32_t> words, att_word(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        att_word[i] = (uint32_t)words.size();
-        const uint32_t nb = atts[i].n_bits;
-        words.resize(words.size() + (nb + 31) / 32);
-        if (nb) pack_bits(bits_arena + atts[i].bits_offset, nb, words.data() + att_word[i]);
+    const uint32_t ng = (uint32_t)rep.size();
+    std::vector<uint32_t> gstart(ng + 1, 0), order(n);  // counting sort: members of group g, in input order
+    for (uint32_t g = 0; g < ng; ++g) gstart[g + 1] = gstart[g] + gcount[g];
+    {
+        std::vector<uint32_t> cur(gstart.begin(), gstart.end() - 1);
+        for (uint32_t i = 0; i < n; ++i) order[cur[gof[i]]++] = i;
     }
-    std::vector<UnionGroup> ug(ng);
-    std::vector<uint32_t> uwords;
-    uint32_t out_words = 0;
-    uint64_t out_bytes = 0;
-    std::vector<uint32_t> out_byte_off(ng);
-    for (uint32_t g = 0; g < ng; ++g) {
-        ug[g].list_start = (uint32_t)uwords.size();
-        ug[g].n_atts = (uint32_t)glist[g].size();
-        ug[g].n_words = (atts[glist[g][0]].n_bits + 31) / 32;
-        ug[g].out_word = out_words;
-        out_words += ug[g].n_words;
-        for (uint32_t i : glist[g]) uwords.push_back(att_word[i]);
-        out_byte_off[g] = (uint32_t)out_bytes;
-        out_bytes += (atts[glist[g][0]].n_bits + 7) / 8;
-    }
-    if (out_bytes > out_arena_cap) return fail(h, PE_ERR_CAPACITY, "output bit arena too small");
-    // ---- aggregate pubkey needs each group's committee ----
-    std::vector<Resolved> gres(ng);
-    CommitteeTable* table = nullptr;
+    lap.mark("agg.1_group");
+    // ---- resolve committees (aggregate pubkey) ----
+    std::vector<Resolved> gres(want_pk ? ng : 0);
+    CommitteeTable* table_pk = nullptr;
     if (want_pk) {
         for (uint32_t g = 0; g < ng; ++g) {
-            const pe_attestation& a = atts[glist[g][0]];
+            const pe_attestation& a = atts[rep[g]];
             CommitteeTable* t = find_table(h, a.target_epoch);
             if (!t) return fail(h, PE_ERR_NO_COMMITTEES, "no committee table for a group's target epoch");
-            if (table && t != table) return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate: one target epoch per call when aggregate pubkeys are requested");
-            table = t;
+            if (table_pk && t != table_pk)
+                return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate: one target epoch per call when aggregate pubkeys are requested");
+            table_pk = t;
             const uint64_t cps = t->n_committees / h->cfg.slots_per_epoch;
-            const uint64_t pos = (a.slot % h->cfg.slots_per_epoch) * cps + a.index;
             if (a.index >= cps) return fail(h, PE_ERR_INVALID_ARG, "committee index out of range");
+            const uint64_t pos = (a.slot % h->cfg.slots_per_epoch) * cps + a.index;
             const uint32_t size = t->offsets[pos + 1] - t->offsets[pos];
             if (a.n_bits != size) return fail(h, PE_ERR_INVALID_ARG, "len(aggregation_bits) != len(committee)");  // pe:730
             gres[g].table = t;
@@ -1227,73 +1353,117 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
             gres[g].size = size;
         }
     }
-    // ---- device: union ----
-    HIP_TRY(h, h->d_arena.ensure(std::max<size_t>(64, words.size() * 4)));
-    HIP_TRY(h, h->d_ugroups.ensure(sizeof(UnionGroup) * ng));
-    HIP_TRY(h, h->d_uwords.ensure(std::max<size_t>(64, uwords.size() * 4)));
-    HIP_TRY(h, h->d_uarena.ensure(std::max<size_t>(64, out_words * 4ull)));
-    HIP_TRY(h, h->d_ucount.ensure(std::max<size_t>(64, ng * 4ull)));
-    HIP_TRY(h, hipMemcpyAsync(h->d_arena.p, words.data(), words.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_ugroups.p, ug.data(), sizeof(UnionGroup) * ng, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_uwords.p, uwords.data(), uwords.size() * 4, hipMemcpyHostToDevice, h->stream));
+    // ---- lay everything out in the staging block ----
+    uint64_t out_words = 0, out_bytes = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+        out_words += (atts[rep[g]].n_bits + 31) / 32;
+        out_bytes += (atts[rep[g]].n_bits + 7) / 8;
+    }
+    if (out_bytes > out_arena_cap) return fail(h, PE_ERR_CAPACITY, "output bit arena too small");
+    Stage st(h);
+    HIP_TRY(h, st.reserve(word_total * 4 + sizeof(UnionGroup) * (size_t)ng + 4ull * n + 2 * sizeof(G1Group) * (size_t)ng +
+                          4ull * n + 8192));
+    const size_t off_words = st.alloc(word_total * 4 + 4);
+    const size_t off_ug = st.alloc(sizeof(UnionGroup) * (size_t)ng);
+    const size_t off_uw = st.alloc(4ull * n);
+    const size_t off_g1 = st.alloc(sizeof(G1Group) * (size_t)ng);
+    const size_t off_g1s = st.alloc(sizeof(G1Group) * (size_t)ng);
+    const size_t off_idx = st.alloc(4ull * n);
+    uint32_t* words = st.host<uint32_t>(off_words);
+    UnionGroup* ug = st.host<UnionGroup>(off_ug);
+    uint32_t* uwords = st.host<uint32_t>(off_uw);
+    std::vector<uint32_t> att_word(n);
+    {
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            att_word[i] = w;
+            const uint32_t nb = atts[i].n_bits;
+            if (nb) pack_bits(bits_arena + atts[i].bits_offset, nb, words + w);
+            w += (nb + 31) / 32;
+        }
+    }
+    std::vector<uint32_t> out_byte_off(ng);
+    {
+        uint32_t ow = 0, obytes = 0;
+        for (uint32_t g = 0; g < ng; ++g) {
+            ug[g].list_start = gstart[g];
+            ug[g].n_atts = gcount[g];
+            ug[g].n_words = (atts[rep[g]].n_bits + 31) / 32;
+            ug[g].out_word = ow;
+            ow += ug[g].n_words;
+            out_byte_off[g] = obytes;
+            obytes += (atts[rep[g]].n_bits + 7) / 8;
+        }
+        for (uint32_t k = 0; k < n; ++k) uwords[k] = att_word[order[k]];
+    }
+    OutBlock ob(h);
+    const size_t off_ouw = ob.alloc(out_words * 4 + 4);
+    const size_t off_ocnt = ob.alloc(4ull * ng);
+    const size_t off_opk = out_aggpk96 ? ob.alloc(96ull * ng) : 0;
+    const size_t off_osig = out_sig96 ? ob.alloc(96ull * ng) : 0;
+    HIP_TRY(h, ob.ensure());
+    G1Plan plan_pk, plan_sig;
+    if (want_pk) {
+        G1Group* gr = st.host<G1Group>(off_g1);
+        plan_g1(ng, [&](uint32_t g) { return gres[g].size; }, gr, &plan_pk);
+        for (uint32_t g = 0; g < ng; ++g) {
+            gr[g].member_start = table_pk->offsets[gres[g].pos];
+            gr[g].bits_word = ug[g].out_word;  // the OR-ed bits, device resident: no round trip
+        }
+    }
+    if (out_sig96) {
+        G1Group* gr = st.host<G1Group>(off_g1s);
+        plan_g1(ng, [&](uint32_t g) { return gcount[g]; }, gr, &plan_sig);
+        for (uint32_t g = 0; g < ng; ++g) gr[g].member_start = gstart[g];
+        memcpy(st.host<uint32_t>(off_idx), order.data(), 4ull * n);  // points indexed by input attestation
+    }
+    lap.mark("agg.2_pack_resolve");
+    // ---- device ----
+    HIP_TRY(h, st.upload());
     {
         ProfScope ps(h, PE_KERNEL_BITS_UNION);
-        launch_bits_union(h->stream, h->d_ugroups.as<UnionGroup>(), ng, h->d_uwords.as<uint32_t>(),
-                          h->d_arena.as<uint32_t>(), h->d_uarena.as<uint32_t>(), h->d_ucount.as<uint32_t>());
+        launch_bits_union(h->stream, st.dev<UnionGroup>(off_ug), ng, st.dev<uint32_t>(off_uw),
+                          st.dev<uint32_t>(off_words), ob.dev<uint32_t>(off_ouw), ob.dev<uint32_t>(off_ocnt));
     }
-    HIP_TRY(h, hipGetLastError());
-    std::vector<uint32_t> h_out_words(out_words), h_count(ng);
-    HIP_TRY(h, hipMemcpyAsync(h_out_words.data(), h->d_uarena.p, out_words * 4ull, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h_count.data(), h->d_ucount.p, ng * 4ull, hipMemcpyDeviceToHost, h->stream));
-    // ---- device: aggregate pubkey over the OR-ed bits (device-resident: no round trip of the bits) ----
     if (want_pk) {
-        std::vector<uint32_t> sizes(ng);
-        for (uint32_t g = 0; g < ng; ++g) sizes[g] = gres[g].size;
-        G1Plan plan;
-        plan_g1(sizes, &plan);
-        for (uint32_t g = 0; g < ng; ++g) {
-            plan.groups[g].member_start = table->offsets[gres[g].pos];
-            plan.groups[g].bits_word = ug[g].out_word;
-        }
-        int rc = run_g1(h, h->d_points.as<uint32_t>(), table->d_members.as<uint32_t>(), h->d_uarena.as<uint32_t>(),
-                        plan, out_aggpk96, static_cast<uint32_t*>(dev_partials));
+        int rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), table_pk->d_members.as<uint32_t>(),
+                                   ob.dev<uint32_t>(off_ouw), st.dev<G1Group>(off_g1), plan_pk,
+                                   out_aggpk96 ? ob.dev<uint8_t>(off_opk) : nullptr,
+                                   static_cast<uint32_t*>(dev_partials));
         if (rc) return rc;
-        table->stamp = ++h->table_stamp;
+        table_pk->stamp = ++h->table_stamp;
     }
-    // ---- device: signature sum (bls.Aggregate): points indexed by input attestation ----
-    if (out_sig96) {
+    if (out_sig96) {  // bls.Aggregate: sum of the members' signature points
         HIP_TRY(h, h->d_tmp_be.ensure(96ull * n));
         HIP_TRY(h, h->d_tmp_points.ensure(96ull * n));
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, h->stream));
         launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
-        std::vector<uint32_t> idx, sizes(ng);
-        idx.reserve(n);
-        G1Plan plan;
-        for (uint32_t g = 0; g < ng; ++g) sizes[g] = (uint32_t)glist[g].size();
-        plan_g1(sizes, &plan);
-        for (uint32_t g = 0; g < ng; ++g) {
-            plan.groups[g].member_start = (uint32_t)idx.size();
-            for (uint32_t i : glist[g]) idx.push_back(i);
-        }
-        HIP_TRY(h, h->d_idx.ensure(4ull * n));
-        HIP_TRY(h, hipMemcpyAsync(h->d_idx.p, idx.data(), 4ull * n, hipMemcpyHostToDevice, h->stream));
-        int rc = run_g1(h, h->d_tmp_points.as<uint32_t>(), h->d_idx.as<uint32_t>(), nullptr, plan, out_sig96, nullptr);
+        int rc = launch_g1_planned(h, h->d_tmp_points.as<uint32_t>(), st.dev<uint32_t>(off_idx), nullptr,
+                                   st.dev<G1Group>(off_g1s), plan_sig, ob.dev<uint8_t>(off_osig), nullptr);
         if (rc) return rc;
     }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, ob.download());
+    lap.mark("agg.3_launch");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    lap.mark("agg.4_wait");
     // ---- outputs ----
-    const uint8_t* ob = reinterpret_cast<const uint8_t*>(h_out_words.data());
+    const uint8_t* obits = ob.host<uint8_t>(off_ouw);
+    const uint32_t* ocnt = ob.host<uint32_t>(off_ocnt);
     for (uint32_t g = 0; g < ng; ++g) {
-        out_atts[g] = atts[glist[g][0]];
+        out_atts[g] = atts[rep[g]];
         out_atts[g].bits_offset = out_byte_off[g];
-        uint32_t fl = PE_ATT_FLAG_SIGNATURE_VALID;
-        for (uint32_t i : glist[g]) fl &= atts[i].flags | ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID;
-        out_atts[g].flags = (atts[glist[g][0]].flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | (fl & PE_ATT_FLAG_SIGNATURE_VALID);
-        memcpy(out_bits_arena + out_byte_off[g], ob + 4ull * ug[g].out_word, (out_atts[g].n_bits + 7) / 8);
-        if (out_count) out_count[g] = h_count[g];
+        uint32_t all_valid = PE_ATT_FLAG_SIGNATURE_VALID;
+        for (uint32_t k = gstart[g]; k < gstart[g + 1]; ++k) all_valid &= atts[order[k]].flags;
+        out_atts[g].flags = (atts[rep[g]].flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | all_valid;
+        memcpy(out_bits_arena + out_byte_off[g], obits + 4ull * ug[g].out_word, (out_atts[g].n_bits + 7) / 8);
+        if (out_count) out_count[g] = ocnt[g];
     }
+    if (out_aggpk96) memcpy(out_aggpk96, ob.host<uint8_t>(off_opk), 96ull * ng);
+    if (out_sig96) memcpy(out_sig96, ob.host<uint8_t>(off_osig), 96ull * ng);
     if (group_of) memcpy(group_of, gof.data(), 4ull * n);
     *out_n_groups = ng;
+    lap.mark("agg.5_outputs");
     return PE_OK;
 }
 
@@ -1334,14 +1504,26 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     cj.epoch = st->current_justified_epoch; cj.root = to_root(st->current_justified_root);
     pj.epoch = st->previous_justified_epoch; pj.root = to_root(st->previous_justified_root);
 
+    HostLap lap(&h->trace);
+    uint64_t word_bound = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
+            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        word_bound += (atts[i].n_bits + 31) / 32 + 1;
+    }
+    Stage stg(h);
+    HIP_TRY(h, stg.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)n + 4096));
+    const size_t off_words = stg.alloc(word_bound * 4);
+    const size_t off_rows = stg.alloc(sizeof(AttRow) * (size_t)n);
+    const size_t off_nslot = stg.alloc(4ull * n);
+    uint32_t* words = stg.host<uint32_t>(off_words);
     struct Acc { AttRow row; uint32_t src; CommitteeTable* table; uint32_t pos; };
     std::vector<Acc> acc;
-    std::vector<uint32_t> words;
+    acc.reserve(n);
+    uint32_t n_words = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const pe_attestation& a = atts[i];
         out_numerators[i] = 0;
-        if ((uint64_t)a.bits_offset + (a.n_bits + 7) / 8 > arena_len)
-            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
         int32_t s = PE_ATT_OK;
         CommitteeTable* t = nullptr;
         uint64_t pos = 0;
@@ -1363,8 +1545,7 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
             const Checkpoint& justified = a.target_epoch == cur_epoch ? cj : pj;
             Checkpoint src;
             src.epoch = a.source_epoch; src.root = to_root(a.source_root);
-            const bool matching_source = src == justified;
-            if (!matching_source) s = PE_ATT_SOURCE_MISMATCH;
+            if (!(src == justified)) s = PE_ATT_SOURCE_MISMATCH;  // assert is_matching_source
             else {
                 // get_block_root(state, epoch) / get_block_root_at_slot(state, slot): the state's chain is the
                 // ancestry of chain_tip_root (both slots are < state.slot by pe:726)
@@ -1379,17 +1560,14 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
             }
         }
         if (s == PE_ATT_OK) {
-            const size_t w0 = words.size();
-            words.resize(w0 + (size + 31) / 32);
-            const uint32_t cnt = size ? pack_bits(bits_arena + a.bits_offset, size, words.data() + w0) : 0;
+            const uint32_t cnt = size ? pack_bits(bits_arena + a.bits_offset, size, words + n_words) : 0;
             if (cnt == 0) s = PE_ATT_EMPTY_OR_INVALID_INDICES;                                 // pe:736
             else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) s = PE_ATT_BAD_SIGNATURE;
-            if (s != PE_ATT_OK) words.resize(w0);
-            else {
+            if (s == PE_ATT_OK) {
                 Acc e;
                 e.row.member_base = t->offsets[pos];
                 e.row.n_bits = size;
-                e.row.bits_word = (uint32_t)w0;
+                e.row.bits_word = n_words;
                 e.row.block_idx = 0;
                 e.row.epoch_p1 = 0;
                 e.row.order = 0;
@@ -1399,17 +1577,19 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                 e.table = t;
                 e.pos = (uint32_t)pos;
                 acc.push_back(e);
+                n_words += (size + 31) / 32;
             }
         }
         status[i] = s;
     }
     if (acc.empty()) return PE_OK;
+    lap.mark("proc.1_validate_pack");
     // ---- rounds: attestations of one round touch pairwise disjoint validators, so the order inside a
     // round is irrelevant; rounds run in order, which keeps the sequential semantics of pe:745-749 ----
     std::vector<uint32_t> round_of(acc.size());
-    uint32_t n_rounds = 0;
     {
         std::unordered_map<uint64_t, uint32_t> seen;  // (table, which, committee) -> attestations so far
+        seen.reserve(acc.size() * 2);
         for (size_t k = 0; k < acc.size(); ++k) {
             uint32_t r;
             if (acc[k].table->is_partition) {
@@ -1419,40 +1599,39 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                 r = (uint32_t)k;  // committees may overlap: fully sequential
             }
             round_of[k] = r;
-            n_rounds = std::max(n_rounds, r + 1);
         }
     }
-    HIP_TRY(h, h->d_arena.ensure(std::max<size_t>(64, words.size() * 4)));
-    HIP_TRY(h, hipMemcpyAsync(h->d_arena.p, words.data(), words.size() * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, h->d_numer.ensure(8ull * n));
-    HIP_TRY(h, hipMemsetAsync(h->d_numer.p, 0, 8ull * n, h->stream));
     // rows sorted by (round, table); one launch per (round, table)
     std::vector<size_t> ord(acc.size());
     std::iota(ord.begin(), ord.end(), size_t(0));
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
-        if (round_of[a] != round_of[b]) return round_of[a] < round_of[b];
-        return acc[a].table < acc[b].table;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+        if (round_of[x] != round_of[y]) return round_of[x] < round_of[y];
+        return acc[x].table < acc[y].table;
     });
-    std::vector<AttRow> rows(acc.size());
-    std::vector<uint32_t> nslot(acc.size());
+    AttRow* rows = stg.host<AttRow>(off_rows);
+    uint32_t* nslot = stg.host<uint32_t>(off_nslot);
     for (size_t k = 0; k < ord.size(); ++k) { rows[k] = acc[ord[k]].row; nslot[k] = acc[ord[k]].src; }
-    HIP_TRY(h, h->d_rows.ensure(sizeof(AttRow) * rows.size()));
-    HIP_TRY(h, h->d_nslot.ensure(4ull * rows.size()));
-    HIP_TRY(h, hipMemcpyAsync(h->d_rows.p, rows.data(), sizeof(AttRow) * rows.size(), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_nslot.p, nslot.data(), 4ull * rows.size(), hipMemcpyHostToDevice, h->stream));
+    OutBlock ob(h);
+    const size_t off_num = ob.alloc(8ull * n);
+    HIP_TRY(h, ob.ensure());
+    HIP_TRY(h, stg.upload());
+    HIP_TRY(h, hipMemsetAsync(ob.dev<uint8_t>(off_num), 0, 8ull * n, h->stream));
     for (size_t k = 0; k < ord.size();) {
         size_t e = k + 1;
         while (e < ord.size() && round_of[ord[e]] == round_of[ord[k]] && acc[ord[e]].table == acc[ord[k]].table) ++e;
         ProfScope ps(h, PE_KERNEL_PARTICIPATION);
-        launch_participation(h->stream, h->d_rows.as<AttRow>() + k, (uint32_t)(e - k),
-                             acc[ord[k]].table->d_members.as<uint32_t>(), h->d_arena.as<uint32_t>(),
+        launch_participation(h->stream, stg.dev<AttRow>(off_rows) + k, (uint32_t)(e - k),
+                             acc[ord[k]].table->d_members.as<uint32_t>(), stg.dev<uint32_t>(off_words),
                              h->d_incr.as<uint16_t>(), st->base_reward_per_increment, h->d_part_cur.as<uint32_t>(),
-                             h->d_part_prev.as<uint32_t>(), h->d_numer.as<uint64_t>(), h->d_nslot.as<uint32_t>() + k);
+                             h->d_part_prev.as<uint32_t>(), ob.dev<uint64_t>(off_num), stg.dev<uint32_t>(off_nslot) + k);
         k = e;
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(out_numerators, h->d_numer.p, 8ull * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, ob.download());
+    lap.mark("proc.2_rounds_h2d_launch");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out_numerators, ob.host<uint64_t>(off_num), 8ull * n);
+    lap.mark("proc.3_wait_d2h");
     return PE_OK;
 }
 
@@ -1484,13 +1663,47 @@ int pe_participation_rotate(pe_engine* h)
 }
 
 // ---------------------------------------------------------------- plain G1 sums
+// Shared by pe_g1_sum / pe_g1_partial: groups over an optional index list, staged and launched.
+static int g1_sum_common(pe_engine* h, const uint32_t* d_pts, uint64_t n_pts, const uint32_t* index,
+                         const uint32_t* offsets, uint32_t n_groups, uint8_t* out96_host, uint32_t* dev_jac)
+{
+    const uint32_t total = offsets[n_groups];
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
+    if (index) {
+        for (uint32_t j = 0; j < total; ++j)
+            if (index[j] >= n_pts) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
+    } else if (total > n_pts) {
+        return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
+    }
+    Stage st(h);
+    HIP_TRY(h, st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
+    const size_t off_g = st.alloc(sizeof(G1Group) * (size_t)n_groups);
+    const size_t off_i = st.alloc(4ull * total + 4);
+    G1Group* gr = st.host<G1Group>(off_g);
+    G1Plan plan;
+    plan_g1(n_groups, [&](uint32_t g) { return offsets[g + 1] - offsets[g]; }, gr, &plan);
+    for (uint32_t g = 0; g < n_groups; ++g) gr[g].member_start = offsets[g];
+    if (index) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
+    OutBlock ob(h);
+    const size_t off_o = out96_host ? ob.alloc(96ull * n_groups) : 0;
+    HIP_TRY(h, ob.ensure());
+    HIP_TRY(h, st.upload());
+    int rc = launch_g1_planned(h, d_pts, index ? st.dev<uint32_t>(off_i) : nullptr, nullptr, st.dev<G1Group>(off_g), plan,
+                               out96_host ? ob.dev<uint8_t>(off_o) : nullptr, dev_jac);
+    if (rc) return rc;
+    if (out96_host) HIP_TRY(h, ob.download());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out96_host) memcpy(out96_host, ob.host<uint8_t>(off_o), 96ull * n_groups);
+    return PE_OK;
+}
+
 int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const uint32_t* index, const uint32_t* offsets,
               uint32_t n_groups, uint8_t* out96)
 {
     if (!h || !offsets || !out96) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     if (n_groups == 0) return PE_OK;
-    const uint32_t total = offsets[n_groups];
     const uint32_t* d_pts;
     uint64_t np;
     if (points96) {
@@ -1506,23 +1719,7 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
         d_pts = h->d_points.as<uint32_t>();
         np = h->n_val;
     }
-    std::vector<uint32_t> sizes(n_groups);
-    for (uint32_t g = 0; g < n_groups; ++g) {
-        if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
-        sizes[g] = offsets[g + 1] - offsets[g];
-    }
-    if (index) {
-        for (uint32_t j = 0; j < total; ++j)
-            if (index[j] >= np) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
-        HIP_TRY(h, h->d_idx.ensure(std::max<size_t>(64, 4ull * total)));
-        HIP_TRY(h, hipMemcpyAsync(h->d_idx.p, index, 4ull * total, hipMemcpyHostToDevice, h->stream));
-    } else if (total > np) {
-        return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
-    }
-    G1Plan plan;
-    plan_g1(sizes, &plan);
-    for (uint32_t g = 0; g < n_groups; ++g) plan.groups[g].member_start = offsets[g];
-    return run_g1(h, d_pts, index ? h->d_idx.as<uint32_t>() : nullptr, nullptr, plan, out96, nullptr);
+    return g1_sum_common(h, d_pts, np, index, offsets, n_groups, out96, nullptr);
 }
 
 int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, void* dev_partials)
@@ -1531,20 +1728,8 @@ int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, 
     (void)hipSetDevice(h->device);
     if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
     if (n_groups == 0) return PE_OK;
-    const uint32_t total = offsets[n_groups];
-    std::vector<uint32_t> sizes(n_groups);
-    for (uint32_t g = 0; g < n_groups; ++g) sizes[g] = offsets[g + 1] - offsets[g];
-    if (index) {
-        for (uint32_t j = 0; j < total; ++j)
-            if (index[j] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
-        HIP_TRY(h, h->d_idx.ensure(std::max<size_t>(64, 4ull * total)));
-        HIP_TRY(h, hipMemcpyAsync(h->d_idx.p, index, 4ull * total, hipMemcpyHostToDevice, h->stream));
-    }
-    G1Plan plan;
-    plan_g1(sizes, &plan);
-    for (uint32_t g = 0; g < n_groups; ++g) plan.groups[g].member_start = offsets[g];
-    return run_g1(h, h->d_points.as<uint32_t>(), index ? h->d_idx.as<uint32_t>() : nullptr, nullptr, plan, nullptr,
-                  static_cast<uint32_t*>(dev_partials));
+    return g1_sum_common(h, h->d_points.as<uint32_t>(), h->n_val, index, offsets, n_groups, nullptr,
+                         static_cast<uint32_t*>(dev_partials));
 }
 
 int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups, uint8_t* out96)

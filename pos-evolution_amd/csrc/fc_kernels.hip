@@ -111,10 +111,12 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
 
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx, uint32_t n_blocks,
-                  uint64_t* direct, VoteTotals* totals)
+                  uint64_t* direct, VoteTotals* totals, int zero_first)
 {
-    (void)hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
-    (void)hipMemsetAsync(totals, 0, sizeof(VoteTotals) * VOTES_MAX_WG, s);
+    if (zero_first) {  // caller-owned exchange buffer; the engine's own buffer is kept zeroed by k_tree
+        (void)hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
+        (void)hipMemsetAsync(totals, 0, sizeof(VoteTotals) * VOTES_MAX_WG, s);
+    }
     if (n_val == 0) return;
     const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
     uint64_t blocks = (n_quads + VOTES_WG - 1) / VOTES_WG;
@@ -134,8 +136,13 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
 constexpr int TREE_WG = 1024;
 constexpr int TREE_PER_THREAD = TREE_MAX_BLOCKS / TREE_WG;  // 8
 
+// LDS index skew: thread t owns items 8t..8t+7, i.e. a lane stride of 8 elements = an 8-way (u32) / 16-way (u64)
+// bank conflict on every own-item access.  i -> i + i/8 turns the stride into 9 elements: conflict-free.
+__device__ __forceinline__ uint32_t SK(uint32_t i) { return i + (i >> 3); }
+constexpr uint32_t TREE_LDS_ENTRIES = TREE_MAX_BLOCKS + 2 + ((TREE_MAX_BLOCKS + 2) >> 3) + 1;
+
 // Exclusive prefix sum over n <= 8192 values held as 8 consecutive items per thread.
-// out[i] (LDS, n+1 entries) = sum of in[0..i); wave shuffles + one LDS hop across the 16 waves.
+// out[SK(i)] (LDS, n+1 entries) = sum of in[0..i); wave shuffles + one LDS hop across the 16 waves.
 template <typename T>
 __device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_THREAD], T* out, T* wave_tot, uint32_t n)
 {
@@ -157,10 +164,10 @@ __device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_TH
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k) {
         const uint32_t i = tid * TREE_PER_THREAD + k;
-        if (i <= n) out[i] = run;
+        if (i <= n) out[SK(i)] = run;
         run += item[k];
     }
-    if (tid == TREE_WG - 1 && (uint32_t)(TREE_WG * TREE_PER_THREAD) <= n) out[n] = run;
+    if (tid == TREE_WG - 1 && (uint32_t)(TREE_WG * TREE_PER_THREAD) <= n) out[SK(n)] = run;
     __syncthreads();
 }
 
@@ -169,34 +176,62 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
        unsigned long long ov_balance, unsigned long long ov_num, int use_override, uint32_t justified_pos,
        uint32_t boost_pos, unsigned long long slots_per_epoch, unsigned long long boost_percent,
        unsigned long long balance_increment, unsigned long long* __restrict__ weights_by_idx,
-       uint32_t* __restrict__ head_idx)
+       uint32_t* __restrict__ head_idx, int clear_direct)
 {
-    // LDS plan (n <= 8192):  S u64[n+1] (later bestW) | L u32[n+1] (later bestRank) | jump u32[n] | scratch
+    // LDS plan (n <= 8192, skewed indices):  S u64 (later bestW) | L u32 (later bestRank) | jump u32 | scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // u64 regions first so that every 64-bit LDS access (ds_*_b64, ds_add_u64, ds_max_u64) is 8-byte aligned
     unsigned long long* S = reinterpret_cast<unsigned long long*>(smem);
-    uint32_t* L = reinterpret_cast<uint32_t*>(S + (TREE_MAX_BLOCKS + 2));
-    uint32_t* jump = L + (TREE_MAX_BLOCKS + 2);
-    unsigned long long* wave_tot64 = reinterpret_cast<unsigned long long*>(jump + TREE_MAX_BLOCKS);
-    uint32_t* wave_tot32 = reinterpret_cast<uint32_t*>(wave_tot64 + 16);
+    unsigned long long* wave_tot64 = S + TREE_LDS_ENTRIES;   // 16 waves
+    unsigned long long* tot = wave_tot64 + 16;                // 2 words
+    uint32_t* L = reinterpret_cast<uint32_t*>(tot + 2);
+    uint32_t* jump = L + TREE_LDS_ENTRIES;
+    uint32_t* wave_tot32 = jump + TREE_LDS_ENTRIES;           // 16 waves
 
     const uint32_t n = tree.n;
     const int tid = threadIdx.x;
 
+    // every global read up front: one round trip of memory latency for the whole kernel
+    unsigned long long w_item[TREE_PER_THREAD];
+    uint32_t l_item[TREE_PER_THREAD], sz[TREE_PER_THREAD], par_g[TREE_PER_THREAD], rk_g[TREE_PER_THREAD],
+        idx_g[TREE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        const bool in = i < n;
+        sz[k] = in ? tree.size[i] : 0u;
+        w_item[k] = in ? direct[i] : 0ull;
+        l_item[k] = (in && tree.leaf_ok[i]) ? 1u : 0u;
+        par_g[k] = in ? tree.parent[i] : NONE32;
+        rk_g[k] = in ? tree.rank[i] + 1 : 0u;  // 0 = "no viable child yet"
+        idx_g[k] = in ? tree.idx_of_pos[i] : 0u;
+    }
+    unsigned long long t_bal = 0, t_num = 0;
+    if (boost_pos != NONE32 && !use_override && tid < VOTES_MAX_WG) {
+        t_bal = totals[tid].total_active_balance;
+        t_num = totals[tid].num_active;
+    }
+    if (clear_direct) {  // leave the engine's weight buffer zeroed for the next get_head (no memset launch)
+#pragma unroll
+        for (int k = 0; k < TREE_PER_THREAD; ++k) {
+            const uint32_t i = tid * TREE_PER_THREAD + k;
+            if (i < n) direct[i] = 0ull;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) l_item[k] = (l_item[k] && sz[k] == 1) ? 1u : 0u;
+
     // proposer boost (A.1): one extra "vote" of proposer_score at the boosted block -- it then
     // counts for that block and every ancestor, exactly the get_ancestor(...) == root test.
-    unsigned long long boost = 0;
     if (boost_pos != NONE32) {
         // sum the votes kernel's per-workgroup partial totals (all ranks' partials after the all-reduce)
-        __shared__ unsigned long long tot[2];
         if (tid == 0) { tot[0] = 0; tot[1] = 0; }
         __syncthreads();
-        if (tid < VOTES_MAX_WG && !use_override) {
-            const unsigned long long b = totals[tid].total_active_balance, c = totals[tid].num_active;
-            if (c) { atomicAdd(&tot[0], b); atomicAdd(&tot[1], c); }
-        }
+        if (t_num) { atomicAdd(&tot[0], t_bal); atomicAdd(&tot[1], t_num); }
         __syncthreads();
         unsigned long long total = use_override ? ov_balance : tot[0];
         const unsigned long long num = use_override ? ov_num : tot[1];
+        unsigned long long boost = 0;
         if (num > 0) {
             if (total < balance_increment) total = balance_increment;  // get_total_balance's max()
             const unsigned long long avg_balance = total / num;
@@ -206,20 +241,11 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
             const unsigned long long q = committee_weight / 100, r = committee_weight % 100;
             boost = q * boost_percent + (r * boost_percent) / 100;
         }
+#pragma unroll
+        for (int k = 0; k < TREE_PER_THREAD; ++k)
+            if ((uint32_t)(tid * TREE_PER_THREAD + k) == boost_pos) w_item[k] += boost;
     }
 
-    unsigned long long w_item[TREE_PER_THREAD];
-    uint32_t l_item[TREE_PER_THREAD], sz[TREE_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < TREE_PER_THREAD; ++k) {
-        const uint32_t i = tid * TREE_PER_THREAD + k;
-        const bool in = i < n;
-        sz[k] = in ? tree.size[i] : 0u;
-        unsigned long long d = in ? direct[i] : 0ull;
-        if (in && i == boost_pos) d += boost;
-        w_item[k] = d;
-        l_item[k] = (in && sz[k] == 1 && tree.leaf_ok[i]) ? 1u : 0u;
-    }
     block_exclusive_scan<unsigned long long>(w_item, S, wave_tot64, n);
     block_exclusive_scan<uint32_t>(l_item, L, wave_tot32, n);
 
@@ -230,9 +256,9 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
         const uint32_t i = tid * TREE_PER_THREAD + k;
         W[k] = 0;
         if (i < n) {
-            W[k] = S[i + sz[k]] - S[i];
-            if (L[i + sz[k]] - L[i] > 0) viable |= 1u << k;
-            weights_by_idx[tree.idx_of_pos[i]] = W[k];
+            W[k] = S[SK(i + sz[k])] - S[SK(i)];
+            if (L[SK(i + sz[k])] - L[SK(i)] > 0) viable |= 1u << k;
+            weights_by_idx[idx_g[k]] = W[k];
         }
     }
     __syncthreads();
@@ -242,57 +268,54 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k) {
         const uint32_t i = tid * TREE_PER_THREAD + k;
-        if (i < n) { bestW[i] = 0; bestRank[i] = 0; jump[i] = i; }
+        if (i < n) { bestW[SK(i)] = 0; bestRank[SK(i)] = 0; jump[SK(i)] = i; }
     }
     __syncthreads();
-    uint32_t par[TREE_PER_THREAD], rk[TREE_PER_THREAD];
+    uint32_t par[TREE_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k) {
-        const uint32_t i = tid * TREE_PER_THREAD + k;
-        par[k] = NONE32; rk[k] = 0;
-        if (i < n && ((viable >> k) & 1u)) {
-            par[k] = tree.parent[i];
-            rk[k] = tree.rank[i] + 1;  // 0 = "no viable child yet"
-            if (par[k] != NONE32) atomicMax(&bestW[par[k]], W[k]);
-        }
+        par[k] = ((viable >> k) & 1u) ? par_g[k] : NONE32;
+        if (par[k] != NONE32) atomicMax(&bestW[SK(par[k])], W[k]);
     }
     __syncthreads();
     // pass 2: among the heaviest, the lexicographically highest root
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k)
-        if (par[k] != NONE32 && W[k] == bestW[par[k]]) atomicMax(&bestRank[par[k]], rk[k]);
+        if (par[k] != NONE32 && W[k] == bestW[SK(par[k])]) atomicMax(&bestRank[SK(par[k])], rk_g[k]);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k)
-        if (par[k] != NONE32 && W[k] == bestW[par[k]] && rk[k] == bestRank[par[k]])
-            jump[par[k]] = tid * TREE_PER_THREAD + k;
+        if (par[k] != NONE32 && W[k] == bestW[SK(par[k])] && rk_g[k] == bestRank[SK(par[k])])
+            jump[SK(par[k])] = tid * TREE_PER_THREAD + k;
     __syncthreads();
-    // descent by pointer jumping: after r rounds jump[i] is 2^r best-child steps below i (or the leaf)
+    // descent by pointer jumping: after r rounds jump[i] is 2^r best-child steps below i (or the leaf);
+    // stop as soon as the justified root's pointer has reached a fixed point (a leaf of the viable tree)
     for (uint32_t span = 1; span < n; span <<= 1) {
+        const uint32_t cur = jump[SK(justified_pos)];  // same address for all lanes: broadcast, uniform
+        if (jump[SK(cur)] == cur) break;
         uint32_t nj[TREE_PER_THREAD];
 #pragma unroll
         for (int k = 0; k < TREE_PER_THREAD; ++k) {
             const uint32_t i = tid * TREE_PER_THREAD + k;
-            nj[k] = i < n ? jump[jump[i]] : 0u;
+            nj[k] = i < n ? jump[SK(jump[SK(i)])] : 0u;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < TREE_PER_THREAD; ++k) {
             const uint32_t i = tid * TREE_PER_THREAD + k;
-            if (i < n) jump[i] = nj[k];
+            if (i < n) jump[SK(i)] = nj[k];
         }
         __syncthreads();
     }
-    if (tid == 0) head_idx[0] = tree.idx_of_pos[jump[justified_pos]];
+    if (tid == 0) head_idx[0] = tree.idx_of_pos[jump[SK(justified_pos)]];
 }
 
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
                  uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
-                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx)
+                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
 {
-    const size_t lds = sizeof(uint64_t) * (TREE_MAX_BLOCKS + 2) + sizeof(uint32_t) * (TREE_MAX_BLOCKS + 2) +
-                       sizeof(uint32_t) * TREE_MAX_BLOCKS + sizeof(uint64_t) * 16 + sizeof(uint32_t) * 16;
+    const size_t lds = sizeof(uint64_t) * (TREE_LDS_ENTRIES + 18) + sizeof(uint32_t) * (2 * TREE_LDS_ENTRIES + 16);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -303,7 +326,7 @@ void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const Vot
                        totals, (unsigned long long)totals_override_balance, (unsigned long long)totals_override_num,
                        use_override, justified_pos, boost_pos, (unsigned long long)slots_per_epoch,
                        (unsigned long long)boost_percent, (unsigned long long)balance_increment,
-                       reinterpret_cast<unsigned long long*>(weights_by_idx), head_idx);
+                       reinterpret_cast<unsigned long long*>(weights_by_idx), head_idx, clear_direct);
 }
 
 // ------------------------------------------------------------------ LMD update
@@ -324,21 +347,18 @@ k_lmd(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restri
     const int lane = threadIdx.x & 63;
     const AttRow r = rows[a];
     const unsigned long long key = lmd_key(r.epoch_p1, r.order);
-    const uint32_t n_words = (r.n_bits + 31) >> 5;
-    for (uint32_t w = lane; w < n_words; w += 64) {
-        uint32_t bits = bit_arena[r.bits_word + w];
-        while (bits) {
-            const uint32_t b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            const uint32_t v = members[r.member_base + (w << 5) + b];
-            if (PHASE == 0) {
-                if (flags[v] & VAL_EQUIVOCATING) continue;  // pe:1438
-                atomicMax(&vote_key[v], key);                // strictly-later epoch wins; first in batch among equals
-            } else {
-                if (vote_key[v] == key) {                    // unique winner: (epoch, order) identifies one attestation
-                    vote_block[v] = r.block_idx;
-                    vote_key[v] = ((unsigned long long)r.epoch_p1 << 32) | 0xFFFFFFFFull;  // settled
-                }
+    // lane-parallel over bit positions: every lane tests its own bit (the 32 lanes sharing a word hit one line)
+    for (uint32_t i = lane; i < r.n_bits; i += 64) {
+        const uint32_t word = bit_arena[r.bits_word + (i >> 5)];
+        if (!((word >> (i & 31)) & 1u)) continue;
+        const uint32_t v = members[r.member_base + i];
+        if (PHASE == 0) {
+            if (flags[v] & VAL_EQUIVOCATING) continue;  // pe:1438
+            atomicMax(&vote_key[v], key);                // strictly-later epoch wins; first in batch among equals
+        } else {
+            if (vote_key[v] == key) {                    // unique winner: (epoch, order) identifies one attestation
+                vote_block[v] = r.block_idx;
+                vote_key[v] = ((unsigned long long)r.epoch_p1 << 32) | 0xFFFFFFFFull;  // settled
             }
         }
     }
@@ -368,24 +388,20 @@ k_participation(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t
     const int lane = threadIdx.x & 63;
     const AttRow r = rows[a];
     uint32_t* part = r.which ? part_prev : part_cur;
-    const uint32_t n_words = (r.n_bits + 31) >> 5;
     unsigned long long num = 0;
-    for (uint32_t w = lane; w < n_words; w += 64) {
-        uint32_t bits = bit_arena[r.bits_word + w];
-        while (bits) {
-            const uint32_t b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            const uint32_t v = members[r.member_base + (w << 5) + b];
-            const uint32_t sh = 8u * (v & 3u);
-            // attestations of one round touch disjoint validators; the word-wide atomic only guards
-            // the three neighbours sharing the 32-bit word
-            const uint32_t old = atomicOr(&part[v >> 2], r.flag_mask << sh);
-            const uint32_t fresh = r.flag_mask & ~(old >> sh) & 0x7u;
-            if (fresh) {
-                // PARTICIPATION_FLAG_WEIGHTS = [14, 26, 14] (Appendix A.9)
-                const uint32_t wsum = ((fresh & 1u) ? 14u : 0u) + ((fresh & 2u) ? 26u : 0u) + ((fresh & 4u) ? 14u : 0u);
-                num += (unsigned long long)eff_increments[v] * base_reward_per_increment * wsum;
-            }
+    for (uint32_t i = lane; i < r.n_bits; i += 64) {
+        const uint32_t word = bit_arena[r.bits_word + (i >> 5)];
+        if (!((word >> (i & 31)) & 1u)) continue;
+        const uint32_t v = members[r.member_base + i];
+        const uint32_t sh = 8u * (v & 3u);
+        // attestations of one round touch disjoint validators; the word-wide atomic only guards
+        // the three neighbours sharing the 32-bit word
+        const uint32_t old = atomicOr(&part[v >> 2], r.flag_mask << sh);
+        const uint32_t fresh = r.flag_mask & ~(old >> sh) & 0x7u;
+        if (fresh) {
+            // PARTICIPATION_FLAG_WEIGHTS = [14, 26, 14] (Appendix A.9)
+            const uint32_t wsum = ((fresh & 1u) ? 14u : 0u) + ((fresh & 2u) ? 26u : 0u) + ((fresh & 4u) ? 14u : 0u);
+            num += (unsigned long long)eff_increments[v] * base_reward_per_increment * wsum;
         }
     }
     num = wave_sum_u64(num);

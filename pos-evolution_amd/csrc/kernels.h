@@ -55,12 +55,12 @@ struct VoteTotals {            // one per K_votes workgroup (VOTES_MAX_WG slots)
 // direct[pos] += effective_balance of every counted validator voting for the block at pos.
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx,
-                  uint32_t n_blocks, uint64_t* direct, VoteTotals* totals);
+                  uint32_t n_blocks, uint64_t* direct, VoteTotals* totals, int zero_first);
 // Subtree sums (prefix scan over pre-order), viability, best child, pointer-jumping descent.
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
                  uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
-                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx);
+                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct);
 
 // One resolved attestation (device row).
 struct AttRow {
