@@ -127,7 +127,10 @@ struct CommitteeTable {
     uint32_t n_committees = 0;
     std::vector<uint32_t> offsets;  // n_committees + 1
     DevBuf d_members;               // u32[offsets.back()]
+    DevBuf d_offsets;               // u32[n_committees + 1]
+    DevBuf d_inv_comm, d_inv_pos;   // partition tables only: validator -> (committee id, index in committee)
     bool is_partition = false;      // every validator in at most one committee (true for a real shuffling)
+    uint64_t n_val_at_load = 0;     // registry size the inverse map was built for
     uint64_t stamp = 0;
 };
 
@@ -752,7 +755,7 @@ void pe_engine_destroy(pe_engine* h)
                       &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_stage,
                       &h->d_outblk, &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
         b->release();
-    for (auto& t : h->tables) t.d_members.release();
+    for (auto& t : h->tables) { t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release(); }
     h->h_pin.release();
     h->h_head.release();
     h->h_stage.release();
@@ -1053,7 +1056,17 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const
         }
     }
     HIP_TRY(h, t->d_members.ensure(std::max<size_t>(64, 4ull * total)));
+    HIP_TRY(h, t->d_offsets.ensure(4ull * (n_committees + 1)));
     HIP_TRY(h, hipMemcpyAsync(t->d_members.p, members, 4ull * total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(t->d_offsets.p, offsets, 4ull * (n_committees + 1), hipMemcpyHostToDevice, h->stream));
+    if (partition && h->n_val) {
+        HIP_TRY(h, t->d_inv_comm.ensure(4ull * h->n_val));
+        HIP_TRY(h, t->d_inv_pos.ensure(4ull * h->n_val));
+        launch_invert_committees(h->stream, t->d_members.as<uint32_t>(), t->d_offsets.as<uint32_t>(), n_committees,
+                                 t->d_inv_comm.as<uint32_t>(), t->d_inv_pos.as<uint32_t>(), h->n_val);
+        HIP_TRY(h, hipGetLastError());
+    }
+    t->n_val_at_load = h->n_val;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     t->epoch = epoch;
     t->n_committees = n_committees;
@@ -1158,7 +1171,9 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
         word_bound += (a.n_bits + 31) / 32 + 1;
     }
     Stage st(h);
-    HIP_TRY(h, st.reserve(word_bound * 4 + (sizeof(AttRow) + sizeof(G1Group)) * (size_t)n + 4096));
+    size_t csr_bound = 4ull * n + 1024;
+    for (auto& t : h->tables) csr_bound += 4ull * (t.n_committees + 1) + 512;
+    HIP_TRY(h, st.reserve(word_bound * 4 + (sizeof(AttRow) + sizeof(G1Group)) * (size_t)n + csr_bound + 4096));
     const size_t off_words = st.alloc(word_bound * 4);
     const size_t off_rows = st.alloc(sizeof(AttRow) * (size_t)n);
     const size_t off_groups = st.alloc(sizeof(G1Group) * (size_t)n);
@@ -1243,6 +1258,29 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
             }
         }
     }
+    // Large batches on a partition table: validator-major LMD pass (streams the V-sized tables once, no atomics).
+    // Small ones: committee-major with atomics (touches only the attesting validators).
+    std::vector<size_t> seg_vm(segs.size(), (size_t)-1), seg_vm_list(segs.size(), 0);
+    for (size_t sg = 0; sg < segs.size(); ++sg) {
+        CommitteeTable* t = segs[sg].first;
+        const uint32_t b0 = segs[sg].second.first, e0 = segs[sg].second.second;
+        uint64_t bits_total = 0;
+        for (uint32_t k = b0; k < e0; ++k) bits_total += rows[k].n_bits;
+        if (!t->is_partition || t->n_val_at_load != h->n_val || !t->d_inv_comm.p || bits_total * 8 < h->n_val) continue;
+        const uint32_t nc = t->n_committees;
+        const size_t off_cs = st.alloc(4ull * (nc + 1));
+        const size_t off_cl = st.alloc(4ull * (e0 - b0));
+        if (st.used > h->h_stage.cap) return fail(h, PE_ERR_OOM, "staging block overflow");
+        uint32_t* cs = st.host<uint32_t>(off_cs);
+        uint32_t* cl = st.host<uint32_t>(off_cl);
+        memset(cs, 0, 4ull * (nc + 1));
+        for (uint32_t k = b0; k < e0; ++k) cs[res[row_src[k]].pos + 1] += 1;
+        for (uint32_t c = 0; c < nc; ++c) cs[c + 1] += cs[c];
+        std::vector<uint32_t> cur(cs, cs + nc);
+        for (uint32_t k = b0; k < e0; ++k) cl[cur[res[row_src[k]].pos]++] = k - b0;  // batch order kept
+        seg_vm[sg] = off_cs;
+        seg_vm_list[sg] = off_cl;
+    }
     lap.mark("att.1_validate_pack");
     HIP_TRY(h, st.upload());
     for (size_t sg = 0; sg < segs.size(); ++sg) {
@@ -1250,9 +1288,16 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
         const uint32_t b0 = segs[sg].second.first, e0 = segs[sg].second.second;
         {
             ProfScope ps(h, PE_KERNEL_LMD);
-            launch_lmd_update(h->stream, st.dev<AttRow>(off_rows) + b0, e0 - b0, t->d_members.as<uint32_t>(),
-                              st.dev<uint32_t>(off_words), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
-                              h->d_vote_block.as<uint32_t>());
+            if (seg_vm[sg] != (size_t)-1)
+                launch_lmd_validator_major(h->stream, st.dev<AttRow>(off_rows) + b0, st.dev<uint32_t>(seg_vm[sg]),
+                                           st.dev<uint32_t>(seg_vm_list[sg]), t->d_inv_comm.as<uint32_t>(),
+                                           t->d_inv_pos.as<uint32_t>(), st.dev<uint32_t>(off_words),
+                                           h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
+                                           h->d_vote_block.as<uint32_t>());
+            else
+                launch_lmd_update(h->stream, st.dev<AttRow>(off_rows) + b0, e0 - b0, t->d_members.as<uint32_t>(),
+                                  st.dev<uint32_t>(off_words), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
+                                  h->d_vote_block.as<uint32_t>());
         }
         if (out_aggpk96) {
             rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(),

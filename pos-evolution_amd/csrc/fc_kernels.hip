@@ -364,6 +364,77 @@ k_lmd(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restri
     }
 }
 
+// Inverse of a committee table that partitions the validators: inv[v] = (committee id, index in committee).
+__global__ void __launch_bounds__(256)
+k_invert_committees(const uint32_t* __restrict__ members, const uint32_t* __restrict__ offsets, uint32_t n_committees,
+                    uint32_t* __restrict__ inv_comm, uint32_t* __restrict__ inv_pos)
+{
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_committees) return;
+    const uint32_t b = offsets[c], e = offsets[c + 1];
+    for (uint32_t i = b + (threadIdx.x & 63); i < e; i += 64) {
+        const uint32_t v = members[i];
+        inv_comm[v] = c;
+        inv_pos[v] = i - b;
+    }
+}
+
+void launch_invert_committees(hipStream_t s, const uint32_t* members, const uint32_t* offsets, uint32_t n_committees,
+                              uint32_t* inv_comm, uint32_t* inv_pos, uint64_t n_val)
+{
+    (void)hipMemsetAsync(inv_comm, 0xFF, 4ull * n_val, s);
+    if (n_committees == 0) return;
+    hipLaunchKernelGGL(k_invert_committees, dim3((n_committees + 3) / 4), dim3(256), 0, s, members, offsets,
+                       n_committees, inv_comm, inv_pos);
+}
+
+// update_latest_messages (pe:1435-1441), validator-major: one lane per validator walks the batch rows of ITS
+// committee in batch order -- literally the spec's sequential loop, so no atomics and no tie-break tag are needed;
+// vote/flag/key tables are streamed (coalesced) instead of hit by a million random 8-byte atomics.
+// crow_start/crow_list: CSR of batch rows per committee id (rows in batch order).
+__global__ void __launch_bounds__(256)
+k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restrict__ crow_start,
+                      const uint32_t* __restrict__ crow_list, const uint32_t* __restrict__ inv_comm,
+                      const uint32_t* __restrict__ inv_pos, const uint32_t* __restrict__ bit_arena,
+                      const uint8_t* __restrict__ flags, uint64_t n_val, unsigned long long* __restrict__ vote_key,
+                      uint32_t* __restrict__ vote_block)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_val) return;
+    const uint32_t c = inv_comm[v];
+    if (c == NONE32) return;
+    const uint32_t kb = crow_start[c], ke = crow_start[c + 1];
+    if (kb == ke) return;
+    if (flags[v] & VAL_EQUIVOCATING) return;  // pe:1438
+    const uint32_t i = inv_pos[v];
+    uint32_t epoch_p1 = (uint32_t)(vote_key[v] >> 32);  // 0 = no latest message
+    uint32_t new_block = NONE32;
+    for (uint32_t k = kb; k < ke; ++k) {
+        const AttRow r = rows[crow_list[k]];
+        if (i >= r.n_bits) continue;
+        if (!((bit_arena[r.bits_word + (i >> 5)] >> (i & 31)) & 1u)) continue;
+        if (r.epoch_p1 > epoch_p1) {  // "i not in latest_messages or target.epoch > latest_messages[i].epoch"
+            epoch_p1 = r.epoch_p1;
+            new_block = r.block_idx;
+        }
+    }
+    if (new_block != NONE32) {
+        vote_key[v] = ((unsigned long long)epoch_p1 << 32) | 0xFFFFFFFFull;
+        vote_block[v] = new_block;
+    }
+}
+
+void launch_lmd_validator_major(hipStream_t s, const AttRow* rows, const uint32_t* crow_start,
+                                const uint32_t* crow_list, const uint32_t* inv_comm, const uint32_t* inv_pos,
+                                const uint32_t* bit_arena, const uint8_t* flags, uint64_t n_val, uint64_t* vote_key,
+                                uint32_t* vote_block)
+{
+    if (n_val == 0) return;
+    hipLaunchKernelGGL(k_lmd_validator_major, dim3((unsigned)((n_val + 255) / 256)), dim3(256), 0, s, rows, crow_start,
+                       crow_list, inv_comm, inv_pos, bit_arena, flags, n_val,
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block);
+}
+
 void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                        const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block)
 {
@@ -393,12 +464,13 @@ k_participation(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t
         const uint32_t word = bit_arena[r.bits_word + (i >> 5)];
         if (!((word >> (i & 31)) & 1u)) continue;
         const uint32_t v = members[r.member_base + i];
-        const uint32_t sh = 8u * (v & 3u);
-        // attestations of one round touch disjoint validators; the word-wide atomic only guards
-        // the three neighbours sharing the 32-bit word
-        const uint32_t old = atomicOr(&part[v >> 2], r.flag_mask << sh);
-        const uint32_t fresh = r.flag_mask & ~(old >> sh) & 0x7u;
+        // attestations of one round touch pairwise disjoint validators, and byte stores do not disturb the
+        // neighbouring bytes: a plain byte read-modify-write is exact here (no atomics on the hot path)
+        uint8_t* pb = reinterpret_cast<uint8_t*>(part) + v;
+        const uint32_t old = *pb;
+        const uint32_t fresh = r.flag_mask & ~old & 0x7u;
         if (fresh) {
+            *pb = (uint8_t)(old | r.flag_mask);
             // PARTICIPATION_FLAG_WEIGHTS = [14, 26, 14] (Appendix A.9)
             const uint32_t wsum = ((fresh & 1u) ? 14u : 0u) + ((fresh & 2u) ? 26u : 0u) + ((fresh & 4u) ? 14u : 0u);
             num += (unsigned long long)eff_increments[v] * base_reward_per_increment * wsum;

@@ -76,6 +76,13 @@ struct AttRow {
 // update_latest_messages for a batch: phase 1 atomicMax of (epoch+1, ~order), phase 2 winners write.
 void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                        const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block);
+// inverse committee map (partition tables only) and the validator-major form of update_latest_messages
+void launch_invert_committees(hipStream_t s, const uint32_t* members, const uint32_t* offsets, uint32_t n_committees,
+                              uint32_t* inv_comm, uint32_t* inv_pos, uint64_t n_val);
+void launch_lmd_validator_major(hipStream_t s, const AttRow* rows, const uint32_t* crow_start,
+                                const uint32_t* crow_list, const uint32_t* inv_comm, const uint32_t* inv_pos,
+                                const uint32_t* bit_arena, const uint8_t* flags, uint64_t n_val, uint64_t* vote_key,
+                                uint32_t* vote_block);
 // process_attestation flag loop for one round of pairwise-disjoint attestations.
 void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                           const uint32_t* bit_arena, const uint16_t* eff_increments,
