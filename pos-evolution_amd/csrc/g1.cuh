@@ -33,7 +33,7 @@ __device__ __forceinline__ void g1j_set_inf(g1j& p)
 __device__ __forceinline__ bool g1j_is_inf(const g1j& p) { return fp_is_zero(p.z); }
 
 // dbl-2009-l (a = 0)
-__device__ __noinline__ void g1j_double(g1j& r, const g1j& p)
+__device__ __forceinline__ void g1j_double(g1j& r, const g1j& p)
 {
     if (g1j_is_inf(p) || fp_is_zero(p.y)) {
         g1j_set_inf(r);
