@@ -102,7 +102,7 @@ def run_step_sharded(e, w, st, sh):
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
-    agg = sh.aggregate(packed=(st["atts"], st["arena"]))    # all-gather of C x 144 B Jacobian partials inside
+    agg = sh.aggregate(packed=(st["atts"], st["arena"]))    # all-gather of C x 192 B XYZZ partials inside
     g = agg["n_groups"]
     rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
     status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))

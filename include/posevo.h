@@ -281,10 +281,10 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
 #define PE_EXCHANGE_EXTRA 512
 int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks);
 int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32]);
-/* G1: per-group Jacobian partial sums (144 B each, Montgomery form) of this shard's
+/* G1: per-group partial sums in XYZZ coordinates (X|Y|ZZ|ZZZ, 4 x 48 B, Montgomery form) of this shard's
  * points into a caller-owned DEVICE buffer; after an all-gather over ranks,
  * pe_g1_finish adds the n_ranks partials per group and normalises to affine. */
-#define PE_G1_PARTIAL_BYTES 144
+#define PE_G1_PARTIAL_BYTES 192
 int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups,
                   void* dev_partials);
 int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups,

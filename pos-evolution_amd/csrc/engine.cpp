@@ -536,7 +536,7 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac)
 {
     if (plan.n_groups == 0) return PE_OK;
-    HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(144, 144ull * plan.n_partials)));
+    HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
     {
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE);
         launch_g1_accumulate(h->stream, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,

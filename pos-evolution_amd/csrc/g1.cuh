@@ -1,189 +1,221 @@
 // g1.cuh -- BLS12-381 G1 (y^2 = x^3 + 4 over Fp) point arithmetic for gfx950, device only.
 //
-// Accumulators are Jacobian (X : Y : Z), Z == 0 <=> infinity; inputs are affine.
-// Every edge case of the group law is exact (inf + Q, P + inf, P + P -> double,
-// P + (-P) -> inf): structured synthetic keys ((i+1)*G) hit the doubling branch
-// and P/-P pairs hit infinity (SURVEY.md 7 "hard parts" (ii)).  The rare
-// branches are divergent on purpose: the common path stays straight-line.
+// Accumulators use extended Jacobian "XYZZ" coordinates (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ,
+// ZZ^3 = ZZZ^2; ZZ == 0 <=> infinity.  Inputs are affine.  XYZZ costs 10 Montgomery products for a
+// mixed add (8M + 2S) and 14 for a full add (12M + 2S) against 11 / 16 for plain Jacobian -- on a
+// part whose only wide multiplier is v_mad_u64_u32 the product count is the whole cost.
 //
-// Replaces: the point additions inside bls.Aggregate / the pubkey sum of
-// bls.FastAggregateVerify -- called by is_valid_indexed_attestation
-// (reference call sites pe:736, pe:976; the reference itself contains no BLS
-// arithmetic, see oracle/g1.py header).
+// Every edge case of the group law is exact (inf + Q, P + inf, P + P -> double, P + (-P) -> inf):
+// structured synthetic keys ((i+1)*G) hit the doubling branch and P/-P pairs hit infinity
+// (SURVEY.md 7 "hard parts" (ii)).  The rare branches are divergent on purpose and INLINED: a
+// non-inlined call inside the accumulation loop made the register allocator spill 160 B per point
+// to scratch (profiles/: WRITE_SIZE 163 MB per launch before, 0.3 MB after).
+//
+// Replaces: the point additions inside bls.Aggregate / the pubkey sum of bls.FastAggregateVerify --
+// called by is_valid_indexed_attestation (reference call sites pe:736, pe:976; the reference
+// itself contains no BLS arithmetic, see oracle/g1.py header).
 #pragma once
 #include "fp381.cuh"
 #include "fp_inv_safegcd.h"
 
 namespace posevo {
 
-struct g1j {
-    fp x, y, z;
+struct g1x {
+    fp x, y, zz, zzz;
 };
-struct g1a {
-    fp x, y;
-    uint32_t inf;
-};
+constexpr int G1X_WORDS = 48;  // u32 words of one XYZZ point (192 bytes = PE_G1_PARTIAL_BYTES)
 
-__device__ __forceinline__ void g1j_set_inf(g1j& p)
+__device__ __forceinline__ void g1x_set_inf(g1x& p)
 {
     fp_set_zero(p.x);
     fp_set_zero(p.y);
-    fp_set_zero(p.z);
+    fp_set_zero(p.zz);
+    fp_set_zero(p.zzz);
 }
-__device__ __forceinline__ bool g1j_is_inf(const g1j& p) { return fp_is_zero(p.z); }
+__device__ __forceinline__ bool g1x_is_inf(const g1x& p) { return fp_is_zero(p.zz); }
 
-// dbl-2009-l (a = 0)
-__device__ __forceinline__ void g1j_double(g1j& r, const g1j& p)
+// dbl-2008-s-1 (a = 0).  Only ever taken when an accumulator meets an equal point.
+// Value in, value out: keeps every coordinate in SSA registers (a by-reference form left the accumulator in
+// private memory behind a pointer phi -- 372 B of scratch per lane in the hot loop).
+__device__ __forceinline__ g1x g1x_double(const g1x p)
 {
-    if (g1j_is_inf(p) || fp_is_zero(p.y)) {
-        g1j_set_inf(r);
-        return;
-    }
-    fp A, B, C, D, E, F, t;
-    fp_sqr(A, p.x);
-    fp_sqr(B, p.y);
-    fp_sqr(C, B);
-    fp_add(t, p.x, B);
-    fp_sqr(t, t);
-    fp_sub(t, t, A);
-    fp_sub(t, t, C);
-    fp_dbl(D, t);
-    fp_dbl(E, A);
-    fp_add(E, E, A);
-    fp_sqr(F, E);
-    fp X3, Y3, Z3;
-    fp_dbl(t, D);
-    fp_sub(X3, F, t);
-    fp_mul(Z3, p.y, p.z);
-    fp_dbl(Z3, Z3);
-    fp_sub(t, D, X3);
-    fp_mul(Y3, E, t);
-    fp_dbl(C, C);
-    fp_dbl(C, C);
-    fp_dbl(C, C);
-    fp_sub(Y3, Y3, C);
+    g1x r;
+    fp U, V, W, S, M, t, X3, Y3;
+    fp_dbl(U, p.y);
+    fp_sqr(V, U);
+    fp_mul(W, U, V);
+    fp_mul(S, p.x, V);
+    fp_sqr(M, p.x);
+    fp_dbl(t, M);
+    fp_add(M, M, t);  // 3 X^2
+    fp_sqr(X3, M);
+    fp_dbl(t, S);
+    fp_sub(X3, X3, t);
+    fp_sub(t, S, X3);
+    fp_mul(Y3, M, t);
+    fp_mul(t, W, p.y);
+    fp_sub(Y3, Y3, t);
+    fp_mul(r.zz, V, p.zz);
+    fp_mul(r.zzz, W, p.zzz);
     r.x = X3;
     r.y = Y3;
-    r.z = Z3;
+    // infinity in, or a point of order two (none exist on this curve, kept for exactness): infinity out
+    const bool inf = fp_is_zero(p.zz) || fp_is_zero(p.y);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        r.x.l[j] = inf ? 0u : r.x.l[j];
+        r.y.l[j] = inf ? 0u : r.y.l[j];
+        r.zz.l[j] = inf ? 0u : r.zz.l[j];
+        r.zzz.l[j] = inf ? 0u : r.zzz.l[j];
+    }
+    return r;
 }
 
-// acc += q (mixed addition, 8M + 3S).  q.inf handled by the caller-visible flag.
-__device__ __forceinline__ void g1j_add_affine(g1j& acc, const fp& qx, const fp& qy, bool q_inf)
+// acc += q  (madd-2008-s: 8M + 2S)
+__device__ __forceinline__ void g1x_add_affine(g1x& acc, const fp& qx, const fp& qy, bool q_inf)
 {
     if (q_inf) return;
-    if (g1j_is_inf(acc)) {
+    if (g1x_is_inf(acc)) {
         acc.x = qx;
         acc.y = qy;
-        fp_set_one(acc.z);
+        fp_set_one(acc.zz);
+        fp_set_one(acc.zzz);
         return;
     }
-    fp Z2, U2, S2, H, Rr;
-    fp_sqr(Z2, acc.z);
-    fp_mul(U2, qx, Z2);
-    fp_mul(S2, qy, Z2);
-    fp_mul(S2, S2, acc.z);
-    fp_sub(H, U2, acc.x);
-    fp_sub(Rr, S2, acc.y);
-    if (fp_is_zero(H)) {
-        if (fp_is_zero(Rr)) {
-            g1j t = acc;
-            g1j_double(acc, t);
-        } else {
-            g1j_set_inf(acc);
-        }
+    fp U2, S2, P, R;
+    fp_mul(U2, qx, acc.zz);
+    fp_mul(S2, qy, acc.zzz);
+    fp_sub(P, U2, acc.x);
+    fp_sub(R, S2, acc.y);
+    if (fp_is_zero(P)) {
+        if (fp_is_zero(R)) acc = g1x_double(acc);
+        else g1x_set_inf(acc);
         return;
     }
-    fp HH, HHH, V, t;
-    fp_sqr(HH, H);
-    fp_mul(HHH, HH, H);
-    fp_mul(V, acc.x, HH);
-    fp X3;
-    fp_sqr(X3, Rr);
-    fp_sub(X3, X3, HHH);
-    fp_dbl(t, V);
+    fp PP, PPP, Q, X3, t;
+    fp_sqr(PP, P);
+    fp_mul(PPP, P, PP);
+    fp_mul(Q, acc.x, PP);
+    fp_sqr(X3, R);
+    fp_sub(X3, X3, PPP);
+    fp_dbl(t, Q);
     fp_sub(X3, X3, t);
-    fp_sub(t, V, X3);
-    fp_mul(t, Rr, t);
-    fp_mul(HHH, acc.y, HHH);
-    fp_sub(acc.y, t, HHH);
-    fp_mul(acc.z, acc.z, H);
+    fp_sub(t, Q, X3);
+    fp_mul(t, R, t);
+    fp_mul(Q, acc.y, PPP);
+    fp_sub(acc.y, t, Q);
+    fp_mul(acc.zz, acc.zz, PP);
+    fp_mul(acc.zzz, acc.zzz, PPP);
     acc.x = X3;
 }
 
-// p += q, both Jacobian (add-2007-bl shape, 12M + 4S)
-__device__ __forceinline__ void g1j_add(g1j& p, const g1j& q)
+// p += q, both XYZZ (add-2008-s: 12M + 2S), single lane, all edge cases
+__device__ __forceinline__ void g1x_add(g1x& p, const g1x& q)
 {
-    if (g1j_is_inf(q)) return;
-    if (g1j_is_inf(p)) {
+    if (g1x_is_inf(q)) return;
+    if (g1x_is_inf(p)) {
         p = q;
         return;
     }
-    fp Z1Z1, Z2Z2, U1, U2, S1, S2, H, Rr;
-    fp_sqr(Z1Z1, p.z);
-    fp_sqr(Z2Z2, q.z);
-    fp_mul(U1, p.x, Z2Z2);
-    fp_mul(U2, q.x, Z1Z1);
-    fp_mul(S1, p.y, Z2Z2);
-    fp_mul(S1, S1, q.z);
-    fp_mul(S2, q.y, Z1Z1);
-    fp_mul(S2, S2, p.z);
-    fp_sub(H, U2, U1);
-    fp_sub(Rr, S2, S1);
-    if (fp_is_zero(H)) {
-        if (fp_is_zero(Rr)) {
-            g1j t = p;
-            g1j_double(p, t);
-        } else {
-            g1j_set_inf(p);
-        }
+    fp U1, U2, S1, S2, P, R;
+    fp_mul(U1, p.x, q.zz);
+    fp_mul(U2, q.x, p.zz);
+    fp_mul(S1, p.y, q.zzz);
+    fp_mul(S2, q.y, p.zzz);
+    fp_sub(P, U2, U1);
+    fp_sub(R, S2, S1);
+    if (fp_is_zero(P)) {
+        if (fp_is_zero(R)) p = g1x_double(p);
+        else g1x_set_inf(p);
         return;
     }
-    fp HH, HHH, V, t;
-    fp_sqr(HH, H);
-    fp_mul(HHH, HH, H);
-    fp_mul(V, U1, HH);
-    fp X3;
-    fp_sqr(X3, Rr);
-    fp_sub(X3, X3, HHH);
-    fp_dbl(t, V);
+    fp PP, PPP, Q, X3, t;
+    fp_sqr(PP, P);
+    fp_mul(PPP, P, PP);
+    fp_mul(Q, U1, PP);
+    fp_sqr(X3, R);
+    fp_sub(X3, X3, PPP);
+    fp_dbl(t, Q);
     fp_sub(X3, X3, t);
-    fp_sub(t, V, X3);
-    fp_mul(t, Rr, t);
-    fp_mul(S1, S1, HHH);
+    fp_sub(t, Q, X3);
+    fp_mul(t, R, t);
+    fp_mul(S1, S1, PPP);
     fp_sub(p.y, t, S1);
-    fp_mul(t, p.z, q.z);
-    fp_mul(p.z, t, H);
+    fp_mul(t, p.zz, q.zz);
+    fp_mul(p.zz, t, PP);
+    fp_mul(t, p.zzz, q.zzz);
+    fp_mul(p.zzz, t, PPP);
     p.x = X3;
 }
 
-// a^(p-2): plain square-and-multiply over the 381 exponent bits (Fermat).
-__device__ __noinline__ void fp_inv_fermat(fp& r, const fp& a)
+// ---- two-lane cooperative add (lanes 2w and 2w+1 of a wave, identical instruction stream) -------------
+// A full add is 14 products of dependency depth 7 when split over two lanes.  Both lanes run the SAME
+// seven fp_mul's on role-selected operands (role = lane & 1) and swap four field elements through DPP:
+//   role 0 ("own" = P1): U1, S1, PP, PPP, Q, R*(Q-X3), S1*PPP                -> produces X3, Y3
+//   role 1 ("own" = P2): U2, S2, RR, ZZ1*ZZ2, ZZZ1*ZZZ2, (..)*PP, (..)*PPP   -> produces ZZ3, ZZZ3
+// In the LDS tree half of the lanes idle anyway, so the second lane is free.
+__device__ __forceinline__ void fp_select(fp& r, bool c, const fp& a, const fp& b)  // r = c ? a : b
 {
-    fp acc, base = a;
-    fp_set_one(acc);
-    for (int i = 0; i < 12; ++i) {
-        uint32_t e = fp_p_limb(0);
-        // p - 2: only limb 0 differs (…aaab - 2 = …aaa9)
-        switch (i) {
-            case 0: e = fp_p_limb(0) - 2u; break;
-            case 1: e = fp_p_limb(1); break;
-            case 2: e = fp_p_limb(2); break;
-            case 3: e = fp_p_limb(3); break;
-            case 4: e = fp_p_limb(4); break;
-            case 5: e = fp_p_limb(5); break;
-            case 6: e = fp_p_limb(6); break;
-            case 7: e = fp_p_limb(7); break;
-            case 8: e = fp_p_limb(8); break;
-            case 9: e = fp_p_limb(9); break;
-            case 10: e = fp_p_limb(10); break;
-            default: e = fp_p_limb(11); break;
-        }
-        for (int b = 0; b < 32; ++b) {
-            if ((e >> b) & 1u) fp_mul(acc, acc, base);
-            fp_sqr(base, base);
-        }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) r.l[j] = c ? a.l[j] : b.l[j];
+}
+__device__ __forceinline__ void fp_xchg(fp& r, const fp& a)  // r = a of the partner lane (lane ^ 1)
+{
+#pragma unroll
+    for (int j = 0; j < 12; ++j) r.l[j] = (uint32_t)__shfl_xor((int)a.l[j], 1, 64);
+}
+
+// Inputs (per lane): own point's X, Y, ZZ, ZZZ and the partner point's ZZ, ZZZ.  role 0 owns P1, role 1 owns P2.
+// Precondition (checked by the caller): neither point is infinity.
+// Returns false (outputs undefined) when P == 0, i.e. P1 = +-P2: the caller takes the slow path.
+// Outputs: role 0: out_a = X3, out_b = Y3;  role 1: out_a = ZZ3, out_b = ZZZ3.
+__device__ __forceinline__ bool g1x_add_pair(fp& out_a, fp& out_b, bool role, const fp& x_own, const fp& y_own,
+                                             const fp& zz_own, const fp& zzz_own, const fp& zz_oth, const fp& zzz_oth)
+{
+    fp m1, m2, o1, o2;
+    fp_mul(m1, x_own, zz_oth);   // U1 | U2
+    fp_mul(m2, y_own, zzz_oth);  // S1 | S2
+    fp_xchg(o1, m1);
+    fp_xchg(o2, m2);
+    fp U1, S1, P, R;
+    {
+        fp U2, S2;
+        fp_select(U1, role, o1, m1);
+        fp_select(U2, role, m1, o1);
+        fp_select(S1, role, o2, m2);
+        fp_select(S2, role, m2, o2);
+        fp_sub(P, U2, U1);
+        fp_sub(R, S2, S1);
     }
-    r = acc;
+    if (fp_is_zero(P)) return false;  // identical in both lanes of the pair
+    fp a, b, m3, x3, m4, x4, m5;
+    fp_select(a, role, R, P);
+    fp_sqr(m3, a);    // PP | RR
+    fp_xchg(x3, m3);  // role 0 receives RR, role 1 receives PP
+    fp_select(a, role, zz_own, P);
+    fp_select(b, role, zz_oth, m3);
+    fp_mul(m4, a, b);  // PPP | ZZ1*ZZ2
+    fp_xchg(x4, m4);   // role 1 receives PPP
+    fp_select(a, role, zzz_own, U1);
+    fp_select(b, role, zzz_oth, m3);
+    fp_mul(m5, a, b);  // Q | ZZZ1*ZZZ2
+    // role 0: X3 = RR - PPP - 2Q, T = Q - X3   (role 1 computes don't-cares)
+    fp X3, T, t;
+    fp_sub(X3, x3, m4);
+    fp_dbl(t, m5);
+    fp_sub(X3, X3, t);
+    fp_sub(T, m5, X3);
+    fp m6, m7;
+    fp_select(a, role, m4, R);   // ZZ1*ZZ2   | R
+    fp_select(b, role, x3, T);   // PP        | Q - X3
+    fp_mul(m6, a, b);            // role 0: R*(Q-X3), role 1: ZZ3
+    fp_select(a, role, m5, S1);  // ZZZ1*ZZZ2 | S1
+    fp_select(b, role, x4, m4);  // PPP (received) | PPP (own)
+    fp_mul(m7, a, b);            // role 0: S1*PPP, role 1: ZZZ3
+    fp_sub(t, m6, m7);           // role 0: Y3
+    fp_select(out_a, role, m6, X3);
+    fp_select(out_b, role, m7, t);
+    return true;
 }
 
 // R^3 mod p: fp_mul(t, R^3) = t * R^2, lifting (xR)^-1 = x^-1 R^-1 back to Montgomery form x^-1 R
@@ -206,6 +238,18 @@ __device__ __noinline__ void fp_inv(fp& r, const fp& a)
         r3.l[j] = fp_r3_limb(j);
     }
     fp_mul(r, t, r3);
+}
+
+// XYZZ -> affine (x, y), Montgomery form.  One inversion: i = 1/(ZZ*ZZZ) = Z^-5; 1/ZZ = i*ZZZ, 1/ZZZ = i*ZZ.
+__device__ __forceinline__ void g1x_to_affine(fp& x, fp& y, const g1x& p)
+{
+    fp t, i, izz, izzz;
+    fp_mul(t, p.zz, p.zzz);
+    fp_inv(i, t);
+    fp_mul(izz, i, p.zzz);
+    fp_mul(izzz, i, p.zz);
+    fp_mul(x, p.x, izz);
+    fp_mul(y, p.y, izzz);
 }
 
 }  // namespace posevo

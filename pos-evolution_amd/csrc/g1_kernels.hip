@@ -65,50 +65,60 @@ __device__ __forceinline__ void load_point(fp& x, fp& y, const uint32_t* __restr
     y.l[8] = v5.x; y.l[9] = v5.y; y.l[10] = v5.z; y.l[11] = v5.w;
 }
 
-// LDS staging of the workgroup's Jacobian partials, limb-major: word k of slot s at lds[k*256 + s].
-__device__ __forceinline__ void lds_store_j(uint32_t* lds, int slot, const g1j& p)
+// LDS staging of the workgroup's XYZZ partials, limb-major: word k of slot s at lds[k*256 + s]
+// (coordinate c occupies words 12c .. 12c+11).
+__device__ __forceinline__ void lds_store_fp(uint32_t* lds, int coord, int slot, const fp& v)
 {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        lds[k * G1_WG + slot] = p.x.l[k];
-        lds[(12 + k) * G1_WG + slot] = p.y.l[k];
-        lds[(24 + k) * G1_WG + slot] = p.z.l[k];
-    }
+    for (int k = 0; k < 12; ++k) lds[(12 * coord + k) * G1_WG + slot] = v.l[k];
 }
-__device__ __forceinline__ void lds_load_j(g1j& p, const uint32_t* lds, int slot)
+__device__ __forceinline__ void lds_load_fp(fp& v, const uint32_t* lds, int coord, int slot)
 {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        p.x.l[k] = lds[k * G1_WG + slot];
-        p.y.l[k] = lds[(12 + k) * G1_WG + slot];
-        p.z.l[k] = lds[(24 + k) * G1_WG + slot];
-    }
+    for (int k = 0; k < 12; ++k) v.l[k] = lds[(12 * coord + k) * G1_WG + slot];
 }
-__device__ __forceinline__ void global_store_j(uint32_t* __restrict__ dst, const g1j& p)
+__device__ __forceinline__ void lds_store_x(uint32_t* lds, int slot, const g1x& p)
 {
-    uint4* d = reinterpret_cast<uint4*>(dst);  // 144-byte rows are 16-byte aligned
-    d[0] = make_uint4(p.x.l[0], p.x.l[1], p.x.l[2], p.x.l[3]);
-    d[1] = make_uint4(p.x.l[4], p.x.l[5], p.x.l[6], p.x.l[7]);
-    d[2] = make_uint4(p.x.l[8], p.x.l[9], p.x.l[10], p.x.l[11]);
-    d[3] = make_uint4(p.y.l[0], p.y.l[1], p.y.l[2], p.y.l[3]);
-    d[4] = make_uint4(p.y.l[4], p.y.l[5], p.y.l[6], p.y.l[7]);
-    d[5] = make_uint4(p.y.l[8], p.y.l[9], p.y.l[10], p.y.l[11]);
-    d[6] = make_uint4(p.z.l[0], p.z.l[1], p.z.l[2], p.z.l[3]);
-    d[7] = make_uint4(p.z.l[4], p.z.l[5], p.z.l[6], p.z.l[7]);
-    d[8] = make_uint4(p.z.l[8], p.z.l[9], p.z.l[10], p.z.l[11]);
+    lds_store_fp(lds, 0, slot, p.x);
+    lds_store_fp(lds, 1, slot, p.y);
+    lds_store_fp(lds, 2, slot, p.zz);
+    lds_store_fp(lds, 3, slot, p.zzz);
 }
-__device__ __forceinline__ void global_load_j(g1j& p, const uint32_t* __restrict__ src)
+__device__ __forceinline__ void lds_load_x(g1x& p, const uint32_t* lds, int slot)
+{
+    lds_load_fp(p.x, lds, 0, slot);
+    lds_load_fp(p.y, lds, 1, slot);
+    lds_load_fp(p.zz, lds, 2, slot);
+    lds_load_fp(p.zzz, lds, 3, slot);
+}
+__device__ __forceinline__ void global_store_fp(uint32_t* __restrict__ dst, const fp& v)  // 48 B, 16-byte aligned
+{
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+}
+__device__ __forceinline__ void global_load_fp(fp& v, const uint32_t* __restrict__ src)
 {
     const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4 v[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = s[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        p.x.l[4 * k] = v[k].x; p.x.l[4 * k + 1] = v[k].y; p.x.l[4 * k + 2] = v[k].z; p.x.l[4 * k + 3] = v[k].w;
-        p.y.l[4 * k] = v[3 + k].x; p.y.l[4 * k + 1] = v[3 + k].y; p.y.l[4 * k + 2] = v[3 + k].z; p.y.l[4 * k + 3] = v[3 + k].w;
-        p.z.l[4 * k] = v[6 + k].x; p.z.l[4 * k + 1] = v[6 + k].y; p.z.l[4 * k + 2] = v[6 + k].z; p.z.l[4 * k + 3] = v[6 + k].w;
-    }
+    const uint4 a = s[0], b = s[1], c = s[2];
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    v.l[8] = c.x; v.l[9] = c.y; v.l[10] = c.z; v.l[11] = c.w;
+}
+__device__ __forceinline__ void global_store_x(uint32_t* __restrict__ dst, const g1x& p)  // 192-byte rows
+{
+    global_store_fp(dst, p.x);
+    global_store_fp(dst + 12, p.y);
+    global_store_fp(dst + 24, p.zz);
+    global_store_fp(dst + 36, p.zzz);
+}
+__device__ __forceinline__ void global_load_x(g1x& p, const uint32_t* __restrict__ src)
+{
+    global_load_fp(p.x, src);
+    global_load_fp(p.y, src + 12);
+    global_load_fp(p.zz, src + 24);
+    global_load_fp(p.zzz, src + 36);
 }
 
 // Slot -> group: last g with slot_base[g] <= slot (groups are laid out in slot order).
@@ -122,20 +132,20 @@ __device__ __forceinline__ uint32_t find_group(const G1Group* __restrict__ group
     return lo;
 }
 
-__global__ void __launch_bounds__(G1_WG, 2)
+__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ members,
                 const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
                 uint32_t n_slots, uint32_t* __restrict__ wg_partials)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 36*256 partial words + 2*256 block info
-    uint32_t* lds_out = lds + 36 * G1_WG;   // output slot of the block a partial belongs to
-    uint32_t* lds_sz = lds_out + G1_WG;     // current block size (0 = empty / retired)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 48*256 partial words + 2*256 block info
+    uint32_t* lds_out = lds + G1X_WORDS * G1_WG;  // output slot of the block a partial belongs to
+    uint32_t* lds_sz = lds_out + G1_WG;           // current block size (0 = empty / retired)
 
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x * G1_WG + tid;
 
-    g1j acc;
-    g1j_set_inf(acc);
+    g1x acc;
+    g1x_set_inf(acc);
     uint32_t my_out = NONE32, my_size = 0;
 
     if (slot < n_slots) {
@@ -171,37 +181,62 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
                 if (j + 1 < count) nhave = fetch(j + 1, nx, ny);
                 if (have) {
                     const bool q_inf = fp_is_zero(qx) && fp_is_zero(qy);  // (0,0) encodes infinity in the table
-                    g1j_add_affine(acc, qx, qy, q_inf);
+                    g1x_add_affine(acc, qx, qy, q_inf);
                 }
                 qx = nx; qy = ny; have = nhave;
             }
         }
     }
-    // ---- workgroup tree over the 256 partials (compacting: level L uses the first 128>>L lanes) ----
+    // ---- workgroup tree over the 256 partials.  Level with n pairs: lanes 2w, 2w+1 add pair w together
+    // (g1x_add_pair: 7 dependent products instead of 14), results compact into slot w. ----
     if (my_size == 1) {  // single-task group: done
-        global_store_j(wg_partials + 36ull * my_out, acc);
+        global_store_x(wg_partials + (size_t)G1X_WORDS * my_out, acc);
         my_size = 0;
     }
-    lds_store_j(lds, tid, acc);
+    lds_store_x(lds, tid, acc);
     lds_out[tid] = my_out;
     lds_sz[tid] = my_size;
     __syncthreads();
     for (int n = G1_WG / 2; n >= 1; n >>= 1) {  // n = number of pairs at this level
-        g1j a;
+        const int w = tid >> 1;
+        const bool role = tid & 1;
+        const bool active = w < n;
+        fp out_a, out_b;
         uint32_t out = NONE32, sz = 0;
-        const bool active = tid < n;
+        bool store_lds = false;
         if (active) {
-            sz = lds_sz[2 * tid];
-            out = lds_out[2 * tid];
+            sz = lds_sz[2 * w];
+            out = lds_out[2 * w];
             if (sz >= 2) {
-                g1j b;
-                lds_load_j(a, lds, 2 * tid);
-                lds_load_j(b, lds, 2 * tid + 1);
-                g1j_add(a, b);
+                const int own = 2 * w + (role ? 1 : 0), oth = 2 * w + (role ? 0 : 1);
+                fp x_own, y_own, zz_own, zzz_own, zz_oth, zzz_oth;
+                lds_load_fp(zz_own, lds, 2, own);
+                lds_load_fp(zz_oth, lds, 2, oth);
+                const bool own_inf = fp_is_zero(zz_own), oth_inf = fp_is_zero(zz_oth);
+                bool fast = !own_inf && !oth_inf;  // identical in both lanes of the pair
+                if (fast) {
+                    lds_load_fp(x_own, lds, 0, own);
+                    lds_load_fp(y_own, lds, 1, own);
+                    lds_load_fp(zzz_own, lds, 3, own);
+                    lds_load_fp(zzz_oth, lds, 3, oth);
+                    fast = g1x_add_pair(out_a, out_b, role, x_own, y_own, zz_own, zzz_own, zz_oth, zzz_oth);
+                }
+                if (!fast) {  // an infinity operand or P1 = +-P2: rare; both lanes run the complete single-lane add
+                    g1x p1, p2;
+                    lds_load_x(p1, lds, 2 * w);
+                    lds_load_x(p2, lds, 2 * w + 1);
+                    g1x_add(p1, p2);
+                    fp_select(out_a, role, p1.zz, p1.x);
+                    fp_select(out_b, role, p1.zzz, p1.y);
+                }
                 sz >>= 1;
-                if (sz == 1) {
-                    global_store_j(wg_partials + 36ull * out, a);
+                if (sz == 1) {  // block finished: role 0 writes X|Y, role 1 writes ZZ|ZZZ of the 192-byte partial
+                    uint32_t* dst = wg_partials + (size_t)G1X_WORDS * out + (role ? 24 : 0);
+                    global_store_fp(dst, out_a);
+                    global_store_fp(dst + 12, out_b);
                     sz = 0;
+                } else {
+                    store_lds = true;
                 }
             } else {
                 sz = 0;
@@ -209,9 +244,14 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
         }
         __syncthreads();
         if (active) {
-            if (sz) lds_store_j(lds, tid, a);
-            lds_out[tid] = out;
-            lds_sz[tid] = sz;
+            if (store_lds) {
+                lds_store_fp(lds, role ? 2 : 0, w, out_a);
+                lds_store_fp(lds, role ? 3 : 1, w, out_b);
+            }
+            if (!role) {
+                lds_out[w] = out;
+                lds_sz[w] = sz;
+            }
         }
         __syncthreads();
     }
@@ -223,7 +263,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const ui
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
-    const size_t lds_bytes = (36 + 2) * G1_WG * sizeof(uint32_t);
+    const size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
     hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), lds_bytes, s, points_mont24, members, bit_arena,
                        groups, n_groups, n_slots, wg_partials36);
 }
@@ -248,29 +288,25 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
         n_parts = n_parts_fixed;
         stride = part_stride;
     }
-    g1j acc;
-    g1j_set_inf(acc);
+    g1x acc;
+    g1x_set_inf(acc);
     for (uint32_t k = 0; k < n_parts; ++k) {
-        g1j q;
-        global_load_j(q, partials + 36ull * (first + (uint64_t)k * stride));
-        g1j_add(acc, q);
+        g1x q;
+        global_load_x(q, partials + (size_t)G1X_WORDS * (first + (uint64_t)k * stride));
+        g1x_add(acc, q);
     }
-    if (out_jac) global_store_j(out_jac + 36ull * g, acc);
+    if (out_jac) global_store_x(out_jac + (size_t)G1X_WORDS * g, acc);
     if (!out_be96) return;
     uint8_t* o = out_be96 + 96ull * g;
     uint32_t* ow = reinterpret_cast<uint32_t*>(o);
-    if (g1j_is_inf(acc)) {
+    if (g1x_is_inf(acc)) {
 #pragma unroll
         for (int j = 0; j < 24; ++j) ow[j] = 0;
         o[0] = 0x40;
         return;
     }
-    fp zi, zi2, zi3, x, y;
-    fp_inv(zi, acc.z);
-    fp_sqr(zi2, zi);
-    fp_mul(zi3, zi2, zi);
-    fp_mul(x, acc.x, zi2);
-    fp_mul(y, acc.y, zi3);
+    fp x, y;
+    g1x_to_affine(x, y, acc);
     fp_from_mont(x, x);
     fp_from_mont(y, y);
     fp_store_be48(o, x);

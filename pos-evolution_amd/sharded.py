@@ -6,7 +6,7 @@ of the (small) block table.  Only two things ever cross ranks:
 
   * get_head:   ONE all-reduce(sum) of (B + PE_EXCHANGE_EXTRA) u64 -- per-block direct vote weight plus the
                 active-balance partials the proposer boost needs.  Integer sums: bit-exact for any order.
-  * aggregate:  ONE all-gather of C x 144 B Jacobian G1 partials (RCCL has no EC-add reduction op), then every rank
+  * aggregate:  ONE all-gather of C x 192 B XYZZ G1 partials (RCCL has no EC-add reduction op), then every rank
                 runs the finishing add + normalisation locally.
 
 Messages are tens of KiB: latency-bound, so ring-vs-tree and per-link bandwidth are irrelevant here.
@@ -37,8 +37,9 @@ class ShardedForkChoice:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.device = device
         self._wbuf = None
-        self._partial = torch.zeros(n_groups_max * 36, dtype=torch.int32, device=device)
-        self._gathered = torch.zeros(self.world * n_groups_max * 36, dtype=torch.int32, device=device)
+        self._pw = _abi.PE_G1_PARTIAL_BYTES // 4  # int32 words per partial
+        self._partial = torch.zeros(n_groups_max * self._pw, dtype=torch.int32, device=device)
+        self._gathered = torch.zeros(self.world * n_groups_max * self._pw, dtype=torch.int32, device=device)
         self.n_groups_max = n_groups_max
         if device.type == "cuda":
             # engine kernels and RCCL ordered on one (non-null) stream
@@ -67,8 +68,8 @@ class ShardedForkChoice:
         res = self.engine.aggregate_partial(self._partial.data_ptr(), rows=rows, packed=packed)
         g = res["n_groups"]
         assert g <= self.n_groups_max
-        part = self._partial[: g * 36]
-        gathered = self._gathered[: self.world * g * 36]
+        part = self._partial[: g * self._pw]
+        gathered = self._gathered[: self.world * g * self._pw]
         if self.dist.is_initialized():
             self.dist.all_gather(list(gathered.chunk(self.world)), part, group=self.group)
         else:

@@ -73,7 +73,8 @@ def test_two_shards_on_one_gpu(engine_factory):
     dev = torch.device("cuda", 0)
     B = tree.roots.shape[0]
     wsum = torch.zeros(B + _abi.PE_EXCHANGE_EXTRA, dtype=torch.int64, device=dev)
-    gathered = torch.zeros(n_shards * C * 36, dtype=torch.int32, device=dev)
+    PW = _abi.PE_G1_PARTIAL_BYTES // 4
+    gathered = torch.zeros(n_shards * C * PW, dtype=torch.int32, device=dev)
     shards = []
     for r in range(n_shards):
         lo, hi = r * V // n_shards, (r + 1) * V // n_shards
@@ -81,11 +82,11 @@ def test_two_shards_on_one_gpu(engine_factory):
         lc = _local_committees(comm, lo, hi)
         _load(e, tree, bal[lo:hi], flags[lo:hi], pts[lo:hi], lc, epoch)
         la, larena = _local_attestations(atts, bit_rows, comm, lo, hi)
-        part = torch.zeros(C * 36, dtype=torch.int32, device=dev)
+        part = torch.zeros(C * PW, dtype=torch.int32, device=dev)
         res = e.aggregate_partial(part.data_ptr(), packed=(la, larena))
         torch.cuda.synchronize()
         assert res["n_groups"] == C
-        gathered[r * C * 36:(r + 1) * C * 36] = part
+        gathered[r * C * PW:(r + 1) * C * PW] = part
         lrows = np.frombuffer(res["atts"], dtype=synth.ATT_DTYPE, count=C)
         st, _, _ = e.on_attestation_batch(packed=(lrows, res["out_arena"]))
         assert (st == 0).all()

@@ -51,15 +51,19 @@ class OracleShardEngine:
         from oracle import cport
         offs = self.comm.offsets
         g = offs.size - 1
+        from pos_evolution_amd import _abi
+        pb = _abi.PE_G1_PARTIAL_BYTES          # the exchange slot size; the oracle's Jacobian partial (144 B) sits in it
         out = cport.g1_partial_groups(self.pts, self.comm.members, offs)      # all bits set: whole committees
-        dst = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(g * 144,))
-        dst[:] = out.reshape(-1)
+        dst = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(g, pb))
+        dst[:, :144] = out
         return dict(n_groups=g)
 
     def g1_finish(self, ptr, n_ranks, n_groups):
         from oracle import cport
-        src = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n_ranks * n_groups * 144,))
-        return cport.g1_finish_partials(src.copy(), n_ranks, n_groups)
+        from pos_evolution_amd import _abi
+        pb = _abi.PE_G1_PARTIAL_BYTES
+        src = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n_ranks * n_groups, pb))
+        return cport.g1_finish_partials(np.ascontiguousarray(src[:, :144]), n_ranks, n_groups)
 
 
 def _worker(rank, world, port, q):

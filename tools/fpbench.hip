@@ -66,14 +66,14 @@ __global__ void __launch_bounds__(256) k_mul_chain2(fp* x, int iters, uint64_t* 
     x[i] = b;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
-__global__ void __launch_bounds__(256) k_madd_chain(const fp* pts, g1j* out, int iters, uint64_t* cyc)
+__global__ void __launch_bounds__(256) k_madd_chain(const fp* pts, g1x* out, int iters, uint64_t* cyc)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    g1j acc;
-    acc.x = pts[2 * i]; acc.y = pts[2 * i + 1]; fp_set_one(acc.z);
+    g1x acc;
+    acc.x = pts[2 * i]; acc.y = pts[2 * i + 1]; fp_set_one(acc.zz); fp_set_one(acc.zzz);
     fp qx = pts[2 * i + 2], qy = pts[2 * i + 3];
     uint64_t t0 = __builtin_readcyclecounter();
-    for (int k = 0; k < iters; ++k) { g1j_add_affine(acc, qx, qy, false); fp_add(qx, qx, acc.z); }
+    for (int k = 0; k < iters; ++k) { g1x_add_affine(acc, qx, qy, false); fp_add(qx, qx, acc.zz); }
     uint64_t t1 = __builtin_readcyclecounter();
     out[i] = acc;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -112,7 +112,7 @@ int main()
     printf("fp_add/sub check: %d mismatches\n", bad);
 
     uint64_t* dcyc; CHECK(hipMalloc(&dcyc, 4096 * 8));
-    g1j* dj; CHECK(hipMalloc(&dj, 256 * 4 * 256 * sizeof(g1j)));
+    g1x* dj; CHECK(hipMalloc(&dj, 256 * 4 * 256 * sizeof(g1x)));
     fp* dx; CHECK(hipMalloc(&dx, (256 * 4 * 256 * 2 + 8) * 48));
     for (size_t off = 0; off < (size_t)256 * 4 * 256 * 2; off += N) CHECK(hipMemcpy(dx + off, da, (size_t)N * 48, hipMemcpyDeviceToDevice));
     auto bench = [&](const char* name, int which, int iters, double mul_per_iter) -> int {
@@ -138,6 +138,6 @@ int main()
     };
     bench("mul_chain", 0, 2000, 1);
     bench("mul_chain2", 1, 1000, 2);
-    bench("madd_chain", 2, 300, 11);
+    bench("madd_chain", 2, 300, 10);
     return 0;
 }
