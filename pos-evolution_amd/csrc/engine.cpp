@@ -1632,27 +1632,34 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     // ---- rounds: attestations of one round touch pairwise disjoint validators, so the order inside a
     // round is irrelevant; rounds run in order, which keeps the sequential semantics of pe:745-749 ----
     std::vector<uint32_t> round_of(acc.size());
+    bool single_round = true;
     {
-        std::unordered_map<uint64_t, uint32_t> seen;  // (table, which, committee) -> attestations so far
-        seen.reserve(acc.size() * 2);
+        // round = how many earlier attestations of this batch hit the same (table, committee); a flat counter per
+        // table replaces a hash map (the common case is one attestation per committee: everything in round 0)
+        std::vector<std::vector<uint16_t>> cnt(h->tables.size());
         for (size_t k = 0; k < acc.size(); ++k) {
             uint32_t r;
             if (acc[k].table->is_partition) {
-                const uint64_t key = ((uint64_t)(acc[k].table - h->tables.data()) << 40) ^ ((uint64_t)acc[k].row.which << 36) ^ acc[k].pos;
-                r = seen[key]++;
+                const size_t ti = (size_t)(acc[k].table - h->tables.data());
+                if (cnt[ti].empty()) cnt[ti].assign(acc[k].table->n_committees, 0);
+                r = cnt[ti][acc[k].pos]++;
             } else {
                 r = (uint32_t)k;  // committees may overlap: fully sequential
             }
             round_of[k] = r;
+            if (r) single_round = false;
         }
     }
     // rows sorted by (round, table); one launch per (round, table)
     std::vector<size_t> ord(acc.size());
     std::iota(ord.begin(), ord.end(), size_t(0));
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
-        if (round_of[x] != round_of[y]) return round_of[x] < round_of[y];
-        return acc[x].table < acc[y].table;
-    });
+    bool one_table = true;
+    for (size_t k = 1; k < acc.size() && one_table; ++k) one_table = acc[k].table == acc[0].table;
+    if (!(single_round && one_table))
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+            if (round_of[x] != round_of[y]) return round_of[x] < round_of[y];
+            return acc[x].table < acc[y].table;
+        });
     AttRow* rows = stg.host<AttRow>(off_rows);
     uint32_t* nslot = stg.host<uint32_t>(off_nslot);
     for (size_t k = 0; k < ord.size(); ++k) { rows[k] = acc[ord[k]].row; nslot[k] = acc[ord[k]].src; }

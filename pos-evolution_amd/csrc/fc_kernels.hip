@@ -53,30 +53,36 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
     unsigned long long act_bal = 0;
     uint32_t act_num = 0;
     const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
-    for (uint64_t q = (uint64_t)blockIdx.x * VOTES_WG + threadIdx.x; q < n_quads; q += (uint64_t)gridDim.x * VOTES_WG) {
-        const uint64_t v0 = q * VOTES_PER_THREAD;
-        uint32_t vb[4];
-        unsigned long long bal[4];
-        uint32_t fl[4];
-        if (v0 + 4 <= n_val) {  // arrays are 16-byte aligned and v0 % 4 == 0: 16 + 32 + 4 byte vector loads
-            const uint4 t = *reinterpret_cast<const uint4*>(vote_block + v0);
-            vb[0] = t.x; vb[1] = t.y; vb[2] = t.z; vb[3] = t.w;
-            const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(eff_balance + v0);
-            const ulonglong2 b23 = *reinterpret_cast<const ulonglong2*>(eff_balance + v0 + 2);
-            bal[0] = b01.x; bal[1] = b01.y; bal[2] = b23.x; bal[3] = b23.y;
-            const uint32_t f = *reinterpret_cast<const uint32_t*>(flags + v0);
-            fl[0] = f & 0xff; fl[1] = (f >> 8) & 0xff; fl[2] = (f >> 16) & 0xff; fl[3] = f >> 24;
-        } else {
+    const uint64_t stride = (uint64_t)gridDim.x * VOTES_WG;
+    // two quads (8 validators: 2 x (16 + 32 + 4) bytes of vector loads) in flight per lane per iteration
+    for (uint64_t q0 = (uint64_t)blockIdx.x * VOTES_WG + threadIdx.x; q0 < n_quads; q0 += 2 * stride) {
+        uint32_t vb[8];
+        unsigned long long bal[8];
+        uint32_t fl[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool ok = v0 + k < n_val;
-                vb[k] = ok ? vote_block[v0 + k] : NONE32;
-                bal[k] = ok ? eff_balance[v0 + k] : 0ull;
-                fl[k] = ok ? flags[v0 + k] : 0u;
+        for (int u = 0; u < 2; ++u) {
+            const uint64_t q = q0 + u * stride;
+            const uint64_t v0 = q * VOTES_PER_THREAD;
+            if (q < n_quads && v0 + 4 <= n_val) {  // arrays are 16-byte aligned and v0 % 4 == 0
+                const uint4 t = *reinterpret_cast<const uint4*>(vote_block + v0);
+                vb[4 * u] = t.x; vb[4 * u + 1] = t.y; vb[4 * u + 2] = t.z; vb[4 * u + 3] = t.w;
+                const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(eff_balance + v0);
+                const ulonglong2 b23 = *reinterpret_cast<const ulonglong2*>(eff_balance + v0 + 2);
+                bal[4 * u] = b01.x; bal[4 * u + 1] = b01.y; bal[4 * u + 2] = b23.x; bal[4 * u + 3] = b23.y;
+                const uint32_t f = *reinterpret_cast<const uint32_t*>(flags + v0);
+                fl[4 * u] = f & 0xff; fl[4 * u + 1] = (f >> 8) & 0xff; fl[4 * u + 2] = (f >> 16) & 0xff; fl[4 * u + 3] = f >> 24;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool ok = q < n_quads && v0 + k < n_val;
+                    vb[4 * u + k] = ok ? vote_block[v0 + k] : NONE32;
+                    bal[4 * u + k] = ok ? eff_balance[v0 + k] : 0ull;
+                    fl[4 * u + k] = ok ? flags[v0 + k] : 0u;
+                }
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             if (!(fl[k] & VAL_ACTIVE)) continue;
             act_bal += bal[k];
             act_num += 1;

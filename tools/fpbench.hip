@@ -33,6 +33,58 @@ static void host_mont_mul(uint64_t* r, const uint64_t* a, const uint64_t* b)
     memcpy(r, t, 48);
 }
 
+// comparison arm: one asm statement per MAC (274 s_nops per product) -- what fp_mul was before tools/gen_fp_mul.py
+#define POSEVO_MAC1(lo64, hi, a, b) asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo64), "+v"(hi) : "v"(a), "v"(b) : "vcc")
+__device__ __forceinline__ void fp_mul_fused(fp& r, const fp& a, const fp& b)  // name kept: the "other" arm
+{
+    uint32_t m[12], t[13];
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) POSEVO_MAC1(lo, hi, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; ++i) { uint32_t pj = fp_p_limb(k - i); POSEVO_MAC1(lo, hi, m[i], pj); }
+        m[k] = (uint32_t)lo * FP_N0;
+        { uint32_t p0 = fp_p_limb(0); POSEVO_MAC1(lo, hi, m[k], p0); }
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+#pragma unroll
+    for (int k = 12; k < 23; ++k) {
+#pragma unroll
+        for (int i = k - 11; i < 12; ++i) POSEVO_MAC1(lo, hi, a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = k - 11; i < 12; ++i) { uint32_t pj = fp_p_limb(k - i); POSEVO_MAC1(lo, hi, m[i], pj); }
+        t[k - 12] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        hi = 0;
+    }
+    t[11] = (uint32_t)lo;
+    t[12] = (uint32_t)(lo >> 32);
+    uint32_t s[12], br = 0;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s[j] = __builtin_subc(t[j], fp_p_limb(j), br, &br);
+    const bool ge = (t[12] != 0) || (br == 0);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) r.l[j] = ge ? s[j] : t[j];
+}
+__global__ void k_mulf_check(const fp* a, const fp* b, fp* out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { fp r; fp_mul_fused(r, a[i], b[i]); out[i] = r; }
+}
+__global__ void __launch_bounds__(256) k_mulf_chain(fp* x, int iters, uint64_t* cyc)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    fp a = x[i], b = x[i + 1];
+    uint64_t t0 = __builtin_readcyclecounter();
+    for (int k = 0; k < iters; ++k) { fp c; fp_mul_fused(c, a, b); a = b; b = c; }
+    uint64_t t1 = __builtin_readcyclecounter();
+    x[i] = b;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 __global__ void k_mul_check(const fp* a, const fp* b, fp* out, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,6 +150,11 @@ int main()
     int bad = 0;
     for (int i = 0; i < N; ++i) { host_mont_mul(&hexp[6 * i], &ha[6 * i], &hb[6 * i]); if (memcmp(&hexp[6 * i], &hr[6 * i], 48)) ++bad; }
     printf("fp_mul check: %d / %d mismatches\n", bad, N);
+    hipLaunchKernelGGL(k_mulf_check, dim3(N / 256), dim3(256), 0, 0, da, db, dr, N);
+    CHECK(hipMemcpy(hr.data(), dr, N * 48, hipMemcpyDeviceToHost));
+    bad = 0;
+    for (int i = 0; i < N; ++i) if (memcmp(&hexp[6 * i], &hr[6 * i], 48)) ++bad;
+    printf("fp_mul (one asm per MAC) check: %d / %d mismatches\n", bad, N);
     // (a+b)(a-b) == a^2 - b^2 : checks add/sub against mul
     hipLaunchKernelGGL(k_addsub_check, dim3(N / 256), dim3(256), 0, 0, da, db, dr, N);
     CHECK(hipMemcpy(hr.data(), dr, N * 48, hipMemcpyDeviceToHost));
@@ -123,6 +180,7 @@ int main()
                 hipEventRecord(e0);
                 if (which == 0) hipLaunchKernelGGL(k_mul_chain, dim3(blocks), dim3(256), 0, 0, dx, iters, dcyc);
                 if (which == 1) hipLaunchKernelGGL(k_mul_chain2, dim3(blocks), dim3(256), 0, 0, dx, iters, dcyc);
+                if (which == 3) hipLaunchKernelGGL(k_mulf_chain, dim3(blocks), dim3(256), 0, 0, dx, iters, dcyc);
                 if (which == 2) hipLaunchKernelGGL(k_madd_chain, dim3(blocks), dim3(256), 0, 0, dx, dj, iters, dcyc);
                 hipEventRecord(e1);
                 CHECK(hipDeviceSynchronize());
@@ -137,6 +195,9 @@ int main()
         return 0;
     };
     bench("mul_chain", 0, 2000, 1);
+    bench("mul_1asm", 3, 2000, 1);
+    bench("mul_chain", 0, 2000, 1);
+    bench("mul_1asm", 3, 2000, 1);
     bench("mul_chain2", 1, 1000, 2);
     bench("madd_chain", 2, 300, 10);
     return 0;
