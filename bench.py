@@ -47,8 +47,11 @@ def build_workload(e, args, rank, n_steps_total):
     steps = []
     for s in range(n_steps_total):
         ep = epoch0 + s
-        comm = synth.random_committees(V, C, 100 * seed + s)
-        e.set_committees(ep, comm.offsets, comm.members)
+        # the epoch's committees: the reference's swap-or-not shuffle (pe:495-534, 90 rounds) run on the GPU
+        import hashlib
+        ep_seed = hashlib.sha256(b"bench-seed" + seed.to_bytes(8, "little") + ep.to_bytes(8, "little")).digest()
+        off, mem = e.compute_committees(ep, ep_seed, np.arange(V, dtype=np.uint32), C, 90)
+        comm = synth.Committees(off, mem)
         atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=seed, density=0.99, parts=args.parts,
                                                   source=(0, tree.roots[0].tobytes()), vote_recent=64)
         steps.append(dict(epoch=ep, comm=comm, atts=atts, arena=arena))

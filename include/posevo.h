@@ -195,6 +195,16 @@ int pe_on_attester_slashing(pe_engine* h,
 int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees,
                       const uint32_t* offsets, const uint32_t* members);
 
+/* The same table computed ON THE GPU from the epoch's seed: compute_committee (pe:495-504) over
+ * compute_shuffled_index (pe:513-534, swap-or-not, shuffle_round_count rounds of SHA-256) for every committee
+ * of the epoch: committee c = [active_indices[shuffled(i)] for i in [n*c/count, n*(c+1)/count)], count =
+ * n_committees.  seed = get_seed(state, epoch, DOMAIN_BEACON_ATTESTER) (pe:481-486) and the active set are the
+ * caller's (state accessors).  Registers the table for `epoch` like pe_set_committees; out_offsets
+ * (n_committees + 1) and out_members (n_active) are optional copies of the result. */
+int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
+                          uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
+                          uint32_t* out_offsets, uint32_t* out_members);
+
 /* ---- the hot path ------------------------------------------------------ */
 /* get_head (pe:1102-1116): full recomputation from the V-entry vote table:
  * get_filtered_block_tree (Appendix A.3), get_latest_attesting_balance

@@ -1076,6 +1076,77 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const
     return PE_OK;
 }
 
+int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
+                          uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
+                          uint32_t* out_offsets, uint32_t* out_members)
+{
+    if (!h || !seed || (n_active && !active_indices)) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n_committees == 0 || n_committees % h->cfg.slots_per_epoch != 0)
+        return fail(h, PE_ERR_INVALID_ARG, "n_committees must be a positive multiple of SLOTS_PER_EPOCH");
+    if (shuffle_round_count > 255) return fail(h, PE_ERR_INVALID_ARG, "shuffle_round_count is a uint8 in the spec");
+    {   // the active set: distinct validator indices (get_active_validator_indices is increasing)
+        std::vector<uint8_t> seen(h->n_val, 0);
+        for (uint32_t i = 0; i < n_active; ++i) {
+            if (active_indices[i] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "active index out of range");
+            if (seen[active_indices[i]]) return fail(h, PE_ERR_INVALID_ARG, "duplicate active index");
+            seen[active_indices[i]] = 1;
+        }
+    }
+    std::vector<uint32_t> offsets(n_committees + 1);
+    for (uint32_t c = 0; c <= n_committees; ++c)
+        offsets[c] = (uint32_t)(((uint64_t)n_active * c) / n_committees);  // start/end of pe:502-503
+    CommitteeTable* t = find_table(h, epoch);
+    if (!t) {
+        if (h->tables.size() < (h->cfg.max_committee_tables ? h->cfg.max_committee_tables : 4u)) {
+            h->tables.emplace_back();
+            t = &h->tables.back();
+        } else {
+            t = &*std::min_element(h->tables.begin(), h->tables.end(),
+                                   [](const CommitteeTable& a, const CommitteeTable& b) { return a.stamp < b.stamp; });
+        }
+    }
+    const uint32_t nb = (n_active + 255) / 256;
+    Stage st(h);
+    HIP_TRY(h, st.reserve(64 + 4ull * n_active + 4ull * (n_committees + 1) + 1024));
+    const size_t off_seed = st.alloc(32);
+    const size_t off_idx = st.alloc(4ull * n_active + 4);
+    const size_t off_offs = st.alloc(4ull * (n_committees + 1));
+    uint32_t* sw = st.host<uint32_t>(off_seed);
+    for (int i = 0; i < 8; ++i)
+        sw[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+    if (n_active) memcpy(st.host<uint32_t>(off_idx), active_indices, 4ull * n_active);
+    memcpy(st.host<uint32_t>(off_offs), offsets.data(), 4ull * (n_committees + 1));
+    HIP_TRY(h, t->d_members.ensure(std::max<size_t>(64, 4ull * n_active)));
+    HIP_TRY(h, t->d_offsets.ensure(4ull * (n_committees + 1)));
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, 32ull * nb * shuffle_round_count + 4ull * shuffle_round_count + 64)));
+    HIP_TRY(h, st.upload());
+    uint32_t* d_source = h->d_tmp_be.as<uint32_t>();
+    uint32_t* d_pivots = d_source + 8ull * nb * shuffle_round_count;
+    launch_shuffle(h->stream, st.dev<uint32_t>(off_seed), n_active, shuffle_round_count, d_source, d_pivots,
+                   st.dev<uint32_t>(off_idx), t->d_members.as<uint32_t>());
+    HIP_TRY(h, hipMemcpyAsync(t->d_offsets.p, st.dev<uint32_t>(off_offs), 4ull * (n_committees + 1),
+                              hipMemcpyDeviceToDevice, h->stream));
+    if (h->n_val) {
+        HIP_TRY(h, t->d_inv_comm.ensure(4ull * h->n_val));
+        HIP_TRY(h, t->d_inv_pos.ensure(4ull * h->n_val));
+        launch_invert_committees(h->stream, t->d_members.as<uint32_t>(), t->d_offsets.as<uint32_t>(), n_committees,
+                                 t->d_inv_comm.as<uint32_t>(), t->d_inv_pos.as<uint32_t>(), h->n_val);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (out_members && n_active)
+        HIP_TRY(h, hipMemcpyAsync(out_members, t->d_members.p, 4ull * n_active, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out_offsets) memcpy(out_offsets, offsets.data(), 4ull * (n_committees + 1));
+    t->epoch = epoch;
+    t->n_committees = n_committees;
+    t->offsets.swap(offsets);
+    t->is_partition = true;  // a permutation of distinct indices, sliced
+    t->n_val_at_load = h->n_val;
+    t->stamp = ++h->table_stamp;
+    return PE_OK;
+}
+
 // ---------------------------------------------------------------- get_head
 int pe_get_head(pe_engine* h, uint8_t out_root[32])
 {

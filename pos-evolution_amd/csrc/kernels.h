@@ -98,4 +98,9 @@ struct UnionGroup {
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
                        const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
 
+// compute_committee / compute_shuffled_index (pe:495-534) for a whole list: members[i] = indices[shuffled(i)].
+// d_source: rounds * ceil(n/256) * 8 words scratch; d_pivots: rounds words; d_indices null = identity.
+int launch_shuffle(hipStream_t s, const uint32_t* d_seed_be, uint32_t n, uint32_t rounds, uint32_t* d_source,
+                   uint32_t* d_pivots, const uint32_t* d_indices, uint32_t* d_members);
+
 }  // namespace posevo

@@ -197,6 +197,18 @@ class Engine:
         self._check(self._lib.pe_set_committees(self._h, epoch, off.size - 1, _ptr(off, C.c_uint32),
                                                 _ptr(mem, C.c_uint32)))
 
+    def compute_committees(self, epoch: int, seed: bytes, active_indices, n_committees: int,
+                           shuffle_round_count: int = 90, want_result: bool = True):
+        """compute_committee / compute_shuffled_index (pe:495-534) for the whole epoch on the GPU; registers the
+        table for `epoch`.  -> (offsets uint32[C+1], members uint32[n_active]) when want_result."""
+        act = np.ascontiguousarray(active_indices, dtype=np.uint32)
+        off = np.zeros(n_committees + 1, dtype=np.uint32) if want_result else None
+        mem = np.zeros(max(act.size, 1), dtype=np.uint32) if want_result else None
+        self._check(self._lib.pe_compute_committees(self._h, epoch, _root(seed), _ptr(act, C.c_uint32), act.size,
+                                                    n_committees, shuffle_round_count, _ptr(off, C.c_uint32),
+                                                    _ptr(mem, C.c_uint32)))
+        return (off, mem[:act.size]) if want_result else None
+
     # -- hot path ---------------------------------------------------------
     def get_head(self) -> bytes:
         out = (C.c_uint8 * 32)()

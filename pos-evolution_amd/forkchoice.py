@@ -143,6 +143,15 @@ class Store:
         self.engine.set_committees(epoch, offsets, members)
 
 
+    def compute_committees(self, epoch: int, seed: bytes, active_indices: Sequence[int], committees_per_slot: int,
+                           shuffle_round_count: int = 90):
+        """The same table computed on the GPU from get_seed(state, epoch, DOMAIN_BEACON_ATTESTER) (pe:481-486)
+        and get_active_validator_indices(state, epoch): compute_committee over compute_shuffled_index
+        (pe:495-534).  Store method so that the client no longer runs the shuffle itself."""
+        n = int(self.engine.cfg.slots_per_epoch) * committees_per_slot
+        return self.engine.compute_committees(epoch, bytes(seed), active_indices, n, shuffle_round_count)
+
+
 def _point96(pt) -> bytes:
     """Affine (x, y) int tuple / None / 96 raw bytes -> 96-byte uncompressed encoding."""
     if isinstance(pt, (bytes, bytearray)):
