@@ -257,6 +257,18 @@ int pe_participation_get(pe_engine* h, int which, uint8_t* out_flags, uint64_t n
 /* process_participation_flag_updates at an epoch boundary: previous = current, current = 0. */
 int pe_participation_rotate(pe_engine* h);
 
+/* The working BeaconState's registry view (the state process_attestation / FFG run on), when it differs from the
+ * justified-checkpoint state given to pe_set_validators: effective balances (get_base_reward, pe:749; FFG sums)
+ * and flags PE_VAL_ACTIVE (active in get_current_epoch(state)), PE_VAL_SLASHED, PE_VAL_ACTIVE_PREV (active in
+ * get_previous_epoch(state)).  Until this is called the engine uses the pe_set_validators data for both. */
+#define PE_VAL_ACTIVE_PREV 0x08u
+int pe_state_set_validators(pe_engine* h, uint64_t n, const uint64_t* effective_balance, const uint8_t* flags);
+/* The balance sums of process_justification_and_finalization (pe:791-802) over the working state and the engine's
+ * participation arrays: out[0] = get_total_active_balance(state), out[1] = previous_target_balance,
+ * out[2] = current_target_balance (each max(EFFECTIVE_BALANCE_INCREMENT, sum), Appendix A.1).  The caller feeds
+ * them to weigh_justification_and_finalization (pe:815-853), which is scalar logic on the state. */
+int pe_ffg_balances(pe_engine* h, uint64_t out[3]);
+
 /* Plain G1 sum over caller-chosen groups: out[g] = sum_{j in [offsets[g], offsets[g+1])}
  * points[index[j]] (index NULL = identity).  points96 NULL = the validators' pubkeys. */
 int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points,

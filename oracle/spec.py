@@ -231,6 +231,7 @@ class BeaconState:
     finalized_checkpoint: Checkpoint = Checkpoint()
     latest_block_root: Root = ZERO_ROOT
     proposer_index_override: Optional[int] = None
+    justification_bits: List[bool] = field(default_factory=lambda: [False] * 4)  # JUSTIFICATION_BITS_LENGTH = 4 (pe:403)
 
     def copy(self) -> "BeaconState":
         return deepcopy(self)
@@ -533,6 +534,76 @@ def process_attestation(state: BeaconState, attestation: Attestation) -> None:
     increase_balance(state, get_beacon_proposer_index(state), proposer_reward)
     # exposed for differential tests (not in the reference):
     state._last_proposer_reward_numerator = proposer_reward_numerator
+
+
+# --------------------------------------------------------------------------
+# FFG: justification and finalization  [REF pe:791-802, pe:815-853]
+# --------------------------------------------------------------------------
+JUSTIFICATION_BITS_LENGTH = 4
+
+
+def get_unslashed_participating_indices(state: BeaconState, flag_index: int, epoch: int) -> Set[int]:
+    """[UPSTREAM-MEMORY, Altair]  (described in prose at pe:805)"""
+    assert epoch in (get_previous_epoch(state), get_current_epoch(state))
+    if epoch == get_current_epoch(state):
+        epoch_participation = state.current_epoch_participation
+    else:
+        epoch_participation = state.previous_epoch_participation
+    active_validator_indices = get_active_validator_indices(state, epoch)
+    participating_indices = [i for i in active_validator_indices if has_flag(epoch_participation[i], flag_index)]
+    return set(filter(lambda index: not state.validators[index].slashed, participating_indices))
+
+
+def weigh_justification_and_finalization(state: BeaconState, total_active_balance: int,
+                                         previous_epoch_target_balance: int, current_epoch_target_balance: int) -> None:
+    """[REF pe:815-853]"""
+    previous_epoch = get_previous_epoch(state)
+    current_epoch = get_current_epoch(state)
+    old_previous_justified_checkpoint = state.previous_justified_checkpoint
+    old_current_justified_checkpoint = state.current_justified_checkpoint
+
+    # Process justifications
+    state.previous_justified_checkpoint = state.current_justified_checkpoint
+    state.justification_bits[1:] = state.justification_bits[:JUSTIFICATION_BITS_LENGTH - 1]
+    state.justification_bits[0] = False
+    if previous_epoch_target_balance * 3 >= total_active_balance * 2:
+        state.current_justified_checkpoint = Checkpoint(epoch=previous_epoch,
+                                                        root=get_block_root(state, previous_epoch))
+        state.justification_bits[1] = True
+    if current_epoch_target_balance * 3 >= total_active_balance * 2:
+        state.current_justified_checkpoint = Checkpoint(epoch=current_epoch,
+                                                        root=get_block_root(state, current_epoch))
+        state.justification_bits[0] = True
+
+    # Process finalizations
+    bits = state.justification_bits
+    # The 2nd/3rd/4th most recent epochs are justified, the 2nd using the 4th as source
+    if all(bits[1:4]) and old_previous_justified_checkpoint.epoch + 3 == current_epoch:
+        state.finalized_checkpoint = old_previous_justified_checkpoint
+    # The 2nd/3rd most recent epochs are justified, the 2nd using the 3rd as source
+    if all(bits[1:3]) and old_previous_justified_checkpoint.epoch + 2 == current_epoch:
+        state.finalized_checkpoint = old_previous_justified_checkpoint
+    # The 1st/2nd/3rd most recent epochs are justified, the 1st using the 3rd as source
+    if all(bits[0:3]) and old_current_justified_checkpoint.epoch + 2 == current_epoch:
+        state.finalized_checkpoint = old_current_justified_checkpoint
+    # The 1st/2nd most recent epochs are justified, the 1st using the 2nd as source
+    if all(bits[0:2]) and old_current_justified_checkpoint.epoch + 1 == current_epoch:
+        state.finalized_checkpoint = old_current_justified_checkpoint
+
+
+def process_justification_and_finalization(state: BeaconState) -> None:
+    """[REF pe:791-802]"""
+    # Initial FFG checkpoint values have a `0x00` stub for `root`.
+    # Skip FFG updates in the first two epochs to avoid corner cases that might result in modifying this stub.
+    if get_current_epoch(state) <= GENESIS_EPOCH + 1:
+        return
+    previous_indices = get_unslashed_participating_indices(state, TIMELY_TARGET_FLAG_INDEX, get_previous_epoch(state))
+    current_indices = get_unslashed_participating_indices(state, TIMELY_TARGET_FLAG_INDEX, get_current_epoch(state))
+    total_active_balance = get_total_active_balance(state)
+    previous_target_balance = get_total_balance(state, previous_indices)
+    current_target_balance = get_total_balance(state, current_indices)
+    state._last_ffg_balances = (total_active_balance, previous_target_balance, current_target_balance)
+    weigh_justification_and_finalization(state, total_active_balance, previous_target_balance, current_target_balance)
 
 
 # --------------------------------------------------------------------------

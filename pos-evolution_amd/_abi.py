@@ -15,7 +15,7 @@ PE_OK = 0
 PE_ERR_NO_DEVICE = -2
 NONE32 = 0xFFFFFFFF
 
-PE_VAL_ACTIVE, PE_VAL_SLASHED, PE_VAL_EQUIVOCATING = 0x01, 0x02, 0x04
+PE_VAL_ACTIVE, PE_VAL_SLASHED, PE_VAL_EQUIVOCATING, PE_VAL_ACTIVE_PREV = 0x01, 0x02, 0x04, 0x08
 PE_ATT_FLAG_SIGNATURE_VALID, PE_ATT_FLAG_FROM_BLOCK = 0x1, 0x2
 PE_G1_PARTIAL_BYTES = 192
 PE_EXCHANGE_EXTRA = 512
@@ -99,6 +99,8 @@ SIGNATURES = {
     "pe_participation_set": (C.c_int, [_H, C.c_int, _u8p, C.c_uint64]),
     "pe_participation_get": (C.c_int, [_H, C.c_int, _u8p, C.c_uint64]),
     "pe_participation_rotate": (C.c_int, [_H]),
+    "pe_state_set_validators": (C.c_int, [_H, C.c_uint64, _u64p, _u8p]),
+    "pe_ffg_balances": (C.c_int, [_H, _u64p]),
     "pe_g1_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
     "pe_num_blocks": (C.c_uint32, [_H]),
     "pe_num_validators": (C.c_uint64, [_H]),

@@ -200,6 +200,8 @@ struct pe_engine {
     uint64_t n_val = 0;
     bool have_points = false;
     DevBuf d_points, d_balance, d_flags, d_incr, d_vote_key, d_vote_block, d_part_cur, d_part_prev;
+    DevBuf d_sbalance, d_sflags;  // working-state view (process_attestation rewards, FFG sums)
+    bool state_view_set = false;  // false: the working state mirrors the pe_set_validators data
     std::vector<uint8_t> h_flags;  // host mirror (equivocating bit is OR-ed in here)
 
     // ---- tree snapshot (pre-order) ----
@@ -627,7 +629,18 @@ int upload_balances(pe_engine* h, uint64_t n, const uint64_t* bal, const uint8_t
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_balance.p, bal, n * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_flags.p, f.data(), n, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->d_incr.p, incr.data(), n * 2, hipMemcpyHostToDevice, h->stream));
+    if (!h->state_view_set) {  // the working state mirrors the registry until pe_state_set_validators says otherwise
+        const size_t n4 = (n + 3) & ~size_t(3);
+        HIP_TRY(h, h->d_sbalance.ensure(std::max<size_t>(64, n4 * 8)));
+        HIP_TRY(h, h->d_sflags.ensure(std::max<size_t>(64, n4)));
+        std::vector<uint8_t> sf(n);
+        for (uint64_t i = 0; i < n; ++i)  // active now => also counted as active in the previous epoch
+            sf[i] = (uint8_t)((flags[i] & (PE_VAL_ACTIVE | PE_VAL_SLASHED)) | ((flags[i] & PE_VAL_ACTIVE) ? PE_VAL_ACTIVE_PREV : 0));
+        HIP_TRY(h, hipMemcpyAsync(h->d_incr.p, incr.data(), n * 2, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_sbalance.p, bal, n * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_sflags.p, sf.data(), n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->h_flags.swap(f);
     return PE_OK;
@@ -750,7 +763,7 @@ void pe_engine_destroy(pe_engine* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_vote_key, &h->d_vote_block,
+    for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
                       &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_stage,
                       &h->d_outblk, &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
@@ -1782,6 +1795,53 @@ int pe_participation_rotate(pe_engine* h)
     (void)hipSetDevice(h->device);
     std::swap(h->d_part_cur, h->d_part_prev);  // previous = current
     if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), h->stream));  // current = 0
+    return PE_OK;
+}
+
+int pe_state_set_validators(pe_engine* h, uint64_t n, const uint64_t* effective_balance, const uint8_t* flags)
+{
+    if (!h || (n && (!effective_balance || !flags))) return PE_ERR_INVALID_ARG;
+    if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_state_set_validators: n differs from the registry size");
+    (void)hipSetDevice(h->device);
+    std::vector<uint16_t> incr(n);
+    const uint64_t inc = h->cfg.effective_balance_increment;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t q = effective_balance[i] / inc;
+        if (q > 0xFFFF) return fail(h, PE_ERR_INVALID_ARG, "effective_balance / increment exceeds 65535");
+        incr[i] = (uint16_t)q;
+    }
+    const size_t n4 = (n + 3) & ~size_t(3);
+    HIP_TRY(h, h->d_sbalance.ensure(std::max<size_t>(64, n4 * 8)));
+    HIP_TRY(h, h->d_sflags.ensure(std::max<size_t>(64, n4)));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sbalance.p, effective_balance, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_sflags.p, flags, n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_incr.p, incr.data(), n * 2, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->state_view_set = true;
+    return PE_OK;
+}
+
+int pe_ffg_balances(pe_engine* h, uint64_t out[3])
+{
+    if (!h || !out) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    OutBlock ob(h);
+    const size_t off = ob.alloc(8ull * 3 * 256);
+    HIP_TRY(h, ob.ensure());
+    uint32_t blocks = 0;
+    if (h->n_val) {
+        blocks = launch_ffg_balances(h->stream, h->d_sbalance.as<uint64_t>(), h->d_sflags.as<uint8_t>(),
+                                     h->d_part_cur.as<uint8_t>(), h->d_part_prev.as<uint8_t>(), h->n_val,
+                                     ob.dev<uint64_t>(off));
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, ob.download());
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    uint64_t s[3] = {0, 0, 0};
+    const uint64_t* p = ob.host<uint64_t>(off);
+    for (uint32_t b = 0; b < blocks; ++b)
+        for (int k = 0; k < 3; ++k) s[k] += p[3 * b + k];
+    for (int k = 0; k < 3; ++k) out[k] = std::max<uint64_t>(h->cfg.effective_balance_increment, s[k]);  // get_total_balance
     return PE_OK;
 }
 

@@ -497,6 +497,53 @@ void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, co
                        part_prev_words, reinterpret_cast<unsigned long long*>(numerators), numerator_slot);
 }
 
+// ------------------------------------------------------------------ FFG balance sums
+// The three Gwei sums process_justification_and_finalization (pe:791-802) feeds to
+// weigh_justification_and_finalization (pe:815-853):
+//   total_active_balance     sum over validators active in the current epoch
+//   previous_target_balance  sum over unslashed validators active in the previous epoch whose
+//                            previous_epoch_participation has TIMELY_TARGET (get_unslashed_participating_indices)
+//   current_target_balance   same for the current epoch
+// One streaming pass (balance u64 + state flags u8 + two participation bytes), per-workgroup partials.
+constexpr uint32_t SVAL_ACTIVE_CUR = 0x01u, SVAL_SLASHED = 0x02u, SVAL_ACTIVE_PREV = 0x08u, TIMELY_TARGET_BIT = 0x02u;
+
+__global__ void __launch_bounds__(256)
+k_ffg_balances(const uint64_t* __restrict__ balance, const uint8_t* __restrict__ sflags,
+               const uint8_t* __restrict__ part_cur, const uint8_t* __restrict__ part_prev, uint64_t n_val,
+               unsigned long long* __restrict__ partials /* [gridDim.x][3] */)
+{
+    unsigned long long tot = 0, prev = 0, cur = 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_val; v += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t f = sflags[v];
+        const unsigned long long b = balance[v];
+        if (f & SVAL_ACTIVE_CUR) tot += b;
+        if (!(f & SVAL_SLASHED)) {
+            if ((f & SVAL_ACTIVE_PREV) && (part_prev[v] & TIMELY_TARGET_BIT)) prev += b;
+            if ((f & SVAL_ACTIVE_CUR) && (part_cur[v] & TIMELY_TARGET_BIT)) cur += b;
+        }
+    }
+    __shared__ unsigned long long acc[3];
+    if (threadIdx.x == 0) { acc[0] = 0; acc[1] = 0; acc[2] = 0; }
+    tot = wave_sum_u64(tot);
+    prev = wave_sum_u64(prev);
+    cur = wave_sum_u64(cur);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&acc[0], tot); atomicAdd(&acc[1], prev); atomicAdd(&acc[2], cur); }
+    __syncthreads();
+    if (threadIdx.x < 3) partials[blockIdx.x * 3 + threadIdx.x] = acc[threadIdx.x];
+}
+
+uint32_t launch_ffg_balances(hipStream_t s, const uint64_t* balance, const uint8_t* sflags, const uint8_t* part_cur,
+                             const uint8_t* part_prev, uint64_t n_val, uint64_t* partials)
+{
+    uint64_t blocks = (n_val + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 256) blocks = 256;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_ffg_balances, dim3((unsigned)blocks), dim3(256), 0, s, balance, sflags, part_cur, part_prev,
+                       n_val, reinterpret_cast<unsigned long long*>(partials));
+    return (uint32_t)blocks;
+}
+
 // ------------------------------------------------------------------ bitfield union
 __global__ void __launch_bounds__(256)
 k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ att_words,

@@ -98,6 +98,11 @@ struct UnionGroup {
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
                        const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
 
+// FFG balance sums (pe:791-802): per-workgroup partials [blocks][3] = {total active, previous target, current target};
+// returns the number of workgroups launched.
+uint32_t launch_ffg_balances(hipStream_t s, const uint64_t* balance, const uint8_t* sflags, const uint8_t* part_cur,
+                             const uint8_t* part_prev, uint64_t n_val, uint64_t* partials);
+
 // compute_committee / compute_shuffled_index (pe:495-534) for a whole list: members[i] = indices[shuffled(i)].
 // d_source: rounds * ceil(n/256) * 8 words scratch; d_pivots: rounds words; d_indices null = identity.
 int launch_shuffle(hipStream_t s, const uint32_t* d_seed_be, uint32_t n, uint32_t rounds, uint32_t* d_source,

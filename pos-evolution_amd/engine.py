@@ -280,6 +280,17 @@ class Engine:
     def participation_rotate(self):
         self._check(self._lib.pe_participation_rotate(self._h))
 
+    def state_set_validators(self, effective_balance, flags):
+        bal = np.ascontiguousarray(effective_balance, dtype=np.uint64)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(self._lib.pe_state_set_validators(self._h, bal.size, _ptr(bal, C.c_uint64), _ptr(fl, C.c_uint8)))
+
+    def ffg_balances(self):
+        """-> (total_active_balance, previous_target_balance, current_target_balance) of pe:791-802."""
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self._lib.pe_ffg_balances(self._h, _ptr(out, C.c_uint64)))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def g1_sum(self, offsets, index=None, points96=None) -> np.ndarray:
         off = np.ascontiguousarray(offsets, dtype=np.uint32)
         idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint32)

@@ -239,6 +239,18 @@ class StateBinding:
         self.base_reward_per_increment = int(base_reward_per_increment)
         engine.participation_set(0, np.asarray(state.current_epoch_participation, dtype=np.uint8))
         engine.participation_set(1, np.asarray(state.previous_epoch_participation, dtype=np.uint8))
+        # the working state's own registry view (effective balances, activity in current/previous epoch, slashed)
+        spe = int(engine.cfg.slots_per_epoch)
+        cur = int(state.slot) // spe
+        prev = max(cur - 1, GENESIS_EPOCH)
+        n = len(state.validators)
+        bal = np.fromiter((int(v.effective_balance) for v in state.validators), dtype=np.uint64, count=n)
+        fl = np.fromiter(
+            ((_abi.PE_VAL_ACTIVE if int(v.activation_epoch) <= cur < int(v.exit_epoch) else 0)
+             | (_abi.PE_VAL_SLASHED if v.slashed else 0)
+             | (_abi.PE_VAL_ACTIVE_PREV if int(v.activation_epoch) <= prev < int(v.exit_epoch) else 0)
+             for v in state.validators), dtype=np.uint8, count=n)
+        engine.state_set_validators(bal, fl)
 
     def ctx(self) -> pe_state_ctx:
         s = self.state
@@ -280,3 +292,54 @@ def process_attestation(state, attestation, *, get_beacon_proposer_index: Option
     proposer = get_beacon_proposer_index(state) if get_beacon_proposer_index else 0
     state.balances[proposer] += proposer_reward
     state._last_proposer_reward_numerator = int(numerators[0])
+
+
+# ----------------------------------------------------------------------------- FFG
+JUSTIFICATION_BITS_LENGTH = 4
+
+
+def weigh_justification_and_finalization(state, total_active_balance: int, previous_epoch_target_balance: int,
+                                         current_epoch_target_balance: int, *, get_block_root: Callable,
+                                         slots_per_epoch: int) -> None:
+    """pe:815-853 -- scalar logic on the state, as in the reference."""
+    current_epoch = int(state.slot) // slots_per_epoch
+    previous_epoch = max(current_epoch - 1, GENESIS_EPOCH)
+    old_previous_justified_checkpoint = state.previous_justified_checkpoint
+    old_current_justified_checkpoint = state.current_justified_checkpoint
+    cp_type = type(old_current_justified_checkpoint)
+
+    # Process justifications
+    state.previous_justified_checkpoint = state.current_justified_checkpoint
+    state.justification_bits[1:] = state.justification_bits[:JUSTIFICATION_BITS_LENGTH - 1]
+    state.justification_bits[0] = False
+    if previous_epoch_target_balance * 3 >= total_active_balance * 2:
+        state.current_justified_checkpoint = cp_type(epoch=previous_epoch, root=get_block_root(state, previous_epoch))
+        state.justification_bits[1] = True
+    if current_epoch_target_balance * 3 >= total_active_balance * 2:
+        state.current_justified_checkpoint = cp_type(epoch=current_epoch, root=get_block_root(state, current_epoch))
+        state.justification_bits[0] = True
+
+    # Process finalizations
+    bits = state.justification_bits
+    if all(bits[1:4]) and old_previous_justified_checkpoint.epoch + 3 == current_epoch:
+        state.finalized_checkpoint = old_previous_justified_checkpoint
+    if all(bits[1:3]) and old_previous_justified_checkpoint.epoch + 2 == current_epoch:
+        state.finalized_checkpoint = old_previous_justified_checkpoint
+    if all(bits[0:3]) and old_current_justified_checkpoint.epoch + 2 == current_epoch:
+        state.finalized_checkpoint = old_current_justified_checkpoint
+    if all(bits[0:2]) and old_current_justified_checkpoint.epoch + 1 == current_epoch:
+        state.finalized_checkpoint = old_current_justified_checkpoint
+
+
+def process_justification_and_finalization(state, *, get_block_root: Callable) -> None:
+    """pe:791-802.  ``state`` must have been bound with ``bind_state`` (its participation arrays live on the GPU);
+    the three balance sums come from one streaming kernel over the working-state registry view."""
+    b = _bindings.get(id(state))
+    assert b is not None, "process_justification_and_finalization: bind_state(engine, state, ...) first"
+    spe = int(b.engine.cfg.slots_per_epoch)
+    if int(state.slot) // spe <= GENESIS_EPOCH + 1:
+        return
+    total_active_balance, previous_target_balance, current_target_balance = b.engine.ffg_balances()
+    state._last_ffg_balances = (total_active_balance, previous_target_balance, current_target_balance)
+    weigh_justification_and_finalization(state, total_active_balance, previous_target_balance,
+                                         current_target_balance, get_block_root=get_block_root, slots_per_epoch=spe)

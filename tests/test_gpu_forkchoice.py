@@ -116,3 +116,45 @@ def test_process_attestation_vs_literal_oracle(engine_factory):
         assert mstate.previous_epoch_participation == state.previous_epoch_participation
         assert mstate.balances == state.balances
     assert sum(state.current_epoch_participation) > 0
+
+
+def test_justification_and_finalization_vs_literal_oracle(engine_factory):
+    """process_justification_and_finalization (pe:791-802) + weigh_justification_and_finalization (pe:815-853):
+    the three Gwei sums come from the GPU, the checkpoint/bit logic is the reference's, both must match L0 through
+    several epochs with uneven balances, slashed and exiting validators, and partial participation."""
+    import pos_evolution_amd.forkchoice as fc
+    rng = np.random.default_rng(9)
+    w = new_world(160, "minimal", engine_factory=engine_factory)
+    anchor = w.store.justified_checkpoint.root
+    spe = spec.SLOTS_PER_EPOCH
+    roots = [anchor]
+    for s in range(1, 5 * spe):
+        w.tick_to_slot(s)
+        roots.append(w.block(roots[-1], s))
+    tip = roots[-1]
+    state = w.store.block_states[tip].copy()          # slot 5*spe - 1: last slot of epoch 4, where process_epoch runs
+    for i, v in enumerate(state.validators):
+        v.effective_balance = int(rng.integers(16, 33)) * 10**9
+        if i % 11 == 0:
+            v.slashed = True
+        if i % 13 == 0:
+            v.exit_epoch = 4                            # active in the previous epoch (3) only
+        if i % 17 == 0:
+            v.activation_epoch = 4                      # active in the current epoch (4) only
+    state.justification_bits = [False, True, True, False]
+    state.previous_justified_checkpoint = spec.Checkpoint(1, spec.get_block_root(state, 1))
+    state.current_justified_checkpoint = spec.Checkpoint(2, spec.get_block_root(state, 2))
+    for target_frac_prev, target_frac_cur in ((0.9, 0.1), (0.5, 0.8), (0.7, 0.69)):
+        st = state.copy()
+        n = len(st.validators)
+        st.previous_epoch_participation = [int(rng.integers(0, 8)) | (2 if rng.random() < target_frac_prev else 0) & 7 for _ in range(n)]
+        st.current_epoch_participation = [int(rng.integers(0, 2)) | (2 if rng.random() < target_frac_cur else 0) for _ in range(n)]
+        mst = st.copy()
+        fc.bind_state(w.mirror.engine, mst, tip, 1)
+        spec.process_justification_and_finalization(st)
+        fc.process_justification_and_finalization(mst, get_block_root=spec.get_block_root)
+        assert mst._last_ffg_balances == st._last_ffg_balances
+        assert mst.justification_bits == st.justification_bits
+        assert mst.current_justified_checkpoint == st.current_justified_checkpoint
+        assert mst.previous_justified_checkpoint == st.previous_justified_checkpoint
+        assert mst.finalized_checkpoint == st.finalized_checkpoint
