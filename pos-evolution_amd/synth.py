@@ -139,13 +139,15 @@ def pack_bit_rows(bit_rows) -> tuple:
 
 def epoch_attestations(comm: Committees, tree: Tree, epoch: int, slots_per_epoch: int, seed: int,
                        density: float = 0.99, parts: int = 1, source=(0, None), vote_recent: int = 8,
-                       from_block: bool = False):
+                       from_block: bool = False, vote_seed: Optional[int] = None):
     """One epoch's attestations: committee c attests in slot epoch*SPE + c // cps with index c % cps,
     voting for one of the `vote_recent` most recent blocks whose slot is <= its slot.  Each committee
     contributes `parts` partial aggregates with disjoint random bit subsets (union density `density`).
 
     Returns (atts ATT_DTYPE[n], arena u8, bit_rows list) with n = C * parts."""
     rng = np.random.Generator(np.random.PCG64(seed + 5000 + epoch))
+    # head votes may need to be the same on every shard of a committee: separate stream
+    vrng = rng if vote_seed is None else np.random.Generator(np.random.PCG64(vote_seed + 7000 + epoch))
     n_comm = comm.offsets.size - 1
     cps = n_comm // slots_per_epoch
     assert cps * slots_per_epoch == n_comm
@@ -164,7 +166,7 @@ def epoch_attestations(comm: Committees, tree: Tree, epoch: int, slots_per_epoch
         cand = order[max(0, hi - vote_recent):hi]
         on = rng.random(size) < density
         part_of = rng.integers(0, parts, size=size)
-        blk = int(cand[rng.integers(0, cand.size)]) if cand.size else 0
+        blk = int(cand[vrng.integers(0, cand.size)]) if cand.size else 0
         target_idx = ancestor_at(tree, blk, epoch * slots_per_epoch)  # FFG target consistent with the LMD vote
         for p in range(parts):
             bits = on & (part_of == p)
