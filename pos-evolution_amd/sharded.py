@@ -71,7 +71,10 @@ class ShardedForkChoice:
         part = self._partial[: g * self._pw]
         gathered = self._gathered[: self.world * g * self._pw]
         if self.dist.is_initialized():
-            self.dist.all_gather(list(gathered.chunk(self.world)), part, group=self.group)
+            if self.dist.get_backend(self.group) == "nccl":  # RCCL: one flat collective, no staging copies
+                self.dist.all_gather_into_tensor(gathered, part, group=self.group)
+            else:                                            # gloo (CPU tests)
+                self.dist.all_gather(list(gathered.chunk(self.world)), part, group=self.group)
         else:
             gathered.copy_(part)
         res["aggpk96"] = self.engine.g1_finish(gathered.data_ptr(), self.world, g)
