@@ -92,7 +92,7 @@ def run_step_single(e, w, st):
     e.participation_rotate()
     agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
     g = agg["n_groups"]
-    rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
+    rows = agg["atts"]
     status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, agg["out_arena"]))
     st2, num = _timed("process_attestation", e.process_attestation_batch, state_ctx(w, ep),
                       packed=(rows, agg["out_arena"]))
@@ -108,7 +108,7 @@ def run_step_sharded(e, w, st, sh):
     e.participation_rotate()
     agg = sh.aggregate(packed=(st["atts"], st["arena"]))    # all-gather of C x 192 B XYZZ partials inside
     g = agg["n_groups"]
-    rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=g)
+    rows = agg["atts"]
     status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
     st2, num = e.process_attestation_batch(state_ctx(w, ep), packed=(rows, agg["out_arena"]))
     head = sh.get_head()                                    # all-reduce of (B + 512) x 8 B inside
@@ -342,7 +342,7 @@ def main():
         e2.set_committees(st0["epoch"], st0["comm"].offsets, st0["comm"].members)
         agg = e2.aggregate(packed=(st0["atts"], st0["arena"]), want_aggregate_pubkeys=True)
         import pos_evolution_amd.synth as synth
-        rows = np.frombuffer(agg["atts"], dtype=synth.ATT_DTYPE, count=agg["n_groups"])
+        rows = agg["atts"]
         cps = C // 32
         pos = ((rows["slot"] % 32) * cps + rows["index"]).astype(np.int64)
         out["checked_against_oracle"] = bool(np.array_equal(agg["aggpk96"], chk["aggpk"][pos]))

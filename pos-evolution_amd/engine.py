@@ -83,17 +83,24 @@ def pack_attestations(rows: Sequence[AttRow]):
     return arr, np.ascontiguousarray(arena)
 
 
+_ATT_DTYPE = np.dtype([
+    ("slot", "<u8"), ("index", "<u8"), ("beacon_block_root", "u1", (32,)),
+    ("source_epoch", "<u8"), ("source_root", "u1", (32,)),
+    ("target_epoch", "<u8"), ("target_root", "u1", (32,)),
+    ("bits_offset", "<u4"), ("n_bits", "<u4"), ("flags", "<u4"), ("reserved0", "<u4"),
+])  # == synth.ATT_DTYPE == struct pe_attestation (144 bytes)
+
+
 class AggregateResult(dict):
     """Result of Engine.aggregate; ``res["bits"]`` decodes the OR-ed bitfields on demand."""
 
     def __getitem__(self, key):
         if key == "bits" and "bits" not in self:
             out, arena = [], dict.__getitem__(self, "out_arena")
-            for k in range(dict.__getitem__(self, "n_groups")):
-                a = dict.__getitem__(self, "atts")[k]
-                nb = (a.n_bits + 7) // 8
-                out.append(np.unpackbits(arena[a.bits_offset:a.bits_offset + nb], bitorder="little")[:a.n_bits]
-                           .astype(bool))
+            for a in dict.__getitem__(self, "atts"):
+                off, nbits = int(a["bits_offset"]), int(a["n_bits"])
+                nb = (nbits + 7) // 8
+                out.append(np.unpackbits(arena[off:off + nb], bitorder="little")[:nbits].astype(bool))
             self["bits"] = out
         return dict.__getitem__(self, key)
 
@@ -225,35 +232,37 @@ class Engine:
         """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        status = np.zeros(max(n, 1), dtype=np.int32)
-        count = np.zeros(max(n, 1), dtype=np.uint32)
-        agg = np.zeros((max(n, 1), 96), dtype=np.uint8) if want_aggregate_pubkeys else None
+        status = np.empty(max(n, 1), dtype=np.int32)
+        count = np.empty(max(n, 1), dtype=np.uint32)
+        agg = np.empty((max(n, 1), 96), dtype=np.uint8) if want_aggregate_pubkeys else None
         self._check(self._lib.pe_on_attestation_batch(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
                                                       _ptr(status, C.c_int32), _ptr(agg, C.c_uint8),
                                                       _ptr(count, C.c_uint32)))
         return status[:n], (agg[:n] if agg is not None else None), count[:n]
 
     def aggregate(self, rows=None, packed=None, sig_points96=None, want_aggregate_pubkeys=False):
-        """-> dict(groups=[AttRow-like tuples], group_of, bits (list of bool arrays), sig96, aggpk96, count)."""
+        """-> AggregateResult(n_groups, atts (ATT_DTYPE rows of the groups), group_of, out_arena, sig96, aggpk96,
+        count; ``["bits"]`` decodes the OR-ed bitfields on demand)."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        out_atts = (pe_attestation * max(n, 1))()
+        m = max(n, 1)
+        out_atts = np.empty(m, dtype=_ATT_DTYPE)  # output buffers: written by the engine, never read before that
         n_groups = C.c_uint32(0)
-        group_of = np.zeros(max(n, 1), dtype=np.uint32)
-        out_arena = np.zeros(max(arena.size, 1), dtype=np.uint8)
+        group_of = np.empty(m, dtype=np.uint32)
+        out_arena = np.empty(max(arena.size, 1), dtype=np.uint8)
         sig = None
         if sig_points96 is not None:
             sig = np.ascontiguousarray(sig_points96, dtype=np.uint8)
             assert sig.size == 96 * n
-        out_sig = np.zeros((max(n, 1), 96), dtype=np.uint8) if sig is not None else None
-        out_pk = np.zeros((max(n, 1), 96), dtype=np.uint8) if want_aggregate_pubkeys else None
-        count = np.zeros(max(n, 1), dtype=np.uint32)
+        out_sig = np.empty((m, 96), dtype=np.uint8) if sig is not None else None
+        out_pk = np.empty((m, 96), dtype=np.uint8) if want_aggregate_pubkeys else None
+        count = np.empty(m, dtype=np.uint32)
         self._check(self._lib.pe_aggregate(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size, _ptr(sig, C.c_uint8),
-                                           out_atts, C.byref(n_groups), _ptr(group_of, C.c_uint32),
+                                           _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
                                            _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
                                            _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
         g = n_groups.value
-        return AggregateResult(n_groups=g, atts=out_atts, group_of=group_of[:n], out_arena=out_arena,
+        return AggregateResult(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena,
                                sig96=None if out_sig is None else out_sig[:g],
                                aggpk96=None if out_pk is None else out_pk[:g], count=count[:g])
 
@@ -261,8 +270,8 @@ class Engine:
         """-> (status int32[n], proposer_reward_numerator uint64[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        status = np.zeros(max(n, 1), dtype=np.int32)
-        num = np.zeros(max(n, 1), dtype=np.uint64)
+        status = np.empty(max(n, 1), dtype=np.int32)
+        num = np.empty(max(n, 1), dtype=np.uint64)
         self._check(self._lib.pe_process_attestation_batch(self._h, C.byref(state_ctx), _att_ptr(arr), n,
                                                            _ptr(arena, C.c_uint8), arena.size,
                                                            _ptr(status, C.c_int32), _ptr(num, C.c_uint64)))
@@ -316,17 +325,17 @@ class Engine:
         """pe_aggregate with the aggregate pubkeys left as this shard's Jacobian partials at dev_ptr."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        out_atts = (pe_attestation * max(n, 1))()
+        out_atts = np.empty(max(n, 1), dtype=_ATT_DTYPE)
         n_groups = C.c_uint32(0)
-        group_of = np.zeros(max(n, 1), dtype=np.uint32)
-        out_arena = np.zeros(max(arena.size, 1), dtype=np.uint8)
-        count = np.zeros(max(n, 1), dtype=np.uint32)
+        group_of = np.empty(max(n, 1), dtype=np.uint32)
+        out_arena = np.empty(max(arena.size, 1), dtype=np.uint8)
+        count = np.empty(max(n, 1), dtype=np.uint32)
         self._check(self._lib.pe_aggregate_partial(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
-                                                   out_atts, C.byref(n_groups), _ptr(group_of, C.c_uint32),
+                                                   _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
                                                    _ptr(out_arena, C.c_uint8), out_arena.size,
                                                    _ptr(count, C.c_uint32), C.c_void_p(dev_ptr)))
         g = n_groups.value
-        return dict(n_groups=g, atts=out_atts, group_of=group_of[:n], out_arena=out_arena, count=count[:g])
+        return dict(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena, count=count[:g])
 
     def g1_partial(self, offsets, index, dev_ptr: int):
         off = np.ascontiguousarray(offsets, dtype=np.uint32)

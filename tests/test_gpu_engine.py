@@ -217,7 +217,7 @@ def test_aggregate_vs_oracle(engine_factory):
         assert res["count"][g] == want_bits.sum()
         out = res["atts"][g]
         cps = 128 // spe
-        c = (out.slot % spe) * cps + out.index
+        c = int((out["slot"] % spe) * cps + out["index"])
         mem = comm.members[comm.offsets[c]:comm.offsets[c + 1]]
         assert res["aggpk96"][g].tobytes() == H.closed_form_sum(mem[want_bits], a, b)
     want_sig = cport.g1_sum_groups(sigs, np.argsort(res["group_of"], kind="stable").astype(np.uint32),

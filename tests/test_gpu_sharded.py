@@ -64,7 +64,7 @@ def test_two_shards_on_one_gpu(engine_factory):
     _load(whole, tree, bal, flags, pts, comm, epoch)
     atts, arena, bit_rows = synth.epoch_attestations(comm, tree, epoch, 32, seed=5, density=0.8, parts=2)
     ref = whole.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
-    rows = np.frombuffer(ref["atts"], dtype=synth.ATT_DTYPE, count=ref["n_groups"])
+    rows = ref["atts"]
     st, _, _ = whole.on_attestation_batch(packed=(rows, ref["out_arena"]))
     assert (st == 0).all()
     ref_head, ref_w = whole.get_head(), whole.get_weights()
@@ -87,7 +87,7 @@ def test_two_shards_on_one_gpu(engine_factory):
         torch.cuda.synchronize()
         assert res["n_groups"] == C
         gathered[r * C * PW:(r + 1) * C * PW] = part
-        lrows = np.frombuffer(res["atts"], dtype=synth.ATT_DTYPE, count=C)
+        lrows = res["atts"]
         st, _, _ = e.on_attestation_batch(packed=(lrows, res["out_arena"]))
         assert (st == 0).all()
         buf = torch.zeros_like(wsum)
@@ -131,7 +131,7 @@ def test_sharded_forkchoice_world_size_one(engine_factory):
         sh = ShardedForkChoice(e, n_groups_max=C)
         got = sh.aggregate(packed=(atts, arena))
         assert np.array_equal(got["aggpk96"], ref["aggpk96"])
-        rows = np.frombuffer(ref["atts"], dtype=synth.ATT_DTYPE, count=C)
+        rows = ref["atts"]
         e.on_attestation_batch(packed=(rows, ref["out_arena"]))
         assert sh.get_head() == e.get_head()
         e.set_stream(0)
