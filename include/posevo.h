@@ -226,6 +226,16 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
                             const uint8_t* bits_arena, uint64_t arena_len,
                             int32_t* status, uint8_t* out_aggpk96, uint32_t* out_count);
 
+/* get_indexed_attestation (Appendix A.6; call sites pe:736, pe:975) x n: attesting_indices =
+ * sorted(committee[i] for i with aggregation_bits[i]), resolved against the committee table of each row's target
+ * epoch exactly as pe_on_attestation_batch resolves it (no store time/root validation: this is the state-only
+ * helper).  out_offsets has n + 1 entries; indices of row i are out_indices[out_offsets[i] .. out_offsets[i+1]).
+ * status[i] = PE_ATT_NO_COMMITTEE_TABLE / _COMMITTEE_INDEX_OUT_OF_RANGE / _BITS_LENGTH_MISMATCH or 0.
+ * out_indices must have room for the total number of set bits (<= sum of n_bits). */
+int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32_t n,
+                                const uint8_t* bits_arena, uint64_t arena_len, int32_t* status,
+                                uint32_t* out_offsets, uint32_t* out_indices, uint64_t out_indices_cap);
+
 /* Aggregation (validator guide, Appendix A.8; reference prose pe:474/659/715/1536):
  * attestations with identical AttestationData and n_bits form one group (groups
  * ordered by first appearance).  Per group: aggregation_bits = OR of the members'

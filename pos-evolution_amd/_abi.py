@@ -92,6 +92,8 @@ SIGNATURES = {
     "pe_get_head": (C.c_int, [_H, _u8p]),
     "pe_get_weights": (C.c_int, [_H, _u64p, C.c_uint32]),
     "pe_on_attestation_batch": (C.c_int, [_H, _P(pe_attestation), C.c_uint32, _u8p, C.c_uint64, _i32p, _u8p, _u32p]),
+    "pe_get_indexed_attestations": (C.c_int, [_H, _P(pe_attestation), C.c_uint32, _u8p, C.c_uint64, _i32p, _u32p, _u32p,
+                                              C.c_uint64]),
     "pe_aggregate": (C.c_int, [_H, _P(pe_attestation), C.c_uint32, _u8p, C.c_uint64, _u8p, _P(pe_attestation),
                                _u32p, _u32p, _u8p, C.c_uint64, _u8p, _u8p, _u32p]),
     "pe_process_attestation_batch": (C.c_int, [_H, _P(pe_state_ctx), _P(pe_attestation), C.c_uint32, _u8p,

@@ -1401,6 +1401,89 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
     return PE_OK;
 }
 
+int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
+                                uint64_t arena_len, int32_t* status, uint32_t* out_offsets, uint32_t* out_indices,
+                                uint64_t out_indices_cap)
+{
+    if (!h || !out_offsets || (n && (!atts || !bits_arena || !status))) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    out_offsets[0] = 0;
+    if (n == 0) return PE_OK;
+    uint64_t word_bound = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
+            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        word_bound += (atts[i].n_bits + 31) / 32 + 1;
+    }
+    Stage st(h);
+    HIP_TRY(h, st.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)(n + 1) + 4096));
+    const size_t off_words = st.alloc(word_bound * 4);
+    const size_t off_rows = st.alloc(sizeof(AttRow) * (size_t)n);
+    const size_t off_offs = st.alloc(4ull * (n + 1));
+    uint32_t* words = st.host<uint32_t>(off_words);
+    AttRow* rows = st.host<AttRow>(off_rows);
+    uint32_t* offs = st.host<uint32_t>(off_offs);
+    std::vector<CommitteeTable*> row_table;
+    std::vector<uint32_t> row_src;
+    uint32_t n_words = 0, n_rows = 0;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pe_attestation& a = atts[i];
+        int32_t s = PE_ATT_OK;
+        CommitteeTable* t = find_table(h, a.target_epoch);
+        uint32_t cnt = 0;
+        if (!t) s = PE_ATT_NO_COMMITTEE_TABLE;
+        else {
+            const uint64_t cps = t->n_committees / h->cfg.slots_per_epoch;
+            const uint64_t pos = (a.slot % h->cfg.slots_per_epoch) * cps + a.index;
+            if (pos >= t->n_committees) s = PE_ATT_COMMITTEE_INDEX_OUT_OF_RANGE;
+            else {
+                const uint32_t size = t->offsets[pos + 1] - t->offsets[pos];
+                if (a.n_bits < size) s = PE_ATT_BITS_LENGTH_MISMATCH;
+                else if (size > 8192) return fail(h, PE_ERR_CAPACITY, "committee larger than 8192 members");
+                else {
+                    cnt = size ? pack_bits(bits_arena + a.bits_offset, size, words + n_words) : 0;
+                    AttRow& r = rows[n_rows];
+                    r.member_base = t->offsets[pos];
+                    r.n_bits = size;
+                    r.bits_word = n_words;
+                    r.block_idx = r.epoch_p1 = r.order = r.flag_mask = r.which = 0;
+                    offs[n_rows] = (uint32_t)total;
+                    n_words += (size + 31) / 32;
+                    row_table.push_back(t);
+                    row_src.push_back(i);
+                    ++n_rows;
+                }
+            }
+        }
+        status[i] = s;
+        out_offsets[i] = (uint32_t)total;
+        total += cnt;
+        if (total > 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "more than 2^32 attesting indices in one call");
+    }
+    out_offsets[n] = (uint32_t)total;
+    if (total > out_indices_cap) return fail(h, PE_ERR_CAPACITY, "out_indices too small");
+    if (n_rows == 0 || total == 0) return PE_OK;
+    if (!out_indices) return PE_ERR_INVALID_ARG;
+    OutBlock ob(h);
+    const size_t off_idx = ob.alloc(4ull * total);
+    HIP_TRY(h, ob.ensure());
+    HIP_TRY(h, st.upload());
+    for (uint32_t k = 0; k < n_rows;) {  // one launch per run of rows sharing a table (members array)
+        uint32_t e = k + 1;
+        while (e < n_rows && row_table[e] == row_table[k]) ++e;
+        launch_indexed_attestations(h->stream, st.dev<AttRow>(off_rows) + k, e - k,
+                                    row_table[k]->d_members.as<uint32_t>(), st.dev<uint32_t>(off_words),
+                                    st.dev<uint32_t>(off_offs) + k, ob.dev<uint32_t>(off_idx));
+        k = e;
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, ob.download());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out_indices, ob.host<uint32_t>(off_idx), 4ull * total);
+    return PE_OK;
+}
+
 // ---------------------------------------------------------------- aggregation
 static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                           uint64_t arena_len, const uint8_t* sig_points96, pe_attestation* out_atts,

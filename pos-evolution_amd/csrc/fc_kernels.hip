@@ -497,6 +497,73 @@ void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, co
                        part_prev_words, reinterpret_cast<unsigned long long*>(numerators), numerator_slot);
 }
 
+// ------------------------------------------------------------------ indexed attestations
+// get_indexed_attestation (call sites pe:736, pe:975): attesting_indices =
+// sorted(committee[i] for i with bits[i]).  One workgroup per attestation: compaction by a block prefix sum over the
+// set bits (wave ballot + popcount), then a bitonic sort in LDS (committees hold <= 8192 members).
+constexpr int IDX_WG = 256;
+constexpr int IDX_MAX = 8192;
+
+__global__ void __launch_bounds__(IDX_WG)
+k_indexed_attestations(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restrict__ members,
+                       const uint32_t* __restrict__ bit_arena, const uint32_t* __restrict__ out_offsets,
+                       uint32_t* __restrict__ out_indices)
+{
+    __shared__ uint32_t keys[IDX_MAX];
+    __shared__ uint32_t wave_cnt[IDX_WG / 64];
+    __shared__ uint32_t base_s;
+    const uint32_t a = blockIdx.x;
+    if (a >= n_rows) return;
+    const AttRow r = rows[a];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    // compaction, 256 bit positions per pass: ballot the set bits, rank = popcount of lower lanes + wave offsets
+    for (uint32_t i0 = 0; i0 < r.n_bits; i0 += IDX_WG) {
+        const uint32_t i = i0 + tid;
+        bool set = false;
+        if (i < r.n_bits) set = (bit_arena[r.bits_word + (i >> 5)] >> (i & 31)) & 1u;
+        const unsigned long long ballot = __ballot(set);
+        const uint32_t below = __builtin_popcountll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __builtin_popcountll(ballot);
+        __syncthreads();
+        uint32_t off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (set) keys[off + below] = members[r.member_base + i];
+        __syncthreads();
+        if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    const uint32_t count = base_s;
+    uint32_t n2 = 1;
+    while (n2 < count) n2 <<= 1;
+    for (uint32_t i = count + tid; i < n2; i += IDX_WG) keys[i] = NONE32;  // pad: sorts to the end
+    __syncthreads();
+    for (uint32_t k = 2; k <= n2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < n2; i += IDX_WG) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t x = keys[i], y = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t o = out_offsets[a];
+    for (uint32_t i = tid; i < count; i += IDX_WG) out_indices[o + i] = keys[i];
+}
+
+void launch_indexed_attestations(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
+                                 const uint32_t* bit_arena, const uint32_t* out_offsets, uint32_t* out_indices)
+{
+    if (n_rows == 0) return;
+    hipLaunchKernelGGL(k_indexed_attestations, dim3(n_rows), dim3(IDX_WG), 0, s, rows, n_rows, members, bit_arena,
+                       out_offsets, out_indices);
+}
+
 // ------------------------------------------------------------------ FFG balance sums
 // The three Gwei sums process_justification_and_finalization (pe:791-802) feeds to
 // weigh_justification_and_finalization (pe:815-853):

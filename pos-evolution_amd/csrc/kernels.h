@@ -98,6 +98,10 @@ struct UnionGroup {
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
                        const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
 
+// get_indexed_attestation: sorted attesting indices per row, written at out_offsets[row] (committees <= 8192 members)
+void launch_indexed_attestations(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
+                                 const uint32_t* bit_arena, const uint32_t* out_offsets, uint32_t* out_indices);
+
 // FFG balance sums (pe:791-802): per-workgroup partials [blocks][3] = {total active, previous target, current target};
 // returns the number of workgroups launched.
 uint32_t launch_ffg_balances(hipStream_t s, const uint64_t* balance, const uint8_t* sflags, const uint8_t* part_cur,

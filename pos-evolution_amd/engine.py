@@ -240,6 +240,19 @@ class Engine:
                                                       _ptr(count, C.c_uint32)))
         return status[:n], (agg[:n] if agg is not None else None), count[:n]
 
+    def get_indexed_attestations(self, rows=None, packed=None):
+        """get_indexed_attestation x n (A.6): -> (status int32[n], offsets uint32[n+1], sorted attesting indices)."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        status = np.empty(max(n, 1), dtype=np.int32)
+        offsets = np.empty(n + 1, dtype=np.uint32)
+        cap = int(sum(int(r.bits.size) for r in rows)) if rows is not None else int(arr["n_bits"].sum())
+        indices = np.empty(max(cap, 1), dtype=np.uint32)
+        self._check(self._lib.pe_get_indexed_attestations(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
+                                                          _ptr(status, C.c_int32), _ptr(offsets, C.c_uint32),
+                                                          _ptr(indices, C.c_uint32), indices.size))
+        return status[:n], offsets, indices[:int(offsets[-1])]
+
     def aggregate(self, rows=None, packed=None, sig_points96=None, want_aggregate_pubkeys=False):
         """-> AggregateResult(n_groups, atts (ATT_DTYPE rows of the groups), group_of, out_arena, sig96, aggpk96,
         count; ``["bits"]`` decodes the OR-ed bitfields on demand)."""

@@ -222,6 +222,15 @@ def on_attester_slashing(store: Store, attester_slashing) -> None:
     store.equivocating_indices |= set(a1.attesting_indices).intersection(a2.attesting_indices)
 
 
+def get_indexed_attestation(store: Store, attestation):
+    """get_indexed_attestation(state, attestation) (Appendix A.6): the sorted attesting indices, resolved against the
+    committee table of the attestation's target epoch on the GPU.  Returns (attesting_indices, data, signature)."""
+    status, offsets, indices = store.engine.get_indexed_attestations([_att_row(attestation)])
+    if status[0] != 0:
+        raise EngineError(int(status[0]), "get_indexed_attestation: " + _abi.ATT_STATUS_NAMES.get(int(status[0]), "?"))
+    return [int(i) for i in indices], attestation.data, getattr(attestation, "signature", None)
+
+
 def get_head(store: Store) -> bytes:
     """pe:1102-1116"""
     return store.engine.get_head()

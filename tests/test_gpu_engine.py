@@ -289,3 +289,36 @@ def test_process_attestation_vs_oracle(engine_factory):
     assert np.array_equal(num[sel], want)
     assert np.array_equal(e.participation_get(0), pc)
     assert np.array_equal(e.participation_get(1), pp)
+
+
+# ---------------------------------------------------------------- get_indexed_attestation
+def test_indexed_attestations_sorted_indices(engine_factory):
+    """attesting_indices = sorted(committee[i] for i with bits[i]) (A.6) for ragged committees up to 2048 members."""
+    e = engine_factory()
+    n_val = 6000
+    e.set_validators(synth.balances(n_val, 31), np.ones(n_val, dtype=np.uint8))
+    sizes = [2048, 0, 1, 2, 63, 64, 65, 1000] + [0] * 23 + [777]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    rng = np.random.default_rng(31)
+    members = rng.permutation(n_val)[: offsets[-1]].astype(np.uint32)
+    e.set_committees(3, offsets, members)
+    rows, want = [], []
+    for slot_in_epoch, dens in [(0, 1.0), (0, 0.5), (1, 1.0), (2, 1.0), (3, 0.5), (4, 0.9), (5, 0.0), (6, 0.3), (7, 0.7),
+                                (31, 0.5), (9, 1.0)]:
+        size = sizes[slot_in_epoch]
+        bits = rng.random(size) < dens
+        rows.append(pea_row(3 * 32 + slot_in_epoch, bits))
+        m = members[offsets[slot_in_epoch]:offsets[slot_in_epoch + 1]]
+        want.append(np.sort(m[bits]))
+    rows.append(pea_row(3 * 32 + 6, np.ones(10)))        # shorter than the committee (65): rejected
+    rows.append(pea_row(4 * 32, np.ones(3)))             # no table for epoch 4
+    status, off, idx = e.get_indexed_attestations(rows)
+    assert list(status) == [0] * 11 + [10, 8]
+    for k, w in enumerate(want):
+        assert np.array_equal(idx[off[k]:off[k + 1]], w), k
+    assert off[-1] == sum(len(w) for w in want)
+
+
+def pea_row(slot, bits):
+    import pos_evolution_amd as pea
+    return pea.AttRow(slot, 0, bytes(32), 0, bytes(32), slot // 32, bytes(32), np.asarray(bits, dtype=np.uint8))

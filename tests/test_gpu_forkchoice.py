@@ -65,6 +65,8 @@ def test_on_attestation_aggregate_pubkey_matches_bls_oracle(engine_factory):
             status, aggpk, count = w.mirror.engine.on_attestation_batch([_att_row(att)], want_aggregate_pubkeys=True)
             idx = spec.get_indexed_attestation(state, att).attesting_indices
             assert status[0] == 0 and count[0] == len(idx)
+            got_idx, got_data, _ = w.fc.get_indexed_attestation(w.mirror, att)   # A.6 through the mirror
+            assert got_idx == list(idx) and got_data == att.data
             assert aggpk[0].tobytes() == g1.to_bytes96(spec.aggregate_pubkeys(state, idx))
 
 
