@@ -284,6 +284,14 @@ int pe_ffg_balances(pe_engine* h, uint64_t out[3]);
 int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points,
               const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, uint8_t* out96);
 
+/* bls.Aggregate over real BLSSignature points (type pe:37, Attestation.signature pe:717; aggregation prose pe:659,
+ * pe:1536): plain G2 sum over caller-chosen groups, out[g] = sum_{j in [offsets[g], offsets[g+1])} points[index[j]]
+ * (index NULL = identity).  Points are 192-byte uncompressed affine, ZCash order x.c1 | x.c0 | y.c1 | y.c0, each 48
+ * bytes big-endian; bit 6 of byte 0 flags infinity.  Outputs are canonical affine in the same format (exact). */
+#define PE_G2_POINT_BYTES 192
+int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points,
+              const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, uint8_t* out192);
+
 /* ---- inspection (parity checks) ---------------------------------------- */
 uint32_t pe_num_blocks(const pe_engine* h);
 uint64_t pe_num_validators(const pe_engine* h);
@@ -341,7 +349,9 @@ int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
 #define PE_KERNEL_LMD           4
 #define PE_KERNEL_PARTICIPATION 5
 #define PE_KERNEL_BITS_UNION    6
-#define PE_KERNEL_COUNT         7
+#define PE_KERNEL_G2_ACCUMULATE 7
+#define PE_KERNEL_G2_NORMALISE  8
+#define PE_KERNEL_COUNT         9
 int pe_profile_enable(pe_engine* h, int on);
 int pe_profile_reset(pe_engine* h);
 int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms);

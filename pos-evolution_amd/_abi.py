@@ -20,8 +20,10 @@ PE_ATT_FLAG_SIGNATURE_VALID, PE_ATT_FLAG_FROM_BLOCK = 0x1, 0x2
 PE_G1_PARTIAL_BYTES = 192
 PE_EXCHANGE_EXTRA = 512
 (PE_KERNEL_G1_ACCUMULATE, PE_KERNEL_G1_NORMALISE, PE_KERNEL_VOTES, PE_KERNEL_TREE, PE_KERNEL_LMD,
- PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_COUNT) = range(8)
-KERNEL_NAMES = ["g1_accumulate", "g1_normalise", "votes", "tree", "lmd", "participation", "bits_union"]
+ PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_G2_ACCUMULATE, PE_KERNEL_G2_NORMALISE,
+ PE_KERNEL_COUNT) = range(10)
+KERNEL_NAMES = ["g1_accumulate", "g1_normalise", "votes", "tree", "lmd", "participation", "bits_union",
+                "g2_accumulate", "g2_normalise"]
 
 ATT_STATUS_NAMES = {
     0: "ok", 1: "target epoch not current or previous", 2: "target epoch != epoch(slot)",
@@ -104,6 +106,7 @@ SIGNATURES = {
     "pe_state_set_validators": (C.c_int, [_H, C.c_uint64, _u64p, _u8p]),
     "pe_ffg_balances": (C.c_int, [_H, _u64p]),
     "pe_g1_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
+    "pe_g2_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
     "pe_num_blocks": (C.c_uint32, [_H]),
     "pe_num_validators": (C.c_uint64, [_H]),
     "pe_block_root_at": (C.c_int, [_H, C.c_uint32, _u8p]),

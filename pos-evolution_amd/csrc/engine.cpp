@@ -487,12 +487,15 @@ struct G1Plan {
 };
 // sizes[g] = members of group g; writes descriptors into `out` (member_start = 0, bits_word = NONE32: the caller
 // fills them in afterwards).
+// wg_slots = task slots per workgroup (G1: one lane per slot; G2: a lane pair per slot), target_slots = slots that
+// fill the chip at two waves per SIMD.
 template <typename SizeFn>
-void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan)
+void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan, uint32_t wg_slots = G1_WG,
+             uint32_t target_slots = G1_TARGET_LANES)
 {
     uint64_t total = 0;
     for (uint32_t g = 0; g < n_groups; ++g) total += size_of(g);
-    const uint32_t k = (uint32_t)std::max<uint64_t>(4, (total + G1_TARGET_LANES - 1) / G1_TARGET_LANES);
+    const uint32_t k = (uint32_t)std::max<uint64_t>(4, (total + target_slots - 1) / target_slots);
     uint32_t cursor = 0, outp = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
         G1Group& d = out[g];
@@ -508,7 +511,7 @@ void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan)
             d.out_base = outp;
             continue;
         }
-        if (d.n_tasks <= (uint32_t)G1_WG) {
+        if (d.n_tasks <= wg_slots) {
             uint32_t l2 = 0;
             while ((1u << l2) < d.n_tasks) ++l2;
             d.log2_block = l2;
@@ -520,10 +523,10 @@ void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan)
             outp += 1;
         } else {
             d.log2_block = 9;  // wide: whole workgroups
-            cursor = (cursor + G1_WG - 1) & ~(uint32_t)(G1_WG - 1);
+            cursor = (cursor + wg_slots - 1) & ~(wg_slots - 1);
             d.slot_base = cursor;
-            const uint32_t wgs = (d.n_tasks + G1_WG - 1) / G1_WG;
-            cursor += wgs * G1_WG;
+            const uint32_t wgs = (d.n_tasks + wg_slots - 1) / wg_slots;
+            cursor += wgs * wg_slots;
             d.out_base = outp;
             outp += wgs;
         }
@@ -2014,6 +2017,61 @@ int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint3
     HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_out96.p, 96ull * n_groups, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     memcpy(out96, h->h_pin.p, 96ull * n_groups);
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- plain G2 sums (8(f) rank 3)
+int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const uint32_t* index, const uint32_t* offsets,
+              uint32_t n_groups, uint8_t* out192)
+{
+    if (!h || !offsets || !out192 || (n_points && !points192)) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n_groups == 0) return PE_OK;
+    if (n_points >= 0xFFFFFFFFull / 48) return fail(h, PE_ERR_CAPACITY, "too many points");
+    const uint32_t total = offsets[n_groups];
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
+    if (index) {
+        for (uint32_t j = 0; j < total; ++j)
+            if (index[j] >= n_points) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
+    } else if (total > n_points) {
+        return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
+    }
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(192, 192ull * n_points)));
+    HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(192, 192ull * n_points)));
+    if (n_points) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points192, 192ull * n_points, hipMemcpyHostToDevice, h->stream));
+        launch_g2_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
+    }
+    Stage st(h);
+    HIP_TRY(h, st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
+    const size_t off_g = st.alloc(sizeof(G1Group) * (size_t)n_groups);
+    const size_t off_i = st.alloc(4ull * total + 4);
+    G1Group* gr = st.host<G1Group>(off_g);
+    G1Plan plan;
+    plan_g1(n_groups, [&](uint32_t g) { return offsets[g + 1] - offsets[g]; }, gr, &plan, G2_WG_SLOTS,
+            G1_TARGET_LANES / 2);
+    for (uint32_t g = 0; g < n_groups; ++g) gr[g].member_start = offsets[g];
+    if (index) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
+    OutBlock ob(h);
+    const size_t off_o = ob.alloc(192ull * n_groups);
+    HIP_TRY(h, ob.ensure());
+    HIP_TRY(h, st.upload());
+    HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(384, 384ull * plan.n_partials)));
+    {
+        ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE);
+        launch_g2_accumulate(h->stream, h->d_tmp_points.as<uint32_t>(), index ? st.dev<uint32_t>(off_i) : nullptr,
+                             st.dev<G1Group>(off_g), plan.n_groups, plan.n_slots, h->d_partials.as<uint32_t>());
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G2_NORMALISE);
+        launch_g2_finish(h->stream, h->d_partials.as<uint32_t>(), st.dev<G1Group>(off_g), plan.n_groups,
+                         ob.dev<uint8_t>(off_o));
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, ob.download());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out192, ob.host<uint8_t>(off_o), 192ull * n_groups);
     return PE_OK;
 }
 

@@ -1,0 +1,272 @@
+// g2_kernels.hip -- BLS12-381 G2 point-sum kernels for gfx950.
+//
+// bls.Aggregate over BLSSignature points (pe:37, pe:717; prose pe:659, pe:1536): the same accumulate -> workgroup
+// tree -> finish structure as g1_kernels.hip, with every point handled by a LANE PAIR (g2.cuh: one Fp2 component
+// per lane).  A 256-lane workgroup therefore covers G2_WG_SLOTS = 128 task slots.
+//
+//   k_g2_convert     192-B big-endian affine (x.c1 | x.c0 | y.c1 | y.c0) -> Montgomery limbs [x0 x1 y0 y1]
+//   k_g2_accumulate  per-pair XYZZ accumulation of k gathered points (mixed adds, 18 products per lane each), then a
+//                    compacting pairwise tree over the workgroup's 128 partials staged in LDS
+//   k_g2_finish      per group: add the workgroup partials, normalise to canonical affine, store big-endian
+//
+// Bound: integer VALU, 36 Montgomery products per gathered 192-byte point.
+#include "g2.cuh"
+#include "kernels.h"
+
+namespace posevo {
+
+// ---------------------------------------------------------------- convert
+__global__ void __launch_bounds__(256) k_g2_convert(const uint8_t* __restrict__ be192, uint32_t* __restrict__ mont48,
+                                                     uint64_t n)
+{
+    // one lane per Fp element: element e of point i; wire order c1 first, stored order c0 first
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 4 * n) return;
+    const uint64_t i = gid >> 2;
+    const uint32_t e = (uint32_t)(gid & 3);             // wire element: 0 x.c1, 1 x.c0, 2 y.c1, 3 y.c0
+    const uint32_t dst_e = (e & 2) | ((e & 1) ^ 1);     // stored: 0 x0, 1 x1, 2 y0, 3 y1
+    const uint8_t* base = be192 + 192 * i;
+    uint32_t* dst = mont48 + 48 * i + 12 * dst_e;
+    if (base[0] & 0x40) {  // infinity flag
+#pragma unroll
+        for (int j = 0; j < 12; ++j) dst[j] = 0;
+        return;
+    }
+    fp v, m;
+    fp_load_be48(v, base + 48 * e);  // masks the three flag bits of the leading byte
+    if (e != 0) v.l[11] = __builtin_bswap32(reinterpret_cast<const uint32_t*>(base + 48 * e)[0]);  // only x.c1 has flags
+    fp_to_mont(m, v);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) dst[j] = m.l[j];
+}
+
+void launch_g2_convert(hipStream_t s, const uint8_t* be192, uint32_t* mont48, uint64_t n)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_g2_convert, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, s, be192, mont48, n);
+}
+
+// ---------------------------------------------------------------- accumulate
+constexpr int G2_WG = 256;  // lanes; G2_WG_SLOTS (kernels.h) = 128 point slots
+
+__device__ __forceinline__ void ld12(fp& v, const uint32_t* __restrict__ src)
+{
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    const uint4 a = s[0], b = s[1], c = s[2];
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    v.l[8] = c.x; v.l[9] = c.y; v.l[10] = c.z; v.l[11] = c.w;
+}
+__device__ __forceinline__ void st12(uint32_t* __restrict__ dst, const fp& v)
+{
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+}
+// XYZZ partial in global memory: [x0 x1 y0 y1 zz0 zz1 zzz0 zzz1] x 12 words; a lane moves its own halves
+__device__ __forceinline__ void g2_global_store(uint32_t* __restrict__ dst, const g2x& p, bool role)
+{
+    const int o = role ? 12 : 0;
+    st12(dst + o, p.x);
+    st12(dst + 24 + o, p.y);
+    st12(dst + 48 + o, p.zz);
+    st12(dst + 72 + o, p.zzz);
+}
+__device__ __forceinline__ void g2_global_load(g2x& p, const uint32_t* __restrict__ src, bool role)
+{
+    const int o = role ? 12 : 0;
+    ld12(p.x, src + o);
+    ld12(p.y, src + 24 + o);
+    ld12(p.zz, src + 48 + o);
+    ld12(p.zzz, src + 72 + o);
+}
+// LDS staging, limb-major over lane positions: word k of position L at lds[k * G2_WG + L]; slot s = positions 2s, 2s+1
+__device__ __forceinline__ void g2_lds_store(uint32_t* lds, int pos, const g2x& p)
+{
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        lds[k * G2_WG + pos] = p.x.l[k];
+        lds[(12 + k) * G2_WG + pos] = p.y.l[k];
+        lds[(24 + k) * G2_WG + pos] = p.zz.l[k];
+        lds[(36 + k) * G2_WG + pos] = p.zzz.l[k];
+    }
+}
+__device__ __forceinline__ void g2_lds_load(g2x& p, const uint32_t* lds, int pos)
+{
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        p.x.l[k] = lds[k * G2_WG + pos];
+        p.y.l[k] = lds[(12 + k) * G2_WG + pos];
+        p.zz.l[k] = lds[(24 + k) * G2_WG + pos];
+        p.zzz.l[k] = lds[(36 + k) * G2_WG + pos];
+    }
+}
+
+__device__ __forceinline__ uint32_t g2_find_group(const G1Group* __restrict__ groups, uint32_t n_groups, uint32_t slot)
+{
+    uint32_t lo = 0, hi = n_groups;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (groups[mid].slot_base <= slot) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(G2_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_g2_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ members,
+                const G1Group* __restrict__ groups, uint32_t n_groups, uint32_t n_slots,
+                uint32_t* __restrict__ wg_partials)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[48 * G2_WG];
+    __shared__ uint32_t lds_out[G2_WG_SLOTS];
+    __shared__ uint32_t lds_sz[G2_WG_SLOTS];
+
+    const int tid = threadIdx.x;
+    const bool role = tid & 1;
+    const int ws = tid >> 1;  // slot inside the workgroup
+    const uint32_t slot = blockIdx.x * G2_WG_SLOTS + ws;
+
+    g2x acc;
+    g2x_set_inf(acc);
+    uint32_t my_out = NONE32, my_size = 0;
+
+    if (slot < n_slots) {
+        const uint32_t g = g2_find_group(groups, n_groups, slot);
+        const G1Group d = groups[g];
+        const uint32_t t = slot - d.slot_base;
+        const bool wide = d.log2_block > 8;
+        const uint32_t block_slots = d.n_tasks == 0 ? 0u
+                                   : wide ? ((d.n_tasks + G2_WG_SLOTS - 1) / G2_WG_SLOTS) * G2_WG_SLOTS
+                                          : (1u << d.log2_block);
+        if (t < block_slots) {
+            my_size = wide ? (uint32_t)G2_WG_SLOTS : (1u << d.log2_block);
+            my_out = d.out_base + (wide ? t / G2_WG_SLOTS : 0u);
+        }
+        if (t < d.n_tasks) {
+            const uint32_t first = t * d.k;
+            const uint32_t count = min(d.k, d.n_members - first);
+            fp qx, qy, nx, ny;
+            auto fetch = [&](uint32_t j, fp& ox, fp& oy) {
+                const uint32_t i = first + j;
+                const uint32_t idx = members ? members[d.member_start + i] : d.member_start + i;
+                const uint32_t* p = pts + 48ull * idx + (role ? 12 : 0);
+                ld12(ox, p);
+                ld12(oy, p + 24);
+            };
+            if (count > 0) fetch(0, qx, qy);
+            for (uint32_t j = 0; j < count; ++j) {
+                if (j + 1 < count) fetch(j + 1, nx, ny);
+                const bool q_inf = pair_and(fp_is_zero(qx) && fp_is_zero(qy));  // (0,0) encodes infinity
+                g2x_add_affine(acc, qx, qy, q_inf, role);
+                qx = nx; qy = ny;
+            }
+        }
+    }
+    // ---- workgroup tree over the 128 slot partials: level with n pairs, slot w < n adds slots 2w and 2w+1 ----
+    if (my_size == 1) {
+        g2_global_store(wg_partials + (size_t)G2X_WORDS * my_out, acc, role);
+        my_size = 0;
+    }
+    g2_lds_store(lds, tid, acc);
+    if (!role) {
+        lds_out[ws] = my_out;
+        lds_sz[ws] = my_size;
+    }
+    __syncthreads();
+    for (int n = G2_WG_SLOTS / 2; n >= 1; n >>= 1) {
+        const bool active = ws < n;
+        g2x p1;
+        uint32_t out = NONE32, sz = 0;
+        bool store_lds = false;
+        if (active) {
+            sz = lds_sz[2 * ws];
+            out = lds_out[2 * ws];
+            if (sz >= 2) {
+                g2x p2;
+                g2_lds_load(p1, lds, 4 * ws + (role ? 1 : 0));
+                g2_lds_load(p2, lds, 4 * ws + 2 + (role ? 1 : 0));
+                g2x_add(p1, p2, role);
+                sz >>= 1;
+                if (sz == 1) {
+                    g2_global_store(wg_partials + (size_t)G2X_WORDS * out, p1, role);
+                    sz = 0;
+                } else {
+                    store_lds = true;
+                }
+            } else {
+                sz = 0;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            if (store_lds) g2_lds_store(lds, tid, p1);
+            if (!role) {
+                lds_out[ws] = out;
+                lds_sz[ws] = sz;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_g2_accumulate(hipStream_t s, const uint32_t* points_mont48, const uint32_t* members,
+                          const G1Group* groups, uint32_t n_groups, uint32_t n_slots, uint32_t* wg_partials96)
+{
+    if (n_groups == 0 || n_slots == 0) return;
+    const unsigned blocks = (n_slots + G2_WG_SLOTS - 1) / G2_WG_SLOTS;
+    hipLaunchKernelGGL(k_g2_accumulate, dim3(blocks), dim3(G2_WG), 0, s, points_mont48, members, groups, n_groups,
+                       n_slots, wg_partials96);
+}
+
+// ---------------------------------------------------------------- finish
+__global__ void __launch_bounds__(64)
+k_g2_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ groups, uint32_t n_groups,
+            uint8_t* __restrict__ out_be192)
+{
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = lane >> 1;
+    const bool role = lane & 1;
+    if (g >= n_groups) return;
+    const G1Group d = groups[g];
+    uint32_t n_parts = d.log2_block > 8 ? (d.n_tasks + G2_WG_SLOTS - 1) / G2_WG_SLOTS : 1u;
+    if (d.n_tasks == 0) n_parts = 0;
+    g2x acc;
+    g2x_set_inf(acc);
+    for (uint32_t k = 0; k < n_parts; ++k) {
+        g2x q;
+        g2_global_load(q, partials + (size_t)G2X_WORDS * (d.out_base + k), role);
+        g2x_add(acc, q, role);
+    }
+    // wire order: x.c1 | x.c0 | y.c1 | y.c0 -- role 1 (c1) writes the leading 48 bytes of each coordinate
+    uint8_t* o = out_be192 + 192ull * g;
+    uint8_t* ox = o + (role ? 0 : 48);
+    uint8_t* oy = o + 96 + (role ? 0 : 48);
+    if (g2x_is_inf(acc)) {
+        uint32_t* wx = reinterpret_cast<uint32_t*>(ox);
+        uint32_t* wy = reinterpret_cast<uint32_t*>(oy);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            wx[j] = 0;
+            wy[j] = 0;
+        }
+        if (role) o[0] = 0x40;
+        return;
+    }
+    fp x, y;
+    g2x_to_affine(x, y, acc, role);
+    fp_from_mont(x, x);
+    fp_from_mont(y, y);
+    fp_store_be48(ox, x);
+    fp_store_be48(oy, y);
+}
+
+void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* groups, uint32_t n_groups,
+                      uint8_t* out_be192)
+{
+    if (n_groups == 0) return;
+    hipLaunchKernelGGL(k_g2_finish, dim3((2 * n_groups + 63) / 64), dim3(64), 0, s, partials96, groups, n_groups,
+                       out_be192);
+}
+
+}  // namespace posevo

@@ -8,6 +8,7 @@
 namespace posevo {
 
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr int G2_WG_SLOTS = 128;        // point slots per 256-lane workgroup of the G2 kernels (a lane pair per point)
 constexpr int G1_WG = 256;             // lanes (task slots) per workgroup of the accumulate kernel
 constexpr int TREE_MAX_BLOCKS = 8192;  // LDS-resident block tree capacity (K_tree)
 constexpr int VOTES_MAX_WG = 256;      // workgroups of K_votes = slots of per-workgroup partial totals
@@ -97,6 +98,13 @@ struct UnionGroup {
 };
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
                        const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
+
+// G2 (g2_kernels.hip): same group descriptors, points as 48 Montgomery words [x0 x1 y0 y1], partials 96 words
+void launch_g2_convert(hipStream_t s, const uint8_t* be192, uint32_t* mont48, uint64_t n);
+void launch_g2_accumulate(hipStream_t s, const uint32_t* points_mont48, const uint32_t* members,
+                          const G1Group* groups, uint32_t n_groups, uint32_t n_slots, uint32_t* wg_partials96);
+void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* groups, uint32_t n_groups,
+                      uint8_t* out_be192);
 
 // get_indexed_attestation: sorted attesting indices per row, written at out_offsets[row] (committees <= 8192 members)
 void launch_indexed_attestations(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,

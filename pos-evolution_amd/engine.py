@@ -324,6 +324,17 @@ class Engine:
                                         _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
         return out[:n_groups]
 
+    def g2_sum(self, points192, offsets, index=None) -> np.ndarray:
+        """bls.Aggregate over G2 signature points (pe:659, pe:1536): 192-byte uncompressed in, 192-byte affine out."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint32)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint32)
+        pts = np.ascontiguousarray(points192, dtype=np.uint8)
+        n_groups = off.size - 1
+        out = np.empty((max(n_groups, 1), 192), dtype=np.uint8)
+        self._check(self._lib.pe_g2_sum(self._h, _ptr(pts, C.c_uint8), pts.size // 192, _ptr(idx, C.c_uint32),
+                                        _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
+        return out[:n_groups]
+
     # -- multi-GPU exchange -------------------------------------------------
     def votes_partial(self, dev_ptr: int):
         """dev_ptr: device buffer of num_blocks + PE_EXCHANGE_EXTRA u64 (weights | per-workgroup active totals)."""

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 import numpy as np  # noqa: E402
 
-from oracle import g1, spec  # noqa: E402
+from oracle import g1, g2, spec  # noqa: E402
 from tests.scenario import new_world, slot_committee_members  # noqa: E402
 
 
@@ -33,6 +33,22 @@ def g1_vectors():
         k = (len(idx) * a + sum(idx) * b) % g1.R_ORDER
         out["subset_sums"].append({"a": hex(a), "b": hex(b), "indices": idx,
                                    "sum_uncompressed": g1.to_bytes96(g1.mul(k, g1.G)).hex()})
+    return out
+
+
+def g2_vectors():
+    """G2 sums (bls.Aggregate over signature points): frozen oracle/g2.py answers, incl. the edge cases."""
+    out = {"generator_compressed": g2.compress(g2.G2).hex(), "two_g_compressed": g2.compress(g2.double(g2.G2)).hex(),
+           "sums": []}
+    A = g2.mul(7, g2.G2)
+    prog = g2.synthetic_points(24, 1, 1)          # (i+1)*G2: 1G + 2G, + 3G doubles
+    rnd = g2.synthetic_points(40, 0x1234567, 0x89ABCDE)
+    cases = [("empty", []), ("single", [A]), ("doubling", [g2.G2, g2.G2]), ("cancel", [A, g2.neg(A)]),
+             ("with_infinity", [None, A, None]), ("progression_24", prog), ("random_40", rnd),
+             ("cancel_then_more", [A, g2.neg(A), rnd[0], rnd[1]])]
+    for name, pts in cases:
+        out["sums"].append({"name": name, "points": [g2.to_bytes192(p).hex() for p in pts],
+                            "sum": g2.to_bytes192(g2.sum_points(pts)).hex()})
     return out
 
 
@@ -109,6 +125,7 @@ def forkchoice_trace(seed=5, steps=40, n_val=96):
 
 if __name__ == "__main__":
     json.dump(g1_vectors(), open(os.path.join(HERE, "g1_vectors.json"), "w"), indent=1)
+    json.dump(g2_vectors(), open(os.path.join(HERE, "g2_vectors.json"), "w"), indent=1)
     json.dump(shuffle_vectors(), open(os.path.join(HERE, "shuffle_vectors.json"), "w"))
     json.dump(forkchoice_trace(), open(os.path.join(HERE, "forkchoice_trace.json"), "w"))
     print("golden fixtures written")

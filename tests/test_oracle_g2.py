@@ -1,0 +1,49 @@
+"""oracle/g2.py pins (CPU): the curve constants, the group law and the wire format."""
+import json
+import os
+
+from oracle import g1, g2
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "g2_vectors.json")
+
+
+def test_generator_and_order():
+    assert g2.is_on_curve(g2.G2)
+    assert g2.mul(g1.R_ORDER, g2.G2) is None              # wrong constants or a wrong group law fail here
+    assert g2.mul(g1.R_ORDER - 1, g2.G2) == g2.neg(g2.G2)
+
+
+def test_external_known_answers():
+    # compressed generator and 2*generator as published with the curve (zkcrypto/bls12_381 test vectors)
+    assert g2.compress(g2.G2).hex().startswith("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049")
+    assert g2.compress(g2.double(g2.G2)).hex().startswith("aa4edef9c1ed7f729f520e47730a124fd70662a904ba1074728114d1031e1572")
+    assert g2.compress(None) == bytes([0xC0]) + bytes(95)
+
+
+def test_group_law_consistency():
+    two = g2.double(g2.G2)
+    assert two == g2.add(g2.G2, g2.G2) == g2.mul(2, g2.G2)
+    assert g2.add(two, g2.G2) == g2.mul(3, g2.G2)
+    assert g2.add(g2.G2, g2.neg(g2.G2)) is None
+    assert g2.add(None, two) == two and g2.add(two, None) == two
+    pts = g2.synthetic_points(40, 5, 3)
+    assert all(g2.is_on_curve(p) for p in pts)
+    assert pts[7] == g2.mul(5 + 21, g2.G2)
+    assert g2.sum_points(pts) == g2.mul(sum(5 + 3 * i for i in range(40)), g2.G2)
+    for p in (two, pts[3], None):
+        assert g2.from_bytes192(g2.to_bytes192(p)) == p
+
+
+def test_fp2_field_axioms():
+    a, b = (3, 5), (g1.P - 7, 11)
+    assert g2.f2_mul(a, g2.f2_inv(a)) == g2.F2_ONE
+    assert g2.f2_mul(a, b) == g2.f2_mul(b, a)
+    assert g2.f2_sqr((0, 1)) == (g1.P - 1, 0)             # u^2 = -1
+
+
+def test_golden_vectors_match_oracle():
+    with open(GOLDEN) as f:
+        vec = json.load(f)
+    for case in vec["sums"]:
+        pts = [g2.from_bytes192(bytes.fromhex(h)) for h in case["points"]]
+        assert g2.to_bytes192(g2.sum_points(pts)).hex() == case["sum"], case["name"]
