@@ -253,9 +253,11 @@ class Engine:
                                                           _ptr(indices, C.c_uint32), indices.size))
         return status[:n], offsets, indices[:int(offsets[-1])]
 
-    def aggregate(self, rows=None, packed=None, sig_points96=None, want_aggregate_pubkeys=False):
+    def aggregate(self, rows=None, packed=None, sig_points96=None, want_aggregate_pubkeys=False, sig_points192=None):
         """-> AggregateResult(n_groups, atts (ATT_DTYPE rows of the groups), group_of, out_arena, sig96, aggpk96,
-        count; ``["bits"]`` decodes the OR-ed bitfields on demand)."""
+        count; ``["bits"]`` decodes the OR-ed bitfields on demand).  sig_points192: the members' signatures as G2
+        points (192-byte uncompressed BLSSignature, pe:717); their per-group sums come back as ``sig192``
+        (pe_g2_sum over pe_aggregate's grouping)."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
@@ -275,8 +277,15 @@ class Engine:
                                            _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
                                            _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
         g = n_groups.value
+        sig192 = None
+        if sig_points192 is not None:
+            s2 = np.ascontiguousarray(sig_points192, dtype=np.uint8)
+            assert s2.size == 192 * n
+            order = np.argsort(group_of[:n], kind="stable").astype(np.uint32)   # members of a group in input order
+            offs = np.concatenate([[0], np.cumsum(np.bincount(group_of[:n], minlength=g))]).astype(np.uint32)
+            sig192 = self.g2_sum(s2, offs, index=order)
         return AggregateResult(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena,
-                               sig96=None if out_sig is None else out_sig[:g],
+                               sig96=None if out_sig is None else out_sig[:g], sig192=sig192,
                                aggpk96=None if out_pk is None else out_pk[:g], count=count[:g])
 
     def process_attestation_batch(self, state_ctx: pe_state_ctx, rows=None, packed=None):

@@ -84,3 +84,30 @@ def test_g2_rejects_bad_arguments(engine_factory):
         e.g2_sum(pts, [0, 2])                      # offsets exceed the points
     with pytest.raises(EngineError):
         e.g2_sum(pts, [0, 1], index=[3])           # index out of range
+
+
+def test_aggregate_with_g2_signatures(engine_factory):
+    """pe_aggregate's grouping + pe_g2_sum: Attestation.signature aggregated as real G2 points (pe:717, pe:1536)."""
+    import pos_evolution_amd.synth as synth
+    from tests import helpers as H
+    e = engine_factory()
+    n_val, spe = 4000, 32
+    tree = synth.random_tree(40, 9, "branchy")
+    H.load_tree(e, tree)
+    e.set_validators(synth.balances(n_val, 9), synth.validator_flags(n_val, 9))
+    comm = synth.random_committees(n_val, 64, 9)
+    e.set_committees(1, comm.offsets, comm.members)
+    atts, arena, bit_rows = synth.epoch_attestations(comm, tree, 1, spe, seed=9, density=0.9, parts=5)
+    perm = np.random.default_rng(9).permutation(len(atts))
+    atts, bit_rows = atts[perm], [bit_rows[i] for i in perm]
+    arena, offs, nb = synth.pack_bit_rows(bit_rows)
+    atts["bits_offset"], atts["n_bits"] = offs, nb
+    a, b = 77, 1001
+    table = g2.synthetic_points(len(atts), a, b)             # signature i = (a + i*b) * G2
+    sigs = _rows(table)
+    res = e.aggregate(packed=(atts, arena), sig_points192=sigs)
+    assert res["n_groups"] == 64 and res["sig192"].shape == (64, 192)
+    for g in range(64):
+        members = np.nonzero(res["group_of"] == g)[0]
+        k = (len(members) * a + int(members.sum()) * b) % g1.R_ORDER
+        assert res["sig192"][g].tobytes() == g2.to_bytes192(g2.mul(k, g2.G2)), g
