@@ -96,6 +96,9 @@ typedef struct pe_config {
     uint64_t reserve_validators;              /* capacity hints (0 = grow on demand) */
     uint32_t reserve_blocks;
     uint32_t max_committee_tables;            /* epochs of committee tables kept resident (0 = 4) */
+    uint64_t vote_expiry_slots;               /* 0 = LMD-GHOST (no expiry).  eta > 0: RLMD-GHOST's vote expiry period
+                                                 (pe:1585-1596; eta = 1 is Goldfish's GHOST-Eph, pe:1549): get_head
+                                                 counts a latest message only if message.slot + eta >= current slot */
 } pe_config;
 
 /* Validator flag bits (T1: the per-validator byte the vote kernel streams). */

@@ -46,7 +46,7 @@ PRESETS = {
         SECONDS_PER_SLOT=12, INTERVALS_PER_SLOT=3, SAFE_SLOTS_TO_UPDATE_JUSTIFIED=8,
         PROPOSER_SCORE_BOOST=40, MIN_ATTESTATION_INCLUSION_DELAY=1, MIN_SEED_LOOKAHEAD=1,
         EPOCHS_PER_HISTORICAL_VECTOR=65536, SLOTS_PER_HISTORICAL_ROOT=8192,
-        BASE_REWARD_FACTOR=64, MAX_ATTESTATIONS=128,
+        BASE_REWARD_FACTOR=64, MAX_ATTESTATIONS=128, VOTE_EXPIRY_SLOTS=0,
     ),
     "minimal": dict(
         SLOTS_PER_EPOCH=8, MAX_COMMITTEES_PER_SLOT=4, TARGET_COMMITTEE_SIZE=4,
@@ -55,7 +55,7 @@ PRESETS = {
         SECONDS_PER_SLOT=6, INTERVALS_PER_SLOT=3, SAFE_SLOTS_TO_UPDATE_JUSTIFIED=2,
         PROPOSER_SCORE_BOOST=40, MIN_ATTESTATION_INCLUSION_DELAY=1, MIN_SEED_LOOKAHEAD=1,
         EPOCHS_PER_HISTORICAL_VECTOR=64, SLOTS_PER_HISTORICAL_ROOT=64,
-        BASE_REWARD_FACTOR=64, MAX_ATTESTATIONS=128,
+        BASE_REWARD_FACTOR=64, MAX_ATTESTATIONS=128, VOTE_EXPIRY_SLOTS=0,
     ),
 }
 GENESIS_EPOCH = 0
@@ -71,6 +71,11 @@ WEIGHT_DENOMINATOR = 64
 # Era switch: this era's get_latest_attesting_balance does not
 # filter slashed validators; later upstream versions (get_weight) do.
 FILTER_SLASHED = False
+# [VARIANT pe:1585-1596] RLMD-GHOST's vote expiry period eta, in slots: only latest messages from the most recent
+# eta slots count in get_latest_attesting_balance (eta = 1: Goldfish's GHOST-Eph, pe:1549).  0 = no expiry = the
+# reference's executable LMD-GHOST.  The reference gives this as prose only; the predicate below is this repo's
+# restatement of it (parity unpinned).
+VOTE_EXPIRY_SLOTS = 0
 
 
 def use_preset(name: str, **overrides) -> None:
@@ -150,6 +155,7 @@ class LatestMessage(object):
     """[REF pe:286-289]"""
     epoch: int
     root: Root
+    slot: int = field(default=0, compare=False)   # [VARIANT pe:1585] slot of the attestation, for vote expiry only
 
 
 @dataclass(eq=True, frozen=True)
@@ -690,6 +696,11 @@ def get_ancestor(store: Store, root: Root, slot: int) -> Root:
     return root
 
 
+def is_vote_expired(store: Store, message: LatestMessage) -> bool:
+    """[VARIANT pe:1585-1596] "only messages from the most recent eta slots are utilized"."""
+    return VOTE_EXPIRY_SLOTS > 0 and message.slot + VOTE_EXPIRY_SLOTS < get_current_slot(store)
+
+
 def get_latest_attesting_balance(store: Store, root: Root) -> int:
     """[UPSTREAM-MEMORY A.1]"""
     state = store.checkpoint_states[store.justified_checkpoint]
@@ -699,6 +710,7 @@ def get_latest_attesting_balance(store: Store, root: Root) -> int:
         if (i in store.latest_messages
             and i not in store.equivocating_indices
             and not (FILTER_SLASHED and state.validators[i].slashed)
+            and not is_vote_expired(store, store.latest_messages[i])
             and get_ancestor(store, store.latest_messages[i].root, store.blocks[root].slot) == root)
     )
     if store.proposer_boost_root == Root():
@@ -849,7 +861,8 @@ def update_latest_messages(store: Store, attesting_indices: Sequence[int], attes
     non_equivocating_attesting_indices = [i for i in attesting_indices if i not in store.equivocating_indices]
     for i in non_equivocating_attesting_indices:
         if i not in store.latest_messages or target.epoch > store.latest_messages[i].epoch:
-            store.latest_messages[i] = LatestMessage(epoch=target.epoch, root=beacon_block_root)
+            store.latest_messages[i] = LatestMessage(epoch=target.epoch, root=beacon_block_root,
+                                                     slot=attestation.data.slot)
 
 
 def on_tick(store: Store, time: int) -> None:

@@ -41,6 +41,7 @@ class pe_config(C.Structure):
         ("effective_balance_increment", C.c_uint64), ("min_attestation_inclusion_delay", C.c_uint64),
         ("max_validators_per_committee", C.c_uint64), ("filter_slashed", C.c_uint32), ("device", C.c_int32),
         ("reserve_validators", C.c_uint64), ("reserve_blocks", C.c_uint32), ("max_committee_tables", C.c_uint32),
+        ("vote_expiry_slots", C.c_uint64),
     ]
 
 

@@ -200,6 +200,7 @@ struct pe_engine {
     uint64_t n_val = 0;
     bool have_points = false;
     DevBuf d_points, d_balance, d_flags, d_incr, d_vote_key, d_vote_block, d_part_cur, d_part_prev;
+    DevBuf d_vote_slot;  // vote-expiry variant only (cfg.vote_expiry_slots > 0): slot of each latest message
     DevBuf d_sbalance, d_sflags;  // working-state view (process_attestation rewards, FFG sums)
     bool state_view_set = false;  // false: the working state mirrors the pe_set_validators data
     std::vector<uint8_t> h_flags;  // host mirror (equivocating bit is OR-ed in here)
@@ -266,6 +267,17 @@ struct ProfScope {
 // ------------------------------------------------------------------ spec helpers (A.10)
 inline uint64_t current_slot(const pe_engine* h) { return (h->time - h->genesis_time) / h->cfg.seconds_per_slot; }
 inline uint64_t epoch_at_slot(const pe_engine* h, uint64_t slot) { return slot / h->cfg.slots_per_epoch; }
+// Vote-expiry variant (RLMD-GHOST, pe:1585-1596; eta = 1 is Goldfish's GHOST-Eph, pe:1549): only latest messages from
+// the most recent eta slots count, i.e. message.slot + eta >= current_slot.  eta = 0 disables it (LMD-GHOST).
+inline const uint32_t* expiry_slots_ptr(const pe_engine* h)
+{
+    return h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr;
+}
+inline uint32_t min_vote_slot(const pe_engine* h)
+{
+    const uint64_t cur = current_slot(h), eta = h->cfg.vote_expiry_slots;
+    return (uint32_t)(cur > eta ? cur - eta : 0);
+}
 inline uint64_t start_slot(const pe_engine* h, uint64_t epoch) { return epoch * h->cfg.slots_per_epoch; }
 inline uint64_t slots_since_epoch_start(const pe_engine* h, uint64_t slot) { return slot % h->cfg.slots_per_epoch; }
 
@@ -766,7 +778,7 @@ void pe_engine_destroy(pe_engine* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block,
+    for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
                       &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_stage,
                       &h->d_outblk, &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
@@ -816,6 +828,7 @@ int pe_store_init(pe_engine* h, uint64_t genesis_time, uint64_t anchor_slot, con
         HIP_TRY(h, hipMemcpyAsync(h->d_flags.p, h->h_flags.data(), h->n_val, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_vote_key.p, 0, h->n_val * 8, h->stream));       // latest_messages = {}
         HIP_TRY(h, hipMemsetAsync(h->d_vote_block.p, 0xFF, h->n_val * 4, h->stream));
+        if (h->cfg.vote_expiry_slots) HIP_TRY(h, hipMemsetAsync(h->d_vote_slot.p, 0, h->n_val * 4, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     h->initialised = true;
@@ -834,11 +847,14 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
     const size_t n4 = (n + 3) & ~size_t(3);
     HIP_TRY(h, h->d_vote_key.ensure(std::max<size_t>(64, n4 * 8), true, h->stream));
     HIP_TRY(h, h->d_vote_block.ensure(std::max<size_t>(64, n4 * 4), true, h->stream));
+    if (h->cfg.vote_expiry_slots) HIP_TRY(h, h->d_vote_slot.ensure(std::max<size_t>(64, n4 * 4), true, h->stream));
     HIP_TRY(h, h->d_part_cur.ensure(std::max<size_t>(64, n4), true, h->stream));
     HIP_TRY(h, h->d_part_prev.ensure(std::max<size_t>(64, n4), true, h->stream));
     if (n > old_n) {  // new validators: no latest message, no participation
         HIP_TRY(h, hipMemsetAsync(h->d_vote_key.as<uint64_t>() + old_n, 0, (n4 - old_n) * 8, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_vote_block.as<uint32_t>() + old_n, 0xFF, (n4 - old_n) * 4, h->stream));
+        if (h->cfg.vote_expiry_slots)
+            HIP_TRY(h, hipMemsetAsync(h->d_vote_slot.as<uint32_t>() + old_n, 0, (n4 - old_n) * 4, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_part_cur.as<uint8_t>() + old_n, 0, n4 - old_n, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->d_part_prev.as<uint8_t>() + old_n, 0, n4 - old_n, h->stream));
     }
@@ -1181,7 +1197,8 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
                      h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(),
-                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 0);
+                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 0, expiry_slots_ptr(h),
+                     min_vote_slot(h));
     }
     lap.mark("head.1_launch_votes");
     uint32_t head;
@@ -1216,7 +1233,7 @@ int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
                      h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), n_blocks, buf,
-                     reinterpret_cast<VoteTotals*>(buf + n_blocks), 1);
+                     reinterpret_cast<VoteTotals*>(buf + n_blocks), 1, expiry_slots_ptr(h), min_vote_slot(h));
     }
     HIP_TRY(h, hipGetLastError());
     return PE_OK;
@@ -1293,6 +1310,7 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
                 r.order = n_rows;
                 r.flag_mask = 0;
                 r.which = 0;
+                r.slot = (uint32_t)a.slot;
                 n_words += (use + 31) / 32;
                 row_src.push_back(i);
                 ++n_rows;
@@ -1380,11 +1398,13 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
                                            st.dev<uint32_t>(seg_vm_list[sg]), t->d_inv_comm.as<uint32_t>(),
                                            t->d_inv_pos.as<uint32_t>(), st.dev<uint32_t>(off_words),
                                            h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
-                                           h->d_vote_block.as<uint32_t>());
+                                           h->d_vote_block.as<uint32_t>(),
+                                           h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr);
             else
                 launch_lmd_update(h->stream, st.dev<AttRow>(off_rows) + b0, e0 - b0, t->d_members.as<uint32_t>(),
                                   st.dev<uint32_t>(off_words), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
-                                  h->d_vote_block.as<uint32_t>());
+                                  h->d_vote_block.as<uint32_t>(),
+                                  h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr);
         }
         if (out_aggpk96) {
             rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(),
@@ -1450,7 +1470,7 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
                     r.member_base = t->offsets[pos];
                     r.n_bits = size;
                     r.bits_word = n_words;
-                    r.block_idx = r.epoch_p1 = r.order = r.flag_mask = r.which = 0;
+                    r.block_idx = r.epoch_p1 = r.order = r.flag_mask = r.which = r.slot = 0;
                     offs[n_rows] = (uint32_t)total;
                     n_words += (size + 31) / 32;
                     row_table.push_back(t);
@@ -1786,6 +1806,7 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                 e.row.block_idx = 0;
                 e.row.epoch_p1 = 0;
                 e.row.order = 0;
+                e.row.slot = 0;
                 e.row.flag_mask = flag_mask;
                 e.row.which = a.target_epoch == cur_epoch ? 0u : 1u;                           // pe:739-742
                 e.src = i;

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(VOTES_WG)
 k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ eff_balance,
         const uint8_t* __restrict__ flags, uint64_t n_val, uint32_t filter_slashed,
         const uint32_t* __restrict__ pos_of_idx, uint32_t n_blocks, unsigned long long* __restrict__ direct,
-        VoteTotals* __restrict__ totals)
+        VoteTotals* __restrict__ totals, const uint32_t* __restrict__ vote_slot, uint32_t min_vote_slot)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];  // n_blocks bins, by insertion index
     for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) hist[b] = 0;
@@ -71,6 +71,13 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
                 bal[4 * u] = b01.x; bal[4 * u + 1] = b01.y; bal[4 * u + 2] = b23.x; bal[4 * u + 3] = b23.y;
                 const uint32_t f = *reinterpret_cast<const uint32_t*>(flags + v0);
                 fl[4 * u] = f & 0xff; fl[4 * u + 1] = (f >> 8) & 0xff; fl[4 * u + 2] = (f >> 16) & 0xff; fl[4 * u + 3] = f >> 24;
+                if (vote_slot) {  // vote-expiry variant (RLMD-GHOST, pe:1585-1596): an expired message counts as none
+                    const uint4 sl = *reinterpret_cast<const uint4*>(vote_slot + v0);
+                    if (sl.x < min_vote_slot) vb[4 * u] = NONE32;
+                    if (sl.y < min_vote_slot) vb[4 * u + 1] = NONE32;
+                    if (sl.z < min_vote_slot) vb[4 * u + 2] = NONE32;
+                    if (sl.w < min_vote_slot) vb[4 * u + 3] = NONE32;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -78,6 +85,7 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
                     vb[4 * u + k] = ok ? vote_block[v0 + k] : NONE32;
                     bal[4 * u + k] = ok ? eff_balance[v0 + k] : 0ull;
                     fl[4 * u + k] = ok ? flags[v0 + k] : 0u;
+                    if (ok && vote_slot && vote_slot[v0 + k] < min_vote_slot) vb[4 * u + k] = NONE32;
                 }
             }
         }
@@ -117,7 +125,7 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
 
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx, uint32_t n_blocks,
-                  uint64_t* direct, VoteTotals* totals, int zero_first)
+                  uint64_t* direct, VoteTotals* totals, int zero_first, const uint32_t* vote_slot, uint32_t min_vote_slot)
 {
     if (zero_first) {  // caller-owned exchange buffer; the engine's own buffer is kept zeroed by k_tree
         (void)hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
@@ -135,7 +143,7 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
     }
     hipLaunchKernelGGL(k_votes, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
                        eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
-                       reinterpret_cast<unsigned long long*>(direct), totals);
+                       reinterpret_cast<unsigned long long*>(direct), totals, vote_slot, min_vote_slot);
 }
 
 // ------------------------------------------------------------------ tree
@@ -346,7 +354,8 @@ template <int PHASE>
 __global__ void __launch_bounds__(256)
 k_lmd(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restrict__ members,
       const uint32_t* __restrict__ bit_arena, const uint8_t* __restrict__ flags,
-      unsigned long long* __restrict__ vote_key, uint32_t* __restrict__ vote_block)
+      unsigned long long* __restrict__ vote_key, uint32_t* __restrict__ vote_block,
+      uint32_t* __restrict__ vote_slot)
 {
     const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= n_rows) return;
@@ -364,6 +373,7 @@ k_lmd(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restri
         } else {
             if (vote_key[v] == key) {                    // unique winner: (epoch, order) identifies one attestation
                 vote_block[v] = r.block_idx;
+                if (vote_slot) vote_slot[v] = r.slot;
                 vote_key[v] = ((unsigned long long)r.epoch_p1 << 32) | 0xFFFFFFFFull;  // settled
             }
         }
@@ -403,7 +413,7 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
                       const uint32_t* __restrict__ crow_list, const uint32_t* __restrict__ inv_comm,
                       const uint32_t* __restrict__ inv_pos, const uint32_t* __restrict__ bit_arena,
                       const uint8_t* __restrict__ flags, uint64_t n_val, unsigned long long* __restrict__ vote_key,
-                      uint32_t* __restrict__ vote_block)
+                      uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot)
 {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_val) return;
@@ -414,7 +424,7 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
     if (flags[v] & VAL_EQUIVOCATING) return;  // pe:1438
     const uint32_t i = inv_pos[v];
     uint32_t epoch_p1 = (uint32_t)(vote_key[v] >> 32);  // 0 = no latest message
-    uint32_t new_block = NONE32;
+    uint32_t new_block = NONE32, new_slot = 0;
     for (uint32_t k = kb; k < ke; ++k) {
         const AttRow r = rows[crow_list[k]];
         if (i >= r.n_bits) continue;
@@ -422,34 +432,37 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
         if (r.epoch_p1 > epoch_p1) {  // "i not in latest_messages or target.epoch > latest_messages[i].epoch"
             epoch_p1 = r.epoch_p1;
             new_block = r.block_idx;
+            new_slot = r.slot;
         }
     }
     if (new_block != NONE32) {
         vote_key[v] = ((unsigned long long)epoch_p1 << 32) | 0xFFFFFFFFull;
         vote_block[v] = new_block;
+        if (vote_slot) vote_slot[v] = new_slot;
     }
 }
 
 void launch_lmd_validator_major(hipStream_t s, const AttRow* rows, const uint32_t* crow_start,
                                 const uint32_t* crow_list, const uint32_t* inv_comm, const uint32_t* inv_pos,
                                 const uint32_t* bit_arena, const uint8_t* flags, uint64_t n_val, uint64_t* vote_key,
-                                uint32_t* vote_block)
+                                uint32_t* vote_block, uint32_t* vote_slot)
 {
     if (n_val == 0) return;
     hipLaunchKernelGGL(k_lmd_validator_major, dim3((unsigned)((n_val + 255) / 256)), dim3(256), 0, s, rows, crow_start,
                        crow_list, inv_comm, inv_pos, bit_arena, flags, n_val,
-                       reinterpret_cast<unsigned long long*>(vote_key), vote_block);
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot);
 }
 
 void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
-                       const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block)
+                       const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block,
+                       uint32_t* vote_slot)
 {
     if (n_rows == 0) return;
     const unsigned blocks = (n_rows + 3) / 4;
     hipLaunchKernelGGL(k_lmd<0>, dim3(blocks), dim3(256), 0, s, rows, n_rows, members, bit_arena, flags,
-                       reinterpret_cast<unsigned long long*>(vote_key), vote_block);
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot);
     hipLaunchKernelGGL(k_lmd<1>, dim3(blocks), dim3(256), 0, s, rows, n_rows, members, bit_arena, flags,
-                       reinterpret_cast<unsigned long long*>(vote_key), vote_block);
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot);
 }
 
 // ------------------------------------------------------------------ participation

@@ -56,7 +56,8 @@ struct VoteTotals {            // one per K_votes workgroup (VOTES_MAX_WG slots)
 // direct[pos] += effective_balance of every counted validator voting for the block at pos.
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx,
-                  uint32_t n_blocks, uint64_t* direct, VoteTotals* totals, int zero_first);
+                  uint32_t n_blocks, uint64_t* direct, VoteTotals* totals, int zero_first,
+                  const uint32_t* vote_slot = nullptr, uint32_t min_vote_slot = 0);
 // Subtree sums (prefix scan over pre-order), viability, best child, pointer-jumping descent.
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
@@ -73,17 +74,19 @@ struct AttRow {
     uint32_t order;        // position in the batch (first-seen wins among equal epochs, pe:1383/1440)
     uint32_t flag_mask;    // participation flags this attestation earns (process_attestation)
     uint32_t which;        // 0 current / 1 previous epoch participation
+    uint32_t slot;         // attestation.data.slot (vote-expiry variant only: recorded with the latest message)
 };
 // update_latest_messages for a batch: phase 1 atomicMax of (epoch+1, ~order), phase 2 winners write.
 void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
-                       const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block);
+                       const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block,
+                       uint32_t* vote_slot = nullptr);
 // inverse committee map (partition tables only) and the validator-major form of update_latest_messages
 void launch_invert_committees(hipStream_t s, const uint32_t* members, const uint32_t* offsets, uint32_t n_committees,
                               uint32_t* inv_comm, uint32_t* inv_pos, uint64_t n_val);
 void launch_lmd_validator_major(hipStream_t s, const AttRow* rows, const uint32_t* crow_start,
                                 const uint32_t* crow_list, const uint32_t* inv_comm, const uint32_t* inv_pos,
                                 const uint32_t* bit_arena, const uint8_t* flags, uint64_t n_val, uint64_t* vote_key,
-                                uint32_t* vote_block);
+                                uint32_t* vote_block, uint32_t* vote_slot = nullptr);
 // process_attestation flag loop for one round of pairwise-disjoint attestations.
 void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                           const uint32_t* bit_arena, const uint16_t* eff_increments,

@@ -301,9 +301,37 @@ def justified_checkpoint_promotion_on_tick(mk):
     assert w.store.justified_checkpoint == just2
 
 
+def rlmd_ghost_vote_expiry(mk):
+    """[VARIANT pe:1585-1596, pe:1549] vote expiry period eta: only latest messages from the most recent eta slots
+    count.  A heavier but stale branch loses to a lighter fresh one; eta = 0 is the reference's LMD-GHOST."""
+    late = spec.SECONDS_PER_SLOT - 1
+    for eta in (0, 1, 2, 5):
+        w = mk(64, VOTE_EXPIRY_SLOTS=eta)
+        anchor = w.store.justified_checkpoint.root
+        w.tick_to_slot(1, offset=late)                       # late blocks: no proposer boost
+        a = w.block(anchor, 1, graffiti=b"a")
+        b = w.block(anchor, 1, graffiti=b"b")
+        w.tick_to_slot(2)
+        stale = slot_committee_members(w.store, 1)
+        w.vote(stale, a, 1)
+        assert w.head() == a                                 # slot 2: slot-1 votes are inside every window
+        w.tick_to_slot(4)
+        fresh = slot_committee_members(w.store, 3)
+        fresh = fresh[: len(fresh) // 2]
+        assert 0 < len(fresh) < len(stale)
+        w.vote(fresh, b, 3)
+        # slot 4: eta in (1, 2) has dropped the slot-1 votes (1 + eta < 4); eta = 5 and LMD-GHOST keep them
+        assert w.head() == (b if eta in (1, 2) else a)
+        assert spec.get_latest_attesting_balance(w.store, a) == (0 if eta in (1, 2) else len(stale) * 32 * ETH)
+        w.tick_to_slot(7)
+        # slot 7: eta = 5 now drops slot 1 (1 + 5 < 7) but keeps slot 3; eta in (1, 2) has nothing left -> root tie-break
+        assert w.head() == {0: a, 5: b}.get(eta, max(a, b))
+    spec.use_preset(spec.PRESET_NAME)                        # leave the module constants at eta = 0
+
+
 ALL = [
     genesis_head, chain_no_attestations, split_tie_breaker_no_attestations, shorter_chain_but_heavier_weight,
     lmd_walkthrough_five_validators, lmd_rule_first_seen_and_strictly_later, proposer_boost_correct_head,
     ex_ante_reorg_arithmetic, discard_equivocations, invalid_handlers_leave_store_untouched, filtered_block_tree,
-    justified_checkpoint_promotion_on_tick,
+    justified_checkpoint_promotion_on_tick, rlmd_ghost_vote_expiry,
 ]

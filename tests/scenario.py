@@ -85,6 +85,12 @@ class World:
         assert {k: (v.epoch, bytes(v.root)) for k, v in s.latest_messages.items()} == \
                {k: (v.epoch, v.root) for k, v in lm.items()}
         assert self.fc.get_head(m) == bytes(spec.get_head(s))
+        # per-block weights (get_latest_attesting_balance incl. proposer boost, A.1) -- after get_head, same view
+        eng = m.engine
+        weights = eng.get_weights()
+        for i in range(eng.num_blocks):
+            root = eng.block_root_at(i)
+            assert int(weights[i]) == spec.get_latest_attesting_balance(s, spec.Root(root)), (i, root.hex())
 
     # ---- handlers, applied to both -----------------------------------------
     def tick(self, time: int):
@@ -206,7 +212,7 @@ def engine_config_for_preset() -> dict:
         effective_balance_increment=spec.EFFECTIVE_BALANCE_INCREMENT,
         min_attestation_inclusion_delay=spec.MIN_ATTESTATION_INCLUSION_DELAY,
         max_validators_per_committee=spec.MAX_VALIDATORS_PER_COMMITTEE,
-        max_committee_tables=16,
+        max_committee_tables=16, vote_expiry_slots=spec.VOTE_EXPIRY_SLOTS,
     )
 
 

@@ -16,11 +16,12 @@ def test_scenario_engine_vs_literal_oracle(scenario, engine_factory):
     scenario(lambda n, **kw: new_world(n, "minimal", engine_factory=engine_factory, **kw))
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_event_stream(engine_factory, seed):
-    """Random ticks / forks / attestations (wire + from-block, valid + stale) / slashings on the minimal preset."""
+@pytest.mark.parametrize("seed,eta", [(1, 0), (2, 0), (3, 0), (4, 1), (5, 3), (6, 9)])
+def test_random_event_stream(engine_factory, seed, eta):
+    """Random ticks / forks / attestations (wire + from-block, valid + stale) / slashings on the minimal preset;
+    eta > 0 runs the same stream under the vote-expiry variant (RLMD-GHOST, pe:1585-1596)."""
     rng = np.random.default_rng(seed)
-    w = new_world(96, "minimal", engine_factory=engine_factory)
+    w = new_world(96, "minimal", engine_factory=engine_factory, VOTE_EXPIRY_SLOTS=eta)
     roots = [w.store.justified_checkpoint.root]
     slot = 0
     for step in range(60):
@@ -46,6 +47,7 @@ def test_random_event_stream(engine_factory, seed):
             d2 = spec.AttestationData(slot=a_slot, index=0, beacon_block_root=roots[0], target=tgt)
             w.slash(spec.IndexedAttestation(eq, d1), spec.IndexedAttestation(eq, d2))
     assert len(w.store.latest_messages) > 0
+    spec.use_preset("minimal")
 
 
 def test_on_attestation_aggregate_pubkey_matches_bls_oracle(engine_factory):
