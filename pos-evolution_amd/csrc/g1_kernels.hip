@@ -132,7 +132,28 @@ __device__ __forceinline__ uint32_t find_group(const G1Group* __restrict__ group
     return lo;
 }
 
-__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// tools/g1_phases.hip builds this file with POSEVO_G1_PHASE_TIMING to stamp the phases of one workgroup.
+#ifdef POSEVO_G1_PHASE_TIMING
+__device__ unsigned long long g1_phase_stamps[16 * 4096];
+#define G1_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g1_phase_stamps[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+__device__ unsigned long long g1_wave_info[3 * 4 * 4096];  // per wave: HW_ID | XCC_ID << 32, accumulate start, accumulate end
+#define G1_WAVE_BEGIN() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) { \
+        unsigned long long* w_ = &g1_wave_info[3 * (blockIdx.x * 4 + (threadIdx.x >> 6))]; \
+        w_[0] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) | \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32); \
+        w_[1] = wall_clock64(); } } while (0)
+#define G1_WAVE_END() do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) \
+        g1_wave_info[3 * (blockIdx.x * 4 + (threadIdx.x >> 6)) + 2] = wall_clock64(); } while (0)
+#else
+#define G1_WAVE_BEGIN() do { } while (0)
+#define G1_WAVE_END() do { } while (0)
+#define G1_STAMP(i) do { } while (0)
+#endif
+
+#ifndef POSEVO_G1_WAVES_PER_EU
+#define POSEVO_G1_WAVES_PER_EU 2
+#endif
+__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
 k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ members,
                 const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
                 uint32_t n_slots, uint32_t* __restrict__ wg_partials)
@@ -143,6 +164,8 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
 
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x * G1_WG + tid;
+    G1_STAMP(0);
+    G1_WAVE_BEGIN();
 
     g1x acc;
     g1x_set_inf(acc);
@@ -189,6 +212,8 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
     }
     // ---- workgroup tree over the 256 partials.  Level with n pairs: lanes 2w, 2w+1 add pair w together
     // (g1x_add_pair: 7 dependent products instead of 14), results compact into slot w. ----
+    G1_STAMP(1);
+    G1_WAVE_END();
     if (my_size == 1) {  // single-task group: done
         global_store_x(wg_partials + (size_t)G1X_WORDS * my_out, acc);
         my_size = 0;
@@ -197,6 +222,10 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
     lds_out[tid] = my_out;
     lds_sz[tid] = my_size;
     __syncthreads();
+    G1_STAMP(2);
+#ifdef POSEVO_G1_PHASE_TIMING
+    int g1_level = 0;
+#endif
     for (int n = G1_WG / 2; n >= 1; n >>= 1) {  // n = number of pairs at this level
         const int w = tid >> 1;
         const bool role = tid & 1;
@@ -254,6 +283,10 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
             }
         }
         __syncthreads();
+#ifdef POSEVO_G1_PHASE_TIMING
+        G1_STAMP(3 + g1_level);
+        ++g1_level;
+#endif
     }
 }
 
