@@ -224,6 +224,11 @@ def main():
         step(w["steps"][s])
     e.profile_enable(True)
     e.profile_reset()
+    # Python's cyclic collector is paused over the timed steps: with torch loaded a full collection walks ~10^6
+    # objects (tens of ms) and, landing inside a 20-step window, would be charged to the engine as +2 ms per step.
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -233,6 +238,7 @@ def main():
         n_att_local += int(last["count"].sum())
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     prof = e.profile()
     e.profile_enable(False)
     assert (last["status"] == 0).all() and (last["pstatus"] == 0).all(), "synthetic attestations were rejected"
