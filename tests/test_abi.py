@@ -68,3 +68,28 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "posevo_oracle" not in text, f
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/posevo.h is the drop-in boundary: it must compile as C99 and as C++ with nothing but <stdint.h>,
+    and a C client must link against the library (the cgo / JNI / bindgen stubs of INTEGRATION.md rely on it)."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "client.c"
+    src.write_text('#include "posevo.h"\n'
+                   'int main(void) {\n'
+                   '    pe_config c; pe_engine* h = 0; int rc;\n'
+                   '    pe_config_default(&c);\n'
+                   '    if (sizeof(pe_attestation) != 144 || pe_abi_version() != 1) return 2;\n'
+                   '    rc = pe_engine_create(&c, &h);            /* no GPU here: must report PE_ERR_NO_DEVICE */\n'
+                   '    if (rc == PE_OK) { pe_engine_destroy(h); return 0; }\n'
+                   '    return rc == PE_ERR_NO_DEVICE ? 0 : 3;\n'
+                   '}\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)])
+    libdir = os.path.join(ROOT, "pos-evolution_amd")
+    exe = tmp_path / "client"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lposevo",
+                           "-Wl,-rpath," + libdir])
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    assert subprocess.call([str(exe)], env=env) == 0
