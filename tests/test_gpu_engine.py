@@ -137,6 +137,37 @@ def _install_votes(e, tree, comm, vote):
     return installed
 
 
+@pytest.mark.parametrize("eta", [1, 20, 48, 10**6])
+def test_get_head_vote_expiry_vs_oracle(engine_factory, eta):
+    """Vote-expiry variant (RLMD-GHOST, pe:1585-1596) at 100 K validators: the engine with vote_expiry_slots = eta
+    equals the C oracle run on the vote table with the expired messages (slot + eta < current slot) removed."""
+    n_val, n_blocks, spe = 100000, 1024, 32
+    e = engine_factory(vote_expiry_slots=eta)
+    tree = synth.random_tree(n_blocks, 77, "bushy")
+    H.load_tree(e, tree)
+    bal = synth.balances(n_val, 77, True)
+    flags = synth.validator_flags(n_val, 77, inactive_frac=0.005, slashed_frac=0.01)
+    e.set_validators(bal, flags)
+    comm = synth.random_committees(n_val, 64, 77)
+    vote = synth.zipf_votes(n_val, n_blocks, 77)
+    installed = _install_votes(e, tree, comm, vote)       # committee c attests at slot E*32 + c // cps; now = (E+2)*32
+    E = int(tree.slot.max()) // spe + 1
+    cps = (comm.offsets.size - 1) // spe
+    slot_of = np.zeros(n_val, dtype=np.int64)
+    for c in range(comm.offsets.size - 1):
+        slot_of[comm.members[comm.offsets[c]:comm.offsets[c + 1]]] = E * spe + c // cps
+    now = (E + 2) * spe
+    alive = installed.copy()
+    alive[slot_of + eta < now] = NONE32
+    assert (eta >= 64) == np.array_equal(alive, installed)          # eta = 48 keeps slots E*32+16.., eta = 1 keeps none
+    leaf_ok = np.ones(n_blocks, dtype=np.uint8)
+    head_o, w_o = cport.get_head(tree.parent.copy(), leaf_ok, tree.roots, alive, bal, flags, 0, NONE32)
+    assert np.array_equal(e.get_weights(), w_o)
+    assert e.get_head() == tree.roots[head_o].tobytes()
+    if eta == 1:
+        assert not w_o.any()
+
+
 # ---------------------------------------------------------------- LMD update (ordering rule)
 def test_lmd_update_vs_oracle(engine_factory):
     e = engine_factory()
