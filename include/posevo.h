@@ -287,6 +287,17 @@ int pe_ffg_balances(pe_engine* h, uint64_t out[3]);
 int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points,
               const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, uint8_t* out96);
 
+/* BLSPubkey wire format (Validator.pubkey: BLSPubkey, pe:37): 48 bytes, big-endian x, flag bits in the leading byte
+ * (bit 7 compressed, bit 6 infinity, bit 5 y > (p-1)/2).  Decompression runs on the GPU (one square root per key);
+ * status[i]: 0 ok, 1 malformed encoding (flag bits, x >= p), 2 x is not on the curve.  No subgroup check.
+ *   pe_g1_decompress          48-byte keys -> 96-byte uncompressed affine (the format pe_set_validators takes)
+ *   pe_set_pubkeys_compressed decompress straight into the registry of the n validators already loaded;
+ *                             any status != 0 fails the call (PE_ERR_INVALID_ARG) and leaves no pubkeys loaded
+ *   pe_g1_compress            96-byte affine -> 48-byte compressed (serialisation only: host, no handle) */
+int pe_g1_decompress(pe_engine* h, const uint8_t* in48, uint64_t n, uint8_t* out96, int32_t* status);
+int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48, int32_t* status);
+int pe_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48);
+
 /* bls.Aggregate over real BLSSignature points (type pe:37, Attestation.signature pe:717; aggregation prose pe:659,
  * pe:1536): plain G2 sum over caller-chosen groups, out[g] = sum_{j in [offsets[g], offsets[g+1])} points[index[j]]
  * (index NULL = identity).  Points are 192-byte uncompressed affine, ZCash order x.c1 | x.c0 | y.c1 | y.c0, each 48

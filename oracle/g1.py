@@ -125,6 +125,28 @@ def compress(pt):
     return bytes(raw)
 
 
+def decompress(b):
+    """48-byte compressed form -> affine point; raises ValueError on a malformed or off-curve encoding."""
+    assert len(b) == 48
+    c, inf, sign = b[0] & 0x80, b[0] & 0x40, b[0] & 0x20
+    x = int.from_bytes(b, "big") & ((1 << 381) - 1)
+    if not c:
+        raise ValueError("not a compressed encoding")
+    if inf:
+        if sign or x:
+            raise ValueError("malformed infinity")
+        return None
+    if x >= P:
+        raise ValueError("x not canonical")
+    rhs = (x * x * x + B_COEFF) % P
+    y = pow(rhs, (P + 1) // 4, P)
+    if y * y % P != rhs:
+        raise ValueError("not on the curve")
+    if (y > (P - 1) // 2) != bool(sign):
+        y = P - y
+    return (x, y)
+
+
 def synthetic_points(n, a_scalar, b_scalar):
     """P_i = A + i*B built incrementally (one add each), A = a*G, B = b*G.
 

@@ -107,6 +107,9 @@ SIGNATURES = {
     "pe_state_set_validators": (C.c_int, [_H, C.c_uint64, _u64p, _u8p]),
     "pe_ffg_balances": (C.c_int, [_H, _u64p]),
     "pe_g1_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
+    "pe_g1_decompress": (C.c_int, [_H, _u8p, C.c_uint64, _u8p, _i32p]),
+    "pe_set_pubkeys_compressed": (C.c_int, [_H, C.c_uint64, _u8p, _i32p]),
+    "pe_g1_compress": (C.c_int, [_u8p, C.c_uint64, _u8p]),
     "pe_g2_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
     "pe_num_blocks": (C.c_uint32, [_H]),
     "pe_num_validators": (C.c_uint64, [_H]),

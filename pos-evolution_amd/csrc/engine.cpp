@@ -2041,6 +2041,76 @@ int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint3
     return PE_OK;
 }
 
+// ---------------------------------------------------------------- BLSPubkey wire format (8(f) rank 3)
+static int g1_decompress_common(pe_engine* h, const uint8_t* in48, uint64_t n, uint32_t* d_mont24, uint8_t* out96,
+                                int32_t* status, uint64_t* n_bad)
+{
+    const uint64_t chunk = 1ull << 20;
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, (48ull + 96ull + 4ull) * std::min(chunk, n))));
+    *n_bad = 0;
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const uint64_t m = std::min(chunk, n - base);
+        uint8_t* d_in = h->d_tmp_be.as<uint8_t>();
+        uint8_t* d_out = d_in + 48ull * m;
+        int32_t* d_st = reinterpret_cast<int32_t*>(d_out + 96ull * m);
+        HIP_TRY(h, hipMemcpyAsync(d_in, in48 + 48ull * base, 48ull * m, hipMemcpyHostToDevice, h->stream));
+        launch_g1_decompress(h->stream, d_in, m, d_mont24 ? d_mont24 + 24ull * base : nullptr, out96 ? d_out : nullptr, d_st);
+        HIP_TRY(h, hipGetLastError());
+        if (out96) HIP_TRY(h, hipMemcpyAsync(out96 + 96ull * base, d_out, 96ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(status + base, d_st, 4ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (uint64_t i = 0; i < m; ++i) *n_bad += status[base + i] != 0;
+    }
+    return PE_OK;
+}
+
+int pe_g1_decompress(pe_engine* h, const uint8_t* in48, uint64_t n, uint8_t* out96, int32_t* status)
+{
+    if (!h || (n && (!in48 || !out96 || !status))) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (n == 0) return PE_OK;
+    uint64_t n_bad = 0;
+    return g1_decompress_common(h, in48, n, nullptr, out96, status, &n_bad);
+}
+
+int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48, int32_t* status)
+{
+    if (!h || (n && (!pubkeys48 || !status))) return PE_ERR_INVALID_ARG;
+    if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_set_pubkeys_compressed: n differs from the registry size");
+    (void)hipSetDevice(h->device);
+    if (n == 0) return PE_OK;
+    HIP_TRY(h, h->d_points.ensure(96ull * n));
+    h->have_points = false;
+    uint64_t n_bad = 0;
+    int rc = g1_decompress_common(h, pubkeys48, n, h->d_points.as<uint32_t>(), nullptr, status, &n_bad);
+    if (rc) return rc;
+    if (n_bad) return fail(h, PE_ERR_INVALID_ARG, std::to_string(n_bad) + " pubkeys do not decode to curve points (see status[])");
+    h->have_points = true;
+    return PE_OK;
+}
+
+// Serialisation only (flag bits from a 48-byte comparison); no device work, no handle.
+int pe_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48)
+{
+    if (n && (!in96 || !out48)) return PE_ERR_INVALID_ARG;
+    static const uint8_t HALF_BE[48] = {  // (p - 1) / 2, big-endian
+        0x0d, 0x00, 0x88, 0xf5, 0x1c, 0xbf, 0xf3, 0x4d, 0x25, 0x8d, 0xd3, 0xdb, 0x21, 0xa5, 0xd6, 0x6b,
+        0xb2, 0x3b, 0xa5, 0xc2, 0x79, 0xc2, 0x89, 0x5f, 0xb3, 0x98, 0x69, 0x50, 0x7b, 0x58, 0x7b, 0x12,
+        0x0f, 0x55, 0xff, 0xff, 0x58, 0xa9, 0xff, 0xff, 0xdc, 0xff, 0x7f, 0xff, 0xff, 0xff, 0xd5, 0x55};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t* p = in96 + 96 * i;
+        uint8_t* o = out48 + 48 * i;
+        if (p[0] & 0x40) {
+            memset(o, 0, 48);
+            o[0] = 0xC0;
+            continue;
+        }
+        memcpy(o, p, 48);
+        o[0] = (uint8_t)((o[0] & 0x1f) | 0x80 | (memcmp(p + 48, HALF_BE, 48) > 0 ? 0x20 : 0));
+    }
+    return PE_OK;
+}
+
 // ---------------------------------------------------------------- plain G2 sums (8(f) rank 3)
 int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const uint32_t* index, const uint32_t* offsets,
               uint32_t n_groups, uint8_t* out192)

@@ -102,6 +102,10 @@ struct UnionGroup {
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
                        const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
 
+// BLSPubkey decompression: 48-byte compressed -> Montgomery rows (nullable) and/or 96-byte uncompressed (nullable)
+void launch_g1_decompress(hipStream_t s, const uint8_t* in48, uint64_t n, uint32_t* out_mont24, uint8_t* out_be96,
+                          int32_t* status);
+
 // G2 (g2_kernels.hip): same group descriptors, points as 48 Montgomery words [x0 x1 y0 y1], partials 96 words
 void launch_g2_convert(hipStream_t s, const uint8_t* be192, uint32_t* mont48, uint64_t n);
 void launch_g2_accumulate(hipStream_t s, const uint32_t* points_mont48, const uint32_t* members,

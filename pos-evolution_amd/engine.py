@@ -333,6 +333,27 @@ class Engine:
                                         _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
         return out[:n_groups]
 
+    def g1_decompress(self, keys48):
+        """48-byte compressed BLSPubkeys (pe:37) -> (96-byte uncompressed (n, 96), status int32[n])."""
+        k = np.ascontiguousarray(keys48, dtype=np.uint8).reshape(-1, 48)
+        n = k.shape[0]
+        out = np.empty((max(n, 1), 96), dtype=np.uint8)
+        status = np.empty(max(n, 1), dtype=np.int32)
+        self._check(self._lib.pe_g1_decompress(self._h, _ptr(k, C.c_uint8), n, _ptr(out, C.c_uint8), _ptr(status, C.c_int32)))
+        return out[:n], status[:n]
+
+    def set_pubkeys_compressed(self, keys48):
+        """Load the registry's pubkeys from their 48-byte wire form; raises if any key does not decode."""
+        k = np.ascontiguousarray(keys48, dtype=np.uint8).reshape(-1, 48)
+        status = np.empty(max(k.shape[0], 1), dtype=np.int32)
+        self._check(self._lib.pe_set_pubkeys_compressed(self._h, k.shape[0], _ptr(k, C.c_uint8), _ptr(status, C.c_int32)))
+
+    def g1_compress(self, points96) -> np.ndarray:
+        p = np.ascontiguousarray(points96, dtype=np.uint8).reshape(-1, 96)
+        out = np.empty((max(p.shape[0], 1), 48), dtype=np.uint8)
+        self._check(self._lib.pe_g1_compress(_ptr(p, C.c_uint8), p.shape[0], _ptr(out, C.c_uint8)))
+        return out[:p.shape[0]]
+
     def g2_sum(self, points192, offsets, index=None) -> np.ndarray:
         """bls.Aggregate over G2 signature points (pe:659, pe:1536): 192-byte uncompressed in, 192-byte affine out."""
         off = np.ascontiguousarray(offsets, dtype=np.uint32)

@@ -353,3 +353,56 @@ def test_indexed_attestations_sorted_indices(engine_factory):
 def pea_row(slot, bits):
     import pos_evolution_amd as pea
     return pea.AttRow(slot, 0, bytes(32), 0, bytes(32), slot // 32, bytes(32), np.asarray(bits, dtype=np.uint8))
+
+
+# ---------------------------------------------------------------- BLSPubkey wire format
+def test_g1_decompress_vs_oracle(engine_factory):
+    """48-byte compressed keys -> affine on the GPU (square root + sign), against oracle/g1.py; malformed and
+    off-curve encodings are reported per key."""
+    e = engine_factory()
+    n = 3000
+    pts96, (a, b) = H.oracle_points(n)
+    pts = [g1.from_bytes96(pts96[i].tobytes()) for i in range(n)]
+    comp = np.frombuffer(b"".join(g1.compress(p) for p in pts), dtype=np.uint8).reshape(n, 48).copy()
+    assert np.array_equal(e.g1_compress(pts96), comp)
+    out, status = e.g1_decompress(comp)
+    assert not status.any() and np.array_equal(out, pts96)
+    gen = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+                        "6c55e83ff97a1aeffb3af00adb22c6bb")
+    # find an x that is not on the curve
+    x = 5
+    while pow((x ** 3 + 4) % g1.P, (g1.P - 1) // 2, g1.P) == 1:
+        x += 1
+    off_curve = bytearray(x.to_bytes(48, "big"))
+    off_curve[0] |= 0x80
+    flipped = bytes([gen[0] ^ 0x20]) + gen[1:]
+    special = [gen, flipped, g1.compress(None), bytes(48), bytes([0xE0]) + bytes(47), bytes([0x9F]) + b"\xff" * 47,
+               bytes(off_curve), bytes([0xC0]) + bytes(46) + b"\x01"]
+    out, status = e.g1_decompress(np.frombuffer(b"".join(special), dtype=np.uint8).reshape(-1, 48))
+    assert list(status) == [0, 0, 0, 1, 1, 1, 2, 1]
+    assert out[0].tobytes() == g1.to_bytes96(g1.G) and out[1].tobytes() == g1.to_bytes96(g1.neg(g1.G))
+    assert out[2][0] == 0x40 and not out[2][1:].any()
+    assert not out[3:].any()
+
+
+def test_registry_from_compressed_pubkeys(engine_factory):
+    """pe_set_pubkeys_compressed loads the same registry as pe_set_validators with uncompressed keys."""
+    import pos_evolution_amd as pea
+    n = 5000
+    pts96, (a, b) = H.oracle_points(n)
+    comp = np.frombuffer(b"".join(g1.compress(g1.from_bytes96(pts96[i].tobytes())) for i in range(n)), dtype=np.uint8)
+    bal, flags = synth.balances(n, 3), np.ones(n, dtype=np.uint8)
+    offsets = [0, 100, 100, 4000, n]
+    e1 = engine_factory()
+    e1.set_validators(bal, flags, pts96)
+    want = e1.g1_sum(offsets)
+    e2 = engine_factory()
+    e2.set_validators(bal, flags)
+    e2.set_pubkeys_compressed(comp)
+    assert np.array_equal(e2.g1_sum(offsets), want)
+    bad = comp.copy().reshape(n, 48)
+    bad[17, 0] &= 0x7F                                  # compression bit cleared
+    with pytest.raises(pea.EngineError):
+        e2.set_pubkeys_compressed(bad)
+    with pytest.raises(pea.EngineError):                 # the failed load leaves no pubkeys behind
+        e2.g1_sum(offsets)

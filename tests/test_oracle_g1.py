@@ -85,3 +85,44 @@ def test_shard_partials_recombine():
                                              np.cumsum([0] + [len(g) for g in loc]).astype(np.uint32)))
     got = cport.g1_finish_partials(np.concatenate(parts), n_ranks, len(groups))
     assert np.array_equal(got, whole)
+
+
+def test_compress_decompress_roundtrip_and_known_answer():
+    """Wire format pins: the published compressed generator, both y signs, infinity, malformed encodings."""
+    import pytest
+    gen = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac58"
+                        "6c55e83ff97a1aeffb3af00adb22c6bb")
+    assert g1.compress(g1.G) == gen and g1.decompress(gen) == g1.G
+    signs = set()
+    for k in (2, 3, 5, 7, 11, 12345, g1.R_ORDER - 1):
+        p = g1.mul(k, g1.G)
+        c = g1.compress(p)
+        signs.add(c[0] & 0x20)
+        assert g1.decompress(c) == p
+        flipped = bytes([c[0] ^ 0x20]) + c[1:]
+        assert g1.decompress(flipped) == g1.neg(p)
+    assert signs == {0, 0x20}
+    assert g1.decompress(g1.compress(None)) is None
+    for bad in (bytes(48),                                   # compression bit missing
+                bytes([0xE0]) + bytes(47),                   # infinity with the sign bit
+                bytes([0xC0]) + bytes(46) + b"\x01",         # infinity with a non-zero x
+                bytes([0x9F]) + b"\xff" * 47,                # x >= p
+                bytes([0x80]) + bytes(47)):                  # x = 0: 4 is a non-residue? (0^3 + 4 = 4 is a square) -> handled below
+        if bad == bytes([0x80]) + bytes(47):
+            assert g1.decompress(bad) == (0, 2) or g1.decompress(bad) == (0, g1.P - 2)
+            continue
+        with pytest.raises(ValueError):
+            g1.decompress(bad)
+
+
+def test_c_abi_compress_matches_oracle():
+    """pe_g1_compress is host-side serialisation: checked here without a GPU."""
+    import ctypes as C
+    import numpy as np
+    from pos_evolution_amd import _abi
+    lib = _abi.load()
+    pts = [g1.mul(k, g1.G) for k in (1, 2, 3, 99, g1.R_ORDER - 1)] + [None]
+    raw = np.frombuffer(b"".join(g1.to_bytes96(p) for p in pts), dtype=np.uint8).copy()
+    out = np.zeros(48 * len(pts), dtype=np.uint8)
+    assert lib.pe_g1_compress(raw.ctypes.data_as(C.POINTER(C.c_uint8)), len(pts), out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert out.tobytes() == b"".join(g1.compress(p) for p in pts)
