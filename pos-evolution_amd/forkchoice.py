@@ -125,13 +125,19 @@ class Store:
         flags = np.fromiter(
             ((_abi.PE_VAL_ACTIVE if int(v.activation_epoch) <= epoch < int(v.exit_epoch) else 0)
              | (_abi.PE_VAL_SLASHED if v.slashed else 0) for v in state.validators), dtype=np.uint8, count=n)
-        pk = None
+        pk = pk48 = None
         if n and all(getattr(v, "pubkey", None) is not None for v in state.validators):
-            pk = np.frombuffer(b"".join(_point96(v.pubkey) for v in state.validators), dtype=np.uint8)
-        if self.engine.num_validators == n and pk is None:
+            if all(isinstance(v.pubkey, (bytes, bytearray)) and len(v.pubkey) == 48 for v in state.validators):
+                # the pyspec's own type: BLSPubkey = 48-byte compressed (pe:37); decompressed on the GPU
+                pk48 = np.frombuffer(b"".join(bytes(v.pubkey) for v in state.validators), dtype=np.uint8)
+            else:
+                pk = np.frombuffer(b"".join(_point96(v.pubkey) for v in state.validators), dtype=np.uint8)
+        if self.engine.num_validators == n and pk is None and pk48 is None:
             self.engine.set_balances(bal, flags)
         else:
             self.engine.set_validators(bal, flags, pk)
+            if pk48 is not None:
+                self.engine.set_pubkeys_compressed(pk48)
 
     def set_committees(self, epoch: int, committees: Sequence[Sequence[int]]):
         """get_beacon_committee(state, slot, index) for every (slot, index) of ``epoch``, in committee-id

@@ -72,6 +72,30 @@ def test_on_attestation_aggregate_pubkey_matches_bls_oracle(engine_factory):
             assert aggpk[0].tobytes() == g1.to_bytes96(spec.aggregate_pubkeys(state, idx))
 
 
+def test_store_from_compressed_pubkeys(engine_factory):
+    """A state whose validators carry 48-byte BLSPubkeys (the pyspec's own type, pe:37) binds through the mirror:
+    decompression on the GPU, same aggregate pubkeys as the affine registry."""
+    from oracle import g1
+    from pos_evolution_amd.forkchoice import _att_row
+    w = new_world(32, "minimal", engine_factory=engine_factory, with_pubkeys=True)
+    state = w.store.block_states[w.store.justified_checkpoint.root]
+    affine = [v.pubkey for v in state.validators]
+    for v in state.validators:
+        v.pubkey = g1.compress(v.pubkey)
+    w.mirror.set_justified_state(state)
+    for v, p in zip(state.validators, affine):
+        v.pubkey = p
+    anchor = w.store.justified_checkpoint.root
+    w.tick_to_slot(1)
+    b1 = w.block(anchor, 1)
+    w.tick_to_slot(2)
+    voters = slot_committee_members(w.store, 1)
+    for att in w.attestation_for(voters, b1, 1):
+        status, aggpk, count = w.mirror.engine.on_attestation_batch([_att_row(att)], want_aggregate_pubkeys=True)
+        idx = spec.get_indexed_attestation(state, att).attesting_indices
+        assert status[0] == 0 and aggpk[0].tobytes() == g1.to_bytes96(spec.aggregate_pubkeys(state, idx))
+
+
 def test_process_attestation_vs_literal_oracle(engine_factory):
     """process_attestation (pe:722-754) through the mirror: participation flags, proposer reward, asserts."""
     import copy
