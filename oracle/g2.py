@@ -197,6 +197,55 @@ def compress(pt):
     return bytes(out)
 
 
+def f2_sqrt(a):
+    """A square root of a in Fp2 or None (p = 3 mod 4, "complex method": two Fp square roots and one inversion)."""
+    a0, a1 = a
+    def fp_sqrt(v):
+        r = pow(v, (P + 1) // 4, P)
+        return r if r * r % P == v % P else None
+    if a1 == 0:
+        r = fp_sqrt(a0)
+        if r is not None:
+            return (r, 0)
+        t = fp_sqrt(-a0 % P)                    # -1 is a non-residue: exactly one of a0, -a0 is a square
+        return (0, t)
+    s = fp_sqrt((a0 * a0 + a1 * a1) % P)       # the norm must be a square in Fp
+    if s is None:
+        return None
+    inv2 = (P + 1) // 2
+    d = (a0 + s) * inv2 % P
+    y0 = fp_sqrt(d)
+    if y0 is None:
+        d = (a0 - s) * inv2 % P
+        y0 = fp_sqrt(d)
+    y1 = a1 * pow(2 * y0, -1, P) % P
+    return (y0, y1)
+
+
+def decompress(b):
+    """96-byte compressed BLSSignature (pe:37) -> affine point; raises ValueError on malformed / off-curve input."""
+    assert len(b) == 96
+    c, inf, sign = b[0] & 0x80, b[0] & 0x40, b[0] & 0x20
+    x1 = int.from_bytes(b[:48], "big") & ((1 << 381) - 1)
+    x0 = int.from_bytes(b[48:], "big")
+    if not c:
+        raise ValueError("not a compressed encoding")
+    if inf:
+        if sign or x0 or x1:
+            raise ValueError("malformed infinity")
+        return None
+    if x0 >= P or x1 >= P:
+        raise ValueError("x not canonical")
+    x = (x0, x1)
+    y = f2_sqrt(f2_add(f2_mul(f2_sqr(x), x), B2))
+    if y is None:
+        raise ValueError("not on the curve")
+    ny = f2_neg(y)
+    if ((y[1], y[0]) > (ny[1], ny[0])) != bool(sign):
+        y = ny
+    return (x, y)
+
+
 def synthetic_points(n, a_scalar, b_scalar):
     """[(a + i*b) * G2 for i in range(n)] by repeated addition (exact), mirroring oracle.g1.synthetic_points."""
     cur = _to_jac(mul(a_scalar, G2))

@@ -110,6 +110,8 @@ SIGNATURES = {
     "pe_g1_decompress": (C.c_int, [_H, _u8p, C.c_uint64, _u8p, _i32p]),
     "pe_set_pubkeys_compressed": (C.c_int, [_H, C.c_uint64, _u8p, _i32p]),
     "pe_g1_compress": (C.c_int, [_u8p, C.c_uint64, _u8p]),
+    "pe_g2_decompress": (C.c_int, [_H, _u8p, C.c_uint64, _u8p, _i32p]),
+    "pe_g2_compress": (C.c_int, [_u8p, C.c_uint64, _u8p]),
     "pe_g2_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
     "pe_num_blocks": (C.c_uint32, [_H]),
     "pe_num_validators": (C.c_uint64, [_H]),

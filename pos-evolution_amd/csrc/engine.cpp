@@ -2089,6 +2089,27 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
     return PE_OK;
 }
 
+int pe_g2_decompress(pe_engine* h, const uint8_t* in96, uint64_t n, uint8_t* out192, int32_t* status)
+{
+    if (!h || (n && (!in96 || !out192 || !status))) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    const uint64_t chunk = 1ull << 19;
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, (96ull + 192ull + 4ull) * std::min(chunk, std::max<uint64_t>(n, 1)))));
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const uint64_t m = std::min(chunk, n - base);
+        uint8_t* d_in = h->d_tmp_be.as<uint8_t>();
+        uint8_t* d_out = d_in + 96ull * m;
+        int32_t* d_st = reinterpret_cast<int32_t*>(d_out + 192ull * m);
+        HIP_TRY(h, hipMemcpyAsync(d_in, in96 + 96ull * base, 96ull * m, hipMemcpyHostToDevice, h->stream));
+        launch_g2_decompress(h->stream, d_in, m, nullptr, d_out, d_st);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(out192 + 192ull * base, d_out, 192ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(status + base, d_st, 4ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return PE_OK;
+}
+
 // Serialisation only (flag bits from a 48-byte comparison); no device work, no handle.
 int pe_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48)
 {
@@ -2107,6 +2128,31 @@ int pe_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48)
         }
         memcpy(o, p, 48);
         o[0] = (uint8_t)((o[0] & 0x1f) | 0x80 | (memcmp(p + 48, HALF_BE, 48) > 0 ? 0x20 : 0));
+    }
+    return PE_OK;
+}
+
+int pe_g2_compress(const uint8_t* in192, uint64_t n, uint8_t* out96)
+{
+    if (n && (!in192 || !out96)) return PE_ERR_INVALID_ARG;
+    static const uint8_t HALF_BE[48] = {
+        0x0d, 0x00, 0x88, 0xf5, 0x1c, 0xbf, 0xf3, 0x4d, 0x25, 0x8d, 0xd3, 0xdb, 0x21, 0xa5, 0xd6, 0x6b,
+        0xb2, 0x3b, 0xa5, 0xc2, 0x79, 0xc2, 0x89, 0x5f, 0xb3, 0x98, 0x69, 0x50, 0x7b, 0x58, 0x7b, 0x12,
+        0x0f, 0x55, 0xff, 0xff, 0x58, 0xa9, 0xff, 0xff, 0xdc, 0xff, 0x7f, 0xff, 0xff, 0xff, 0xd5, 0x55};
+    static const uint8_t ZERO48[48] = {0};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t* p = in192 + 192 * i;
+        uint8_t* o = out96 + 96 * i;
+        if (p[0] & 0x40) {
+            memset(o, 0, 96);
+            o[0] = 0xC0;
+            continue;
+        }
+        memcpy(o, p, 96);  // x.c1 | x.c0
+        const uint8_t* y1 = p + 96;
+        const uint8_t* y0 = p + 144;
+        const bool larger = memcmp(y1, ZERO48, 48) != 0 ? memcmp(y1, HALF_BE, 48) > 0 : memcmp(y0, HALF_BE, 48) > 0;
+        o[0] = (uint8_t)((o[0] & 0x1f) | 0x80 | (larger ? 0x20 : 0));
     }
     return PE_OK;
 }

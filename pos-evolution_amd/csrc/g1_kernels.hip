@@ -16,6 +16,7 @@
 // Bound: integer VALU (about 11 Montgomery products = 6.4k v_mad_u64_u32/v_addc per
 // 100 bytes gathered), not HBM and not MFMA -- see DESIGN.md "G1 roofline".
 #include "g1.cuh"
+#include "fp_sqrt.cuh"
 #include "kernels.h"
 
 namespace posevo {
@@ -58,22 +59,6 @@ void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uin
 // y = (x^3 + 4)^((p+1)/4) (p = 3 mod 4), verified by squaring.  ~620 Montgomery products per key, once per registry
 // load.  status: 0 ok, 1 malformed encoding (flag bits / x >= p), 2 x is not the abscissa of a curve point.
 // No subgroup check here (KeyValidate's r*P == infinity is a separate scalar multiplication).
-__device__ const uint32_t FP_SQRT_EXP[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
-                                             0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};  // (p+1)/4
-__device__ const uint32_t FP_HALF[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
-                                         0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};     // (p-1)/2
-
-__device__ __forceinline__ bool limbs_gt(const fp& a, const uint32_t* b)  // a > b as 384-bit integers
-{
-    bool gt = false, eq = true;
-#pragma unroll
-    for (int j = 11; j >= 0; --j) {
-        gt = gt || (eq && a.l[j] > b[j]);
-        eq = eq && a.l[j] == b[j];
-    }
-    return gt;
-}
-
 __global__ void __launch_bounds__(256)
 k_g1_decompress(const uint8_t* __restrict__ in48, uint64_t n, uint32_t* __restrict__ out_mont24,
                 uint8_t* __restrict__ out_be96, int32_t* __restrict__ status)
@@ -91,14 +76,8 @@ k_g1_decompress(const uint8_t* __restrict__ in48, uint64_t n, uint32_t* __restri
     else if (inf_flag) {
         if (sign_flag || !fp_is_zero(x)) st = 1;
         is_inf = true;
-    } else {
-        uint32_t p[12];
-#pragma unroll
-        for (int j = 0; j < 12; ++j) p[j] = fp_p_limb(j);
-        bool eq = true;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) eq = eq && x.l[j] == p[j];
-        if (eq || limbs_gt(x, p)) st = 1;  // x must be canonical (< p)
+    } else if (!fp_is_canonical(x)) {
+        st = 1;
     }
     fp xm, ym;
     fp_set_zero(xm);
@@ -112,19 +91,11 @@ k_g1_decompress(const uint8_t* __restrict__ in48, uint64_t n, uint32_t* __restri
         four.l[0] = 4;
         fp_to_mont(four, four);
         fp_add(rhs, t, four);
-        fp_set_one(r);
-        for (int b = 378; b >= 0; --b) {  // square-and-multiply over the fixed exponent (uniform branches)
-            fp_sqr(r, r);
-            if ((FP_SQRT_EXP[b >> 5] >> (b & 31)) & 1u) fp_mul(r, r, rhs);
-        }
-        fp_sqr(t, r);
-        if (!fp_eq(t, rhs)) st = 2;
+        if (!fp_sqrt(r, rhs)) st = 2;
         else {
-            fp plain, neg;
-            fp_from_mont(plain, r);
-            const bool larger = limbs_gt(plain, FP_HALF);
+            fp neg;
             fp_neg(neg, r);
-            fp_select(ym, larger != sign_flag, neg, r);
+            fp_select(ym, fp_is_larger_half(r) != sign_flag, neg, r);
         }
     }
     status[i] = st;

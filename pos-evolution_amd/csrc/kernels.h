@@ -110,6 +110,8 @@ void launch_g1_decompress(hipStream_t s, const uint8_t* in48, uint64_t n, uint32
 void launch_g2_convert(hipStream_t s, const uint8_t* be192, uint32_t* mont48, uint64_t n);
 void launch_g2_accumulate(hipStream_t s, const uint32_t* points_mont48, const uint32_t* members,
                           const G1Group* groups, uint32_t n_groups, uint32_t n_slots, uint32_t* wg_partials96);
+void launch_g2_decompress(hipStream_t s, const uint8_t* in96, uint64_t n, uint32_t* out_mont48, uint8_t* out_be192,
+                          int32_t* status);
 void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* groups, uint32_t n_groups,
                       uint8_t* out_be192);
 

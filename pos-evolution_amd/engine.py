@@ -354,6 +354,21 @@ class Engine:
         self._check(self._lib.pe_g1_compress(_ptr(p, C.c_uint8), p.shape[0], _ptr(out, C.c_uint8)))
         return out[:p.shape[0]]
 
+    def g2_decompress(self, sigs96):
+        """96-byte compressed BLSSignatures (pe:37) -> (192-byte uncompressed (n, 192), status int32[n])."""
+        k = np.ascontiguousarray(sigs96, dtype=np.uint8).reshape(-1, 96)
+        n = k.shape[0]
+        out = np.empty((max(n, 1), 192), dtype=np.uint8)
+        status = np.empty(max(n, 1), dtype=np.int32)
+        self._check(self._lib.pe_g2_decompress(self._h, _ptr(k, C.c_uint8), n, _ptr(out, C.c_uint8), _ptr(status, C.c_int32)))
+        return out[:n], status[:n]
+
+    def g2_compress(self, points192) -> np.ndarray:
+        p = np.ascontiguousarray(points192, dtype=np.uint8).reshape(-1, 192)
+        out = np.empty((max(p.shape[0], 1), 96), dtype=np.uint8)
+        self._check(self._lib.pe_g2_compress(_ptr(p, C.c_uint8), p.shape[0], _ptr(out, C.c_uint8)))
+        return out[:p.shape[0]]
+
     def g2_sum(self, points192, offsets, index=None) -> np.ndarray:
         """bls.Aggregate over G2 signature points (pe:659, pe:1536): 192-byte uncompressed in, 192-byte affine out."""
         off = np.ascontiguousarray(offsets, dtype=np.uint32)

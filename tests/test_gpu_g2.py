@@ -111,3 +111,31 @@ def test_aggregate_with_g2_signatures(engine_factory):
         members = np.nonzero(res["group_of"] == g)[0]
         k = (len(members) * a + int(members.sum()) * b) % g1.R_ORDER
         assert res["sig192"][g].tobytes() == g2.to_bytes192(g2.mul(k, g2.G2)), g
+
+
+def test_g2_decompress_vs_oracle(engine_factory):
+    """96-byte compressed signatures -> affine on the GPU (Fp2 square root + sign) against oracle/g2.py."""
+    e = engine_factory()
+    pts = g2.synthetic_points(1500, 0x1234567, 0x89ABCDE)
+    comp = np.frombuffer(b"".join(g2.compress(p) for p in pts), dtype=np.uint8).reshape(-1, 96).copy()
+    want = _rows(pts)
+    assert np.array_equal(e.g2_compress(want), comp)
+    out, status = e.g2_decompress(comp)
+    assert not status.any() and np.array_equal(out, want)
+    gen = g2.compress(g2.G2)
+    assert gen.hex().startswith("93e02b6052719f60")
+    # an x whose right-hand side is not a square in Fp2
+    x0 = 1
+    while g2.f2_sqrt(g2.f2_add(g2.f2_mul(g2.f2_sqr((x0, 0)), (x0, 0)), g2.B2)) is not None:
+        x0 += 1
+    off = bytearray(bytes(48) + x0.to_bytes(48, "big"))
+    off[0] |= 0x80
+    special = [gen, bytes([gen[0] ^ 0x20]) + gen[1:], g2.compress(None), bytes(96), bytes([0xE0]) + bytes(95),
+               bytes([0x9F]) + b"\xff" * 95, bytes(off)]
+    out, status = e.g2_decompress(np.frombuffer(b"".join(special), dtype=np.uint8).reshape(-1, 96))
+    assert list(status) == [0, 0, 0, 1, 1, 1, 2]
+    assert out[0].tobytes() == g2.to_bytes192(g2.G2) and out[1].tobytes() == g2.to_bytes192(g2.neg(g2.G2))
+    assert out[2][0] == 0x40 and not out[2][1:].any() and not out[3:].any()
+    # wire-to-wire: compressed signatures in, compressed aggregate out
+    agg = e.g2_compress(e.g2_sum(e.g2_decompress(comp[:64])[0], [0, 64]))[0].tobytes()
+    assert agg == g2.compress(g2.sum_points(pts[:64]))

@@ -47,3 +47,34 @@ def test_golden_vectors_match_oracle():
     for case in vec["sums"]:
         pts = [g2.from_bytes192(bytes.fromhex(h)) for h in case["points"]]
         assert g2.to_bytes192(g2.sum_points(pts)).hex() == case["sum"], case["name"]
+
+
+def test_compress_decompress_roundtrip():
+    import pytest
+    assert g2.decompress(g2.compress(g2.G2)) == g2.G2
+    signs = set()
+    for p in g2.synthetic_points(60, 7, 11):
+        c = g2.compress(p)
+        signs.add(c[0] & 0x20)
+        assert g2.decompress(c) == p
+        assert g2.decompress(bytes([c[0] ^ 0x20]) + c[1:]) == g2.neg(p)
+    assert signs == {0, 0x20}
+    assert g2.decompress(g2.compress(None)) is None
+    for a in [(4, 0), (g1.P - 4, 0), (9, 0), (5, 0), (g1.P - 5, 0)]:        # the a1 == 0 branches of the Fp2 root
+        r = g2.f2_sqrt(a)
+        assert g2.f2_sqr(r) == a
+    for bad in (bytes(96), bytes([0xE0]) + bytes(95), bytes([0x9F]) + b"\xff" * 95):
+        with pytest.raises(ValueError):
+            g2.decompress(bad)
+
+
+def test_c_abi_g2_compress_matches_oracle():
+    import ctypes as C
+    import numpy as np
+    from pos_evolution_amd import _abi
+    lib = _abi.load()
+    pts = g2.synthetic_points(20, 3, 5) + [None, g2.G2, g2.neg(g2.G2)]
+    raw = np.frombuffer(b"".join(g2.to_bytes192(p) for p in pts), dtype=np.uint8).copy()
+    out = np.zeros(96 * len(pts), dtype=np.uint8)
+    assert lib.pe_g2_compress(raw.ctypes.data_as(C.POINTER(C.c_uint8)), len(pts), out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
+    assert out.tobytes() == b"".join(g2.compress(p) for p in pts)
