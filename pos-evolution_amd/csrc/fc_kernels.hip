@@ -159,19 +159,23 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
 }
 
 // ------------------------------------------------------------------ tree
-constexpr int TREE_WG = 1024;
-constexpr int TREE_PER_THREAD = TREE_MAX_BLOCKS / TREE_WG;  // 8
-
-// LDS index skew: thread t owns items 8t..8t+7, i.e. a lane stride of 8 elements = an 8-way (u32) / 16-way (u64)
-// bank conflict on every own-item access.  i -> i + i/8 turns the stride into 9 elements: conflict-free.
-__device__ __forceinline__ uint32_t SK(uint32_t i) { return i + (i >> 3); }
+// The kernel is instantiated for a few items-per-thread counts: 1024 lanes x PER >= n, picked by the host from the
+// block count.  The per-item loops, not the ~25 barriers, set the time: a 4096-block tree measures 19.8 us at
+// 1024 x 4, 26 us at 512 x 8 or 1024 x 8 (half the lanes idle) and 34 us at 256 x 16.
+//
+// LDS index skew: thread t owns items PER*t .. PER*t+PER-1, i.e. a lane stride of PER elements = a PER-way (u32) bank
+// conflict on every own-item access.  i -> i + i/PER turns the stride into PER+1 (odd): conflict-free.
+template <int PER>
+__device__ __forceinline__ uint32_t SKT(uint32_t i) { return PER == 1 ? i : i + i / PER; }
+// largest skewed index over the shapes in use: 8192 blocks at PER = 8 (PER = 4 only serves n <= 4096)
 constexpr uint32_t TREE_LDS_ENTRIES = TREE_MAX_BLOCKS + 2 + ((TREE_MAX_BLOCKS + 2) >> 3) + 1;
 
 // Exclusive prefix sum over n <= 8192 values held as 8 consecutive items per thread.
 // out[SK(i)] (LDS, n+1 entries) = sum of in[0..i); wave shuffles + one LDS hop across the 16 waves.
-template <typename T>
+template <typename T, int TREE_WG, int TREE_PER_THREAD>
 __device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_THREAD], T* out, T* wave_tot, uint32_t n)
 {
+    auto SK = [](uint32_t i) { return SKT<TREE_PER_THREAD>(i); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T local = 0;
 #pragma unroll
@@ -197,6 +201,7 @@ __device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_TH
     __syncthreads();
 }
 
+template <int TREE_WG, int TREE_PER_THREAD>
 __global__ void __launch_bounds__(TREE_WG)
 k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* __restrict__ totals,
        unsigned long long ov_balance, unsigned long long ov_num, int use_override, uint32_t justified_pos,
@@ -216,6 +221,7 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
 
     const uint32_t n = tree.n;
     const int tid = threadIdx.x;
+    auto SK = [](uint32_t i) { return SKT<TREE_PER_THREAD>(i); };
 
     // every global read up front: one round trip of memory latency for the whole kernel
     unsigned long long w_item[TREE_PER_THREAD];
@@ -233,9 +239,11 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
         idx_g[k] = in ? tree.idx_of_pos[i] : 0u;
     }
     unsigned long long t_bal = 0, t_num = 0;
-    if (boost_pos != NONE32 && !use_override && tid < VOTES_MAX_WG) {
-        t_bal = totals[tid].total_active_balance;
-        t_num = totals[tid].num_active;
+    if (boost_pos != NONE32 && !use_override) {
+        for (int j = tid; j < VOTES_MAX_WG; j += TREE_WG) {
+            t_bal += totals[j].total_active_balance;
+            t_num += totals[j].num_active;
+        }
     }
     if (clear_direct) {  // leave the engine's weight buffer zeroed for the next get_head (no memset launch)
 #pragma unroll
@@ -272,8 +280,8 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
             if ((uint32_t)(tid * TREE_PER_THREAD + k) == boost_pos) w_item[k] += boost;
     }
 
-    block_exclusive_scan<unsigned long long>(w_item, S, wave_tot64, n);
-    block_exclusive_scan<uint32_t>(l_item, L, wave_tot32, n);
+    block_exclusive_scan<unsigned long long, TREE_WG, TREE_PER_THREAD>(w_item, S, wave_tot64, n);
+    block_exclusive_scan<uint32_t, TREE_WG, TREE_PER_THREAD>(l_item, L, wave_tot32, n);
 
     unsigned long long W[TREE_PER_THREAD];
     uint32_t viable = 0;
@@ -336,23 +344,38 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
     if (tid == 0) head_idx[0] = tree.idx_of_pos[jump[SK(justified_pos)]];
 }
 
+template <int WG, int PER>
+static void launch_tree_shape(hipStream_t s, size_t lds, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
+                              uint64_t ovb, uint64_t ovn, int use_override, uint32_t justified_pos, uint32_t boost_pos,
+                              uint64_t slots_per_epoch, uint64_t boost_percent, uint64_t balance_increment,
+                              uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
+{
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<WG, PER>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_tree<WG, PER>), dim3(1), dim3(WG), lds, s, tree, reinterpret_cast<unsigned long long*>(direct),
+                       totals, (unsigned long long)ovb, (unsigned long long)ovn, use_override, justified_pos, boost_pos,
+                       (unsigned long long)slots_per_epoch, (unsigned long long)boost_percent,
+                       (unsigned long long)balance_increment, reinterpret_cast<unsigned long long*>(weights_by_idx),
+                       head_idx, clear_direct);
+}
+
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
                  uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
                  uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
 {
     const size_t lds = sizeof(uint64_t) * (TREE_LDS_ENTRIES + 18) + sizeof(uint32_t) * (2 * TREE_LDS_ENTRIES + 16);
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_tree, dim3(1), dim3(TREE_WG), lds, s, tree, reinterpret_cast<unsigned long long*>(direct),
-                       totals, (unsigned long long)totals_override_balance, (unsigned long long)totals_override_num,
-                       use_override, justified_pos, boost_pos, (unsigned long long)slots_per_epoch,
-                       (unsigned long long)boost_percent, (unsigned long long)balance_increment,
-                       reinterpret_cast<unsigned long long*>(weights_by_idx), head_idx, clear_direct);
+#define POSEVO_TREE_ARGS s, lds, tree, direct, totals, totals_override_balance, totals_override_num, use_override, justified_pos, \
+        boost_pos, slots_per_epoch, boost_percent, balance_increment, weights_by_idx, head_idx, clear_direct
+    if (tree.n <= 1024) launch_tree_shape<1024, 1>(POSEVO_TREE_ARGS);
+    else if (tree.n <= 2048) launch_tree_shape<1024, 2>(POSEVO_TREE_ARGS);
+    else if (tree.n <= 4096) launch_tree_shape<1024, 4>(POSEVO_TREE_ARGS);
+    else launch_tree_shape<1024, 8>(POSEVO_TREE_ARGS);
+#undef POSEVO_TREE_ARGS
 }
 
 // ------------------------------------------------------------------ LMD update
