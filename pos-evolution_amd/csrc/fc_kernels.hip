@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 }
 
 // ------------------------------------------------------------------ votes
-constexpr int VOTES_WG = 512;
+constexpr int VOTES_WG = 512;  // 256 lanes: 21 us, 512: 15.8, 1024: 15.4 at 1 M validators / 64 workgroups
 constexpr int VOTES_PER_THREAD = 4;
 
 __global__ void __launch_bounds__(VOTES_WG)
