@@ -690,7 +690,21 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
                     h->d_weights.as<uint64_t>(), h->h_head.as<uint32_t>(), clear_direct);
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // k_tree's last act is a system-scope release store of the head index into this host-coherent word: polling it
+    // sees the result a few microseconds before hipStreamSynchronize returns.  Bounded: after ~200 us (a hung or
+    // faulted kernel) the stream sync takes over and reports the error.
+    static const bool spin = [] { const char* e = getenv("POSEVO_HEAD_SPIN"); return !e || atoi(e) != 0; }();
+    bool seen = false;
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 0;; ++it) {
+            if (*head_word != NONE32) { seen = true; break; }
+            if ((it & 63) == 63 &&
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 200.0)
+                break;
+        }
+    }
+    if (!seen) HIP_TRY(h, hipStreamSynchronize(h->stream));
     *head_out = *head_word;
     if (*head_out >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
     return PE_OK;

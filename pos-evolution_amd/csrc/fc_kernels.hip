@@ -341,7 +341,8 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
         }
         __syncthreads();
     }
-    if (tid == 0) head_idx[0] = tree.idx_of_pos[jump[SK(justified_pos)]];
+    if (tid == 0)  // host-coherent pinned word polled by the host: system-scope release
+        __hip_atomic_store(head_idx, tree.idx_of_pos[jump[SK(justified_pos)]], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int WG, int PER>

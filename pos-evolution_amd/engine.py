@@ -24,15 +24,25 @@ class EngineError(AssertionError):
         self.status = status
 
 
-def _ptr(a, ctype):
-    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+_c_char = C.c_char
+
+
+def _ptr(a, ctype=None):
+    """Address of a C-contiguous numpy buffer (None stays NULL).  c_char.from_buffer + addressof is the cheapest route
+    ctypes offers; read-only or empty arrays take the slower ndarray.ctypes path."""
+    if a is None:
+        return None
+    try:
+        return C.addressof(_c_char.from_buffer(a))
+    except (TypeError, ValueError, BufferError):
+        return a.ctypes.data
 
 
 def _att_ptr(arr):
-    """ctypes array of pe_attestation or numpy structured array (synth.ATT_DTYPE) -> pointer."""
+    """ctypes array of pe_attestation or numpy structured array (synth.ATT_DTYPE) -> address."""
     if isinstance(arr, np.ndarray):
         assert arr.dtype.itemsize == 144 and arr.flags["C_CONTIGUOUS"]
-        return arr.ctypes.data_as(C.POINTER(pe_attestation))
+        return _ptr(arr)
     return arr
 
 
