@@ -1231,6 +1231,7 @@ int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)
     uint8_t root[32];
     rc = pe_get_head(h, root);  // recompute, then read the per-block weights it left behind
     if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // get_head returns on the polled head word, not on kernel completion
     HIP_TRY(h, hipMemcpy(out_weights, h->d_weights.p, 8ull * n, hipMemcpyDeviceToHost));
     return PE_OK;
 }

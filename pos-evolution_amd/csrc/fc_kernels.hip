@@ -159,6 +159,9 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
 }
 
 // ------------------------------------------------------------------ tree
+// (A fused get_head -- votes phase in every workgroup, tree phase in the last one to pass a device-scope ticket --
+// was built and measured: p50 46 us against 33 us for the two launches below.  The fat 1024-lane / 147 KB-LDS
+// workgroups slow the votes phase by more than the saved launch gap; dropped.)
 // The kernel is instantiated for a few items-per-thread counts: 1024 lanes x PER >= n, picked by the host from the
 // block count.  The per-item loops, not the ~25 barriers, set the time: a 4096-block tree measures 19.8 us at
 // 1024 x 4, 26 us at 512 x 8 or 1024 x 8 (half the lanes idle) and 34 us at 256 x 16.
