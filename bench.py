@@ -12,7 +12,7 @@ cached or skipped.  Inputs (registry, tree, committee tables) are resident in HB
 the per-step attestation rows + bits (~1.7 MB) cross PCIe inside it, as the C ABI hands over host buffers.
 
 N > 1 (launched by torch.distributed.run): validators are range-sharded (weak scaling: 1M per GPU); the
-exchange steps are one RCCL all-gather of G1 Jacobian partials and one all-reduce of per-block weights.
+exchange steps are one RCCL all-gather of G1 XYZZ partials (192 B per committee) and one all-reduce of per-block weights.
 
 Prints ONE JSON line on rank 0.
 """
@@ -305,7 +305,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 limbs (381-bit Fp, integer) + u64 Gwei",
+        "dtype": "u32",
+        "dtype_detail": "12 x u32 Montgomery limbs (381-bit Fp, exact integer arithmetic); u64 Gwei weights",
         "data": "synthetic",
         "config": {
             "workload": f"BASELINE configs[3] shape on {world} GPU(s): {args.validators} validators/GPU, "
@@ -320,7 +321,7 @@ def main():
             "kernel": "k_g1_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms, "launches": acc["launches"],
-            "note": "integer-VALU bound (about 11 Montgomery products per 100 B gathered), not HBM bound: "
+            "note": "integer-VALU bound (10 Montgomery products per 100 B gathered), not HBM bound: "
                     "see DESIGN.md; votes kernel below is the HBM-streaming one",
         },
         "roofline_valu": {

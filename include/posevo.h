@@ -349,7 +349,7 @@ int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, 
                   void* dev_partials);
 int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups,
                  uint8_t* out96);
-/* pe_aggregate whose aggregate pubkeys stay Jacobian partials of THIS shard's committee
+/* pe_aggregate whose aggregate pubkeys stay projective (XYZZ) partials of THIS shard's committee
  * members, written to a caller-owned DEVICE buffer (PE_G1_PARTIAL_BYTES per group, group
  * order as in out_atts); all-gather them and call pe_g1_finish.  Asynchronous w.r.t. the
  * partials; everything else as pe_aggregate. */

@@ -873,7 +873,7 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
         HIP_TRY(h, hipMemsetAsync(h->d_part_prev.as<uint8_t>() + old_n, 0, n4 - old_n, h->stream));
     }
     if (pubkeys96 && n) {
-        HIP_TRY(h, h->d_points.ensure(96ull * n));
+        HIP_TRY(h, h->d_points.ensure(4ull * G1_ROW_WORDS * n));
         // convert in chunks through a bounded device staging buffer
         const uint64_t chunk = std::min<uint64_t>(n, 1u << 20);
         HIP_TRY(h, h->d_tmp_be.ensure(96ull * chunk));
@@ -881,7 +881,7 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
             const uint64_t m = std::min(chunk, n - base);
             HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, pubkeys96 + 96ull * base, 96ull * m, hipMemcpyHostToDevice,
                                       h->stream));
-            launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_points.as<uint32_t>() + 24ull * base, m);
+            launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_points.as<uint32_t>() + (uint64_t)G1_ROW_WORDS * base, m);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
         }
         HIP_TRY(h, hipGetLastError());
@@ -1685,7 +1685,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     }
     if (out_sig96) {  // bls.Aggregate: sum of the members' signature points
         HIP_TRY(h, h->d_tmp_be.ensure(96ull * n));
-        HIP_TRY(h, h->d_tmp_points.ensure(96ull * n));
+        HIP_TRY(h, h->d_tmp_points.ensure(4ull * G1_ROW_WORDS * n));
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, h->stream));
         launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
         int rc = launch_g1_planned(h, h->d_tmp_points.as<uint32_t>(), st.dev<uint32_t>(off_idx), nullptr,
@@ -2014,7 +2014,7 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
     if (points96) {
         if (n_points >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "too many points");
         HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(96, 96ull * n_points)));
-        HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(96, 96ull * n_points)));
+        HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(128, 4ull * G1_ROW_WORDS * n_points)));
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n_points, hipMemcpyHostToDevice, h->stream));
         launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
         d_pts = h->d_tmp_points.as<uint32_t>();
@@ -2069,7 +2069,7 @@ static int g1_decompress_common(pe_engine* h, const uint8_t* in48, uint64_t n, u
         uint8_t* d_out = d_in + 48ull * m;
         int32_t* d_st = reinterpret_cast<int32_t*>(d_out + 96ull * m);
         HIP_TRY(h, hipMemcpyAsync(d_in, in48 + 48ull * base, 48ull * m, hipMemcpyHostToDevice, h->stream));
-        launch_g1_decompress(h->stream, d_in, m, d_mont24 ? d_mont24 + 24ull * base : nullptr, out96 ? d_out : nullptr, d_st);
+        launch_g1_decompress(h->stream, d_in, m, d_mont24 ? d_mont24 + (uint64_t)G1_ROW_WORDS * base : nullptr, out96 ? d_out : nullptr, d_st);
         HIP_TRY(h, hipGetLastError());
         if (out96) HIP_TRY(h, hipMemcpyAsync(out96 + 96ull * base, d_out, 96ull * m, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipMemcpyAsync(status + base, d_st, 4ull * m, hipMemcpyDeviceToHost, h->stream));
@@ -2094,7 +2094,7 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
     if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_set_pubkeys_compressed: n differs from the registry size");
     (void)hipSetDevice(h->device);
     if (n == 0) return PE_OK;
-    HIP_TRY(h, h->d_points.ensure(96ull * n));
+    HIP_TRY(h, h->d_points.ensure(4ull * G1_ROW_WORDS * n));
     h->have_points = false;
     uint64_t n_bad = 0;
     int rc = g1_decompress_common(h, pubkeys48, n, h->d_points.as<uint32_t>(), nullptr, status, &n_bad);

@@ -1,6 +1,6 @@
 // fp_inv_safegcd.h -- modular inversion in Fp381 by Bernstein-Yang "safegcd" divsteps.
 //
-// Why: normalising a Jacobian sum to affine needs one inversion per output.  Fermat
+// Why: normalising a projective (XYZZ) sum to affine needs one inversion per output.  Fermat
 // (a^(p-2)) is ~570 DEPENDENT Montgomery products = ~1 ms of pure latency per lane on
 // gfx950 (tools/fpbench: 1.8 us per dependent fp_mul) -- it was the single largest item
 // of the first profile (profiles/r01_kernel_stats_first.txt: k_g1_finish 1012 us).

@@ -6,14 +6,14 @@
 //
 // Kernels
 //   k_g1_convert     96-B big-endian affine -> Montgomery limbs (registry load, once)
-//   k_g1_accumulate  HOT: per-lane Jacobian accumulation of k gathered points (mixed
+//   k_g1_accumulate  HOT: per-lane XYZZ accumulation of k gathered points (mixed
 //                    adds), then a compacting pairwise tree over the workgroup's 256
-//                    partials staged in LDS (limb-major, conflict-light), one Jacobian
+//                    partials staged in LDS (limb-major, conflict-light), one XYZZ
 //                    partial out per (group, workgroup)
 //   k_g1_finish      per group: add the few workgroup (or rank) partials, normalise
 //                    to canonical affine, store big-endian
 //
-// Bound: integer VALU (about 11 Montgomery products = 6.4k v_mad_u64_u32/v_addc per
+// Bound: integer VALU (10 Montgomery products per mixed add = 5.8k v_mad_u64_u32/v_addc per
 // 100 bytes gathered), not HBM and not MFMA -- see DESIGN.md "G1 roofline".
 #include "g1.cuh"
 #include "fp_sqrt.cuh"
@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) k_g1_convert(const uint8_t* __restrict__ 
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* src = be96 + 96 * i;
-    uint32_t* dst = mont24 + 24 * i;
+    uint32_t* dst = mont24 + (uint64_t)G1_ROW_WORDS * i;
     if (src[0] & 0x40) {  // infinity flag
 #pragma unroll
         for (int j = 0; j < 24; ++j) dst[j] = 0;
@@ -101,7 +101,7 @@ k_g1_decompress(const uint8_t* __restrict__ in48, uint64_t n, uint32_t* __restri
     status[i] = st;
     const bool bad = st != 0;
     if (out_mont24) {
-        uint32_t* d = out_mont24 + 24 * i;
+        uint32_t* d = out_mont24 + (uint64_t)G1_ROW_WORDS * i;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             d[j] = (bad || is_inf) ? 0u : xm.l[j];
@@ -135,7 +135,7 @@ void launch_g1_decompress(hipStream_t s, const uint8_t* in48, uint64_t n, uint32
 // ---------------------------------------------------------------- accumulate
 __device__ __forceinline__ void load_point(fp& x, fp& y, const uint32_t* __restrict__ pts, uint32_t idx)
 {
-    const uint4* p = reinterpret_cast<const uint4*>(pts + 24ull * idx);  // 96-byte rows are 16-byte aligned
+    const uint4* p = reinterpret_cast<const uint4*>(pts + (uint64_t)G1_ROW_WORDS * idx);  // one 128-byte line per point
     uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4], v5 = p[5];
     x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w;
     x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
@@ -372,13 +372,13 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
 
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
-                          uint32_t* wg_partials36)
+                          uint32_t* wg_partials48)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     const size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
     hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), lds_bytes, s, points_mont24, members, bit_arena,
-                       groups, n_groups, n_slots, wg_partials36);
+                       groups, n_groups, n_slots, wg_partials48);
 }
 
 // ---------------------------------------------------------------- finish
@@ -426,12 +426,12 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
     fp_store_be48(o + 48, y);
 }
 
-void launch_g1_finish(hipStream_t s, const uint32_t* partials36, const G1Group* groups, uint32_t n_groups,
-                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_jac36)
+void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
+                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_xyzz48)
 {
     if (n_groups == 0) return;
-    hipLaunchKernelGGL(k_g1_finish, dim3((n_groups + 63) / 64), dim3(64), 0, s, partials36, groups, n_groups,
-                       n_parts_fixed, part_stride, out_be96, out_jac36);
+    hipLaunchKernelGGL(k_g1_finish, dim3((n_groups + 63) / 64), dim3(64), 0, s, partials48, groups, n_groups,
+                       n_parts_fixed, part_stride, out_be96, out_xyzz48);
 }
 
 }  // namespace posevo

@@ -8,6 +8,10 @@
 namespace posevo {
 
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+// Registry / point-table rows: 24 Montgomery words (x | y) padded to 32 = 128 bytes, so that a gathered point is
+// exactly one 128-byte memory line (96-byte rows straddle two lines half of the time: PMC showed 2x the
+// algorithmic bytes fetched by k_g1_accumulate's random gather).
+constexpr int G1_ROW_WORDS = 32;
 constexpr int G2_WG_SLOTS = 128;        // point slots per 256-lane workgroup of the G2 kernels (a lane pair per point)
 constexpr int G1_WG = 256;             // lanes (task slots) per workgroup of the accumulate kernel
 constexpr int TREE_MAX_BLOCKS = 8192;  // LDS-resident block tree capacity (K_tree)
@@ -30,14 +34,14 @@ struct G1Group {
 // ---- G1 ----
 // 96-byte big-endian uncompressed affine -> 24 u32 Montgomery limbs (x | y); infinity -> all zero.
 void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uint64_t n);
-// Per-lane Jacobian accumulation + LDS tree; writes one 36-u32 Jacobian partial per (group, workgroup).
+// Per-lane XYZZ accumulation + LDS tree; writes one 48-u32 XYZZ partial (192 bytes) per (group, workgroup).
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups,
-                          uint32_t n_slots, uint32_t* wg_partials36);
+                          uint32_t n_slots, uint32_t* wg_partials48);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
-// g when first == null), then either write the Jacobian (36 u32) or normalise to 96-byte affine.
-void launch_g1_finish(hipStream_t s, const uint32_t* partials36, const G1Group* groups, uint32_t n_groups,
-                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_jac36);
+// g when first == null), then either write the XYZZ sum (48 u32) or normalise to 96-byte affine.
+void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
+                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_xyzz48);
 
 // ---- fork choice ----
 struct TreeDev {               // block tree in DFS pre-order (device arrays of n entries)

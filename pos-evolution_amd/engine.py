@@ -401,7 +401,7 @@ class Engine:
         return bytes(out)
 
     def aggregate_partial(self, dev_ptr: int, rows=None, packed=None):
-        """pe_aggregate with the aggregate pubkeys left as this shard's Jacobian partials at dev_ptr."""
+        """pe_aggregate with the aggregate pubkeys left as this shard's XYZZ partials (192 B each) at dev_ptr."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         out_atts = np.empty(max(n, 1), dtype=_ATT_DTYPE)

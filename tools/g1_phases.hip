@@ -17,7 +17,7 @@ int main(int argc, char** argv)
 {
     const uint32_t n_groups = 2048, size = 512, k = argc > 1 ? atoi(argv[1]) : 8;
     const uint32_t n_pts = n_groups * size;
-    std::vector<uint32_t> pts(24ull * n_pts), members(n_pts);
+    std::vector<uint32_t> pts((size_t)G1_ROW_WORDS * n_pts), members(n_pts);
     std::mt19937 rng(1);
     for (auto& w : pts) w = rng() & 0x0fffffffu;  // arbitrary field elements < p: the add formulas do not care
     for (uint32_t i = 0; i < n_pts; ++i) members[i] = i;
