@@ -240,12 +240,26 @@ __device__ __noinline__ void fp_inv(fp& r, const fp& a)
     fp_mul(r, t, r3);
 }
 
-// XYZZ -> affine (x, y), Montgomery form.  One inversion: i = 1/(ZZ*ZZZ) = Z^-5; 1/ZZ = i*ZZZ, 1/ZZZ = i*ZZ.
-__device__ __forceinline__ void g1x_to_affine(fp& x, fp& y, const g1x& p)
+// r = a^-1 as a PLAIN residue (Montgomery in): a Montgomery product of it with a Montgomery-form value yields the
+// plain product, so a chain that ends in serialisation needs no separate fp_from_mont.
+__device__ __noinline__ void fp_inv_plain(fp& r, const fp& a)
+{
+    uint32_t plain[12];
+    sg_modinv(plain, a.l, SG_PINV30);  // a^-1 R^-1
+    fp t, r2;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) t.l[j] = plain[j];
+    fp_set_r2(r2);
+    fp_mul(r, t, r2);  // a^-1 R^-1 * R^2 * R^-1 = a^-1
+}
+
+// XYZZ -> affine (x, y) as PLAIN residues ready for fp_store_be48.  One inversion: i = 1/(ZZ*ZZZ) = Z^-5;
+// 1/ZZ = i*ZZZ, 1/ZZZ = i*ZZ.  i is taken in the plain domain, which makes every later product plain as well.
+__device__ __forceinline__ void g1x_to_affine_plain(fp& x, fp& y, const g1x& p)
 {
     fp t, i, izz, izzz;
     fp_mul(t, p.zz, p.zzz);
-    fp_inv(i, t);
+    fp_inv_plain(i, t);
     fp_mul(izz, i, p.zzz);
     fp_mul(izzz, i, p.zz);
     fp_mul(x, p.x, izz);

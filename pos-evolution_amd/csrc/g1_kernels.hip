@@ -419,9 +419,7 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
         return;
     }
     fp x, y;
-    g1x_to_affine(x, y, acc);
-    fp_from_mont(x, x);
-    fp_from_mont(y, y);
+    g1x_to_affine_plain(x, y, acc);
     fp_store_be48(o, x);
     fp_store_be48(o + 48, y);
 }

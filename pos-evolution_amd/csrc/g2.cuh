@@ -49,14 +49,14 @@ __device__ __forceinline__ void f2_sqr(fp& r, const fp& a, bool role)
     fp_select(n, role, ao, d);
     fp_mul(r, m, n);
 }
-// r = a^-1 = conj(a) / (a0^2 + a1^2); a == 0 yields 0
-__device__ __forceinline__ void f2_inv(fp& r, const fp& a, bool role)
+// r = a^-1 = conj(a) / (a0^2 + a1^2) as a PLAIN Fp2 value (see fp_inv_plain); a == 0 yields 0
+__device__ __forceinline__ void f2_inv_plain(fp& r, const fp& a, bool role)
 {
     fp sq, sqo, n, ni, t, nt;
     fp_sqr(sq, a);
     fp_xchg(sqo, sq);
     fp_add(n, sq, sqo);
-    fp_inv(ni, n);
+    fp_inv_plain(ni, n);
     fp_mul(t, a, ni);
     fp_neg(nt, t);
     fp_select(r, role, nt, t);
@@ -193,12 +193,12 @@ __device__ __forceinline__ void g2x_add(g2x& p, const g2x& q, bool role)
     p.x = X3;
 }
 
-// XYZZ -> affine (this lane's halves of x and y), Montgomery form; one Fp inversion per pair (done in both lanes)
-__device__ __forceinline__ void g2x_to_affine(fp& x, fp& y, const g2x& p, bool role)
+// XYZZ -> affine (this lane's halves of x and y) as PLAIN residues; one Fp inversion per pair (done in both lanes)
+__device__ __forceinline__ void g2x_to_affine_plain(fp& x, fp& y, const g2x& p, bool role)
 {
     fp t, i, izz, izzz;
     f2_mul(t, p.zz, p.zzz, role);
-    f2_inv(i, t, role);
+    f2_inv_plain(i, t, role);
     f2_mul(izz, i, p.zzz, role);
     f2_mul(izzz, i, p.zz, role);
     f2_mul(x, p.x, izz, role);

@@ -392,9 +392,7 @@ k_g2_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
         return;
     }
     fp x, y;
-    g2x_to_affine(x, y, acc, role);
-    fp_from_mont(x, x);
-    fp_from_mont(y, y);
+    g2x_to_affine_plain(x, y, acc, role);
     fp_store_be48(ox, x);
     fp_store_be48(oy, y);
 }
