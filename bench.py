@@ -193,12 +193,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    # Dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks share a device, collectives over gloo):
+    #   POSEVO_DIST_BACKEND=gloo POSEVO_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+    # It validates the sharded code path end to end; its numbers are not a scaling measurement.
+    backend = os.environ.get("POSEVO_DIST_BACKEND", "nccl")
+    if os.environ.get("POSEVO_SHARE_GPU"):
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("POSEVO_FORCE_DIST"):
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
 
     import pos_evolution_amd as pea
@@ -254,7 +263,7 @@ def main():
     lat = np.sort(np.array(lat))
 
     if dist is not None:
-        t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

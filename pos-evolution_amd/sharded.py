@@ -58,8 +58,17 @@ class ShardedForkChoice:
         buf = self._weights_buffer()
         self.engine.votes_partial(buf.data_ptr())
         if self.dist.is_initialized():  # also with world == 1: keeps the RCCL path exercised on one GPU
-            self.dist.all_reduce(buf, group=self.group)
+            if self._staged():
+                host = buf.cpu()
+                self.dist.all_reduce(host, group=self.group)
+                buf.copy_(host)
+            else:
+                self.dist.all_reduce(buf, group=self.group)
         return self.engine.head_from_weights(buf.data_ptr())
+
+    def _staged(self) -> bool:
+        """gloo with device buffers (dry runs of the N > 1 path on one GPU): collectives go through host copies."""
+        return self.device.type == "cuda" and self.dist.get_backend(self.group) != "nccl"
 
     def aggregate(self, rows=None, packed=None):
         """pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.
@@ -73,6 +82,10 @@ class ShardedForkChoice:
         if self.dist.is_initialized():
             if self.dist.get_backend(self.group) == "nccl":  # RCCL: one flat collective, no staging copies
                 self.dist.all_gather_into_tensor(gathered, part, group=self.group)
+            elif self._staged():                             # gloo + device buffers: through the host
+                host = [self.torch.empty(part.numel(), dtype=part.dtype) for _ in range(self.world)]
+                self.dist.all_gather(host, part.cpu(), group=self.group)
+                gathered.copy_(self.torch.cat(host))
             else:                                            # gloo (CPU tests)
                 self.dist.all_gather(list(gathered.chunk(self.world)), part, group=self.group)
         else:
