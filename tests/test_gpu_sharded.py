@@ -138,3 +138,22 @@ def test_sharded_forkchoice_world_size_one(engine_factory):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_two_ranks_dry_run_on_one_gpu():
+    """bench.py's N > 1 path end to end with two processes sharing this GPU (gloo, host-staged collectives): both ranks
+    must reach the same head (bench.py asserts it) and rank 0 must print the contract's JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEVO_DIST_BACKEND="gloo", POSEVO_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--validators", "65536", "--blocks", "512", "--committees", "256", "--head-calls", "5", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "validator-range shards x2"
