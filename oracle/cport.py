@@ -12,12 +12,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libposevo_oracle.so")
+# POSEVO_ORACLE_LIB selects another build of the same source (tests/test_oracle_properties.py: the ASan/UBSan build)
+_LIB_PATH = os.environ.get("POSEVO_ORACLE_LIB") or os.path.join(_HERE, "libposevo_oracle.so")
 NONE = 0xFFFFFFFF
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "posevo_oracle.c")
+    if os.environ.get("POSEVO_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libposevo_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -201,3 +201,44 @@ def test_config5_shape_mixed_balances(engine_factory):
     assert np.array_equal(e.get_weights(), w_o)
     assert e.get_head() == tree.roots[head_o].tobytes()
     assert int(w_o[0]) > 2**62
+
+
+def test_results_are_deterministic_run_to_run(engine_factory):
+    """SURVEY.md 5 "race detection": the batch kernels use atomics (LDS histograms, 64-bit atomicMax tie-break, global
+    weight adds) -- all of them on integers, so two runs of the same inputs on fresh engines must agree bit for bit in
+    everything they return: latest messages, participation flags, weights, head, aggregates."""
+    from pos_evolution_amd._abi import pe_state_ctx
+
+    def run():
+        e = engine_factory()
+        n_val, spe = 60000, 32
+        tree = synth.random_tree(500, 33, "branchy")
+        H.load_tree(e, tree)
+        pts, _ = H.oracle_points(n_val)
+        e.set_validators(synth.balances(n_val, 33, True), synth.validator_flags(n_val, 33), pts)
+        E = int(tree.slot.max()) // spe + 1
+        comm = synth.random_committees(n_val, 128, 33)
+        e.set_committees(E, comm.offsets, comm.members)
+        e.on_tick((E + 1) * spe * 12)
+        e.set_proposer_boost(tree.roots[499].tobytes())
+        atts, arena, _ = synth.epoch_attestations(comm, tree, E, spe, seed=33, density=0.8, parts=3,
+                                                  source=(0, tree.roots[0].tobytes()), vote_recent=40)
+        agg = e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+        # the un-aggregated rows too: overlapping committees in one batch exercise the atomicMax tie-break path
+        st_raw, _, _ = e.on_attestation_batch(packed=(atts, arena))
+        st_agg, pk, cnt = e.on_attestation_batch(packed=(agg["atts"], agg["out_arena"]), want_aggregate_pubkeys=True)
+        ctx = pe_state_ctx()
+        ctx.slot = (E + 1) * spe
+        ctx.chain_tip_root[:] = tree.roots[499].tobytes()
+        ctx.current_justified_root[:] = tree.roots[0].tobytes()
+        ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+        ctx.base_reward_per_increment = 9000
+        st_p, num = e.process_attestation_batch(ctx, packed=(agg["atts"], agg["out_arena"]))
+        ep, blk = e.latest_messages()
+        return [agg["aggpk96"].tobytes(), agg["out_arena"].tobytes(), agg["count"].tobytes(), st_raw.tobytes(),
+                st_agg.tobytes(), pk.tobytes(), cnt.tobytes(), st_p.tobytes(), num.tobytes(), ep.tobytes(), blk.tobytes(),
+                e.participation_get(0).tobytes(), e.participation_get(1).tobytes(), e.get_weights().tobytes(), e.get_head()]
+
+    a, b = run(), run()
+    assert all(x == y for x, y in zip(a, b))
+    assert any(a[13])  # the weights are not trivially zero
