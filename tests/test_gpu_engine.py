@@ -406,3 +406,51 @@ def test_registry_from_compressed_pubkeys(engine_factory):
         e2.set_pubkeys_compressed(bad)
     with pytest.raises(pea.EngineError):                 # the failed load leaves no pubkeys behind
         e2.g1_sum(offsets)
+
+
+# ---------------------------------------------------------------- hypothesis: generated worlds through the engine
+def test_get_head_generated_worlds_vs_definition(engine_factory):
+    """Small generated block trees / votes / balances / flags / leaf tests / boosts through the ENGINE (votes installed
+    by on_attestation) against the definition-level get_head of tests/test_oracle_properties.py: odd shapes a seeded
+    generator rarely hits (single-block tree, no validators, all leaves filtered out, boost on a dead branch)."""
+    from hypothesis import given, settings, HealthCheck
+    from tests.test_oracle_properties import definition_get_head, worlds
+    e = engine_factory(max_committee_tables=2)
+    spe = 32
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(worlds())
+    def check(wd):
+        parent, leaf_ok, roots, vote, bal, flags, boost = wd
+        if len(set(roots)) != len(roots):
+            return
+        n, n_val = len(parent), len(vote)
+        slot = [0] * n
+        for i in range(1, n):
+            slot[i] = slot[parent[i]] + 1
+        tree = synth.Tree(np.frombuffer(b"".join(roots), dtype=np.uint8).reshape(-1, 32).copy(),
+                          np.array(parent, dtype=np.uint32), np.array(slot, dtype=np.uint64))
+        good = (1, roots[0])
+        bad = (1, roots[min(1, n - 1)] if n > 1 else bytes(32))
+        leaf_cp = [((good if leaf_ok[i] else bad), good) for i in range(n)]
+        H.load_tree(e, tree, leaf_cp)
+        e.set_checkpoints(good, good)
+        fl = np.array(flags, dtype=np.uint8)
+        e.set_validators(np.array(bal, dtype=np.uint64), fl & 3)
+        equiv = np.nonzero(fl & 4)[0]
+        if equiv.size:
+            e.mark_equivocating(equiv)
+        installed = np.full(n_val, NONE32, dtype=np.uint32)
+        if n_val:
+            comm = synth.random_committees(n_val, spe, 5)
+            installed = _install_votes(e, tree, comm, np.array(vote, dtype=np.uint32))
+            installed[equiv] = NONE32                      # pe:1438: equivocators' messages are never recorded
+        else:
+            e.on_tick((max(slot) // spe + 3) * spe * 12)
+        if boost != NONE32:
+            e.set_proposer_boost(roots[boost])
+        head_d, w_d = definition_get_head(parent, leaf_ok, roots, installed, bal, flags, 0, boost)
+        assert [int(x) for x in e.get_weights()] == w_d
+        assert e.get_head() == roots[head_d]
+
+    check()
