@@ -221,6 +221,16 @@ struct pe_engine {
     DevBuf d_stage, d_outblk, d_partials, d_out96, d_tmp_points, d_tmp_be;
     PinBuf h_stage;  // H2D staging (mirrors d_stage)
 
+    // ---- accumulate-shape autotune (large pubkey aggregations) ----
+    // 131072 task slots (two waves per SIMD, 6 tree levels at 512-member committees) or 65536 (one wave, 5 levels):
+    // which one is faster depends on the box (fast boxes: one wave/SIMD by ~8 %, slow boxes: two by ~3 %;
+    // profiles/r01_g1_phases_k8.txt / _k16.txt).  The first four large calls alternate A, B, A, B under a pair of
+    // events, the better minimum is kept.  POSEVO_G1_TARGET_SLOTS pins the choice.
+    int g1_tune_calls = 0;          // trials done so far (4 = decided)
+    float g1_tune_best[2] = {1e30f, 1e30f};
+    uint32_t g1_target_slots = 0;   // 0 = undecided
+    hipEvent_t g1_tune_ev[2] = {nullptr, nullptr};
+
     // ---- profiling ----
     bool profiling = false;
     KernelProfile prof[PE_KERNEL_COUNT];
@@ -803,7 +813,12 @@ void pe_engine_destroy(pe_engine* h)
     h->h_stage.release();
     for (auto& p : h->prof)
         for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (hipEvent_t ev : h->g1_tune_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->trace.on && h->g1_tune_calls)
+        fprintf(stderr, "[posevo host] accumulate autotune: 131072 slots %.3f ms, 65536 slots %.3f ms -> %u\n",
+                h->g1_tune_best[0], h->g1_tune_best[1], h->g1_target_slots);
     if (h->trace.on)
         for (auto& kv : h->trace.acc)
             fprintf(stderr, "[posevo host] %-28s calls %6llu  avg %9.1f us\n", kv.first.c_str(),
@@ -1653,9 +1668,22 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     const size_t off_osig = out_sig96 ? ob.alloc(96ull * ng) : 0;
     HIP_TRY(h, ob.ensure());
     G1Plan plan_pk, plan_sig;
+    int tune_arm = -1;  // >= 0: this call is an autotune trial of shape `tune_arm`
     if (want_pk) {
         G1Group* gr = st.host<G1Group>(off_g1);
-        plan_g1(ng, [&](uint32_t g) { return gres[g].size; }, gr, &plan_pk);
+        uint64_t total_pk = 0;
+        for (uint32_t g = 0; g < ng; ++g) total_pk += gres[g].size;
+        uint32_t target = G1_TARGET_LANES;
+        if (total_pk >= (1ull << 19)) {
+            static const uint32_t pinned = [] { const char* e = getenv("POSEVO_G1_TARGET_SLOTS"); return e ? (uint32_t)atol(e) : 0u; }();
+            if (pinned) h->g1_target_slots = pinned;
+            if (h->g1_target_slots) target = h->g1_target_slots;
+            else {
+                tune_arm = h->g1_tune_calls & 1;
+                target = tune_arm ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
+            }
+        }
+        plan_g1(ng, [&](uint32_t g) { return gres[g].size; }, gr, &plan_pk, G1_WG, target);
         for (uint32_t g = 0; g < ng; ++g) {
             gr[g].member_start = table_pk->offsets[gres[g].pos];
             gr[g].bits_word = ug[g].out_word;  // the OR-ed bits, device resident: no round trip
@@ -1676,11 +1704,21 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
                           st.dev<uint32_t>(off_words), ob.dev<uint32_t>(off_ouw), ob.dev<uint32_t>(off_ocnt));
     }
     if (want_pk) {
+        if (tune_arm >= 0) {
+            if (!h->g1_tune_ev[0] && (hipEventCreate(&h->g1_tune_ev[0]) != hipSuccess ||
+                                      hipEventCreate(&h->g1_tune_ev[1]) != hipSuccess)) {
+                h->g1_tune_ev[0] = h->g1_tune_ev[1] = nullptr;
+                tune_arm = -1;
+            } else {
+                (void)hipEventRecord(h->g1_tune_ev[0], h->stream);
+            }
+        }
         int rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), table_pk->d_members.as<uint32_t>(),
                                    ob.dev<uint32_t>(off_ouw), st.dev<G1Group>(off_g1), plan_pk,
                                    out_aggpk96 ? ob.dev<uint8_t>(off_opk) : nullptr,
                                    static_cast<uint32_t*>(dev_partials));
         if (rc) return rc;
+        if (tune_arm >= 0) (void)hipEventRecord(h->g1_tune_ev[1], h->stream);
         table_pk->stamp = ++h->table_stamp;
     }
     if (out_sig96) {  // bls.Aggregate: sum of the members' signature points
@@ -1697,6 +1735,13 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     lap.mark("agg.3_launch");
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     lap.mark("agg.4_wait");
+    if (tune_arm >= 0) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->g1_tune_ev[0], h->g1_tune_ev[1]) == hipSuccess && ms > 0)
+            h->g1_tune_best[tune_arm] = std::min(h->g1_tune_best[tune_arm], ms);
+        if (++h->g1_tune_calls >= 4)
+            h->g1_target_slots = h->g1_tune_best[1] < h->g1_tune_best[0] ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
+    }
     // ---- outputs ----
     const uint8_t* obits = ob.host<uint8_t>(off_ouw);
     const uint32_t* ocnt = ob.host<uint32_t>(off_ocnt);

@@ -287,6 +287,9 @@ class Engine:
                                            _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
                                            _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
         g = n_groups.value
+        if g:  # the groups' unions are laid out back to back: hand back only the written part of the arena
+            last = out_atts[g - 1]
+            out_arena = out_arena[: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
         sig192 = None
         if sig_points192 is not None:
             s2 = np.ascontiguousarray(sig_points192, dtype=np.uint8)
@@ -414,6 +417,9 @@ class Engine:
                                                    _ptr(out_arena, C.c_uint8), out_arena.size,
                                                    _ptr(count, C.c_uint32), C.c_void_p(dev_ptr)))
         g = n_groups.value
+        if g:
+            last = out_atts[g - 1]
+            out_arena = out_arena[: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
         return dict(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena, count=count[:g])
 
     def g1_partial(self, offsets, index, dev_ptr: int):

@@ -240,5 +240,5 @@ def test_results_are_deterministic_run_to_run(engine_factory):
                 e.participation_get(0).tobytes(), e.participation_get(1).tobytes(), e.get_weights().tobytes(), e.get_head()]
 
     a, b = run(), run()
-    assert all(x == y for x, y in zip(a, b))
+    assert [i for i, (x, y) in enumerate(zip(a, b)) if x != y] == []
     assert any(a[13])  # the weights are not trivially zero
