@@ -320,6 +320,22 @@ int pe_block_index_of(const pe_engine* h, const uint8_t root[32], uint32_t* out_
 /* store.latest_messages: epoch and block index per validator; block index
  * 0xFFFFFFFF = no message. */
 int pe_get_latest_messages(pe_engine* h, uint64_t* out_epoch, uint32_t* out_block_index, uint64_t n);
+/* ---- checkpoint / resume: the store is a handful of flat arrays -------------------------------
+ * Export: pe_get_store_scalars, pe_get_block x pe_num_blocks (insertion order: parents first), pe_get_validator_flags
+ * (incl. PE_VAL_EQUIVOCATING), pe_get_latest_messages (+ _slots under the vote-expiry variant), pe_participation_get.
+ * Import into a fresh handle: pe_store_init(genesis_time, block 0) -> pe_add_block in order -> pe_set_validators
+ * (balances, flags without the equivocating bit, pubkeys) -> pe_mark_equivocating -> pe_set_latest_messages ->
+ * pe_on_tick(time) -> pe_set_checkpoints / pe_set_best_justified / pe_set_proposer_boost -> pe_participation_set.
+ * pos_evolution_amd.Engine.export_state / import_state do exactly this. */
+int pe_get_block(const pe_engine* h, uint32_t block_index, uint8_t root[32], uint32_t* parent_index, uint64_t* slot,
+                 uint64_t* post_justified_epoch, uint8_t post_justified_root[32],
+                 uint64_t* post_finalized_epoch, uint8_t post_finalized_root[32]);
+int pe_get_validator_flags(const pe_engine* h, uint8_t* out_flags, uint64_t n);
+int pe_get_latest_message_slots(pe_engine* h, uint32_t* out_slot, uint64_t n);
+/* block_index 0xFFFFFFFF = no message; slot may be NULL (only read under the vote-expiry variant). */
+int pe_set_latest_messages(pe_engine* h, uint64_t n, const uint64_t* epoch, const uint32_t* block_index,
+                           const uint32_t* slot);
+int pe_set_best_justified(pe_engine* h, uint64_t epoch, const uint8_t root[32]);
 int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_time,
                          uint64_t* justified_epoch, uint8_t justified_root[32],
                          uint64_t* finalized_epoch, uint8_t finalized_root[32],

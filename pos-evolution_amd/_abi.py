@@ -109,6 +109,11 @@ SIGNATURES = {
     "pe_state_set_validators": (C.c_int, [_H, C.c_uint64, _u64p, _u8p]),
     "pe_ffg_balances": (C.c_int, [_H, _u64p]),
     "pe_g1_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
+    "pe_get_block": (C.c_int, [_H, C.c_uint32, _u8p, _u32p, _u64p, _u64p, _u8p, _u64p, _u8p]),
+    "pe_get_validator_flags": (C.c_int, [_H, _u8p, C.c_uint64]),
+    "pe_get_latest_message_slots": (C.c_int, [_H, _u32p, C.c_uint64]),
+    "pe_set_latest_messages": (C.c_int, [_H, C.c_uint64, _u64p, _u32p, _u32p]),
+    "pe_set_best_justified": (C.c_int, [_H, C.c_uint64, _u8p]),
     "pe_g1_decompress": (C.c_int, [_H, _u8p, C.c_uint64, _u8p, _i32p]),
     "pe_set_pubkeys_compressed": (C.c_int, [_H, C.c_uint64, _u8p, _i32p]),
     "pe_g1_compress": (C.c_int, [_u8p, C.c_uint64, _u8p]),

@@ -2304,6 +2304,71 @@ int pe_get_latest_messages(pe_engine* h, uint64_t* out_epoch, uint32_t* out_bloc
     }
     return PE_OK;
 }
+// ---- checkpoint / resume: the store is a handful of flat arrays; these export and re-import them ----
+int pe_get_block(const pe_engine* h, uint32_t i, uint8_t root[32], uint32_t* parent_index, uint64_t* slot,
+                 uint64_t* pj_epoch, uint8_t pj_root[32], uint64_t* pf_epoch, uint8_t pf_root[32])
+{
+    if (!h || i >= h->blocks.size()) return PE_ERR_INVALID_ARG;
+    const Block& b = h->blocks[i];
+    if (root) memcpy(root, b.root.data(), 32);
+    if (parent_index) *parent_index = b.parent;
+    if (slot) *slot = b.slot;
+    if (pj_epoch) *pj_epoch = b.post_justified.epoch;
+    if (pj_root) memcpy(pj_root, b.post_justified.root.data(), 32);
+    if (pf_epoch) *pf_epoch = b.post_finalized.epoch;
+    if (pf_root) memcpy(pf_root, b.post_finalized.root.data(), 32);
+    return PE_OK;
+}
+int pe_get_validator_flags(const pe_engine* h, uint8_t* out_flags, uint64_t n)
+{
+    if (!h || !out_flags || n != h->n_val) return PE_ERR_INVALID_ARG;
+    memcpy(out_flags, h->h_flags.data(), n);
+    return PE_OK;
+}
+int pe_get_latest_message_slots(pe_engine* h, uint32_t* out_slot, uint64_t n)
+{
+    if (!h || !out_slot || n != h->n_val) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (!h->cfg.vote_expiry_slots) { memset(out_slot, 0, 4 * n); return PE_OK; }
+    if (n) HIP_TRY(h, hipMemcpyAsync(out_slot, h->d_vote_slot.p, 4 * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PE_OK;
+}
+int pe_set_latest_messages(pe_engine* h, uint64_t n, const uint64_t* epoch, const uint32_t* block_index,
+                           const uint32_t* slot)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (n != h->n_val || (n && (!epoch || !block_index))) return fail(h, PE_ERR_INVALID_ARG, "n must equal the registry size");
+    (void)hipSetDevice(h->device);
+    if (n == 0) return PE_OK;
+    std::vector<uint64_t> key(n);
+    std::vector<uint32_t> blk(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (block_index[i] == NONE32) { key[i] = 0; blk[i] = NONE32; continue; }
+        if (block_index[i] >= h->blocks.size()) return fail(h, PE_ERR_INVALID_ARG, "latest message names an unknown block");
+        if (epoch[i] >= 0xFFFFFFFEull) return fail(h, PE_ERR_CAPACITY, "target epoch does not fit 32 bits");
+        key[i] = ((epoch[i] + 1) << 32) | 0xFFFFFFFFull;  // settled vote (see k_lmd)
+        blk[i] = block_index[i];
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_vote_key.p, key.data(), 8 * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_vote_block.p, blk.data(), 4 * n, hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.vote_expiry_slots) {
+        if (slot) HIP_TRY(h, hipMemcpyAsync(h->d_vote_slot.p, slot, 4 * n, hipMemcpyHostToDevice, h->stream));
+        else HIP_TRY(h, hipMemsetAsync(h->d_vote_slot.p, 0, 4 * n, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // the host vectors die at scope exit
+    return PE_OK;
+}
+int pe_set_best_justified(pe_engine* h, uint64_t epoch, const uint8_t root[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!root) return PE_ERR_INVALID_ARG;
+    h->best_justified.epoch = epoch;
+    h->best_justified.root = to_root(root);
+    return PE_OK;
+}
 int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_time, uint64_t* je, uint8_t jr[32],
                          uint64_t* fe, uint8_t fr[32], uint64_t* be, uint8_t br[32], uint8_t boost[32])
 {

@@ -460,6 +460,60 @@ class Engine:
         self._check(self._lib.pe_get_latest_messages(self._h, _ptr(ep, C.c_uint64), _ptr(bi, C.c_uint32), n))
         return ep[:n], bi[:n]
 
+    # -- checkpoint / resume ------------------------------------------------
+    def export_state(self) -> dict:
+        """The store's dynamic state as flat arrays (SURVEY.md 5 "checkpoint / resume"): scalars, the block table in
+        insertion order, validator flags (incl. the equivocating bit), latest messages, participation flags.  The
+        registry itself (balances, pubkeys) is the caller's input and is passed again to import_state."""
+        nb, nv = self.num_blocks, self.num_validators
+        roots = np.zeros((nb, 32), dtype=np.uint8)
+        parent = np.zeros(nb, dtype=np.uint32)
+        slot = np.zeros(nb, dtype=np.uint64)
+        pj_e, pf_e = np.zeros(nb, dtype=np.uint64), np.zeros(nb, dtype=np.uint64)
+        pj_r, pf_r = np.zeros((nb, 32), dtype=np.uint8), np.zeros((nb, 32), dtype=np.uint8)
+        r, jr, fr = ((C.c_uint8 * 32)() for _ in range(3))
+        pi, sl, je, fe = C.c_uint32(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        for i in range(nb):
+            self._check(self._lib.pe_get_block(self._h, i, r, C.byref(pi), C.byref(sl), C.byref(je), jr, C.byref(fe), fr))
+            roots[i], parent[i], slot[i] = np.frombuffer(r, dtype=np.uint8), pi.value, sl.value
+            pj_e[i], pf_e[i] = je.value, fe.value
+            pj_r[i], pf_r[i] = np.frombuffer(jr, dtype=np.uint8), np.frombuffer(fr, dtype=np.uint8)
+        flags = np.zeros(max(nv, 1), dtype=np.uint8)
+        lm_slot = np.zeros(max(nv, 1), dtype=np.uint32)
+        if nv:
+            self._check(self._lib.pe_get_validator_flags(self._h, _ptr(flags), nv))
+            self._check(self._lib.pe_get_latest_message_slots(self._h, _ptr(lm_slot), nv))
+        ep, bi = self.latest_messages()
+        return dict(scalars=self.store_scalars(), roots=roots, parent=parent, slot=slot, post_justified_epoch=pj_e,
+                    post_justified_root=pj_r, post_finalized_epoch=pf_e, post_finalized_root=pf_r, flags=flags[:nv],
+                    lm_epoch=ep.copy(), lm_block=bi.copy(), lm_slot=lm_slot[:nv],
+                    participation=(self.participation_get(0), self.participation_get(1)))
+
+    def import_state(self, st: dict, effective_balance, pubkeys96=None):
+        """Rebuild the store exported by export_state on this (fresh) handle."""
+        sc = st["scalars"]
+        roots = st["roots"]
+        self.store_init(sc["genesis_time"], int(st["slot"][0]), roots[0].tobytes())
+        for i in range(1, roots.shape[0]):
+            self.add_block(roots[i].tobytes(), roots[int(st["parent"][i])].tobytes(), int(st["slot"][i]),
+                           (int(st["post_justified_epoch"][i]), st["post_justified_root"][i].tobytes()),
+                           (int(st["post_finalized_epoch"][i]), st["post_finalized_root"][i].tobytes()))
+        flags = np.ascontiguousarray(st["flags"], dtype=np.uint8)
+        self.set_validators(effective_balance, flags & np.uint8(0xFF ^ _abi.PE_VAL_EQUIVOCATING), pubkeys96)
+        equiv = np.nonzero(flags & _abi.PE_VAL_EQUIVOCATING)[0]
+        if equiv.size:
+            self.mark_equivocating(equiv)
+        ep = np.ascontiguousarray(st["lm_epoch"], dtype=np.uint64)
+        bi = np.ascontiguousarray(st["lm_block"], dtype=np.uint32)
+        sl = np.ascontiguousarray(st["lm_slot"], dtype=np.uint32)
+        self._check(self._lib.pe_set_latest_messages(self._h, ep.size, _ptr(ep), _ptr(bi), _ptr(sl)))
+        self.on_tick(sc["time"])
+        self.set_checkpoints(sc["justified"], sc["finalized"])
+        self._check(self._lib.pe_set_best_justified(self._h, sc["best_justified"][0], _root(sc["best_justified"][1])))
+        self.set_proposer_boost(sc["proposer_boost_root"])
+        self.participation_set(0, st["participation"][0])
+        self.participation_set(1, st["participation"][1])
+
     def store_scalars(self) -> dict:
         t, g, je, fe, be = (C.c_uint64(0) for _ in range(5))
         jr, fr, br, boost = ((C.c_uint8 * 32)() for _ in range(4))

@@ -454,3 +454,59 @@ def test_get_head_generated_worlds_vs_definition(engine_factory):
         assert e.get_head() == roots[head_d]
 
     check()
+
+
+# ---------------------------------------------------------------- checkpoint / resume
+def test_export_import_state_round_trip(engine_factory):
+    """SURVEY.md 5 "checkpoint / resume": a store exported as flat arrays and imported into a fresh handle answers
+    every query identically and keeps evolving identically (vote-expiry variant on, so the slots travel too)."""
+    n_val, n_blocks, spe = 30000, 400, 32
+    cfg = dict(vote_expiry_slots=200, max_committee_tables=4)
+    a = engine_factory(**cfg)
+    tree = synth.random_tree(n_blocks, 91, "branchy")
+    rng = np.random.default_rng(91)
+    good = (1, tree.roots[0].tobytes())
+    bad = (1, tree.roots[1].tobytes())
+    leaf_cp = [((good if rng.random() > 0.1 or i == 0 else bad), good) for i in range(n_blocks)]
+    H.load_tree(a, tree, leaf_cp)
+    a.set_checkpoints(good, good)
+    bal = synth.balances(n_val, 91, True)
+    flags = synth.validator_flags(n_val, 91, inactive_frac=0.01, slashed_frac=0.01)
+    a.set_validators(bal, flags)
+    equiv = rng.choice(n_val, size=300, replace=False)
+    a.mark_equivocating(equiv)
+    comm = synth.random_committees(n_val, 64, 91)
+    _install_votes(a, tree, comm, synth.zipf_votes(n_val, n_blocks, 91))
+    a.set_proposer_boost(tree.roots[n_blocks - 1].tobytes())
+    a.participation_set(0, rng.integers(0, 8, size=n_val).astype(np.uint8))
+    a.participation_set(1, rng.integers(0, 8, size=n_val).astype(np.uint8))
+
+    st = a.export_state()
+    b = engine_factory(**cfg)
+    b.import_state(st, bal)
+    assert b.store_scalars() == a.store_scalars()
+    st_b = b.export_state()
+    for k, v in st.items():
+        if k == "scalars":
+            continue
+        if k == "participation":
+            assert all(np.array_equal(x, y) for x, y in zip(v, st_b[k]))
+        else:
+            assert np.array_equal(v, st_b[k]), k
+    assert np.array_equal(a.get_weights(), b.get_weights()) and a.get_head() == b.get_head()
+
+    # both keep evolving identically: a later epoch's attestations, then time moves on until votes start to expire
+    E = int(tree.slot.max()) // spe + 1
+    comm2 = synth.random_committees(n_val, 64, 92)
+    atts, arena, _ = synth.epoch_attestations(comm2, tree, E + 1, spe, seed=92, density=0.5, parts=2,
+                                              source=(0, tree.roots[0].tobytes()), vote_recent=30)
+    for e in (a, b):
+        e.set_committees(E + 1, comm2.offsets, comm2.members)
+        e.on_tick((E + 2) * spe * 12)
+        status, _, _ = e.on_attestation_batch(packed=(atts, arena))
+        assert not status.any()
+    assert np.array_equal(a.get_weights(), b.get_weights()) and a.get_head() == b.get_head()
+    for e in (a, b):
+        e.on_tick((E + 7) * spe * 12)                     # epoch-E votes cast before slot E*32+24 are now older than 200 slots
+    wa = a.get_weights()
+    assert np.array_equal(wa, b.get_weights()) and a.get_head() == b.get_head() and wa.any()
