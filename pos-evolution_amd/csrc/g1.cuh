@@ -218,6 +218,68 @@ __device__ __forceinline__ bool g1x_add_pair(fp& out_a, fp& out_b, bool role, co
     return true;
 }
 
+// ---- four-lane cooperative add (lanes 4w .. 4w+3) ---------------------------------------------------------
+// Past the first tree level at most a quarter of the lanes hold work, so a pair of points can take four lanes: the 14
+// products of an XYZZ add in four rounds of one product per lane (dependency depth 4 instead of 7):
+//   round 1   q0: U1 = X1 ZZ2     q1: U2 = X2 ZZ1     q2: S1 = Y1 ZZZ2    q3: S2 = Y2 ZZZ1
+//   round 2   q0: PP = P^2        q1: A = ZZ1 ZZ2     q2: RR = R^2        q3: B = ZZZ1 ZZZ2
+//   round 3   q0: PPP = P PP      q1: ZZ3 = A PP      q2: Q = U1 PP       q3: (Q)
+//   round 4   q0: T2 = S1 PPP     q1: --              q2: T1 = R (Q - X3) q3: ZZZ3 = B PPP
+// with P = U2 - U1 (q0), R = S2 - S1 (q2), X3 = RR - PPP - 2Q and Y3 = T1 - T2 (q2).
+// Inputs per lane: a, b = (X1, ZZ2) | (X2, ZZ1) | (Y1, ZZZ2) | (Y2, ZZZ1).  Neither point may be infinity (caller).
+// Returns false when P == 0 (P1 = +-P2: the caller takes the complete single-lane add).
+// Outputs: q2: out_a = X3, out_b = Y3;  q1: out_a = ZZ3;  q3: out_a = ZZZ3.
+__device__ __forceinline__ void fp_from_lane(fp& r, const fp& a, int src_lane)
+{
+#pragma unroll
+    for (int j = 0; j < 12; ++j) r.l[j] = (uint32_t)__shfl((int)a.l[j], src_lane, 64);
+}
+__device__ __forceinline__ bool g1x_add_quad(fp& out_a, fp& out_b, int q, const fp& a, const fp& b)
+{
+    const int base = (int)(threadIdx.x & 63) & ~3;
+    const bool even = (q & 1) == 0;
+    fp m1, t, d, send;
+    fp_mul(m1, a, b);                 // U1 | U2 | S1 | S2
+    fp_select(send, even, b, m1);     // q0: ZZ2, q1: U2, q2: ZZZ2, q3: S2
+    fp_xchg(t, send);                 // q0: U2,  q1: ZZ2, q2: S2,  q3: ZZZ2
+    fp_sub(d, t, m1);                 // q0: P,   q2: R   (odd lanes: unused)
+    const int p_zero = __shfl((int)fp_is_zero(d), base, 64);
+    if (p_zero) return false;         // identical in the four lanes
+    fp x, y, m2;
+    fp_select(x, even, d, b);
+    fp_select(y, even, d, t);
+    fp_mul(m2, x, y);                 // PP | A | RR | B
+    fp pp, u1;
+    fp_from_lane(pp, m2, base);       // PP to everyone
+    fp_from_lane(u1, m1, base);       // U1 to everyone (q3 needs it)
+    fp m3, sel;
+    fp_select(sel, q == 1, m2, u1);
+    fp_select(x, q == 0, d, sel);     // q0: P, q1: A, q2 and q3: U1
+    fp_select(y, q == 0, m2, pp);     // q0: PP, others: PP
+    fp_mul(m3, x, y);                 // q0: PPP, q1: ZZ3, q2 and q3: Q = U1 PP (q2 keeps its own copy)
+    fp ppp, s1;
+    fp_from_lane(ppp, m3, base);      // PPP to everyone
+    fp_from_lane(s1, m1, base + 2);   // S1 to everyone (q0 needs it)
+    fp X3, T, tmp;
+    fp_sub(X3, m2, ppp);              // q2: RR - PPP
+    fp_dbl(tmp, m3);
+    fp_sub(X3, X3, tmp);              // q2: X3 = RR - PPP - 2Q
+    fp_sub(T, m3, X3);                // q2: Q - X3
+    fp m4;
+    fp_select(sel, q == 2, d, m2);
+    fp_select(x, q == 0, s1, sel);    // q0: S1, q2: R, q3: B (q1: A, unused)
+    fp_select(sel, q == 2, T, ppp);
+    fp_select(y, q == 0, m3, sel);    // q0: PPP, q2: Q - X3, q3: PPP
+    fp_mul(m4, x, y);                 // q0: T2, q2: T1, q3: ZZZ3
+    fp t2;
+    fp_from_lane(t2, m4, base);
+    fp_sub(tmp, m4, t2);              // q2: Y3
+    fp_select(sel, q == 1, m3, m4);
+    fp_select(out_a, q == 2, X3, sel);
+    out_b = tmp;
+    return true;
+}
+
 // R^3 mod p: fp_mul(t, R^3) = t * R^2, lifting (xR)^-1 = x^-1 R^-1 back to Montgomery form x^-1 R
 __device__ __forceinline__ constexpr uint32_t fp_r3_limb(int j)
 {

@@ -307,6 +307,66 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
     int g1_level = 0;
 #endif
     for (int n = G1_WG / 2; n >= 1; n >>= 1) {  // n = number of pairs at this level
+        if (n <= G1_WG / 4) {  // four lanes per pair from the second level on (g1x_add_quad: depth 4 instead of 7)
+            const int w = tid >> 2, q = tid & 3;
+            const bool active = w < n;
+            fp out_a, out_b;
+            uint32_t out = NONE32, sz = 0;
+            bool store_lds = false;
+            if (active) {
+                sz = lds_sz[2 * w];
+                out = lds_out[2 * w];
+                if (sz >= 2) {
+                    fp a, b;
+                    lds_load_fp(a, lds, q >> 1, 2 * w + (q & 1));             // X1 | X2 | Y1 | Y2
+                    lds_load_fp(b, lds, 2 + (q >> 1), 2 * w + ((q & 1) ^ 1));  // ZZ2 | ZZ1 | ZZZ2 | ZZZ1
+                    // ZZZ == 0 <=> ZZ == 0, so every lane sees "its" partner point's infinity in b
+                    const unsigned long long inf_lanes = __ballot(fp_is_zero(b));
+                    bool fast = ((inf_lanes >> ((tid & 63) & ~3)) & 0xFull) == 0;
+                    if (fast) fast = g1x_add_quad(out_a, out_b, q, a, b);
+                    if (!fast) {  // an infinity operand or P1 = +-P2: rare; the four lanes run the complete add
+                        g1x p1, p2;
+                        lds_load_x(p1, lds, 2 * w);
+                        lds_load_x(p2, lds, 2 * w + 1);
+                        g1x_add(p1, p2);
+                        fp sel;
+                        fp_select(sel, q == 1, p1.zz, p1.zzz);
+                        fp_select(out_a, q == 2, p1.x, sel);
+                        out_b = p1.y;
+                    }
+                    sz >>= 1;
+                    if (sz == 1) {  // block finished: q2 writes X|Y, q1 ZZ, q3 ZZZ of the 192-byte partial
+                        uint32_t* dst = wg_partials + (size_t)G1X_WORDS * out;
+                        if (q == 2) { global_store_fp(dst, out_a); global_store_fp(dst + 12, out_b); }
+                        else if (q == 1) global_store_fp(dst + 24, out_a);
+                        else if (q == 3) global_store_fp(dst + 36, out_a);
+                        sz = 0;
+                    } else {
+                        store_lds = true;
+                    }
+                } else {
+                    sz = 0;
+                }
+            }
+            __syncthreads();
+            if (active) {
+                if (store_lds) {
+                    if (q == 2) { lds_store_fp(lds, 0, w, out_a); lds_store_fp(lds, 1, w, out_b); }
+                    else if (q == 1) lds_store_fp(lds, 2, w, out_a);
+                    else if (q == 3) lds_store_fp(lds, 3, w, out_a);
+                }
+                if (q == 0) {
+                    lds_out[w] = out;
+                    lds_sz[w] = sz;
+                }
+            }
+            __syncthreads();
+#ifdef POSEVO_G1_PHASE_TIMING
+            G1_STAMP(3 + g1_level);
+            ++g1_level;
+#endif
+            continue;
+        }
         const int w = tid >> 1;
         const bool role = tid & 1;
         const bool active = w < n;

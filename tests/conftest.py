@@ -17,6 +17,14 @@ def engine_factory():
     """Engine constructor for -m gpu tests.  Fails loudly (no fallback) when the HIP library or device is absent."""
     import pos_evolution_amd as pea
 
+    # torch (used by the sharded tests for exchange buffers and collectives) initialises its HIP context first: a lazy
+    # init after dozens of engines had come and gone was seen to fail once with "No HIP GPUs are available".
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     made = []
 
     def make(**cfg):
