@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out
 mkdir -p $OUT/prof_$TAG $OUT/pmc_$TAG
 python bench.py > $OUT/${TAG}_bench_full.json 2> $OUT/${TAG}_bench_full.err
-rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o $TAG -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline \
+rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o $TAG -- python bench.py --steps 60 --warmup 6 --no-cpu-baseline \
     > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_$TAG/err.log
 python tools/rocpd_stats.py $OUT/prof_$TAG/${TAG}_results.db $OUT/${TAG}_kernel_stats.txt > /dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline \
