@@ -56,7 +56,10 @@ def build_workload(e, args, rank, n_steps_total):
                                                   source=(0, tree.roots[0].tobytes()), vote_recent=64,
                                                   vote_seed=4)  # committee c votes the same block on every shard
         steps.append(dict(epoch=ep, comm=comm, atts=atts, arena=arena))
-    return dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe)
+    w = dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe)
+    for st in steps:  # the working state's context of each step is an input like the attestations: built up front
+        st["ctx"] = state_ctx(w, st["epoch"])
+    return w
 
 
 def state_ctx(w, ep):
@@ -85,32 +88,26 @@ def _timed(name, fn, *a, **k):
 
 
 def run_step_single(e, w, st):
-    import pos_evolution_amd.synth as synth
-
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
     agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
-    g = agg["n_groups"]
     rows = agg["atts"]
     status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, agg["out_arena"]))
-    st2, num = _timed("process_attestation", e.process_attestation_batch, state_ctx(w, ep),
+    st2, num = _timed("process_attestation", e.process_attestation_batch, st["ctx"],
                       packed=(rows, agg["out_arena"]))
     head = _timed("get_head", e.get_head)
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
 def run_step_sharded(e, w, st, sh):
-    import pos_evolution_amd.synth as synth
-
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
     agg = sh.aggregate(packed=(st["atts"], st["arena"]))    # all-gather of C x 192 B XYZZ partials inside
-    g = agg["n_groups"]
     rows = agg["atts"]
     status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
-    st2, num = e.process_attestation_batch(state_ctx(w, ep), packed=(rows, agg["out_arena"]))
+    st2, num = e.process_attestation_batch(st["ctx"], packed=(rows, agg["out_arena"]))
     head = sh.get_head()                                    # all-reduce of (B + 512) x 8 B inside
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
