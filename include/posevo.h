@@ -19,7 +19,10 @@
  *    A failing call leaves the store unmodified ("Invalid calls to handlers
  *    must not modify store", pe:1041).
  *  - one thread per handle at a time (the spec is sequential, pe:929-1039).
- *    Calls are synchronous: they return after the device work has completed.
+ *    Calls are synchronous: they return once their results are complete in the
+ *    caller's buffers (pe_get_head polls the head word its kernel releases to host
+ *    memory instead of waiting for the stream to drain; later calls are ordered
+ *    behind it on the engine's stream).
  *  - roots are 32 opaque bytes; the all-zero root is "unset" (Root(), pe:943).
  *  - G1 points cross the boundary in the 96-byte uncompressed form: big-endian
  *    x (48 B) || big-endian y (48 B); bit 6 of byte 0 set = point at infinity.
