@@ -37,6 +37,20 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
+// Function attributes are per device: one flag per (kernel tag, device) so that a process driving several GPUs
+// through several handles opts every device in.
+template <int TAG>
+static bool first_use_on_this_device()
+{
+    static bool done[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 // ------------------------------------------------------------------ votes
 constexpr int VOTES_WG = 512;  // 256 lanes: 21 us, 512: 15.8, 1024: 15.4 at 1 M validators / 64 workgroups
 constexpr int VOTES_PER_THREAD = 4;
@@ -147,11 +161,9 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
     cap = cap < 64 ? 64 : cap > (uint64_t)VOTES_MAX_WG ? (uint64_t)VOTES_MAX_WG : cap;
     if (forced) cap = (uint64_t)forced;
     if (blocks > cap) blocks = cap;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_use_on_this_device<0>()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(uint64_t) * TREE_MAX_BLOCKS));
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_votes, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
                        eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
@@ -354,11 +366,9 @@ static void launch_tree_shape(hipStream_t s, size_t lds, const TreeDev& tree, ui
                               uint64_t slots_per_epoch, uint64_t boost_percent, uint64_t balance_increment,
                               uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
 {
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+    if (first_use_on_this_device<1000 + WG + PER>()) {  // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<WG, PER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((k_tree<WG, PER>), dim3(1), dim3(WG), lds, s, tree, reinterpret_cast<unsigned long long*>(direct),
                        totals, (unsigned long long)ovb, (unsigned long long)ovn, use_override, justified_pos, boost_pos,
