@@ -315,7 +315,10 @@ def main():
         "dtype_detail": "12 x u32 Montgomery limbs (381-bit Fp, exact integer arithmetic); u64 Gwei weights",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[3] shape on {world} GPU(s): {args.validators} validators/GPU, "
+            "workload": ("BASELINE configs[3] shape" if (args.validators, C, args.blocks) == (1 << 20, 2048, 4096)
+                         else "BASELINE configs[4] shape" if (args.validators, args.blocks) == (1 << 22, 8192)
+                         else "BASELINE configs[2] shape" if (args.validators, args.blocks) == (1 << 18, 4096)
+                         else "custom shape") + f" on {world} GPU(s): {args.validators} validators/GPU, "
                         f"{C} committees x {args.validators // C}, {args.parts} partial aggregates/committee, "
                         f"99% participation, {args.blocks}-block tree, one epoch per step",
             "validators_per_gpu": args.validators, "blocks": args.blocks, "committees": C,
