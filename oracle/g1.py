@@ -2,7 +2,7 @@
 
 This file is part of ``oracle/``: a CPU restatement used by ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg as the
-checker.  The product path (``pos-evolution_amd/``) never imports it.
+checker.  The product path (``pos_evolution_amd/``) never imports it.
 
 PARITY UNPINNED for this file: the reference (``/root/reference/pos-evolution.md``)
 contains no BLS arithmetic at all -- its only ``bls.`` call is ``bls.Verify`` in

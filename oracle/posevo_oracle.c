@@ -3,7 +3,7 @@
  *
  * ORACLE / TEST INFRASTRUCTURE ONLY.  Linked/loaded only by tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg, as the checker and
- * as the timed CPU baseline -- never by the product path (pos-evolution_amd/).
+ * as the timed CPU baseline -- never by the product path (pos_evolution_amd/).
  *
  * What it restates (pe:N = /root/reference/pos-evolution.md line N):
  *   po_get_head                 get_head pe:1102-1116 over get_filtered_block_tree and

@@ -2,7 +2,7 @@
 
 ORACLE / TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()``
 and ``bench.py``'s ``cpu_baseline`` leg may import this; the product path
-(``pos-evolution_amd/``) never does.
+(``pos_evolution_amd/``) never does.
 
 Citation convention: ``pe:N`` = ``/root/reference/pos-evolution.md`` line N.
 

@@ -1,4 +1,4 @@
-"""pos-evolution_amd: MI355X-native attestation aggregation + LMD-GHOST fork choice.
+"""pos_evolution_amd: MI355X-native attestation aggregation + LMD-GHOST fork choice.
 
 The product is ``libposevo.so`` (HIP kernels + C ABI, ``include/posevo.h``); this package is
 the thin Python host layer above it:

@@ -1,6 +1,6 @@
 """ctypes declarations of include/posevo.h -- the only way Python reaches the engine.
 
-The library is built in-tree (``pos-evolution_amd/libposevo.so``, see
+The library is built in-tree (``pos_evolution_amd/libposevo.so``, see
 ``__graft_entry__.build``).  There is no fallback: a missing library raises.
 """
 from __future__ import annotations

@@ -1,6 +1,6 @@
-// fp_sqrt.cuh -- square roots in Fp381 (p = 3 mod 4) for the point decompression kernels, device only.
+// fp_sqrt.h -- square roots in Fp381 (p = 3 mod 4) for the point decompression kernels, device only.
 #pragma once
-#include "g1.cuh"
+#include "g1.h"
 
 namespace posevo {
 

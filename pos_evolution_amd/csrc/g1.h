@@ -1,4 +1,4 @@
-// g1.cuh -- BLS12-381 G1 (y^2 = x^3 + 4 over Fp) point arithmetic for gfx950, device only.
+// g1.h -- BLS12-381 G1 (y^2 = x^3 + 4 over Fp) point arithmetic for gfx950, device only.
 //
 // Accumulators use extended Jacobian "XYZZ" coordinates (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ,
 // ZZ^3 = ZZZ^2; ZZ == 0 <=> infinity.  Inputs are affine.  XYZZ costs 10 Montgomery products for a
@@ -15,7 +15,7 @@
 // called by is_valid_indexed_attestation (reference call sites pe:736, pe:976; the reference
 // itself contains no BLS arithmetic, see oracle/g1.py header).
 #pragma once
-#include "fp381.cuh"
+#include "fp381.h"
 #include "fp_inv_safegcd.h"
 
 namespace posevo {

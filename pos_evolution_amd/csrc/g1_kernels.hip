@@ -15,8 +15,8 @@
 //
 // Bound: integer VALU (10 Montgomery products per mixed add = 5.8k v_mad_u64_u32/v_addc per
 // 100 bytes gathered), not HBM and not MFMA -- see DESIGN.md "G1 roofline".
-#include "g1.cuh"
-#include "fp_sqrt.cuh"
+#include "g1.h"
+#include "fp_sqrt.h"
 #include "kernels.h"
 
 namespace posevo {

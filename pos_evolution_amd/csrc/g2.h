@@ -1,4 +1,4 @@
-// g2.cuh -- BLS12-381 G2 (the twist y^2 = x^3 + 4(1+u) over Fp2 = Fp[u]/(u^2+1)) for gfx950, device only.
+// g2.h -- BLS12-381 G2 (the twist y^2 = x^3 + 4(1+u) over Fp2 = Fp[u]/(u^2+1)) for gfx950, device only.
 //
 // bls.Aggregate over real BLSSignature points (types pe:37, pe:717; prose pe:659, pe:1536).
 //
@@ -12,7 +12,7 @@
 // Every predicate (is-zero, equality) is combined across the pair, so the two lanes always take the same branch
 // and the exchanges inside the rare branches stay well defined.
 #pragma once
-#include "g1.cuh"
+#include "g1.h"
 
 namespace posevo {
 

@@ -1,7 +1,7 @@
 // g2_kernels.hip -- BLS12-381 G2 point-sum kernels for gfx950.
 //
 // bls.Aggregate over BLSSignature points (pe:37, pe:717; prose pe:659, pe:1536): the same accumulate -> workgroup
-// tree -> finish structure as g1_kernels.hip, with every point handled by a LANE PAIR (g2.cuh: one Fp2 component
+// tree -> finish structure as g1_kernels.hip, with every point handled by a LANE PAIR (g2.h: one Fp2 component
 // per lane).  A 256-lane workgroup therefore covers G2_WG_SLOTS = 128 task slots.
 //
 //   k_g2_convert     192-B big-endian affine (x.c1 | x.c0 | y.c1 | y.c0) -> Montgomery limbs [x0 x1 y0 y1]
@@ -10,8 +10,8 @@
 //   k_g2_finish      per group: add the workgroup partials, normalise to canonical affine, store big-endian
 //
 // Bound: integer VALU, 36 Montgomery products per gathered 192-byte point.
-#include "g2.cuh"
-#include "fp_sqrt.cuh"
+#include "g2.h"
+#include "fp_sqrt.h"
 #include "kernels.h"
 
 namespace posevo {

@@ -1,5 +1,5 @@
 // Host build of the engine's safegcd inversion (plain C++ path of fp_inv_safegcd.h) for CPU tests.
-#include "../../pos-evolution_amd/csrc/fp_inv_safegcd.h"
+#include "../../pos_evolution_amd/csrc/fp_inv_safegcd.h"
 extern "C" int host_modinv(uint32_t* out, const uint32_t* x) { return posevo::sg_modinv(out, x, posevo::SG_PINV30); }
 extern "C" int host_modinv_many(uint32_t* out, const uint32_t* x, int n)
 {

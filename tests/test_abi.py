@@ -61,10 +61,10 @@ def _abi_no_device():
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "pos-evolution_amd")
+    pkg = os.path.join(ROOT, "pos_evolution_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h", ".cuh")):
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "posevo_oracle" not in text, f
@@ -87,7 +87,7 @@ def test_header_is_plain_c_and_cxx(tmp_path):
                    '}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++", "-fsyntax-only", str(src)])
-    libdir = os.path.join(ROOT, "pos-evolution_amd")
+    libdir = os.path.join(ROOT, "pos_evolution_amd")
     exe = tmp_path / "client"
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lposevo",
                            "-Wl,-rpath," + libdir])

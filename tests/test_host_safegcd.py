@@ -1,4 +1,4 @@
-"""CPU: the engine's safegcd inversion (pos-evolution_amd/csrc/fp_inv_safegcd.h, plain C++ path shared by host
+"""CPU: the engine's safegcd inversion (pos_evolution_amd/csrc/fp_inv_safegcd.h, plain C++ path shared by host
 and device) against Python's pow(x, -1, p)."""
 import ctypes as C
 import os
@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _lib():
     src = os.path.join(HERE, "native", "host_safegcd.cpp")
     out = os.path.join(HERE, "native", "libhost_safegcd.so")
-    hdr = os.path.join(HERE, "..", "pos-evolution_amd", "csrc", "fp_inv_safegcd.h")
+    hdr = os.path.join(HERE, "..", "pos_evolution_amd", "csrc", "fp_inv_safegcd.h")
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src])
     return C.CDLL(out)

@@ -1,12 +1,12 @@
 // fpbench.hip -- correctness + throughput of the device Fp381 multiply and the mixed G1 add.
-// Build: hipcc --offload-arch=gfx950 -O3 -I../pos-evolution_amd/csrc -o fpbench fpbench.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -I../pos_evolution_amd/csrc -o fpbench fpbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <random>
 #include <vector>
-#include "g1.cuh"
+#include "g1.h"
 
 using namespace posevo;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)

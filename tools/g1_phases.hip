@@ -1,14 +1,14 @@
 // g1_phases.hip -- where does k_g1_accumulate spend its time?  Stamps wall_clock64() (100 MHz) in every workgroup at:
 // start, end of wave 0's accumulation, after the first barrier (all waves accumulated), after each tree level.
 // Workload = the bench's pubkey leg: 2048 groups x 512 members, k = 8 -> 64 tasks per group, all bits set.
-// Build (in tools/): hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPOSEVO_G1_PHASE_TIMING -I../pos-evolution_amd/csrc -o g1_phases g1_phases.hip
+// Build (in tools/): hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPOSEVO_G1_PHASE_TIMING -I../pos_evolution_amd/csrc -o g1_phases g1_phases.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <map>
 #include <random>
 #include <vector>
-#include "../pos-evolution_amd/csrc/g1_kernels.hip"
+#include "../pos_evolution_amd/csrc/g1_kernels.hip"
 
 using namespace posevo;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
