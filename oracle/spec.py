@@ -18,6 +18,14 @@ Two kinds of function live here and every one is tagged:
 * ``[STAND-IN]`` -- replaces machinery that is out of scope for the hot path
   (SSZ merkleisation, full state transition, pairing check).
 
+ORACLE OF RECORD.  At import the reference's OWN text of every ``[REF]`` function (``oracle/_ref/``, generated
+by ``oracle/ref_extract.py`` from ``/root/reference/pos-evolution.md``; a git-ignored build output) is executed
+inside this module's namespace and REPLACES the transcriptions below: ``spec.get_head``, ``spec.on_block``,
+``spec.compute_shuffled_index`` ... are then the reference's code objects calling this file's
+``[UPSTREAM-MEMORY]`` / ``[STAND-IN]`` callees.  ``ORACLE_OF_RECORD`` says which is in force ("reference" or
+"transcription").  The transcriptions stay as the fallback and are held equal to the reference text, AST for AST
+modulo the integer-cast stand-ins, by ``tests/test_oracle_ref_pin.py``.
+
 Stand-in types: SSZ containers are plain dataclasses, ``Root`` is 32 raw bytes,
 ``hash`` is SHA-256, ``hash_tree_root`` is a SHA-256 over a deterministic field
 dump (NOT SSZ merkleisation -- the hot path only compares and looks up roots,
@@ -25,6 +33,7 @@ pe:1110, pe:1116), uintN are Python ints.
 """
 from __future__ import annotations
 
+import builtins as _builtins
 import hashlib
 from copy import copy as _shallow_copy
 from copy import deepcopy
@@ -32,6 +41,8 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 from . import g1 as _g1
+
+_builtin_hash = _builtins.hash
 
 # --------------------------------------------------------------------------
 # Constants (names cited in the reference, values
@@ -107,9 +118,39 @@ def sha256(data: bytes) -> Root:
     return Root(hashlib.sha256(data).digest())
 
 
-def uint_to_bytes(n: int, length: int = 8) -> bytes:
-    """[UPSTREAM-MEMORY A.10] little-endian fixed width."""
+class uint64(int):
+    """[STAND-IN] SSZ uintN: a Python int that remembers its serialised width (the pyspec's ``uint_to_bytes`` takes
+    the width from the type: pe:522 hashes ONE byte of ``uint8(current_round)``, pe:525 FOUR of ``uint32(...)``).
+    Arithmetic returns plain ints (unbounded; the reference's "Avoid underflow" forms stay harmless)."""
+    BYTE_LEN = 8
+
+
+class uint32(int):
+    BYTE_LEN = 4
+
+
+class uint8(int):
+    BYTE_LEN = 1
+
+
+Epoch = Slot = Gwei = ValidatorIndex = CommitteeIndex = uint64  # [STAND-IN] SSZ aliases used as casts (pe:485, pe:752)
+
+
+def uint_to_bytes(n: int, length: Optional[int] = None) -> bytes:
+    """[UPSTREAM-MEMORY A.10] little-endian, width of the SSZ type (plain ints are uint64: every untyped call site
+    in the reference passes an Epoch, pe:486)."""
+    if length is None:
+        length = getattr(type(n), "BYTE_LEN", 8)
     return int(n).to_bytes(length, "little")
+
+
+def hash(data):  # noqa: A001 -- the pyspec's name (pe:486, 522, 525)
+    """The pyspec's ``hash`` = SHA-256 for the reference's own code (oracle/_ref).  Anything that is not a byte
+    string goes to the builtin: the frozen dataclasses' generated ``__hash__`` calls ``hash((fields...))`` through
+    this module's globals."""
+    if isinstance(data, (bytes, bytearray)):
+        return sha256(bytes(data))
+    return _builtin_hash(data)
 
 
 def bytes_to_uint64(data: bytes) -> int:
@@ -155,7 +196,6 @@ class LatestMessage(object):
     """[REF pe:286-289]"""
     epoch: int
     root: Root
-    slot: int = field(default=0, compare=False)   # [VARIANT pe:1585] slot of the attestation, for vote expiry only
 
 
 @dataclass(eq=True, frozen=True)
@@ -538,8 +578,6 @@ def process_attestation(state: BeaconState, attestation: Attestation) -> None:
     proposer_reward_denominator = (WEIGHT_DENOMINATOR - PROPOSER_WEIGHT) * WEIGHT_DENOMINATOR // PROPOSER_WEIGHT
     proposer_reward = proposer_reward_numerator // proposer_reward_denominator
     increase_balance(state, get_beacon_proposer_index(state), proposer_reward)
-    # exposed for differential tests (not in the reference):
-    state._last_proposer_reward_numerator = proposer_reward_numerator
 
 
 # --------------------------------------------------------------------------
@@ -571,15 +609,15 @@ def weigh_justification_and_finalization(state: BeaconState, total_active_balanc
     # Process justifications
     state.previous_justified_checkpoint = state.current_justified_checkpoint
     state.justification_bits[1:] = state.justification_bits[:JUSTIFICATION_BITS_LENGTH - 1]
-    state.justification_bits[0] = False
+    state.justification_bits[0] = 0b0
     if previous_epoch_target_balance * 3 >= total_active_balance * 2:
         state.current_justified_checkpoint = Checkpoint(epoch=previous_epoch,
                                                         root=get_block_root(state, previous_epoch))
-        state.justification_bits[1] = True
+        state.justification_bits[1] = 0b1
     if current_epoch_target_balance * 3 >= total_active_balance * 2:
         state.current_justified_checkpoint = Checkpoint(epoch=current_epoch,
                                                         root=get_block_root(state, current_epoch))
-        state.justification_bits[0] = True
+        state.justification_bits[0] = 0b1
 
     # Process finalizations
     bits = state.justification_bits
@@ -608,7 +646,6 @@ def process_justification_and_finalization(state: BeaconState) -> None:
     total_active_balance = get_total_active_balance(state)
     previous_target_balance = get_total_balance(state, previous_indices)
     current_target_balance = get_total_balance(state, current_indices)
-    state._last_ffg_balances = (total_active_balance, previous_target_balance, current_target_balance)
     weigh_justification_and_finalization(state, total_active_balance, previous_target_balance, current_target_balance)
 
 
@@ -696,9 +733,13 @@ def get_ancestor(store: Store, root: Root, slot: int) -> Root:
     return root
 
 
-def is_vote_expired(store: Store, message: LatestMessage) -> bool:
-    """[VARIANT pe:1585-1596] "only messages from the most recent eta slots are utilized"."""
-    return VOTE_EXPIRY_SLOTS > 0 and message.slot + VOTE_EXPIRY_SLOTS < get_current_slot(store)
+def is_vote_expired(store: Store, index: int) -> bool:
+    """[VARIANT pe:1585-1596] "only messages from the most recent eta slots are utilized".  The slot of the
+    attestation behind a latest message is not part of the reference's ``LatestMessage`` (pe:286-289): the variant
+    keeps it in a side table, ``store.latest_message_slots`` (see ``_record_message_slots``)."""
+    if VOTE_EXPIRY_SLOTS == 0:
+        return False
+    return store.__dict__.get("latest_message_slots", {}).get(index, 0) + VOTE_EXPIRY_SLOTS < get_current_slot(store)
 
 
 def get_latest_attesting_balance(store: Store, root: Root) -> int:
@@ -710,7 +751,7 @@ def get_latest_attesting_balance(store: Store, root: Root) -> int:
         if (i in store.latest_messages
             and i not in store.equivocating_indices
             and not (FILTER_SLASHED and state.validators[i].slashed)
-            and not is_vote_expired(store, store.latest_messages[i])
+            and not is_vote_expired(store, i)
             and get_ancestor(store, store.latest_messages[i].root, store.blocks[root].slot) == root)
     )
     if store.proposer_boost_root == Root():
@@ -861,8 +902,7 @@ def update_latest_messages(store: Store, attesting_indices: Sequence[int], attes
     non_equivocating_attesting_indices = [i for i in attesting_indices if i not in store.equivocating_indices]
     for i in non_equivocating_attesting_indices:
         if i not in store.latest_messages or target.epoch > store.latest_messages[i].epoch:
-            store.latest_messages[i] = LatestMessage(epoch=target.epoch, root=beacon_block_root,
-                                                     slot=attestation.data.slot)
+            store.latest_messages[i] = LatestMessage(epoch=target.epoch, root=beacon_block_root)
 
 
 def on_tick(store: Store, time: int) -> None:
@@ -909,8 +949,8 @@ def on_attestation(store: Store, attestation: Attestation, is_from_block: bool =
 
 
 def on_block(store: Store, signed_block: SignedBeaconBlock) -> None:
-    """[REF pe:986-1036]  (the Bellatrix merge-transition check pe:1011-1013 is
-    execution-layer validation, out of scope, omitted)."""
+    """[REF pe:986-1036]  (the Bellatrix merge-transition check pe:1011-1013 calls two [STAND-IN]s:
+    execution-layer validation is out of scope)."""
     block = signed_block.message
     # Parent block must be known
     assert block.parent_root in store.block_states
@@ -928,6 +968,10 @@ def on_block(store: Store, signed_block: SignedBeaconBlock) -> None:
     # Check the block is valid and compute the post-state
     state = pre_state.copy()
     state_transition(state, signed_block, True)
+
+    # [New in Bellatrix]
+    if is_merge_transition_block(pre_state, block.body):
+        validate_merge_block(block)
 
     # Add new block to the store
     store.blocks[hash_tree_root(block)] = block
@@ -953,6 +997,16 @@ def on_block(store: Store, signed_block: SignedBeaconBlock) -> None:
         store.justified_checkpoint = state.current_justified_checkpoint
 
 
+def is_merge_transition_block(state: BeaconState, body: BeaconBlockBody) -> bool:
+    """[STAND-IN] pe:1012: execution-layer (PoW -> PoS transition) check; this chain is post-merge from genesis."""
+    return False
+
+
+def validate_merge_block(block: BeaconBlock) -> None:
+    """[STAND-IN] pe:1013: never reached (is_merge_transition_block is False)."""
+    raise AssertionError("validate_merge_block is out of scope")
+
+
 def is_slashable_attestation_data(data_1: AttestationData, data_2: AttestationData) -> bool:
     """[REF pe:1134-1143]"""
     return (
@@ -975,3 +1029,34 @@ def on_attester_slashing(store: Store, attester_slashing: AttesterSlashing) -> N
     indices = set(attestation_1.attesting_indices).intersection(attestation_2.attesting_indices)
     for index in indices:
         store.equivocating_indices.add(index)
+
+
+# --------------------------------------------------------------------------
+# The reference's own text takes over (see the module docstring).  Everything ABOVE this line that is tagged
+# [REF] is replaced by the code object compiled from the fence it cites.
+# --------------------------------------------------------------------------
+from . import ref_extract as _ref_extract  # noqa: E402
+
+REF_MANIFEST = _ref_extract.overlay(globals())
+ORACLE_OF_RECORD = "reference" if REF_MANIFEST else "transcription"
+
+
+def _record_message_slots(literal):
+    """[VARIANT pe:1585-1596] wraps the (reference's, literal) ``update_latest_messages`` so that the RLMD-GHOST /
+    Goldfish variant knows the slot of every latest message.  With VOTE_EXPIRY_SLOTS == 0 -- the reference's
+    executable protocol -- the wrapper is a straight call."""
+    def update_latest_messages(store, attesting_indices, attestation):
+        if VOTE_EXPIRY_SLOTS == 0:
+            return literal(store, attesting_indices, attestation)
+        before = {i: store.latest_messages.get(i) for i in attesting_indices}
+        literal(store, attesting_indices, attestation)
+        slots = store.__dict__.setdefault("latest_message_slots", {})
+        for i in attesting_indices:
+            if store.latest_messages.get(i) is not before[i]:
+                slots[i] = attestation.data.slot
+    update_latest_messages.literal = literal
+    update_latest_messages.__doc__ = literal.__doc__
+    return update_latest_messages
+
+
+update_latest_messages = _record_message_slots(update_latest_messages)

@@ -1,12 +1,16 @@
 #!/usr/bin/env python
-"""Regenerates the fixtures in tests/golden/ from the L0 literal oracle (oracle/spec.py, oracle/g1.py).
+"""Regenerates the fixtures in tests/golden/ by RUNNING THE REFERENCE'S OWN pyspec text.
 
-The reference itself (/root/reference/pos-evolution.md) is a document: it cannot be imported or run, so these are
-NOT reference outputs -- they freeze the oracle's answers (for the functions the reference defines verbatim:
-compute_shuffled_index / compute_committee pe:495-534, get_head pe:1102-1116, update_latest_messages pe:1435-1441)
-so that a later edit of the oracle or of the engine that changes a result is caught against a committed file.
+``oracle/ref_extract.py`` pulls the fenced Python out of /root/reference/pos-evolution.md and executes it inside
+``oracle.spec``'s namespace (``spec.ORACLE_OF_RECORD == "reference"``): compute_shuffled_index / compute_committee
+(pe:495-534), get_head (pe:1102-1116), on_tick / on_block / on_attestation (pe:934-1036, pe:1423), update_latest_messages
+(pe:1435-1441) below are the reference's code objects; only the callees the reference never defines
+(get_ancestor, get_latest_attesting_balance, get_filtered_block_tree, validate_on_attestation, get_beacon_committee:
+SURVEY.md Appendix A) and the G1/G2 arithmetic (oracle/g1.py, oracle/g2.py: no BLS code in the reference at all) are
+this repo's restatements.  The script refuses to write fork-choice / shuffle fixtures from the transcription.
 
-    python tests/golden/generate.py        # rewrites the *.json next to this script
+    python tests/golden/generate.py        # rewrites the *.json next to this script (needs /root/reference)
+    python tests/golden/generate.py --digest   # prints sha256 of the fork-choice trace + shuffle vectors it would write
 """
 import json
 import os
@@ -123,7 +127,23 @@ def forkchoice_trace(seed=5, steps=40, n_val=96):
             "committees_epoch": {str(k): v for k, v in tables.items()}, "events": events}
 
 
+def ref_pins():
+    from oracle import ref_extract
+    return ref_extract.pins_from_reference()
+
+
+def digest():
+    import hashlib
+    blob = json.dumps({"trace": forkchoice_trace(), "shuffle": shuffle_vectors()}, sort_keys=True).encode()
+    return hashlib.sha256(blob).hexdigest()
+
+
 if __name__ == "__main__":
+    if "--digest" in sys.argv:
+        print(spec.ORACLE_OF_RECORD, digest())
+        sys.exit(0)
+    assert spec.ORACLE_OF_RECORD == "reference", "fixtures are generated from the reference's own text only"
+    json.dump(ref_pins(), open(os.path.join(HERE, "ref_pins.json"), "w"), indent=1)
     json.dump(g1_vectors(), open(os.path.join(HERE, "g1_vectors.json"), "w"), indent=1)
     json.dump(g2_vectors(), open(os.path.join(HERE, "g2_vectors.json"), "w"), indent=1)
     json.dump(shuffle_vectors(), open(os.path.join(HERE, "shuffle_vectors.json"), "w"))

@@ -202,6 +202,30 @@ class World:
         return h
 
 
+def l0_proposer_reward_numerator(state, pre_current: Sequence[int], pre_previous: Sequence[int]) -> int:
+    """proposer_reward_numerator of the process_attestation call that turned (pre_current, pre_previous) into the
+    state's participation arrays: sum of get_base_reward(i) * weight over the flags it newly set (pe:746-749).  The
+    reference keeps the numerator in a local, so the harness recovers it from the before/after flags."""
+    total = 0
+    for pre, post in ((pre_current, state.current_epoch_participation), (pre_previous, state.previous_epoch_participation)):
+        for i, (a, b) in enumerate(zip(pre, post)):
+            new = b & ~a
+            if new:
+                for flag_index, weight in enumerate(spec.PARTICIPATION_FLAG_WEIGHTS):
+                    if spec.has_flag(new, flag_index):
+                        total += spec.get_base_reward(state, i) * weight
+    return total
+
+
+def l0_ffg_balances(state):
+    """The three Gwei sums process_justification_and_finalization (pe:797-801) hands to
+    weigh_justification_and_finalization, computed with the same calls."""
+    previous_indices = spec.get_unslashed_participating_indices(state, spec.TIMELY_TARGET_FLAG_INDEX, spec.get_previous_epoch(state))
+    current_indices = spec.get_unslashed_participating_indices(state, spec.TIMELY_TARGET_FLAG_INDEX, spec.get_current_epoch(state))
+    return (spec.get_total_active_balance(state), spec.get_total_balance(state, previous_indices),
+            spec.get_total_balance(state, current_indices))
+
+
 def engine_config_for_preset() -> dict:
     """pe_config fields matching the constants currently bound in oracle.spec."""
     return dict(
