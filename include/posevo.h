@@ -22,7 +22,8 @@
  *    Calls are synchronous: they return once their results are complete in the
  *    caller's buffers (pe_get_head polls the head word its kernel releases to host
  *    memory instead of waiting for the stream to drain; later calls are ordered
- *    behind it on the engine's stream).
+ *    behind it on the engine's stream).  The exception is opt-in: between pe_pipeline_begin
+ *    and pe_pipeline_end the batch calls return once their work is enqueued (see there).
  *  - roots are 32 opaque bytes; the all-zero root is "unset" (Root(), pe:943).
  *  - G1 points cross the boundary in the 96-byte uncompressed form: big-endian
  *    x (48 B) || big-endian y (48 B); bit 6 of byte 0 set = point at infinity.
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 1
+#define PE_ABI_VERSION 2
 
 typedef struct pe_engine pe_engine;
 
@@ -113,6 +114,11 @@ typedef struct pe_config {
  * in the caller's bit arena + the injected signature verdict (pe:717). */
 #define PE_ATT_FLAG_SIGNATURE_VALID 0x1u  /* result of the out-of-scope pairing check */
 #define PE_ATT_FLAG_FROM_BLOCK      0x2u  /* is_from_block (pe:1423) */
+#define PE_ATT_FLAG_OVERLAPPING_BITS 0x4u /* set by pe_aggregate on an output row whose members share a bit: the summed
+                                             signature counts that validator twice while bits and aggregate pubkey count
+                                             it once, so the aggregate can never verify (validator guide, Appendix A.8:
+                                             "aggregates with overlapping bits are not merged").  PE_ATT_FLAG_SIGNATURE_VALID
+                                             is cleared on such a row; re-aggregate without the duplicate members. */
 typedef struct pe_attestation {
     uint64_t slot;                  /* data.slot */
     uint64_t index;                 /* data.index: committee index within the slot */
@@ -210,6 +216,38 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees,
 int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
                           uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
                           uint32_t* out_offsets, uint32_t* out_members);
+
+/* ---- pipelined calls: one wait per step --------------------------------- */
+/* Between pe_pipeline_begin and pe_pipeline_end the batch calls (pe_aggregate, pe_on_attestation_batch,
+ * pe_process_attestation_batch) validate on the host, enqueue their device work and RETURN WITHOUT WAITING:
+ *   - what is host-derived is complete at return: out_atts rows, out_n_groups, group_of, every status[] entry that
+ *     names a failed host-side assert;
+ *   - device results (OR-ed bits, counts, aggregate pubkeys, numerators, and the status of rows whose verdict needs the
+ *     bits: PE_ATT_EMPTY_OR_INVALID_INDICES / PE_ATT_BAD_SIGNATURE for overlapping members) are written into the
+ *     caller's buffers when pe_pipeline_end returns -- the buffers must stay alive until then;
+ *   - pe_get_head stays synchronous (it returns a root) and is ordered behind everything enqueued before it; the G1
+ *     sums of a pipelined pe_aggregate run on a second stream beside the fork-choice kernels;
+ *   - any other entry point first completes the pipeline's outstanding work.
+ * Results are the same as with synchronous calls.  pe_pipeline_end returns the first deferred error, if any. */
+int pe_pipeline_begin(pe_engine* h);
+int pe_pipeline_end(pe_engine* h);
+/* Lagged end, for a caller that streams step after step: returns once the pipeline BEFORE this one is complete (its
+ * buffers filled, its deferred error returned); this one completes at the next pe_pipeline_end / _end_lagged or any
+ * other synchronous call.  The G1 sums of step N then run while the host prepares and enqueues step N+1.  Buffers
+ * handed to the calls of a lagged pipeline must stay alive until that later completion. */
+int pe_pipeline_end_lagged(pe_engine* h);
+/* pe_pipeline_begin for a pipeline that will end lagged: the G1 sums of its pe_aggregate are not launched by that call
+ * but by pe_pipeline_end_lagged, BEHIND the step's fork-choice kernels.  k_g1_accumulate fills every CU for its whole
+ * run, so launched first it would hold pe_get_head (and with it the host's preparation of the next step) back until it
+ * ends; launched last it overlaps exactly that preparation.  Results are unchanged. */
+int pe_pipeline_begin_streaming(pe_engine* h);
+/* Device-resident hand-over: pass PE_BITS_RESIDENT as bits_arena (arena_len ignored) to pe_on_attestation_batch /
+ * pe_process_attestation_batch when `atts` are rows of out_atts of the LAST pe_aggregate on this handle (any subset,
+ * any order, fields other than flags unchanged): their OR-ed bits are used where pe_aggregate left them in HBM --
+ * nothing is re-packed or re-uploaded, and it works inside a pipeline where out_bits_arena is not filled yet.  Rows
+ * whose members overlapped (PE_ATT_FLAG_OVERLAPPING_BITS) are rejected with PE_ATT_BAD_SIGNATURE; len(aggregation_bits)
+ * must equal the committee length. */
+#define PE_BITS_RESIDENT ((const uint8_t*)(uintptr_t)1)
 
 /* ---- the hot path ------------------------------------------------------ */
 /* get_head (pe:1102-1116): full recomputation from the V-entry vote table:

@@ -132,10 +132,17 @@ SIGNATURES = {
                                        _u32p, _u32p, _u8p, C.c_uint64, _u32p, C.c_void_p]),
     "pe_g1_partial": (C.c_int, [_H, _u32p, _u32p, C.c_uint32, C.c_void_p]),
     "pe_g1_finish": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, _u8p]),
+    "pe_pipeline_begin": (C.c_int, [_H]),
+    "pe_pipeline_end": (C.c_int, [_H]),
+    "pe_pipeline_end_lagged": (C.c_int, [_H]),
+    "pe_pipeline_begin_streaming": (C.c_int, [_H]),
     "pe_profile_enable": (C.c_int, [_H, C.c_int]),
     "pe_profile_reset": (C.c_int, [_H]),
     "pe_profile_get": (C.c_int, [_H, C.c_int, _u64p, _P(C.c_double)]),
 }
+
+PE_BITS_RESIDENT = 1  # the address include/posevo.h defines as "bits are where the last pe_aggregate left them"
+PE_ATT_FLAG_OVERLAPPING_BITS = 0x4
 
 _lib = None
 

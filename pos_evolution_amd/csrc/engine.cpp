@@ -22,6 +22,8 @@
 #include <map>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <new>
 #include <numeric>
 #include <string>
@@ -137,7 +139,17 @@ struct CommitteeTable {
 // Diagnostic only (POSEVO_HOST_TRACE=1): wall time of host phases, printed at pe_engine_destroy.
 struct HostTrace {
     bool on = std::getenv("POSEVO_HOST_TRACE") != nullptr;
-    std::map<std::string, std::pair<double, uint64_t>> acc;
+    struct Acc { double sum = 0, mn = 1e30, mx = 0; uint64_t n = 0; std::vector<float> all; };
+    std::map<std::string, Acc> acc;
+    void add(const char* name, double us)
+    {
+        Acc& a = acc[name];
+        a.sum += us;
+        a.mn = std::min(a.mn, us);
+        a.mx = std::max(a.mx, us);
+        a.n += 1;
+        a.all.push_back((float)us);
+    }
 };
 struct HostScope {
     HostTrace* t;
@@ -150,9 +162,7 @@ struct HostScope {
     ~HostScope()
     {
         if (!t->on) return;
-        auto& a = t->acc[name];
-        a.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        a.second += 1;
+        t->add(name, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     }
 };
 
@@ -167,9 +177,7 @@ struct HostLap {  // lap timer: mark(name) charges the time since the previous m
     {
         if (!t->on) return;
         auto now = std::chrono::steady_clock::now();
-        auto& a = t->acc[name];
-        a.first += std::chrono::duration<double, std::micro>(now - last).count();
-        a.second += 1;
+        t->add(name, std::chrono::duration<double, std::micro>(now - last).count());
         last = now;
     }
 };
@@ -209,17 +217,52 @@ struct pe_engine {
     bool tree_dirty = true;
     DevBuf d_tsize, d_tparent, d_trank, d_tleaf, d_tpos, d_tidx, d_direct, d_weights, d_totals, d_head;
     std::vector<uint32_t> h_pos_of_idx;
-    PinBuf h_pin;   // D2H landing zone (mirrors d_outblk)
     PinBuf h_head;  // 64 B of host-coherent pinned memory the tree kernel writes the head index into
     uint32_t votes_grid = 0;  // workgroups of the last k_votes launch on the engine's own buffers
 
     // ---- committees ----
     std::vector<CommitteeTable> tables;
     uint64_t table_stamp = 0;
+    size_t last_table = 0;  // index of the table find_table returned last
 
     // ---- scratch ----
-    DevBuf d_stage, d_outblk, d_partials, d_out96, d_tmp_points, d_tmp_be;
-    PinBuf h_stage;  // H2D staging (mirrors d_stage)
+    DevBuf d_partials, d_out96, d_tmp_points, d_tmp_be;
+
+    // ---- pipelined calls (pe_pipeline_begin / _end): one wait per step instead of one per call ----
+    // A batch call lays out its inputs at stage_cursor / its outputs at out_cursor of the current arena, enqueues
+    // copies + kernels and registers a completion (results pinned block -> caller buffers).  Outside a pipeline the
+    // call then waits and runs it; inside one the cursors just advance and pe_pipeline_end (or any other synchronous
+    // entry point) waits once for everything.  Two arenas: pe_pipeline_end_lagged fences the current one and hands
+    // the next pipeline the other, so that a step's G1 sums may still run while the host prepares the next step.
+    struct PipeArena {
+        DevBuf d_stage, d_outblk;         // H2D staging block | device output block
+        PinBuf h_stage, h_pin;            // their pinned host mirrors (h_pin is host-coherent: kernels write into it)
+        DevBuf d_res_bits, d_res_info;    // resident hand-over: OR-ed bit words | {popcount, overlap} per group
+        DevBuf d_partials;                // accumulate -> finish hand-over of this arena's pipelined aggregate
+        size_t stage_cursor = 0, out_cursor = 0;
+        std::vector<std::function<int()>> pending;
+        hipEvent_t ev_main = nullptr, ev_side = nullptr;  // recorded by pe_pipeline_end_lagged
+        bool fenced = false, side_used = false;
+    };
+    PipeArena arena[2];
+    int cur = 0;
+    PipeArena& A() { return arena[cur]; }
+    bool pipelining = false;
+    hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
+    hipStream_t fin_stream = nullptr;   // ... and its k_g1_finish here, beside the NEXT aggregate's accumulation
+    hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool side_busy = false;             // the side stream holds work of the current arena nobody has waited for yet
+    bool side_ever = false;             // ev_join has been recorded at least once
+    bool streaming = false;             // pe_pipeline_begin_streaming: G1 launches are deferred to the pipeline's end
+    std::vector<std::function<int()>> deferred;  // ... these
+    // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
+    struct ResGroup { uint32_t byte_off, n_bits, word, sig_valid; };
+    std::vector<ResGroup> res_groups;     // sorted by byte_off (= group order)
+    std::shared_ptr<std::vector<uint32_t>> res_info_host;  // copy of d_res_info, filled when that aggregate completes
+    bool res_valid = false;
+    int res_arena = 0;                    // which arena holds the resident bits
+    uint64_t res_generation = 0;          // which pe_aggregate the resident data belongs to
 
     // ---- accumulate-shape autotune (large pubkey aggregations) ----
     // 131072 task slots (two waves per SIMD, 6 tree levels at 512-member committees) or 65536 (one wave, 5 levels):
@@ -255,24 +298,87 @@ int hip_fail(pe_engine* h, hipError_t e, const char* what)
         hipError_t _e = (expr);                                 \
         if (_e != hipSuccess) return hip_fail((h), _e, #expr);  \
     } while (0)
+#define PE_TRY(expr)              \
+    do {                          \
+        const int _rc = (expr);   \
+        if (_rc) return _rc;      \
+    } while (0)
 
 struct ProfScope {
     pe_engine* h;
     int k;
+    hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(pe_engine* h_, int k_) : h(h_), k(k_)
+    ProfScope(pe_engine* h_, int k_, hipStream_t s_ = nullptr) : h(h_), k(k_), s(s_ ? s_ : h_->stream)
     {
         if (!h->profiling) return;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        (void)hipEventRecord(a, h->stream);
+        (void)hipEventRecord(a, s);
     }
     ~ProfScope()
     {
         if (!a) return;
-        (void)hipEventRecord(b, h->stream);
+        (void)hipEventRecord(b, s);
         h->prof[k].pending.emplace_back(a, b);
     }
 };
+
+// ------------------------------------------------------------------ completion of batch calls
+// Launches a streaming pipeline held back (the G1 sums of its pe_aggregate): issue them now.
+int run_deferred(pe_engine* h)
+{
+    if (h->deferred.empty()) return PE_OK;
+    std::vector<std::function<int()>> todo;
+    todo.swap(h->deferred);
+    int rc = PE_OK;
+    for (auto& f : todo) {
+        const int r = f();
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+// Wait for what the batch calls put into one arena, then run their completions in call order.
+int complete_arena(pe_engine* h, int ai)
+{
+    pe_engine::PipeArena& a = h->arena[ai];
+    if (a.pending.empty() && !a.fenced && a.stage_cursor == 0 && a.out_cursor == 0) return PE_OK;
+    if (ai == h->cur) PE_TRY(run_deferred(h));  // deferred launches belong to the arena the calls are going into
+    hipError_t e = hipSuccess;
+    if (a.fenced) {  // a lagged pipeline: its end was marked on both streams
+        e = hipEventSynchronize(a.ev_main);
+        if (a.side_used) {
+            hipError_t e2 = hipEventSynchronize(a.ev_side);
+            if (e == hipSuccess) e = e2;
+        }
+    } else {         // the arena the calls are still going into
+        e = hipStreamSynchronize(h->stream);
+        if (h->side_busy) {
+            hipError_t e2 = hipStreamSynchronize(h->side_stream);
+            if (e == hipSuccess) e = e2;
+            e2 = hipStreamSynchronize(h->fin_stream);
+            if (e == hipSuccess) e = e2;
+            h->side_busy = false;
+        }
+    }
+    std::vector<std::function<int()>> todo;
+    todo.swap(a.pending);
+    a.stage_cursor = a.out_cursor = 0;
+    a.fenced = a.side_used = false;
+    if (e != hipSuccess) return hip_fail(h, e, "waiting for the enqueued batch calls");
+    int rc = PE_OK;
+    for (auto& f : todo) {
+        const int r = f();
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+// Everything: the lagged arena first (it is the older one), then the current one.
+int flush_pending(pe_engine* h)
+{
+    const int rc0 = complete_arena(h, h->cur ^ 1);
+    const int rc1 = complete_arena(h, h->cur);
+    return rc0 ? rc0 : rc1;
+}
 
 // ------------------------------------------------------------------ spec helpers (A.10)
 inline uint64_t current_slot(const pe_engine* h) { return (h->time - h->genesis_time) / h->cfg.seconds_per_slot; }
@@ -429,8 +535,13 @@ int insert_block(pe_engine* h, const Root& root, uint32_t parent, uint64_t slot,
 
 CommitteeTable* find_table(pe_engine* h, uint64_t epoch)
 {
-    for (auto& t : h->tables)
+    // the rows of a batch nearly always share one target epoch: try the table of the previous hit first
+    if (h->last_table < h->tables.size()) {
+        CommitteeTable& t = h->tables[h->last_table];
         if (t.epoch == epoch && t.n_committees) return &t;
+    }
+    for (size_t i = 0; i < h->tables.size(); ++i)
+        if (h->tables[i].epoch == epoch && h->tables[i].n_committees) { h->last_table = i; return &h->tables[i]; }
     return nullptr;
 }
 
@@ -452,16 +563,29 @@ uint32_t pack_bits(const uint8_t* src, uint32_t n_use, uint32_t* dst_words)
 // One pinned host block mirrored by one device block: a call lays out everything the kernels need (bit words,
 // rows, group descriptors) in the pinned block, uploads it with ONE hipMemcpyAsync, and reads results back
 // from one device output block with ONE copy.  (Separate pageable copies cost 30-50 us each on this box.)
+// Offsets are relative to the block's cursor at the start of the call: inside a pipeline consecutive calls take
+// consecutive regions (nothing an enqueued copy or kernel still needs is overwritten); outside one the cursor is 0.
+// Growing a block re-allocates it, so a call reserves BEFORE it takes pointers, and a reservation that has to grow a
+// block with enqueued work behind it first waits for that work (flush_pending).
 struct Stage {
     pe_engine* h;
-    size_t used = 0;
-    explicit Stage(pe_engine* h_) : h(h_) {}
-    hipError_t reserve(size_t bytes)
+    size_t base, used = 0;
+    explicit Stage(pe_engine* h_) : h(h_), base((h_->A().stage_cursor + 255) & ~size_t(255)) {}
+    int reserve(size_t bytes)
     {
         bytes += 4096;
-        hipError_t e = h->h_stage.ensure(bytes);
-        if (e != hipSuccess) return e;
-        return h->d_stage.ensure(bytes);
+        if (base + bytes > h->A().h_stage.cap || base + bytes > h->A().d_stage.cap) {
+            // does not fit behind the calls already enqueued: wait for them once, then make room for two such steps
+            // so that the next pipeline does not wait again
+            const size_t want = base ? 2 * (base + bytes) : bytes;
+            int rc = complete_arena(h, h->cur);
+            if (rc) return rc;
+            base = 0;
+            hipError_t e = h->A().h_stage.ensure(want);
+            if (e == hipSuccess) e = h->A().d_stage.ensure(want);
+            if (e != hipSuccess) return hip_fail(h, e, "staging block");
+        }
+        return PE_OK;
     }
     size_t alloc(size_t bytes)
     {
@@ -469,38 +593,79 @@ struct Stage {
         used = off + bytes;
         return off;
     }
-    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(h->h_stage.as<uint8_t>() + off); }
-    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(h->d_stage.as<uint8_t>() + off); }
+    bool overflow() const { return base + used > h->A().h_stage.cap || base + used > h->A().d_stage.cap; }
+    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(h->A().h_stage.as<uint8_t>() + base + off); }
+    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(h->A().d_stage.as<uint8_t>() + base + off); }
     hipError_t upload() const
     {
         if (used == 0) return hipSuccess;
-        return hipMemcpyAsync(h->d_stage.p, h->h_stage.p, used, hipMemcpyHostToDevice, h->stream);
+        return hipMemcpyAsync(h->A().d_stage.as<uint8_t>() + base, h->A().h_stage.as<uint8_t>() + base, used,
+                              hipMemcpyHostToDevice, h->stream);
     }
+    size_t end() const { return base + used; }
 };
 struct OutBlock {  // device output block + pinned landing zone with the same layout
     pe_engine* h;
-    size_t used = 0;
-    explicit OutBlock(pe_engine* h_) : h(h_) {}
+    size_t base, used = 0;
+    explicit OutBlock(pe_engine* h_) : h(h_), base((h_->A().out_cursor + 255) & ~size_t(255)) {}
     size_t alloc(size_t bytes)
     {
         const size_t off = (used + 255) & ~size_t(255);
         used = off + bytes;
         return off;
     }
-    hipError_t ensure()
+    int ensure()  // after the allocs, before anything of this call is enqueued
     {
-        hipError_t e = h->d_outblk.ensure(used + 256);
-        if (e != hipSuccess) return e;
-        return h->h_pin.ensure(used + 256);
+        const size_t need = base + used + 256;
+        if (need > h->A().d_outblk.cap || need > h->A().h_pin.cap) {
+            const size_t want = base ? 2 * need : need;
+            int rc = complete_arena(h, h->cur);
+            if (rc) return rc;
+            base = 0;
+            hipError_t e = h->A().d_outblk.ensure(want);
+            if (e == hipSuccess) e = h->A().h_pin.ensure(want);
+            if (e != hipSuccess) return hip_fail(h, e, "output block");
+        }
+        return PE_OK;
     }
-    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(h->d_outblk.as<uint8_t>() + off); }
-    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(h->h_pin.as<uint8_t>() + off); }
-    hipError_t download() const
+    template <typename T> T* dev(size_t off) const { return reinterpret_cast<T*>(h->A().d_outblk.as<uint8_t>() + base + off); }
+    template <typename T> T* host(size_t off) const { return reinterpret_cast<T*>(h->A().h_pin.as<uint8_t>() + base + off); }
+    hipError_t download(hipStream_t s = nullptr) const  // whole region of this call
     {
         if (used == 0) return hipSuccess;
-        return hipMemcpyAsync(h->h_pin.p, h->d_outblk.p, used, hipMemcpyDeviceToHost, h->stream);
+        return hipMemcpyAsync(h->A().h_pin.as<uint8_t>() + base, h->A().d_outblk.as<uint8_t>() + base, used,
+                              hipMemcpyDeviceToHost, s ? s : h->stream);
     }
+    hipError_t download(size_t off, size_t bytes, hipStream_t s = nullptr) const
+    {
+        if (bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(h->A().h_pin.as<uint8_t>() + base + off, h->A().d_outblk.as<uint8_t>() + base + off, bytes,
+                              hipMemcpyDeviceToHost, s ? s : h->stream);
+    }
+    size_t end() const { return base + used; }
 };
+
+// Register a batch call's completion.  Outside a pipeline: wait now and run it (the call is synchronous, as
+// include/posevo.h promises).  Inside one: advance the cursors and return; pe_pipeline_end waits once.
+int finish_call(pe_engine* h, const Stage& st, const OutBlock& ob, std::function<int()> complete, bool force_sync = false)
+{
+    h->A().pending.push_back(std::move(complete));
+    h->A().stage_cursor = st.end();
+    h->A().out_cursor = ob.end();
+    if (!h->pipelining || force_sync) return flush_pending(h);
+    return PE_OK;
+}
+
+// A device buffer other enqueued work may still read: wait for that work before re-allocating it.
+int ensure_quiesced(pe_engine* h, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return PE_OK;
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, b.ensure(bytes));
+    return PE_OK;
+}
 
 // ------------------------------------------------------------------ G1 plan
 constexpr uint32_t G1_TARGET_LANES = 131072;  // 2 waves per SIMD on 256 CUs
@@ -558,20 +723,40 @@ void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan, uint
     plan->n_partials = outp;
 }
 
+// G1 work of one pe_aggregate may run on the side stream (pipelined calls): anything else that is about to use the
+// shared G1 scratch (d_partials) on another stream first waits for it.
+void g1_stream_guard(pe_engine* h, hipStream_t s)
+{
+    // ev_join marks the end of the last G1 launch on the side stream (a lagged pipeline may still be running it);
+    // waiting on a completed event costs nothing
+    if (h->side_ever && s != h->side_stream && s != h->fin_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+}
+
 // Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
+// fin != s: the finish kernel goes to its own stream behind an event (a pipelined aggregate: it then overlaps the next
+// aggregate's accumulation); partials: the scratch the two kernels hand over through (per arena when pipelined).
 int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
-                      const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac)
+                      const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
+                      hipStream_t s = nullptr, hipStream_t fin = nullptr, DevBuf* partials = nullptr)
 {
     if (plan.n_groups == 0) return PE_OK;
-    HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
+    if (!s) s = h->stream;
+    if (!fin) fin = s;
+    if (!partials) partials = &h->d_partials;
+    PE_TRY(ensure_quiesced(h, *partials,
+                           std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
     {
-        ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE);
-        launch_g1_accumulate(h->stream, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             h->d_partials.as<uint32_t>());
+        ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s);
+        launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
+                             partials->as<uint32_t>());
+    }
+    if (fin != s) {
+        HIP_TRY(h, hipEventRecord(h->ev_acc, s));
+        HIP_TRY(h, hipStreamWaitEvent(fin, h->ev_acc, 0));
     }
     {
-        ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
-        launch_g1_finish(h->stream, h->d_partials.as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac);
+        ProfScope ps(h, PE_KERNEL_G1_NORMALISE, fin);
+        launch_g1_finish(fin, partials->as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac);
     }
     HIP_TRY(h, hipGetLastError());
     return PE_OK;
@@ -585,8 +770,37 @@ struct Resolved {
     uint32_t block_idx = 0;  // beacon_block_root
 };
 
+// Per-call memo for the host-side walks of a batch: consecutive rows mostly name the same few roots.
+struct BatchMemo {
+    // direct-mapped root -> block index cache (a batch votes for a few dozen distinct blocks; the store's node-based
+    // map costs two cache misses per lookup)
+    struct Slot { uint8_t root[32]; uint32_t idx; uint32_t used; };
+    Slot slots[256];
+    std::vector<uint64_t> anc;  // per block index: (slot + 1) << 32 | ancestor index of the last get_ancestor asked
+    BatchMemo() { for (auto& s : slots) s.used = 0; }
+    bool find(const pe_engine* h, int /*which*/, const uint8_t* root, uint32_t* idx)
+    {
+        Slot& s = slots[root[0]];  // roots are hash outputs: any byte is uniform
+        if (s.used && memcmp(s.root, root, 32) == 0) { *idx = s.idx; return true; }
+        if (!find_block(h, to_root(root), idx)) return false;
+        memcpy(s.root, root, 32);
+        s.idx = *idx;
+        s.used = 1;
+        return true;
+    }
+    uint32_t ancestor(const pe_engine* h, uint32_t idx, uint64_t slot)
+    {
+        if (anc.size() != h->blocks.size()) anc.assign(h->blocks.size(), 0);
+        const uint64_t tag = (slot + 1) << 32;
+        if ((anc[idx] & 0xFFFFFFFF00000000ull) == tag && slot < 0xFFFFFFFEull) return (uint32_t)anc[idx];
+        const uint32_t r = get_ancestor(h, idx, slot);
+        if (slot < 0xFFFFFFFEull) anc[idx] = tag | r;
+        return r;
+    }
+};
+
 // validate_on_attestation (A.4) + committee resolution for on_attestation (pe:970-976).
-int32_t validate_for_fork_choice(pe_engine* h, const pe_attestation& a, Resolved* out)
+int32_t validate_for_fork_choice(pe_engine* h, const pe_attestation& a, Resolved* out, BatchMemo* memo)
 {
     const bool from_block = (a.flags & PE_ATT_FLAG_FROM_BLOCK) != 0;
     const uint64_t cur_slot = current_slot(h);
@@ -598,10 +812,10 @@ int32_t validate_for_fork_choice(pe_engine* h, const pe_attestation& a, Resolved
     }
     if (a.target_epoch != epoch_at_slot(h, a.slot)) return PE_ATT_TARGET_EPOCH_SLOT_MISMATCH;
     uint32_t tgt_idx, blk_idx;
-    if (!find_block(h, to_root(a.target_root), &tgt_idx)) return PE_ATT_UNKNOWN_TARGET_ROOT;
-    if (!find_block(h, to_root(a.beacon_block_root), &blk_idx)) return PE_ATT_UNKNOWN_BEACON_BLOCK_ROOT;
+    if (!memo->find(h, 1, a.target_root, &tgt_idx)) return PE_ATT_UNKNOWN_TARGET_ROOT;
+    if (!memo->find(h, 0, a.beacon_block_root, &blk_idx)) return PE_ATT_UNKNOWN_BEACON_BLOCK_ROOT;
     if (h->blocks[blk_idx].slot > a.slot) return PE_ATT_BLOCK_AFTER_ATTESTATION_SLOT;
-    if (get_ancestor(h, blk_idx, start_slot(h, a.target_epoch)) != tgt_idx) return PE_ATT_TARGET_NOT_ANCESTOR;
+    if (memo->ancestor(h, blk_idx, start_slot(h, a.target_epoch)) != tgt_idx) return PE_ATT_TARGET_NOT_ANCESTOR;
     if (cur_slot < a.slot + 1) return PE_ATT_SLOT_NOT_IN_PAST;
     // get_indexed_attestation -> get_beacon_committee(target_state, slot, index) (A.6)
     CommitteeTable* t = find_table(h, a.target_epoch);
@@ -671,12 +885,18 @@ int upload_balances(pe_engine* h, uint64_t n, const uint64_t* bal, const uint8_t
     return PE_OK;
 }
 
-int need_init(pe_engine* h)
+// Entry of a call that is not part of the pipelined hot path: complete whatever the batch calls left enqueued.
+int enter(pe_engine* h)
+{
+    (void)hipSetDevice(h->device);
+    return flush_pending(h);
+}
+int need_init(pe_engine* h, bool flush = true)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     if (!h->initialised) return fail(h, PE_ERR_STATE, "store not initialised: call pe_store_init first");
     (void)hipSetDevice(h->device);
-    return PE_OK;
+    return flush ? flush_pending(h) : PE_OK;
 }
 
 // get_head's device part on arbitrary weight buffer.
@@ -792,6 +1012,23 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
         return PE_ERR_NO_DEVICE;
     }
     h->stream = h->own_stream;
+    // Pipelined steps run three things at once: the fork-choice kernels of step N+1, k_g1_accumulate of step N and
+    // k_g1_finish of step N-1/N, each on its own stream.  (CU-masked streams -- a private CU partition for the
+    // latency-sized fork-choice kernels -- were measured and dropped: hipExtStreamCreateWithCUMask with 16 / 32 / 48
+    // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
+    const bool ok_streams = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess &&
+                            hipStreamCreateWithFlags(&h->fin_stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok_streams ||
+        hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[0].ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[0].ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[1].ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[1].ev_side, hipEventDisableTiming) != hipSuccess) {
+        pe_engine_destroy(h);
+        return PE_ERR_NO_DEVICE;
+    }
     h->tables.reserve(c.max_committee_tables ? c.max_committee_tables : 4u);
     *out = h;
     return PE_OK;
@@ -801,34 +1038,56 @@ void pe_engine_destroy(pe_engine* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    for (auto& a : h->arena) {
+        a.d_res_bits.release();
+        a.d_res_info.release();
+        a.d_partials.release();
+        a.d_stage.release();
+        a.d_outblk.release();
+        a.h_stage.release();
+        a.h_pin.release();
+        if (a.ev_main) (void)hipEventDestroy(a.ev_main);
+        if (a.ev_side) (void)hipEventDestroy(a.ev_side);
+    }
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
-                      &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head, &h->d_stage,
-                      &h->d_outblk, &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
+                      &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head,
+                      &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
         b->release();
     for (auto& t : h->tables) { t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release(); }
-    h->h_pin.release();
     h->h_head.release();
-    h->h_stage.release();
     for (auto& p : h->prof)
         for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (hipEvent_t ev : h->g1_tune_ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->fin_stream) (void)hipStreamDestroy(h->fin_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->trace.on && h->g1_tune_calls)
         fprintf(stderr, "[posevo host] accumulate autotune: 131072 slots %.3f ms, 65536 slots %.3f ms -> %u\n",
                 h->g1_tune_best[0], h->g1_tune_best[1], h->g1_target_slots);
     if (h->trace.on)
-        for (auto& kv : h->trace.acc)
-            fprintf(stderr, "[posevo host] %-28s calls %6llu  avg %9.1f us\n", kv.first.c_str(),
-                    (unsigned long long)kv.second.second, kv.second.first / kv.second.second);
+        for (auto& kv : h->trace.acc) {
+            std::vector<float> v = kv.second.all;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[posevo host] %-30s calls %5llu  avg %8.1f  min %8.1f  p50 %8.1f  max %8.1f us\n",
+                    kv.first.c_str(), (unsigned long long)kv.second.n, kv.second.sum / kv.second.n, kv.second.mn,
+                    v.empty() ? 0.0 : (double)v[v.size() / 2], kv.second.mx);
+        }
     delete h;
 }
 
 int pe_set_stream(pe_engine* h, void* hip_stream)
 {
     if (!h) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
     (void)hipStreamSynchronize(h->stream);
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return PE_OK;
@@ -838,9 +1097,24 @@ int pe_set_stream(pe_engine* h, void* hip_stream)
 int pe_store_init(pe_engine* h, uint64_t genesis_time, uint64_t anchor_slot, const uint8_t anchor_root[32])
 {
     if (!h || !anchor_root) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     h->blocks.clear();
     h->index_of.clear();
+    // nothing of the previous store may resolve against the new one: committee tables (get_beacon_committee of the old
+    // chain's states), the working-state view and its participation arrays, the resident aggregate
+    for (auto& t : h->tables) { t.n_committees = 0; t.offsets.clear(); t.is_partition = false; t.stamp = 0; }
+    h->state_view_set = false;
+    h->res_valid = false;
+    if (h->n_val) {
+        const size_t n4 = (h->n_val + 3) & ~size_t(3);
+        HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, n4, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_part_prev.p, 0, n4, h->stream));
+        // the working state mirrors the registry again until pe_state_set_validators says otherwise
+        HIP_TRY(h, hipMemcpyAsync(h->d_sbalance.p, h->d_balance.p, 8 * h->n_val, hipMemcpyDeviceToDevice, h->stream));
+        launch_state_view_from_registry(h->stream, h->d_flags.as<uint8_t>(), h->d_balance.as<uint64_t>(),
+                                        h->cfg.effective_balance_increment, h->n_val, h->d_sflags.as<uint8_t>(),
+                                        h->d_incr.as<uint16_t>());
+    }
     h->genesis_time = genesis_time;
     h->time = genesis_time + h->cfg.seconds_per_slot * anchor_slot;       // pe:1085
     const uint64_t anchor_epoch = anchor_slot / h->cfg.slots_per_epoch;   // get_current_epoch(anchor_state)
@@ -869,7 +1143,7 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
 {
     if (!h || (n && (!effective_balance || !flags))) return PE_ERR_INVALID_ARG;
     if (n >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "validator index must fit 32 bits");
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     const uint64_t old_n = h->n_val;
     int rc = upload_balances(h, n, effective_balance, flags);
     if (rc) return rc;
@@ -914,13 +1188,13 @@ int pe_set_balances(pe_engine* h, uint64_t n, const uint64_t* effective_balance,
 {
     if (!h || !effective_balance || !flags) return PE_ERR_INVALID_ARG;
     if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_set_balances: n differs from the registry size");
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     return upload_balances(h, n, effective_balance, flags);
 }
 
 int pe_on_tick(pe_engine* h, uint64_t time)
 {
-    int rc = need_init(h);
+    int rc = need_init(h, /*flush=*/false);  // host-side scalars only
     if (rc) return rc;
     if (time < h->genesis_time) return fail(h, PE_ERR_INVALID_ARG, "time before genesis");
     const uint64_t previous_slot = current_slot(h);
@@ -1082,7 +1356,7 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const
                       const uint32_t* members)
 {
     if (!h || !offsets || (n_committees && offsets[n_committees] && !members)) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n_committees == 0 || n_committees % h->cfg.slots_per_epoch != 0)
         return fail(h, PE_ERR_INVALID_ARG, "n_committees must be a positive multiple of SLOTS_PER_EPOCH");
     if (offsets[0] != 0) return fail(h, PE_ERR_INVALID_ARG, "offsets[0] must be 0");
@@ -1142,7 +1416,7 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
                           uint32_t* out_offsets, uint32_t* out_members)
 {
     if (!h || !seed || (n_active && !active_indices)) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n_committees == 0 || n_committees % h->cfg.slots_per_epoch != 0)
         return fail(h, PE_ERR_INVALID_ARG, "n_committees must be a positive multiple of SLOTS_PER_EPOCH");
     if (shuffle_round_count > 255) return fail(h, PE_ERR_INVALID_ARG, "shuffle_round_count is a uint8 in the spec");
@@ -1169,7 +1443,7 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
     }
     const uint32_t nb = (n_active + 255) / 256;
     Stage st(h);
-    HIP_TRY(h, st.reserve(64 + 4ull * n_active + 4ull * (n_committees + 1) + 1024));
+    PE_TRY(st.reserve(64 + 4ull * n_active + 4ull * (n_committees + 1) + 1024));
     const size_t off_seed = st.alloc(32);
     const size_t off_idx = st.alloc(4ull * n_active + 4);
     const size_t off_offs = st.alloc(4ull * (n_committees + 1));
@@ -1211,7 +1485,7 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
 // ---------------------------------------------------------------- get_head
 int pe_get_head(pe_engine* h, uint8_t out_root[32])
 {
-    int rc = need_init(h);
+    int rc = need_init(h, /*flush=*/false);  // ordered behind the enqueued batch calls on the stream: no wait needed
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
     HostLap lap(&h->trace);
@@ -1286,62 +1560,106 @@ int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_block
 }
 
 // ---------------------------------------------------------------- on_attestation
+// Rows handed over resident (bits_arena == PE_BITS_RESIDENT): which group of the last pe_aggregate is this row?
+static bool find_resident(const pe_engine* h, const pe_attestation& a, uint32_t* g_out, uint32_t guess)
+{
+    if (!h->res_valid) return false;
+    const auto& rg = h->res_groups;
+    if (guess < rg.size() && rg[guess].byte_off == a.bits_offset && rg[guess].n_bits == a.n_bits) {  // rows in group order
+        *g_out = guess;
+        return true;
+    }
+    size_t lo = 0, hi = rg.size();
+    while (lo < hi) {  // byte_off is strictly increasing over the groups with bits; empty bitfields share an offset
+        const size_t mid = (lo + hi) / 2;
+        if (rg[mid].byte_off < a.bits_offset) lo = mid + 1; else hi = mid;
+    }
+    for (; lo < rg.size() && rg[lo].byte_off == a.bits_offset; ++lo)
+        if (rg[lo].n_bits == a.n_bits) { *g_out = (uint32_t)lo; return true; }
+    return false;
+}
+
 int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                             uint64_t arena_len, int32_t* status, uint8_t* out_aggpk96, uint32_t* out_count)
 {
-    int rc = need_init(h);
+    int rc = need_init(h, /*flush=*/false);
     if (rc) return rc;
     if (n && (!atts || !bits_arena || !status)) return PE_ERR_INVALID_ARG;
     if (out_aggpk96 && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     if (n == 0) return PE_OK;
+    const bool resident = bits_arena == PE_BITS_RESIDENT;
+    if (resident && !h->res_valid) return fail(h, PE_ERR_STATE, "PE_BITS_RESIDENT: no pe_aggregate result is resident");
     HostLap lap(&h->trace);
     // ---- sizes first: the staging block must not move once pointers into it exist ----
     uint64_t word_bound = 0;
+    std::vector<uint32_t> res_group(resident ? n : 0);
     for (uint32_t i = 0; i < n; ++i) {
         const pe_attestation& a = atts[i];
+        if (a.target_epoch >= 0xFFFFFFFEull) return fail(h, PE_ERR_INVALID_ARG, "target epoch must fit 32 bits");
+        if (resident) {
+            if (!find_resident(h, a, &res_group[i], i))
+                return fail(h, PE_ERR_INVALID_ARG, "PE_BITS_RESIDENT: row is not a row of the last pe_aggregate");
+            continue;
+        }
         if ((uint64_t)a.bits_offset + (a.n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
-        if (a.target_epoch >= 0xFFFFFFFEull) return fail(h, PE_ERR_INVALID_ARG, "target epoch must fit 32 bits");
         word_bound += (a.n_bits + 31) / 32 + 1;
     }
+    lap.mark("att.1a_sizes_resident");
     Stage st(h);
     size_t csr_bound = 4ull * n + 1024;
     for (auto& t : h->tables) csr_bound += 4ull * (t.n_committees + 1) + 512;
-    HIP_TRY(h, st.reserve(word_bound * 4 + (sizeof(AttRow) + sizeof(G1Group)) * (size_t)n + csr_bound + 4096));
-    const size_t off_words = st.alloc(word_bound * 4);
+    PE_TRY(st.reserve(word_bound * 4 + (sizeof(AttRow) + sizeof(G1Group)) * (size_t)n + csr_bound + 4096));
+    const size_t off_words = st.alloc(word_bound * 4 + 4);
     const size_t off_rows = st.alloc(sizeof(AttRow) * (size_t)n);
     const size_t off_groups = st.alloc(sizeof(G1Group) * (size_t)n);
     uint32_t* words = st.host<uint32_t>(off_words);
     AttRow* rows = st.host<AttRow>(off_rows);
+    lap.mark("att.1b_reserve");
     // ---- validate everything (validation reads only time/blocks/tables, never latest_messages) ----
     std::vector<Resolved> res(n);
-    std::vector<uint32_t> row_src;  // accepted row -> attestation index
+    auto row_src_p = std::make_shared<std::vector<uint32_t>>();  // accepted row -> attestation index
+    std::vector<uint32_t>& row_src = *row_src_p;
     row_src.reserve(n);
     uint32_t n_words = 0, n_rows = 0;
     CommitteeTable* first_table = nullptr;
     bool multi_table = false;
+    BatchMemo memo;
     for (uint32_t i = 0; i < n; ++i) {
         const pe_attestation& a = atts[i];
-        int32_t stt = validate_for_fork_choice(h, a, &res[i]);
+        int32_t stt = validate_for_fork_choice(h, a, &res[i], &memo);
         uint32_t cnt = 0;
         if (stt == PE_ATT_OK) {
             const uint32_t use = res[i].size;  // bits beyond the committee length are never read (A.6)
-            cnt = use ? pack_bits(bits_arena + a.bits_offset, use, words + n_words) : 0;
+            uint32_t bits_word;
+            if (resident) {
+                // the OR-ed bits are on the device: emptiness (and member overlap) is settled there -- an empty or
+                // gated row changes nothing -- and reported when the call completes
+                if (a.n_bits != use) stt = PE_ATT_BITS_LENGTH_MISMATCH;
+                bits_word = h->res_groups[res_group[i]].word;
+                cnt = 1;
+            } else {
+                cnt = use ? pack_bits(bits_arena + a.bits_offset, use, words + n_words) : 0;
+                bits_word = n_words;
+            }
             // is_valid_indexed_attestation (A.7): non-empty sorted-unique indices, then the signature verdict
-            if (cnt == 0) stt = PE_ATT_EMPTY_OR_INVALID_INDICES;
-            else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) stt = PE_ATT_BAD_SIGNATURE;
+            if (stt == PE_ATT_OK) {
+                if (cnt == 0) stt = PE_ATT_EMPTY_OR_INVALID_INDICES;
+                else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) stt = PE_ATT_BAD_SIGNATURE;
+            }
             if (stt == PE_ATT_OK) {
                 AttRow& r = rows[n_rows];
                 r.member_base = res[i].table->offsets[res[i].pos];
                 r.n_bits = use;
-                r.bits_word = n_words;
+                r.bits_word = bits_word;
                 r.block_idx = res[i].block_idx;
                 r.epoch_p1 = (uint32_t)a.target_epoch + 1;
                 r.order = n_rows;
                 r.flag_mask = 0;
                 r.which = 0;
                 r.slot = (uint32_t)a.slot;
-                n_words += (use + 31) / 32;
+                r.gate = resident ? 2 * res_group[i] + 1 : NONE32;
+                if (!resident) n_words += (use + 31) / 32;
                 row_src.push_back(i);
                 ++n_rows;
                 if (first_table && first_table != res[i].table) multi_table = true;
@@ -1349,10 +1667,11 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
             }
         }
         status[i] = stt;
-        if (out_count) out_count[i] = stt == PE_ATT_OK ? cnt : 0;
+        if (out_count) out_count[i] = (stt == PE_ATT_OK && !resident) ? cnt : 0;
     }
     if (out_aggpk96)
         for (uint32_t i = 0; i < n; ++i) { memset(out_aggpk96 + 96ull * i, 0, 96); out_aggpk96[96ull * i] = 0x40; }
+    lap.mark("att.1c_validate");
     if (n_rows == 0) return PE_OK;
     // Rows of different target epochs index different member arrays: make each table's rows contiguous (stable, so
     // the batch order inside a table is kept; `order` stays global).  Different tables = different epochs, where
@@ -1382,7 +1701,7 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
     std::vector<G1Plan> plans(segs.size());
     if (out_aggpk96) {
         off_out96 = ob.alloc(96ull * n_rows);
-        HIP_TRY(h, ob.ensure());
+        PE_TRY(ob.ensure());
         G1Group* groups = st.host<G1Group>(off_groups);
         for (size_t sg = 0; sg < segs.size(); ++sg) {
             const uint32_t b0 = segs[sg].second.first, e0 = segs[sg].second.second;
@@ -1405,7 +1724,7 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
         const uint32_t nc = t->n_committees;
         const size_t off_cs = st.alloc(4ull * (nc + 1));
         const size_t off_cl = st.alloc(4ull * (e0 - b0));
-        if (st.used > h->h_stage.cap) return fail(h, PE_ERR_OOM, "staging block overflow");
+        if (st.overflow()) return fail(h, PE_ERR_OOM, "staging block overflow");
         uint32_t* cs = st.host<uint32_t>(off_cs);
         uint32_t* cl = st.host<uint32_t>(off_cl);
         memset(cs, 0, 4ull * (nc + 1));
@@ -1416,7 +1735,9 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
         seg_vm[sg] = off_cs;
         seg_vm_list[sg] = off_cl;
     }
-    lap.mark("att.1_validate_pack");
+    lap.mark("att.1d_segments_csr");
+    const uint32_t* d_bits = resident ? h->arena[h->res_arena].d_res_bits.as<uint32_t>() : st.dev<uint32_t>(off_words);
+    const uint32_t* d_gates = resident ? h->arena[h->res_arena].d_res_info.as<uint32_t>() : nullptr;
     HIP_TRY(h, st.upload());
     for (size_t sg = 0; sg < segs.size(); ++sg) {
         CommitteeTable* t = segs[sg].first;
@@ -1426,32 +1747,54 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
             if (seg_vm[sg] != (size_t)-1)
                 launch_lmd_validator_major(h->stream, st.dev<AttRow>(off_rows) + b0, st.dev<uint32_t>(seg_vm[sg]),
                                            st.dev<uint32_t>(seg_vm_list[sg]), t->d_inv_comm.as<uint32_t>(),
-                                           t->d_inv_pos.as<uint32_t>(), st.dev<uint32_t>(off_words),
+                                           t->d_inv_pos.as<uint32_t>(), d_bits,
                                            h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
                                            h->d_vote_block.as<uint32_t>(),
-                                           h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr);
+                                           h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr, d_gates);
             else
                 launch_lmd_update(h->stream, st.dev<AttRow>(off_rows) + b0, e0 - b0, t->d_members.as<uint32_t>(),
-                                  st.dev<uint32_t>(off_words), h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
+                                  d_bits, h->d_flags.as<uint8_t>(), h->d_vote_key.as<uint64_t>(),
                                   h->d_vote_block.as<uint32_t>(),
-                                  h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr);
+                                  h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr, d_gates);
         }
         if (out_aggpk96) {
-            rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(),
-                                   st.dev<uint32_t>(off_words), st.dev<G1Group>(off_groups) + b0, plans[sg],
-                                   ob.dev<uint8_t>(off_out96) + 96ull * b0, nullptr);
+            g1_stream_guard(h, h->stream);
+            rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), t->d_members.as<uint32_t>(), d_bits,
+                                   st.dev<G1Group>(off_groups) + b0, plans[sg],
+                                   ob.host<uint8_t>(off_out96) + 96ull * b0, nullptr);
             if (rc) return rc;
         }
         t->stamp = ++h->table_stamp;
     }
     HIP_TRY(h, hipGetLastError());
-    if (out_aggpk96) HIP_TRY(h, ob.download());
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (out_aggpk96)
-        for (uint32_t k = 0; k < n_rows; ++k)
-            memcpy(out_aggpk96 + 96ull * row_src[k], ob.host<uint8_t>(off_out96) + 96ull * k, 96);
-    lap.mark("att.2_device");
-    return PE_OK;
+    lap.mark("att.2_launch");
+    const size_t ob_base = ob.base;
+    auto res_group_p = std::make_shared<std::vector<uint32_t>>(std::move(res_group));
+    std::shared_ptr<std::vector<uint32_t>> info_p = resident ? h->res_info_host : nullptr;
+    const int ai = h->cur;
+    auto complete = [h, row_src_p, res_group_p, n_rows, resident, status, out_aggpk96, out_count, ob_base, off_out96,
+                     info_p, ai]() -> int {
+        const std::vector<uint32_t>& src = *row_src_p;
+        if (out_aggpk96)
+            for (uint32_t k = 0; k < n_rows; ++k)
+                memcpy(out_aggpk96 + 96ull * src[k], h->arena[ai].h_pin.as<uint8_t>() + ob_base + off_out96 + 96ull * k, 96);
+        if (resident) {  // emptiness / overlap of the resident unions, now that the aggregate's counts are here
+            const std::vector<uint32_t>& info = *info_p;
+            for (uint32_t k = 0; k < n_rows; ++k) {
+                const uint32_t i = src[k], g = (*res_group_p)[i];
+                if (2 * (size_t)g + 1 >= info.size()) return fail(h, PE_ERR_STATE, "resident aggregate did not complete");
+                const uint32_t cnt = info[2 * g], overlap = info[2 * g + 1];
+                if (overlap) status[i] = PE_ATT_BAD_SIGNATURE;
+                else if (cnt == 0) status[i] = PE_ATT_EMPTY_OR_INVALID_INDICES;
+                if (out_count) out_count[i] = status[i] == PE_ATT_OK ? cnt : 0;
+            }
+        }
+        return PE_OK;
+    };
+    HostLap lap2(&h->trace);
+    rc = finish_call(h, st, ob, complete);
+    lap2.mark("att.3_wait_outputs");
+    return rc;
 }
 
 int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
@@ -1459,7 +1802,7 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
                                 uint64_t out_indices_cap)
 {
     if (!h || !out_offsets || (n && (!atts || !bits_arena || !status))) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     out_offsets[0] = 0;
     if (n == 0) return PE_OK;
     uint64_t word_bound = 0;
@@ -1469,7 +1812,7 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
         word_bound += (atts[i].n_bits + 31) / 32 + 1;
     }
     Stage st(h);
-    HIP_TRY(h, st.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)(n + 1) + 4096));
+    PE_TRY(st.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)(n + 1) + 4096));
     const size_t off_words = st.alloc(word_bound * 4);
     const size_t off_rows = st.alloc(sizeof(AttRow) * (size_t)n);
     const size_t off_offs = st.alloc(4ull * (n + 1));
@@ -1501,6 +1844,7 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
                     r.n_bits = size;
                     r.bits_word = n_words;
                     r.block_idx = r.epoch_p1 = r.order = r.flag_mask = r.which = r.slot = 0;
+                    r.gate = NONE32;
                     offs[n_rows] = (uint32_t)total;
                     n_words += (size + 31) / 32;
                     row_table.push_back(t);
@@ -1520,7 +1864,7 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
     if (!out_indices) return PE_ERR_INVALID_ARG;
     OutBlock ob(h);
     const size_t off_idx = ob.alloc(4ull * total);
-    HIP_TRY(h, ob.ensure());
+    PE_TRY(ob.ensure());
     HIP_TRY(h, st.upload());
     for (uint32_t k = 0; k < n_rows;) {  // one launch per run of rows sharing a table (members array)
         uint32_t e = k + 1;
@@ -1538,6 +1882,18 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
 }
 
 // ---------------------------------------------------------------- aggregation
+struct AggState {  // what the completion of one pe_aggregate needs after the wait
+    std::vector<uint32_t> rep, gstart, order, gof, out_byte_off, out_word;
+    std::vector<uint32_t> all_valid;
+    const pe_attestation* atts = nullptr;
+    pe_attestation* out_atts = nullptr;
+    uint8_t *out_bits_arena = nullptr, *out_sig96 = nullptr, *out_aggpk96 = nullptr;
+    uint32_t* out_count = nullptr;
+    uint32_t ng = 0;
+    size_t base = 0, off_obits = 0, off_oinfo = 0, off_opk = 0, off_osig = 0;
+    int tune_arm = -1;
+};
+
 static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                           uint64_t arena_len, const uint8_t* sig_points96, pe_attestation* out_atts,
                           uint32_t* out_n_groups, uint32_t* group_of, uint8_t* out_bits_arena, uint64_t out_arena_cap,
@@ -1552,6 +1908,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     *out_n_groups = 0;
     if (n == 0) return PE_OK;
     HostLap lap(&h->trace);
+    auto stp = std::make_shared<AggState>();
+    AggState& A = *stp;
     // ---- group by identical AttestationData + n_bits, in order of first appearance (flat open addressing) ----
     auto hash_att = [](const pe_attestation& a) {
         uint64_t hsh = a.slot * 0x9E3779B97F4A7C15ull ^ (a.index + 0x7F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
@@ -1565,12 +1923,15 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     uint32_t tab_size = 16;
     while (tab_size < 2 * n) tab_size <<= 1;
     std::vector<uint32_t> table(tab_size, NONE32);  // slot -> group id
-    std::vector<uint32_t> gof(n), rep, gcount;      // rep[g] = first attestation of group g
-    uint64_t word_total = 0;
+    std::vector<uint32_t>& gof = A.gof;
+    std::vector<uint32_t>& rep = A.rep;             // rep[g] = first attestation of group g
+    std::vector<uint32_t> gcount;
+    gof.resize(n);
+    uint64_t lo = ~0ull, hi = 0;                    // byte span of the arena this call reads
     for (uint32_t i = 0; i < n; ++i) {
-        if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
-            return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
-        word_total += (atts[i].n_bits + 31) / 32;
+        const uint64_t b0 = atts[i].bits_offset, b1 = b0 + (atts[i].n_bits + 7) / 8;
+        if (b1 > arena_len) return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        if (atts[i].n_bits) { lo = std::min(lo, b0); hi = std::max(hi, b1); }
         uint32_t slot = (uint32_t)hash_att(atts[i]) & (tab_size - 1);
         uint32_t g;
         for (;;) {
@@ -1589,8 +1950,15 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         gof[i] = g;
         gcount[g] += 1;
     }
+    if (lo > hi) lo = hi = 0;
+    lo &= ~uint64_t(3);                              // keep the members' word alignment relative to the upload
+    if (hi - lo >= 0xFFFFFFF0ull) return fail(h, PE_ERR_CAPACITY, "bit arena span exceeds 4 GiB");
     const uint32_t ng = (uint32_t)rep.size();
-    std::vector<uint32_t> gstart(ng + 1, 0), order(n);  // counting sort: members of group g, in input order
+    A.ng = ng;
+    std::vector<uint32_t>& gstart = A.gstart;        // counting sort: members of group g, in input order
+    std::vector<uint32_t>& order = A.order;
+    gstart.assign(ng + 1, 0);
+    order.resize(n);
     for (uint32_t g = 0; g < ng; ++g) gstart[g + 1] = gstart[g] + gcount[g];
     {
         std::vector<uint32_t> cur(gstart.begin(), gstart.end() - 1);
@@ -1625,48 +1993,54 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         out_bytes += (atts[rep[g]].n_bits + 7) / 8;
     }
     if (out_bytes > out_arena_cap) return fail(h, PE_ERR_CAPACITY, "output bit arena too small");
+    const size_t span = (size_t)(hi - lo);
     Stage st(h);
-    HIP_TRY(h, st.reserve(word_total * 4 + sizeof(UnionGroup) * (size_t)ng + 4ull * n + 2 * sizeof(G1Group) * (size_t)ng +
-                          4ull * n + 8192));
-    const size_t off_words = st.alloc(word_total * 4 + 4);
+    PE_TRY(st.reserve(span + 64 + sizeof(UnionGroup) * (size_t)ng + 4ull * n + 2 * sizeof(G1Group) * (size_t)ng +
+                      4ull * n + 8192));
+    const size_t off_arena = st.alloc(span + 16);
     const size_t off_ug = st.alloc(sizeof(UnionGroup) * (size_t)ng);
-    const size_t off_uw = st.alloc(4ull * n);
+    const size_t off_ub = st.alloc(4ull * n);
     const size_t off_g1 = st.alloc(sizeof(G1Group) * (size_t)ng);
     const size_t off_g1s = st.alloc(sizeof(G1Group) * (size_t)ng);
     const size_t off_idx = st.alloc(4ull * n);
-    uint32_t* words = st.host<uint32_t>(off_words);
+    // the caller's bits travel as they are (one copy into the pinned block): k_bits_union reads the members at
+    // their byte offsets, masks the tail of the last word and never needs re-packed words
+    lap.mark("agg.2a_resolve_reserve");
+    memcpy(st.host<uint8_t>(off_arena), bits_arena + lo, span);
+    memset(st.host<uint8_t>(off_arena) + span, 0, 16);
+    lap.mark("agg.2b_memcpy_arena");
     UnionGroup* ug = st.host<UnionGroup>(off_ug);
-    uint32_t* uwords = st.host<uint32_t>(off_uw);
-    std::vector<uint32_t> att_word(n);
-    {
-        uint32_t w = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            att_word[i] = w;
-            const uint32_t nb = atts[i].n_bits;
-            if (nb) pack_bits(bits_arena + atts[i].bits_offset, nb, words + w);
-            w += (nb + 31) / 32;
-        }
-    }
-    std::vector<uint32_t> out_byte_off(ng);
+    uint32_t* ubytes = st.host<uint32_t>(off_ub);
+    A.out_byte_off.resize(ng);
+    A.out_word.resize(ng);
+    A.all_valid.resize(ng);
     {
         uint32_t ow = 0, obytes = 0;
         for (uint32_t g = 0; g < ng; ++g) {
             ug[g].list_start = gstart[g];
             ug[g].n_atts = gcount[g];
-            ug[g].n_words = (atts[rep[g]].n_bits + 31) / 32;
+            ug[g].n_bits = atts[rep[g]].n_bits;
             ug[g].out_word = ow;
-            ow += ug[g].n_words;
-            out_byte_off[g] = obytes;
+            A.out_word[g] = ow;
+            ow += (atts[rep[g]].n_bits + 31) / 32;
+            A.out_byte_off[g] = obytes;
             obytes += (atts[rep[g]].n_bits + 7) / 8;
+            uint32_t all_valid = PE_ATT_FLAG_SIGNATURE_VALID;
+            for (uint32_t k = gstart[g]; k < gstart[g + 1]; ++k) all_valid &= atts[order[k]].flags;
+            A.all_valid[g] = all_valid;
         }
-        for (uint32_t k = 0; k < n; ++k) uwords[k] = att_word[order[k]];
+        for (uint32_t k = 0; k < n; ++k) ubytes[k] = (uint32_t)(atts[order[k]].bits_offset - lo);
     }
+    lap.mark("agg.2c_union_groups");
+    // resident outputs: the OR-ed bits and {popcount, overlap} stay on the device for the calls that follow
+    PE_TRY(ensure_quiesced(h, h->A().d_res_bits, out_words * 4 + 64));
+    PE_TRY(ensure_quiesced(h, h->A().d_res_info, 8ull * ng + 64));
     OutBlock ob(h);
-    const size_t off_ouw = ob.alloc(out_words * 4 + 4);
-    const size_t off_ocnt = ob.alloc(4ull * ng);
+    const size_t off_obits = ob.alloc(out_words * 4 + 4);
+    const size_t off_oinfo = ob.alloc(8ull * ng);
     const size_t off_opk = out_aggpk96 ? ob.alloc(96ull * ng) : 0;
     const size_t off_osig = out_sig96 ? ob.alloc(96ull * ng) : 0;
-    HIP_TRY(h, ob.ensure());
+    PE_TRY(ob.ensure());
     G1Plan plan_pk, plan_sig;
     int tune_arm = -1;  // >= 0: this call is an autotune trial of shape `tune_arm`
     if (want_pk) {
@@ -1686,7 +2060,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         plan_g1(ng, [&](uint32_t g) { return gres[g].size; }, gr, &plan_pk, G1_WG, target);
         for (uint32_t g = 0; g < ng; ++g) {
             gr[g].member_start = table_pk->offsets[gres[g].pos];
-            gr[g].bits_word = ug[g].out_word;  // the OR-ed bits, device resident: no round trip
+            gr[g].bits_word = A.out_word[g];  // the OR-ed bits, device resident: no round trip
         }
     }
     if (out_sig96) {
@@ -1695,71 +2069,158 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         for (uint32_t g = 0; g < ng; ++g) gr[g].member_start = gstart[g];
         memcpy(st.host<uint32_t>(off_idx), order.data(), 4ull * n);  // points indexed by input attestation
     }
-    lap.mark("agg.2_pack_resolve");
+    lap.mark("agg.2d_ensure_plan");
+    if (st.overflow()) return fail(h, PE_ERR_OOM, "staging block overflow");
+    // the rows of the result are host data: complete at return, also inside a pipeline (bits / counts / sums follow)
+    for (uint32_t g = 0; g < ng; ++g) {
+        out_atts[g] = atts[rep[g]];
+        out_atts[g].bits_offset = A.out_byte_off[g];
+        out_atts[g].flags = (atts[rep[g]].flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | A.all_valid[g];
+    }
+    if (group_of) memcpy(group_of, gof.data(), 4ull * n);
+    *out_n_groups = ng;
+    h->res_groups.resize(ng);
+    for (uint32_t g = 0; g < ng; ++g)
+        h->res_groups[g] = {A.out_byte_off[g], atts[rep[g]].n_bits, A.out_word[g], A.all_valid[g]};
+    auto info_p = std::make_shared<std::vector<uint32_t>>();
+    h->res_info_host = info_p;
+    h->res_valid = true;
+    h->res_arena = h->cur;
+    ++h->res_generation;
+    lap.mark("agg.2e_out_rows");
     // ---- device ----
+    hipStream_t ms = h->stream;
+    // pipelined + host outputs: the G1 sums run on the side stream, beside the fork-choice kernels of the calls that
+    // follow (they only need the union).  Sharded partials stay on the main stream, where the caller's collective is.
+    static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
+    const bool on_side = want_pk && !dev_partials && h->pipelining && side_ok && h->side_stream && h->stream == h->own_stream;
+    hipStream_t gs = on_side ? h->side_stream : ms;
+    // a previous aggregate of THIS pipeline may still read the arena's d_res_* on the side stream
+    if (h->A().side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
     HIP_TRY(h, st.upload());
+    lap.mark("agg.3a_h2d");
     {
         ProfScope ps(h, PE_KERNEL_BITS_UNION);
-        launch_bits_union(h->stream, st.dev<UnionGroup>(off_ug), ng, st.dev<uint32_t>(off_uw),
-                          st.dev<uint32_t>(off_words), ob.dev<uint32_t>(off_ouw), ob.dev<uint32_t>(off_ocnt));
+        // the kernels write their host-bound outputs straight into the pinned block (host-coherent, like the head
+        // word): no device-to-host copy commands in a step
+        launch_bits_union(ms, st.dev<UnionGroup>(off_ug), ng, st.dev<uint32_t>(off_ub), st.dev<uint8_t>(off_arena),
+                          h->A().d_res_bits.as<uint32_t>(), h->A().d_res_info.as<uint32_t>(), ob.host<uint32_t>(off_obits),
+                          ob.host<uint32_t>(off_oinfo));
     }
+    lap.mark("agg.3b_union");
     if (want_pk) {
-        if (tune_arm >= 0) {
-            if (!h->g1_tune_ev[0] && (hipEventCreate(&h->g1_tune_ev[0]) != hipSuccess ||
-                                      hipEventCreate(&h->g1_tune_ev[1]) != hipSuccess)) {
-                h->g1_tune_ev[0] = h->g1_tune_ev[1] = nullptr;
-                tune_arm = -1;
+        pe_engine::PipeArena* arena = &h->A();
+        const uint32_t* d_points = h->d_points.as<uint32_t>();
+        const uint32_t* d_members = table_pk->d_members.as<uint32_t>();
+        const uint32_t* d_union = arena->d_res_bits.as<uint32_t>();
+        const G1Group* d_groups = st.dev<G1Group>(off_g1);
+        uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
+        uint32_t* jac = static_cast<uint32_t*>(dev_partials);
+        const bool defer = on_side && h->streaming;
+        if (defer) tune_arm = -1;  // the autotune's event pair assumes launch and read-back in one call
+        auto launch_g1 = [h, arena, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, on_side, gs, tune_arm]() -> int {
+            hipStream_t ms_ = h->stream;
+            if (on_side) {
+                // everything enqueued on the engine's stream so far comes first: the union this sum reads, and -- when
+                // the launch was deferred to the end of a streaming pipeline -- the step's fork-choice kernels, which
+                // would otherwise queue behind an accumulation that fills every CU
+                HIP_TRY(h, hipEventRecord(h->ev_fork, ms_));
+                HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
+                // a second aggregate in the SAME pipeline shares this arena's d_partials with the first one's finish
+                if (arena->side_used) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
             } else {
-                (void)hipEventRecord(h->g1_tune_ev[0], h->stream);
+                g1_stream_guard(h, gs);
             }
+            int arm = tune_arm;
+            if (arm >= 0) {
+                if (!h->g1_tune_ev[0] && (hipEventCreate(&h->g1_tune_ev[0]) != hipSuccess ||
+                                          hipEventCreate(&h->g1_tune_ev[1]) != hipSuccess)) {
+                    h->g1_tune_ev[0] = h->g1_tune_ev[1] = nullptr;
+                    arm = -1;
+                } else {
+                    (void)hipEventRecord(h->g1_tune_ev[0], gs);
+                }
+            }
+            int rc = launch_g1_planned(h, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, gs,
+                                       on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr);
+            if (rc) return rc;
+            if (arm >= 0) (void)hipEventRecord(h->g1_tune_ev[1], on_side ? h->fin_stream : gs);
+            if (on_side) {
+                HIP_TRY(h, hipEventRecord(h->ev_join, h->fin_stream));
+                h->side_busy = true;
+                h->side_ever = true;
+                arena->side_used = true;
+            }
+            return PE_OK;
+        };
+        if (defer) {
+            // scratch sizes are settled now, while nothing of the launch is in flight
+            PE_TRY(ensure_quiesced(h, arena->d_partials,
+                                   std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
+            h->deferred.push_back(launch_g1);
+        } else {
+            int rc = launch_g1();
+            if (rc) return rc;
         }
-        int rc = launch_g1_planned(h, h->d_points.as<uint32_t>(), table_pk->d_members.as<uint32_t>(),
-                                   ob.dev<uint32_t>(off_ouw), st.dev<G1Group>(off_g1), plan_pk,
-                                   out_aggpk96 ? ob.dev<uint8_t>(off_opk) : nullptr,
-                                   static_cast<uint32_t*>(dev_partials));
-        if (rc) return rc;
-        if (tune_arm >= 0) (void)hipEventRecord(h->g1_tune_ev[1], h->stream);
+        lap.mark("agg.3d_g1_launch");
         table_pk->stamp = ++h->table_stamp;
     }
-    if (out_sig96) {  // bls.Aggregate: sum of the members' signature points
+    if (out_sig96) {  // bls.Aggregate: sum of the members' signature points (engine-owned scratch: completes in-call)
+        g1_stream_guard(h, ms);
         HIP_TRY(h, h->d_tmp_be.ensure(96ull * n));
         HIP_TRY(h, h->d_tmp_points.ensure(4ull * G1_ROW_WORDS * n));
-        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, h->stream));
-        launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, ms));
+        launch_g1_convert(ms, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
         int rc = launch_g1_planned(h, h->d_tmp_points.as<uint32_t>(), st.dev<uint32_t>(off_idx), nullptr,
-                                   st.dev<G1Group>(off_g1s), plan_sig, ob.dev<uint8_t>(off_osig), nullptr);
+                                   st.dev<G1Group>(off_g1s), plan_sig, ob.host<uint8_t>(off_osig), nullptr, ms);
         if (rc) return rc;
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, ob.download());
-    lap.mark("agg.3_launch");
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    lap.mark("agg.4_wait");
-    if (tune_arm >= 0) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, h->g1_tune_ev[0], h->g1_tune_ev[1]) == hipSuccess && ms > 0)
-            h->g1_tune_best[tune_arm] = std::min(h->g1_tune_best[tune_arm], ms);
-        if (++h->g1_tune_calls >= 4)
-            h->g1_target_slots = h->g1_tune_best[1] < h->g1_tune_best[0] ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
-    }
-    // ---- outputs ----
-    const uint8_t* obits = ob.host<uint8_t>(off_ouw);
-    const uint32_t* ocnt = ob.host<uint32_t>(off_ocnt);
-    for (uint32_t g = 0; g < ng; ++g) {
-        out_atts[g] = atts[rep[g]];
-        out_atts[g].bits_offset = out_byte_off[g];
-        uint32_t all_valid = PE_ATT_FLAG_SIGNATURE_VALID;
-        for (uint32_t k = gstart[g]; k < gstart[g + 1]; ++k) all_valid &= atts[order[k]].flags;
-        out_atts[g].flags = (atts[rep[g]].flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | all_valid;
-        memcpy(out_bits_arena + out_byte_off[g], obits + 4ull * ug[g].out_word, (out_atts[g].n_bits + 7) / 8);
-        if (out_count) out_count[g] = ocnt[g];
-    }
-    if (out_aggpk96) memcpy(out_aggpk96, ob.host<uint8_t>(off_opk), 96ull * ng);
-    if (out_sig96) memcpy(out_sig96, ob.host<uint8_t>(off_osig), 96ull * ng);
-    if (group_of) memcpy(group_of, gof.data(), 4ull * n);
-    *out_n_groups = ng;
-    lap.mark("agg.5_outputs");
-    return PE_OK;
+    lap.mark("agg.3e_d2h_pk_join");
+    A.atts = atts;
+    A.out_atts = out_atts;
+    A.out_bits_arena = out_bits_arena;
+    A.out_sig96 = out_sig96;
+    A.out_aggpk96 = out_aggpk96;
+    A.out_count = out_count;
+    A.base = ob.base;
+    A.off_obits = off_obits;
+    A.off_oinfo = off_oinfo;
+    A.off_opk = off_opk;
+    A.off_osig = off_osig;
+    A.tune_arm = tune_arm;
+    const int ai = h->cur;
+    auto complete = [h, stp, info_p, ai]() -> int {
+        AggState& S = *stp;
+        const uint8_t* pin = h->arena[ai].h_pin.as<uint8_t>() + S.base;
+        if (S.tune_arm >= 0) {
+            float ms_ = 0;
+            if (hipEventElapsedTime(&ms_, h->g1_tune_ev[0], h->g1_tune_ev[1]) == hipSuccess && ms_ > 0)
+                h->g1_tune_best[S.tune_arm] = std::min(h->g1_tune_best[S.tune_arm], ms_);
+            if (++h->g1_tune_calls >= 4)
+                h->g1_target_slots = h->g1_tune_best[1] < h->g1_tune_best[0] ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
+        }
+        const uint8_t* obits = pin + S.off_obits;
+        const uint32_t* oinfo = reinterpret_cast<const uint32_t*>(pin + S.off_oinfo);
+        for (uint32_t g = 0; g < S.ng; ++g) {
+            const uint32_t nb = S.out_atts[g].n_bits;
+            memcpy(S.out_bits_arena + S.out_byte_off[g], obits + 4ull * S.out_word[g], (nb + 7) / 8);
+            if (S.out_count) S.out_count[g] = oinfo[2 * g];
+            if (oinfo[2 * g + 1]) {
+                // members overlap: the summed signature counts a validator twice while bits and pubkey count it
+                // once -- such an aggregate can never verify (A.8).  Say so instead of returning it as valid.
+                S.out_atts[g].flags = (S.out_atts[g].flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | PE_ATT_FLAG_OVERLAPPING_BITS;
+            }
+        }
+        info_p->assign(oinfo, oinfo + 2 * (size_t)S.ng);
+        if (S.out_aggpk96) memcpy(S.out_aggpk96, pin + S.off_opk, 96ull * S.ng);
+        if (S.out_sig96) memcpy(S.out_sig96, pin + S.off_osig, 96ull * S.ng);
+        return PE_OK;
+    };
+    HostLap lap2(&h->trace);
+    const int rc = finish_call(h, st, ob, complete, /*force_sync=*/out_sig96 != nullptr);
+    lap2.mark("agg.4_wait_outputs");
+    return rc;
 }
 
 int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena, uint64_t arena_len,
@@ -1785,10 +2246,12 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                                  const uint8_t* bits_arena, uint64_t arena_len, int32_t* status,
                                  uint64_t* out_numerators)
 {
-    int rc = need_init(h);
+    int rc = need_init(h, /*flush=*/false);
     if (rc) return rc;
     if (!st || (n && (!atts || !bits_arena || !status || !out_numerators))) return PE_ERR_INVALID_ARG;
     if (n == 0) return PE_OK;
+    const bool resident = bits_arena == PE_BITS_RESIDENT;
+    if (resident && !h->res_valid) return fail(h, PE_ERR_STATE, "PE_BITS_RESIDENT: no pe_aggregate result is resident");
     uint32_t tip;
     if (!find_block(h, to_root(st->chain_tip_root), &tip)) return fail(h, PE_ERR_UNKNOWN_ROOT, "chain tip unknown");
     const uint64_t spe = h->cfg.slots_per_epoch;
@@ -1801,14 +2264,30 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
 
     HostLap lap(&h->trace);
     uint64_t word_bound = 0;
+    auto res_group_p = std::make_shared<std::vector<uint32_t>>(resident ? n : 0);
+    std::vector<uint32_t>& res_group = *res_group_p;
     for (uint32_t i = 0; i < n; ++i) {
+        if (resident) {
+            if (!find_resident(h, atts[i], &res_group[i], i))
+                return fail(h, PE_ERR_INVALID_ARG, "PE_BITS_RESIDENT: row is not a row of the last pe_aggregate");
+            continue;
+        }
         if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
         word_bound += (atts[i].n_bits + 31) / 32 + 1;
     }
+    // get_block_root* walks from the chain tip: one per distinct slot asked, not one per row
+    uint64_t anc_slot[64];
+    uint32_t anc_idx[64];
+    for (int k = 0; k < 64; ++k) anc_slot[k] = ~0ull;
+    auto tip_ancestor = [&](uint64_t slot) {
+        const int k = (int)(slot & 63);
+        if (anc_slot[k] != slot) { anc_slot[k] = slot; anc_idx[k] = get_ancestor(h, tip, slot); }
+        return anc_idx[k];
+    };
     Stage stg(h);
-    HIP_TRY(h, stg.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)n + 4096));
-    const size_t off_words = stg.alloc(word_bound * 4);
+    PE_TRY(stg.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)n + 4096));
+    const size_t off_words = stg.alloc(word_bound * 4 + 4);
     const size_t off_rows = stg.alloc(sizeof(AttRow) * (size_t)n);
     const size_t off_nslot = stg.alloc(4ull * n);
     uint32_t* words = stg.host<uint32_t>(off_words);
@@ -1844,9 +2323,9 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
             else {
                 // get_block_root(state, epoch) / get_block_root_at_slot(state, slot): the state's chain is the
                 // ancestry of chain_tip_root (both slots are < state.slot by pe:726)
-                const uint32_t tgt_blk = get_ancestor(h, tip, a.target_epoch * spe);
+                const uint32_t tgt_blk = tip_ancestor(a.target_epoch * spe);
                 const bool matching_target = memcmp(h->blocks[tgt_blk].root.data(), a.target_root, 32) == 0;
-                const uint32_t head_blk = get_ancestor(h, tip, a.slot);
+                const uint32_t head_blk = tip_ancestor(a.slot);
                 const bool matching_head = matching_target && memcmp(h->blocks[head_blk].root.data(), a.beacon_block_root, 32) == 0;
                 const uint64_t delay = st->slot - a.slot;
                 if (delay <= sqrt_spe) flag_mask |= 1u;                                        // TIMELY_SOURCE
@@ -1855,14 +2334,16 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
             }
         }
         if (s == PE_ATT_OK) {
-            const uint32_t cnt = size ? pack_bits(bits_arena + a.bits_offset, size, words + n_words) : 0;
+            // resident rows: emptiness / member overlap are settled on the device and reported at completion
+            const uint32_t cnt = resident ? 1u : size ? pack_bits(bits_arena + a.bits_offset, size, words + n_words) : 0;
             if (cnt == 0) s = PE_ATT_EMPTY_OR_INVALID_INDICES;                                 // pe:736
             else if (!(a.flags & PE_ATT_FLAG_SIGNATURE_VALID)) s = PE_ATT_BAD_SIGNATURE;
             if (s == PE_ATT_OK) {
                 Acc e;
                 e.row.member_base = t->offsets[pos];
                 e.row.n_bits = size;
-                e.row.bits_word = n_words;
+                e.row.bits_word = resident ? h->res_groups[res_group[i]].word : n_words;
+                e.row.gate = resident ? 2 * res_group[i] + 1 : NONE32;
                 e.row.block_idx = 0;
                 e.row.epoch_p1 = 0;
                 e.row.order = 0;
@@ -1873,7 +2354,7 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                 e.table = t;
                 e.pos = (uint32_t)pos;
                 acc.push_back(e);
-                n_words += (size + 31) / 32;
+                if (!resident) n_words += (size + 31) / 32;
             }
         }
         status[i] = s;
@@ -1916,32 +2397,55 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     for (size_t k = 0; k < ord.size(); ++k) { rows[k] = acc[ord[k]].row; nslot[k] = acc[ord[k]].src; }
     OutBlock ob(h);
     const size_t off_num = ob.alloc(8ull * n);
-    HIP_TRY(h, ob.ensure());
+    PE_TRY(ob.ensure());
+    const uint32_t* d_bits = resident ? h->arena[h->res_arena].d_res_bits.as<uint32_t>() : stg.dev<uint32_t>(off_words);
+    const uint32_t* d_gates = resident ? h->arena[h->res_arena].d_res_info.as<uint32_t>() : nullptr;
     HIP_TRY(h, stg.upload());
-    HIP_TRY(h, hipMemsetAsync(ob.dev<uint8_t>(off_num), 0, 8ull * n, h->stream));
+    memset(ob.host<uint8_t>(off_num), 0, 8ull * n);  // the kernel writes the numerators straight into the pinned block
     for (size_t k = 0; k < ord.size();) {
         size_t e = k + 1;
         while (e < ord.size() && round_of[ord[e]] == round_of[ord[k]] && acc[ord[e]].table == acc[ord[k]].table) ++e;
         ProfScope ps(h, PE_KERNEL_PARTICIPATION);
         launch_participation(h->stream, stg.dev<AttRow>(off_rows) + k, (uint32_t)(e - k),
-                             acc[ord[k]].table->d_members.as<uint32_t>(), stg.dev<uint32_t>(off_words),
+                             acc[ord[k]].table->d_members.as<uint32_t>(), d_bits,
                              h->d_incr.as<uint16_t>(), st->base_reward_per_increment, h->d_part_cur.as<uint32_t>(),
-                             h->d_part_prev.as<uint32_t>(), ob.dev<uint64_t>(off_num), stg.dev<uint32_t>(off_nslot) + k);
+                             h->d_part_prev.as<uint32_t>(), ob.host<uint64_t>(off_num), stg.dev<uint32_t>(off_nslot) + k,
+                             d_gates);
         k = e;
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, ob.download());
     lap.mark("proc.2_rounds_h2d_launch");
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    memcpy(out_numerators, ob.host<uint64_t>(off_num), 8ull * n);
-    lap.mark("proc.3_wait_d2h");
-    return PE_OK;
+    auto src_p = std::make_shared<std::vector<uint32_t>>();
+    if (resident)
+        for (size_t k = 0; k < acc.size(); ++k) src_p->push_back(acc[k].src);
+    std::shared_ptr<std::vector<uint32_t>> info_p = resident ? h->res_info_host : nullptr;
+    const size_t ob_base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, n, out_numerators, status, ob_base, off_num, resident, src_p, res_group_p, info_p, ai]() -> int {
+        memcpy(out_numerators, h->arena[ai].h_pin.as<uint8_t>() + ob_base + off_num, 8ull * n);
+        if (resident) {
+            const std::vector<uint32_t>& info = *info_p;
+            for (uint32_t i : *src_p) {
+                const uint32_t g = (*res_group_p)[i];
+                if (2 * (size_t)g + 1 >= info.size()) return fail(h, PE_ERR_STATE, "resident aggregate did not complete");
+                if (info[2 * g + 1]) status[i] = PE_ATT_BAD_SIGNATURE;
+                else if (info[2 * g] == 0) status[i] = PE_ATT_EMPTY_OR_INVALID_INDICES;
+            }
+        }
+        return PE_OK;
+    };
+    HostLap lap2(&h->trace);
+    rc = finish_call(h, stg, ob, complete);
+    lap2.mark("proc.3_wait_d2h");
+    return rc;
 }
+
+
 
 int pe_participation_set(pe_engine* h, int which, const uint8_t* flags, uint64_t n)
 {
     if (!h || !flags || n != h->n_val || (which != 0 && which != 1)) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     DevBuf& b = which ? h->d_part_prev : h->d_part_cur;
     HIP_TRY(h, hipMemcpyAsync(b.p, flags, n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1950,7 +2454,7 @@ int pe_participation_set(pe_engine* h, int which, const uint8_t* flags, uint64_t
 int pe_participation_get(pe_engine* h, int which, uint8_t* out_flags, uint64_t n)
 {
     if (!h || !out_flags || n != h->n_val || (which != 0 && which != 1)) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     DevBuf& b = which ? h->d_part_prev : h->d_part_cur;
     HIP_TRY(h, hipMemcpyAsync(out_flags, b.p, n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1969,7 +2473,7 @@ int pe_state_set_validators(pe_engine* h, uint64_t n, const uint64_t* effective_
 {
     if (!h || (n && (!effective_balance || !flags))) return PE_ERR_INVALID_ARG;
     if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_state_set_validators: n differs from the registry size");
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     std::vector<uint16_t> incr(n);
     const uint64_t inc = h->cfg.effective_balance_increment;
     for (uint64_t i = 0; i < n; ++i) {
@@ -1991,10 +2495,10 @@ int pe_state_set_validators(pe_engine* h, uint64_t n, const uint64_t* effective_
 int pe_ffg_balances(pe_engine* h, uint64_t out[3])
 {
     if (!h || !out) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     OutBlock ob(h);
     const size_t off = ob.alloc(8ull * 3 * 256);
-    HIP_TRY(h, ob.ensure());
+    PE_TRY(ob.ensure());
     uint32_t blocks = 0;
     if (h->n_val) {
         blocks = launch_ffg_balances(h->stream, h->d_sbalance.as<uint64_t>(), h->d_sflags.as<uint8_t>(),
@@ -2027,7 +2531,7 @@ static int g1_sum_common(pe_engine* h, const uint32_t* d_pts, uint64_t n_pts, co
         return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
     }
     Stage st(h);
-    HIP_TRY(h, st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
+    PE_TRY(st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
     const size_t off_g = st.alloc(sizeof(G1Group) * (size_t)n_groups);
     const size_t off_i = st.alloc(4ull * total + 4);
     G1Group* gr = st.host<G1Group>(off_g);
@@ -2037,7 +2541,7 @@ static int g1_sum_common(pe_engine* h, const uint32_t* d_pts, uint64_t n_pts, co
     if (index) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
     OutBlock ob(h);
     const size_t off_o = out96_host ? ob.alloc(96ull * n_groups) : 0;
-    HIP_TRY(h, ob.ensure());
+    PE_TRY(ob.ensure());
     HIP_TRY(h, st.upload());
     int rc = launch_g1_planned(h, d_pts, index ? st.dev<uint32_t>(off_i) : nullptr, nullptr, st.dev<G1Group>(off_g), plan,
                                out96_host ? ob.dev<uint8_t>(off_o) : nullptr, dev_jac);
@@ -2052,7 +2556,7 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
               uint32_t n_groups, uint8_t* out96)
 {
     if (!h || !offsets || !out96) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n_groups == 0) return PE_OK;
     const uint32_t* d_pts;
     uint64_t np;
@@ -2075,7 +2579,7 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
 int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, void* dev_partials)
 {
     if (!h || !offsets || !dev_partials) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
     if (n_groups == 0) return PE_OK;
     return g1_sum_common(h, h->d_points.as<uint32_t>(), h->n_val, index, offsets, n_groups, nullptr,
@@ -2085,7 +2589,7 @@ int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, 
 int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups, uint8_t* out96)
 {
     if (!h || !dev_gathered || !out96 || n_ranks == 0) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n_groups == 0) return PE_OK;
     HIP_TRY(h, h->d_out96.ensure(96ull * n_groups));
     {
@@ -2094,10 +2598,10 @@ int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint3
                          h->d_out96.as<uint8_t>(), nullptr);
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, h->h_pin.ensure(96ull * n_groups));
-    HIP_TRY(h, hipMemcpyAsync(h->h_pin.p, h->d_out96.p, 96ull * n_groups, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, h->A().h_pin.ensure(96ull * n_groups));
+    HIP_TRY(h, hipMemcpyAsync(h->A().h_pin.p, h->d_out96.p, 96ull * n_groups, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    memcpy(out96, h->h_pin.p, 96ull * n_groups);
+    memcpy(out96, h->A().h_pin.p, 96ull * n_groups);
     return PE_OK;
 }
 
@@ -2127,7 +2631,7 @@ static int g1_decompress_common(pe_engine* h, const uint8_t* in48, uint64_t n, u
 int pe_g1_decompress(pe_engine* h, const uint8_t* in48, uint64_t n, uint8_t* out96, int32_t* status)
 {
     if (!h || (n && (!in48 || !out96 || !status))) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n == 0) return PE_OK;
     uint64_t n_bad = 0;
     return g1_decompress_common(h, in48, n, nullptr, out96, status, &n_bad);
@@ -2137,7 +2641,7 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
 {
     if (!h || (n && (!pubkeys48 || !status))) return PE_ERR_INVALID_ARG;
     if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_set_pubkeys_compressed: n differs from the registry size");
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n == 0) return PE_OK;
     HIP_TRY(h, h->d_points.ensure(4ull * G1_ROW_WORDS * n));
     h->have_points = false;
@@ -2152,7 +2656,7 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
 int pe_g2_decompress(pe_engine* h, const uint8_t* in96, uint64_t n, uint8_t* out192, int32_t* status)
 {
     if (!h || (n && (!in96 || !out192 || !status))) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     const uint64_t chunk = 1ull << 19;
     HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, (96ull + 192ull + 4ull) * std::min(chunk, std::max<uint64_t>(n, 1)))));
     for (uint64_t base = 0; base < n; base += chunk) {
@@ -2222,7 +2726,7 @@ int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const u
               uint32_t n_groups, uint8_t* out192)
 {
     if (!h || !offsets || !out192 || (n_points && !points192)) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n_groups == 0) return PE_OK;
     if (n_points >= 0xFFFFFFFFull / 48) return fail(h, PE_ERR_CAPACITY, "too many points");
     const uint32_t total = offsets[n_groups];
@@ -2241,7 +2745,7 @@ int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const u
         launch_g2_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
     }
     Stage st(h);
-    HIP_TRY(h, st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
+    PE_TRY(st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
     const size_t off_g = st.alloc(sizeof(G1Group) * (size_t)n_groups);
     const size_t off_i = st.alloc(4ull * total + 4);
     G1Group* gr = st.host<G1Group>(off_g);
@@ -2252,7 +2756,7 @@ int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const u
     if (index) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
     OutBlock ob(h);
     const size_t off_o = ob.alloc(192ull * n_groups);
-    HIP_TRY(h, ob.ensure());
+    PE_TRY(ob.ensure());
     HIP_TRY(h, st.upload());
     HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(384, 384ull * plan.n_partials)));
     {
@@ -2292,7 +2796,7 @@ int pe_block_index_of(const pe_engine* h, const uint8_t root[32], uint32_t* out_
 int pe_get_latest_messages(pe_engine* h, uint64_t* out_epoch, uint32_t* out_block_index, uint64_t n)
 {
     if (!h || !out_epoch || !out_block_index || n != h->n_val) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (n == 0) return PE_OK;
     std::vector<uint64_t> key(n);
     HIP_TRY(h, hipMemcpyAsync(key.data(), h->d_vote_key.p, 8 * n, hipMemcpyDeviceToHost, h->stream));
@@ -2328,7 +2832,7 @@ int pe_get_validator_flags(const pe_engine* h, uint8_t* out_flags, uint64_t n)
 int pe_get_latest_message_slots(pe_engine* h, uint32_t* out_slot, uint64_t n)
 {
     if (!h || !out_slot || n != h->n_val) return PE_ERR_INVALID_ARG;
-    (void)hipSetDevice(h->device);
+    PE_TRY(enter(h));
     if (!h->cfg.vote_expiry_slots) { memset(out_slot, 0, 4 * n); return PE_OK; }
     if (n) HIP_TRY(h, hipMemcpyAsync(out_slot, h->d_vote_slot.p, 4 * n, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -2385,6 +2889,56 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
     return PE_OK;
 }
 
+// ---------------------------------------------------------------- pipelined calls
+int pe_pipeline_begin(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    PE_TRY(complete_arena(h, h->cur));  // a lagged pipeline in the other arena stays in flight
+    h->pipelining = true;
+    return PE_OK;
+}
+int pe_pipeline_end(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    h->pipelining = false;
+    h->streaming = false;
+    HostLap lap(&h->trace);
+    const int rc = flush_pending(h);
+    lap.mark("pipe.end_wait_outputs");
+    return rc;
+}
+
+int pe_pipeline_begin_streaming(pe_engine* h)
+{
+    const int rc = pe_pipeline_begin(h);
+    if (rc == PE_OK) h->streaming = true;
+    return rc;
+}
+
+int pe_pipeline_end_lagged(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    h->pipelining = false;
+    h->streaming = false;
+    HostLap lap(&h->trace);
+    PE_TRY(run_deferred(h));  // the step's G1 sums start now, behind its fork-choice kernels
+    lap.mark("pipe.end_lagged_launch_g1");
+    pe_engine::PipeArena& a = h->A();
+    // mark the end of this pipeline on both streams; its completions run when the NEXT lagged end (or any
+    // synchronous call) has waited for the marks
+    HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
+    if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->fin_stream));  // the last kernel of the G1 chain runs there
+    a.fenced = true;
+    h->side_busy = false;   // accounted for by the fence from here on
+    h->cur ^= 1;
+    const int rc = complete_arena(h, h->cur);  // the pipeline before this one
+    lap.mark("pipe.end_lagged_wait_previous");
+    return rc;
+}
+
 // ---------------------------------------------------------------- profiling
 int pe_profile_enable(pe_engine* h, int on)
 {
@@ -2394,7 +2948,9 @@ int pe_profile_enable(pe_engine* h, int on)
 }
 static void prof_drain(pe_engine* h)
 {
+    (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     for (auto& p : h->prof) {
         for (auto& ev : p.pending) {
             float ms = 0;

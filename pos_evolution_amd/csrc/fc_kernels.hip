@@ -404,12 +404,13 @@ __global__ void __launch_bounds__(256)
 k_lmd(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t* __restrict__ members,
       const uint32_t* __restrict__ bit_arena, const uint8_t* __restrict__ flags,
       unsigned long long* __restrict__ vote_key, uint32_t* __restrict__ vote_block,
-      uint32_t* __restrict__ vote_slot)
+      uint32_t* __restrict__ vote_slot, const uint32_t* __restrict__ gates)
 {
     const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= n_rows) return;
     const int lane = threadIdx.x & 63;
     const AttRow r = rows[a];
+    if (gates && r.gate != NONE32 && gates[r.gate] != 0) return;  // voided on the device (overlapping members)
     const unsigned long long key = lmd_key(r.epoch_p1, r.order);
     // lane-parallel over bit positions: every lane tests its own bit (the 32 lanes sharing a word hit one line)
     for (uint32_t i = lane; i < r.n_bits; i += 64) {
@@ -462,7 +463,8 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
                       const uint32_t* __restrict__ crow_list, const uint32_t* __restrict__ inv_comm,
                       const uint32_t* __restrict__ inv_pos, const uint32_t* __restrict__ bit_arena,
                       const uint8_t* __restrict__ flags, uint64_t n_val, unsigned long long* __restrict__ vote_key,
-                      uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot)
+                      uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot,
+                      const uint32_t* __restrict__ gates)
 {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_val) return;
@@ -477,6 +479,7 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
     for (uint32_t k = kb; k < ke; ++k) {
         const AttRow r = rows[crow_list[k]];
         if (i >= r.n_bits) continue;
+        if (gates && r.gate != NONE32 && gates[r.gate] != 0) continue;  // voided on the device
         if (!((bit_arena[r.bits_word + (i >> 5)] >> (i & 31)) & 1u)) continue;
         if (r.epoch_p1 > epoch_p1) {  // "i not in latest_messages or target.epoch > latest_messages[i].epoch"
             epoch_p1 = r.epoch_p1;
@@ -494,24 +497,24 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
 void launch_lmd_validator_major(hipStream_t s, const AttRow* rows, const uint32_t* crow_start,
                                 const uint32_t* crow_list, const uint32_t* inv_comm, const uint32_t* inv_pos,
                                 const uint32_t* bit_arena, const uint8_t* flags, uint64_t n_val, uint64_t* vote_key,
-                                uint32_t* vote_block, uint32_t* vote_slot)
+                                uint32_t* vote_block, uint32_t* vote_slot, const uint32_t* gates)
 {
     if (n_val == 0) return;
     hipLaunchKernelGGL(k_lmd_validator_major, dim3((unsigned)((n_val + 255) / 256)), dim3(256), 0, s, rows, crow_start,
                        crow_list, inv_comm, inv_pos, bit_arena, flags, n_val,
-                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot);
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot, gates);
 }
 
 void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                        const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block,
-                       uint32_t* vote_slot)
+                       uint32_t* vote_slot, const uint32_t* gates)
 {
     if (n_rows == 0) return;
     const unsigned blocks = (n_rows + 3) / 4;
     hipLaunchKernelGGL(k_lmd<0>, dim3(blocks), dim3(256), 0, s, rows, n_rows, members, bit_arena, flags,
-                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot);
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot, gates);
     hipLaunchKernelGGL(k_lmd<1>, dim3(blocks), dim3(256), 0, s, rows, n_rows, members, bit_arena, flags,
-                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot);
+                       reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot, gates);
 }
 
 // ------------------------------------------------------------------ participation
@@ -520,7 +523,7 @@ k_participation(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t
                 const uint32_t* __restrict__ bit_arena, const uint16_t* __restrict__ eff_increments,
                 unsigned long long base_reward_per_increment, uint32_t* __restrict__ part_cur,
                 uint32_t* __restrict__ part_prev, unsigned long long* __restrict__ numerators,
-                const uint32_t* __restrict__ numerator_slot)
+                const uint32_t* __restrict__ numerator_slot, const uint32_t* __restrict__ gates)
 {
     const uint32_t a = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= n_rows) return;
@@ -528,7 +531,8 @@ k_participation(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t
     const AttRow r = rows[a];
     uint32_t* part = r.which ? part_prev : part_cur;
     unsigned long long num = 0;
-    for (uint32_t i = lane; i < r.n_bits; i += 64) {
+    const uint32_t n_use = (gates && r.gate != NONE32 && gates[r.gate] != 0) ? 0u : r.n_bits;  // voided on the device
+    for (uint32_t i = lane; i < n_use; i += 64) {
         const uint32_t word = bit_arena[r.bits_word + (i >> 5)];
         if (!((word >> (i & 31)) & 1u)) continue;
         const uint32_t v = members[r.member_base + i];
@@ -551,12 +555,12 @@ k_participation(const AttRow* __restrict__ rows, uint32_t n_rows, const uint32_t
 void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                           const uint32_t* bit_arena, const uint16_t* eff_increments,
                           uint64_t base_reward_per_increment, uint32_t* part_cur_words, uint32_t* part_prev_words,
-                          uint64_t* numerators, const uint32_t* numerator_slot)
+                          uint64_t* numerators, const uint32_t* numerator_slot, const uint32_t* gates)
 {
     if (n_rows == 0) return;
     hipLaunchKernelGGL(k_participation, dim3((n_rows + 3) / 4), dim3(256), 0, s, rows, n_rows, members, bit_arena,
                        eff_increments, (unsigned long long)base_reward_per_increment, part_cur_words,
-                       part_prev_words, reinterpret_cast<unsigned long long*>(numerators), numerator_slot);
+                       part_prev_words, reinterpret_cast<unsigned long long*>(numerators), numerator_slot, gates);
 }
 
 // ------------------------------------------------------------------ indexed attestations
@@ -673,33 +677,80 @@ uint32_t launch_ffg_balances(hipStream_t s, const uint64_t* balance, const uint8
     return (uint32_t)blocks;
 }
 
-// ------------------------------------------------------------------ bitfield union
+// ------------------------------------------------------------------ working-state view = registry
 __global__ void __launch_bounds__(256)
-k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ att_words,
-             const uint32_t* __restrict__ bit_arena, uint32_t* __restrict__ out_arena,
-             uint32_t* __restrict__ out_count)
+k_state_view_from_registry(const uint8_t* __restrict__ flags, const unsigned long long* __restrict__ balance,
+                           unsigned long long increment, uint64_t n_val, uint8_t* __restrict__ sflags,
+                           uint16_t* __restrict__ increments)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_val) return;
+    const uint32_t f = flags[i];
+    sflags[i] = (uint8_t)((f & (VAL_ACTIVE | VAL_SLASHED)) | ((f & VAL_ACTIVE) ? 0x08u : 0u));  // PE_VAL_ACTIVE_PREV
+    increments[i] = (uint16_t)(balance[i] / increment);
+}
+void launch_state_view_from_registry(hipStream_t s, const uint8_t* flags, const uint64_t* balance, uint64_t increment,
+                                     uint64_t n_val, uint8_t* sflags, uint16_t* increments)
+{
+    if (n_val == 0) return;
+    hipLaunchKernelGGL(k_state_view_from_registry, dim3((unsigned)((n_val + 255) / 256)), dim3(256), 0, s, flags,
+                       reinterpret_cast<const unsigned long long*>(balance), (unsigned long long)increment, n_val,
+                       sflags, increments);
+}
+
+// ------------------------------------------------------------------ bitfield union
+// One wave per group.  The members' bitfields are read straight from the caller's arena as uploaded (byte offsets:
+// an aligned dword pair + v_alignbyte_b32), so the host packs nothing.  Besides the OR and its popcount the wave sums
+// the members' own popcounts: sum > popcount(OR) <=> two members share a bit (A.8: such aggregates are not merged --
+// the aggregate signature would count that validator twice).
+__global__ void __launch_bounds__(256)
+k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ att_bytes,
+             const uint8_t* __restrict__ bit_arena, uint32_t* __restrict__ out_arena,
+             uint32_t* __restrict__ out_info, uint32_t* __restrict__ host_arena, uint32_t* __restrict__ host_info)
 {
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_groups) return;
     const int lane = threadIdx.x & 63;
     const UnionGroup d = groups[g];
-    uint32_t cnt = 0;
-    for (uint32_t w = lane; w < d.n_words; w += 64) {
+    const uint32_t n_words = (d.n_bits + 31) >> 5;
+    const uint32_t tail_mask = (d.n_bits & 31) ? ((1u << (d.n_bits & 31)) - 1u) : 0xFFFFFFFFu;
+    const uint32_t* arena_w = reinterpret_cast<const uint32_t*>(bit_arena);  // staging block: 256-byte aligned
+    uint32_t cnt = 0, member_sum = 0;
+    for (uint32_t w = lane; w < n_words; w += 64) {
         uint32_t acc = 0;
-        for (uint32_t k = 0; k < d.n_atts; ++k) acc |= bit_arena[att_words[d.list_start + k] + w];
+        const uint32_t mask = (w == n_words - 1) ? tail_mask : 0xFFFFFFFFu;
+        for (uint32_t k = 0; k < d.n_atts; ++k) {
+            const uint32_t off = att_bytes[d.list_start + k] + 4u * w;
+            const uint32_t lo = arena_w[off >> 2], hi = arena_w[(off >> 2) + 1];
+            const uint32_t v = __builtin_amdgcn_alignbyte(hi, lo, off & 3u) & mask;
+            member_sum += __builtin_popcount(v);
+            acc |= v;
+        }
         out_arena[d.out_word + w] = acc;
+        if (host_arena) host_arena[d.out_word + w] = acc;
         cnt += __builtin_popcount(acc);
     }
     cnt = wave_sum_u32(cnt);
-    if (lane == 0 && out_count) out_count[g] = cnt;
+    member_sum = wave_sum_u32(member_sum);
+    if (lane == 0) {
+        if (out_info) {
+            out_info[2 * g] = cnt;
+            out_info[2 * g + 1] = member_sum - cnt;
+        }
+        if (host_info) {
+            host_info[2 * g] = cnt;
+            host_info[2 * g + 1] = member_sum - cnt;
+        }
+    }
 }
 
-void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
-                       const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count)
+void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_bytes,
+                       const uint8_t* bit_arena, uint32_t* out_arena, uint32_t* out_info, uint32_t* host_arena,
+                       uint32_t* host_info)
 {
     if (n_groups == 0) return;
-    hipLaunchKernelGGL(k_bits_union, dim3((n_groups + 3) / 4), dim3(256), 0, s, groups, n_groups, att_words,
-                       bit_arena, out_arena, out_count);
+    hipLaunchKernelGGL(k_bits_union, dim3((n_groups + 3) / 4), dim3(256), 0, s, groups, n_groups, att_bytes,
+                       bit_arena, out_arena, out_info, host_arena, host_info);
 }
 
 }  // namespace posevo

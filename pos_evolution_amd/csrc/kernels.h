@@ -79,32 +79,46 @@ struct AttRow {
     uint32_t flag_mask;    // participation flags this attestation earns (process_attestation)
     uint32_t which;        // 0 current / 1 previous epoch participation
     uint32_t slot;         // attestation.data.slot (vote-expiry variant only: recorded with the latest message)
+    uint32_t gate;         // index into the gate array (NONE32 = ungated): a non-zero gate word voids the row on the
+                           // device (rows handed over resident by pe_aggregate whose members overlapped, A.8)
 };
 // update_latest_messages for a batch: phase 1 atomicMax of (epoch+1, ~order), phase 2 winners write.
 void launch_lmd_update(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                        const uint32_t* bit_arena, const uint8_t* flags, uint64_t* vote_key, uint32_t* vote_block,
-                       uint32_t* vote_slot = nullptr);
+                       uint32_t* vote_slot = nullptr, const uint32_t* gates = nullptr);
 // inverse committee map (partition tables only) and the validator-major form of update_latest_messages
 void launch_invert_committees(hipStream_t s, const uint32_t* members, const uint32_t* offsets, uint32_t n_committees,
                               uint32_t* inv_comm, uint32_t* inv_pos, uint64_t n_val);
 void launch_lmd_validator_major(hipStream_t s, const AttRow* rows, const uint32_t* crow_start,
                                 const uint32_t* crow_list, const uint32_t* inv_comm, const uint32_t* inv_pos,
                                 const uint32_t* bit_arena, const uint8_t* flags, uint64_t n_val, uint64_t* vote_key,
-                                uint32_t* vote_block, uint32_t* vote_slot = nullptr);
+                                uint32_t* vote_block, uint32_t* vote_slot = nullptr, const uint32_t* gates = nullptr);
 // process_attestation flag loop for one round of pairwise-disjoint attestations.
 void launch_participation(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,
                           const uint32_t* bit_arena, const uint16_t* eff_increments,
                           uint64_t base_reward_per_increment, uint32_t* part_cur_words,
-                          uint32_t* part_prev_words, uint64_t* numerators, const uint32_t* numerator_slot);
+                          uint32_t* part_prev_words, uint64_t* numerators, const uint32_t* numerator_slot,
+                          const uint32_t* gates = nullptr);
 // aggregation_bits = OR over the group's member attestations; count = popcount (wave reduce).
 struct UnionGroup {
-    uint32_t list_start;   // into att_words[]: the member attestations' bit word offsets
+    uint32_t list_start;   // into att_bytes[]: BYTE offsets of the member attestations' bits in the raw arena
     uint32_t n_atts;
-    uint32_t n_words;
+    uint32_t n_bits;       // len(aggregation_bits): bits past it in the last word are masked off
     uint32_t out_word;     // word offset of the output bitfield
 };
-void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_words,
-                       const uint32_t* bit_arena, uint32_t* out_arena, uint32_t* out_count);
+// bit_arena: the caller's packed bit arena as uploaded (any byte alignment per member; readable 8 bytes past the last
+// member).  out_info[2g] = popcount of the union, out_info[2g + 1] = sum of the members' popcounts minus that: non-zero
+// <=> members of the group overlap (their signatures would be counted twice, validator guide A.8).
+// host_arena / host_info (nullable): the same two outputs written a second time straight into host-coherent pinned
+// memory, so that no device-to-host copy command has to follow the kernel.
+void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_bytes,
+                       const uint8_t* bit_arena, uint32_t* out_arena, uint32_t* out_info,
+                       uint32_t* host_arena = nullptr, uint32_t* host_info = nullptr);
+
+// The working-state view mirrors the registry (pe_store_init): sflags = active/slashed (+ active-in-previous-epoch),
+// increments = balance / effective_balance_increment.
+void launch_state_view_from_registry(hipStream_t s, const uint8_t* flags, const uint64_t* balance, uint64_t increment,
+                                     uint64_t n_val, uint8_t* sflags, uint16_t* increments);
 
 // BLSPubkey decompression: 48-byte compressed -> Montgomery rows (nullable) and/or 96-byte uncompressed (nullable)
 void launch_g1_decompress(hipStream_t s, const uint8_t* in48, uint64_t n, uint32_t* out_mont24, uint8_t* out_be96,

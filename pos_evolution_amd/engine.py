@@ -101,6 +101,18 @@ _ATT_DTYPE = np.dtype([
 ])  # == synth.ATT_DTYPE == struct pe_attestation (144 bytes)
 
 
+class _Resident:
+    """Sentinel for ``packed=(rows, RESIDENT)``: the rows are rows of the last ``aggregate`` result and their OR-ed
+    bits are used where pe_aggregate left them on the device (PE_BITS_RESIDENT, include/posevo.h)."""
+    size = 0
+
+    def __repr__(self):
+        return "RESIDENT"
+
+
+RESIDENT = _Resident()
+
+
 class AggregateResult(dict):
     """Result of Engine.aggregate; ``res["bits"]`` decodes the OR-ed bitfields on demand."""
 
@@ -113,6 +125,34 @@ class AggregateResult(dict):
                 out.append(np.unpackbits(arena[off:off + nb], bitorder="little")[:nbits].astype(bool))
             self["bits"] = out
         return dict.__getitem__(self, key)
+
+
+class _Pipeline:
+    def __init__(self, engine, lagged=False):
+        self.e = engine
+        self.lagged = lagged
+
+    def __enter__(self):
+        e = self.e
+        # a lagged pipeline still in flight stays in flight
+        e._check((e._lib.pe_pipeline_begin_streaming if self.lagged else e._lib.pe_pipeline_begin)(e._h))
+        e._pipe_keep = []
+        return e
+
+    def __exit__(self, exc_type, exc, tb):
+        e = self.e
+        if self.lagged and exc_type is None:
+            rc = e._lib.pe_pipeline_end_lagged(e._h)
+            e._lagged_keep = e._pipe_keep   # the previous lagged generation is complete now: drop its buffers
+        else:
+            rc = e._lib.pe_pipeline_end(e._h)
+            e._lagged_keep = None
+        e._pipe_keep = None
+        if e._ring is not None:
+            e._ring_i = (e._ring_i + 1) % len(e._ring)
+        if exc_type is None:
+            e._check(rc)
+        return False
 
 
 class Engine:
@@ -134,8 +174,35 @@ class Engine:
             raise EngineError(rc, self._lib.pe_strerror(rc).decode() +
                               " (the engine needs a HIP device; there is no CPU fallback)")
         self._h = h
+        self._pipe_keep = None
+        self._lagged_keep = None
+        self._ring = None
+        self._ring_i = 0
 
     # -- plumbing ---------------------------------------------------------
+    def reuse_outputs(self, depth: int = 3):
+        """Opt in to output-buffer reuse: the arrays the batch calls return come from a ring of `depth` buffer sets that
+        advances at every pipeline exit, instead of fresh ``np.empty`` allocations (whose first touch page-faults: 50+ us
+        per step for the 1 MB of rows and bits an epoch returns).  An array stays valid for depth - 1 further pipelines;
+        copy what must live longer.  depth >= 3 with lagged pipelines."""
+        self._ring = [dict() for _ in range(max(depth, 1))]
+        self._ring_i = 0
+
+    def _out(self, name, shape, dtype):
+        if self._ring is None:
+            return np.empty(shape, dtype=dtype)
+        d = self._ring[self._ring_i]
+        key = (name, shape if isinstance(shape, tuple) else (shape,), np.dtype(dtype).str)
+        a = d.get(key)
+        if a is None:
+            a = d[key] = np.zeros(shape, dtype=dtype)  # zeros: touch the pages once, here
+        return a
+
+    def _keep(self, *buffers):
+        """Inside a pipeline the engine writes into these buffers at pe_pipeline_end: keep them alive until then."""
+        if self._pipe_keep is not None:
+            self._pipe_keep.extend(b for b in buffers if b is not None)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.pe_engine_destroy(self._h)
@@ -151,6 +218,19 @@ class Engine:
         if rc != _abi.PE_OK:
             detail = self._lib.pe_last_error(self._h).decode()
             raise EngineError(rc, f"{self._lib.pe_strerror(rc).decode()}: {detail}")
+
+    def pipeline(self, lagged: bool = False):
+        """``with engine.pipeline(): ...`` -- the batch calls inside return once their device work is enqueued
+        (pe_pipeline_begin); their output arrays are complete when the block exits (pe_pipeline_end): one wait per
+        step instead of one per call.  get_head() inside the block is still synchronous.
+        lagged=True (pe_pipeline_end_lagged): the block's outputs are complete when the NEXT pipeline block exits (or
+        at drain() / any other synchronous call) -- step N's G1 sums run while step N+1 is being prepared."""
+        return _Pipeline(self, lagged)
+
+    def drain(self):
+        """Complete every pipelined call still in flight (pe_pipeline_end outside a pipeline does exactly that)."""
+        self._check(self._lib.pe_pipeline_end(self._h))
+        self._lagged_keep = None
 
     def set_stream(self, hip_stream: int):
         self._check(self._lib.pe_set_stream(self._h, C.c_void_p(hip_stream)))
@@ -242,10 +322,12 @@ class Engine:
         """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        status = np.empty(max(n, 1), dtype=np.int32)
-        count = np.empty(max(n, 1), dtype=np.uint32)
-        agg = np.empty((max(n, 1), 96), dtype=np.uint8) if want_aggregate_pubkeys else None
-        self._check(self._lib.pe_on_attestation_batch(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
+        status = self._out("att.status", max(n, 1), np.int32)
+        count = self._out("att.count", max(n, 1), np.uint32)
+        agg = self._out("att.aggpk", (max(n, 1), 96), np.uint8) if want_aggregate_pubkeys else None
+        arena_p = _abi.PE_BITS_RESIDENT if arena is RESIDENT else _ptr(arena, C.c_uint8)
+        self._keep(arr, status, count, agg)
+        self._check(self._lib.pe_on_attestation_batch(self._h, _att_ptr(arr), n, arena_p, arena.size,
                                                       _ptr(status, C.c_int32), _ptr(agg, C.c_uint8),
                                                       _ptr(count, C.c_uint32)))
         return status[:n], (agg[:n] if agg is not None else None), count[:n]
@@ -271,17 +353,18 @@ class Engine:
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
-        out_atts = np.empty(m, dtype=_ATT_DTYPE)  # output buffers: written by the engine, never read before that
+        out_atts = self._out("agg.atts", m, _ATT_DTYPE)  # output buffers: written by the engine, never read before that
         n_groups = C.c_uint32(0)
-        group_of = np.empty(m, dtype=np.uint32)
-        out_arena = np.empty(max(arena.size, 1), dtype=np.uint8)
+        group_of = self._out("agg.group_of", m, np.uint32)
+        out_arena = self._out("agg.arena", max(arena.size, 1), np.uint8)
         sig = None
         if sig_points96 is not None:
             sig = np.ascontiguousarray(sig_points96, dtype=np.uint8)
             assert sig.size == 96 * n
-        out_sig = np.empty((m, 96), dtype=np.uint8) if sig is not None else None
-        out_pk = np.empty((m, 96), dtype=np.uint8) if want_aggregate_pubkeys else None
-        count = np.empty(m, dtype=np.uint32)
+        out_sig = self._out("agg.sig", (m, 96), np.uint8) if sig is not None else None
+        out_pk = self._out("agg.pk", (m, 96), np.uint8) if want_aggregate_pubkeys else None
+        count = self._out("agg.count", m, np.uint32)
+        self._keep(arr, arena, sig, out_atts, group_of, out_arena, out_sig, out_pk, count)
         self._check(self._lib.pe_aggregate(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size, _ptr(sig, C.c_uint8),
                                            _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
                                            _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
@@ -305,10 +388,12 @@ class Engine:
         """-> (status int32[n], proposer_reward_numerator uint64[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        status = np.empty(max(n, 1), dtype=np.int32)
-        num = np.empty(max(n, 1), dtype=np.uint64)
+        status = self._out("proc.status", max(n, 1), np.int32)
+        num = self._out("proc.num", max(n, 1), np.uint64)
+        arena_p = _abi.PE_BITS_RESIDENT if arena is RESIDENT else _ptr(arena, C.c_uint8)
+        self._keep(arr, status, num)
         self._check(self._lib.pe_process_attestation_batch(self._h, C.byref(state_ctx), _att_ptr(arr), n,
-                                                           _ptr(arena, C.c_uint8), arena.size,
+                                                           arena_p, arena.size,
                                                            _ptr(status, C.c_int32), _ptr(num, C.c_uint64)))
         return status[:n], num[:n]
 
