@@ -111,8 +111,10 @@ def run_step_single(e, w, st, pipelined=True, lagged=True):
         agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
         rows = agg["atts"]
         status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, RESIDENT))
-        st2, num = _timed("process_attestation", e.process_attestation_batch, st["ctx"], packed=(rows, RESIDENT))
+        # fork choice first (the head depends on the LMD update only), then the state transition's flag pass: the
+        # step's G1 sums are launched behind k_tree, so the flag kernel and its host work overlap them
         head = _timed("get_head", e.get_head)
+        st2, num = _timed("process_attestation", e.process_attestation_batch, st["ctx"], packed=(rows, RESIDENT))
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
@@ -251,7 +253,7 @@ def main():
         step(w["steps"][s])
     e.drain()
     if ex is None and not args.no_pipeline:
-        e.reuse_outputs(3)  # a streaming caller reuses its output buffers; results are consumed one step behind
+        e.reuse_outputs(4)  # a streaming caller reuses its output buffers; results are consumed two steps behind
     e.profile_enable(True)
     e.profile_reset()
     # Python's cyclic collector is paused over the timed steps: with torch loaded a full collection walks ~10^6
@@ -262,16 +264,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     last = None
+    inflight = []
     n_att_local = n_rejected = 0
     for s in range(args.warmup, total):
-        cur = step(w["steps"][s])
-        if last is not None:  # complete by now (a lagged step completes when the next one's block exits)
-            n_att_local += int(last["count"].sum())
-            n_rejected += int((last["status"] != 0).sum()) + int((last["pstatus"] != 0).sum())
-        last = cur
-    e.drain()  # the last (lagged) step's outputs: inside the timed region
-    n_att_local += int(last["count"].sum())
-    n_rejected += int((last["status"] != 0).sum()) + int((last["pstatus"] != 0).sum())
+        inflight.append(step(w["steps"][s]))
+        if len(inflight) > 2:  # complete by now (a lagged step completes when the second next one's block exits)
+            done = inflight.pop(0)
+            n_att_local += int(done["count"].sum())
+            n_rejected += int((done["status"] != 0).sum()) + int((done["pstatus"] != 0).sum())
+    e.drain()  # the last (lagged) steps' outputs: inside the timed region
+    for done in inflight:
+        n_att_local += int(done["count"].sum())
+        n_rejected += int((done["status"] != 0).sum()) + int((done["pstatus"] != 0).sum())
+    last = inflight[-1]
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()

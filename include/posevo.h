@@ -231,10 +231,10 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
  * Results are the same as with synchronous calls.  pe_pipeline_end returns the first deferred error, if any. */
 int pe_pipeline_begin(pe_engine* h);
 int pe_pipeline_end(pe_engine* h);
-/* Lagged end, for a caller that streams step after step: returns once the pipeline BEFORE this one is complete (its
- * buffers filled, its deferred error returned); this one completes at the next pe_pipeline_end / _end_lagged or any
- * other synchronous call.  The G1 sums of step N then run while the host prepares and enqueues step N+1.  Buffers
- * handed to the calls of a lagged pipeline must stay alive until that later completion. */
+/* Lagged end, for a caller that streams step after step: returns once the pipeline TWO before this one is complete
+ * (its buffers filled, its deferred error returned); this one completes at the second next pe_pipeline_end_lagged, at
+ * pe_pipeline_end or at any other synchronous call.  The G1 sums of step N then run while the host prepares and
+ * enqueues step N+1.  Buffers handed to the calls of a lagged pipeline must stay alive until that later completion. */
 int pe_pipeline_end_lagged(pe_engine* h);
 /* pe_pipeline_begin for a pipeline that will end lagged: the G1 sums of its pe_aggregate are not launched by that call
  * but by pe_pipeline_end_lagged, BEHIND the step's fork-choice kernels.  k_g1_accumulate fills every CU for its whole

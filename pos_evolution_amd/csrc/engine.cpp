@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <map>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -244,7 +245,9 @@ struct pe_engine {
         hipEvent_t ev_main = nullptr, ev_side = nullptr;  // recorded by pe_pipeline_end_lagged
         bool fenced = false, side_used = false;
     };
-    PipeArena arena[2];
+    static constexpr int N_ARENAS = 3;  // lag depth 2: a lagged end waits for the pipeline TWO back, never for the
+                                        // finish kernel of the one that has only just been fenced
+    PipeArena arena[N_ARENAS];
     int cur = 0;
     PipeArena& A() { return arena[cur]; }
     bool pipelining = false;
@@ -277,6 +280,7 @@ struct pe_engine {
     // ---- profiling ----
     bool profiling = false;
     KernelProfile prof[PE_KERNEL_COUNT];
+    std::vector<hipEvent_t> event_pool;
     HostTrace trace;
 };
 
@@ -309,10 +313,18 @@ struct ProfScope {
     int k;
     hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
+    static hipEvent_t take(pe_engine* h)  // hipEventCreate costs ~5 us: recycle (prof_drain returns them)
+    {
+        if (!h->event_pool.empty()) { hipEvent_t e = h->event_pool.back(); h->event_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
     ProfScope(pe_engine* h_, int k_, hipStream_t s_ = nullptr) : h(h_), k(k_), s(s_ ? s_ : h_->stream)
     {
         if (!h->profiling) return;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        a = take(h);
+        b = take(h);
+        if (!a || !b) { a = b = nullptr; return; }
         (void)hipEventRecord(a, s);
     }
     ~ProfScope()
@@ -375,9 +387,12 @@ int complete_arena(pe_engine* h, int ai)
 // Everything: the lagged arena first (it is the older one), then the current one.
 int flush_pending(pe_engine* h)
 {
-    const int rc0 = complete_arena(h, h->cur ^ 1);
-    const int rc1 = complete_arena(h, h->cur);
-    return rc0 ? rc0 : rc1;
+    int rc = PE_OK;
+    for (int k = 1; k <= pe_engine::N_ARENAS; ++k) {  // oldest first, the current one last
+        const int r = complete_arena(h, (h->cur + k) % pe_engine::N_ARENAS);
+        if (r && !rc) rc = r;
+    }
+    return rc;
 }
 
 // ------------------------------------------------------------------ spec helpers (A.10)
@@ -832,12 +847,9 @@ int32_t validate_for_fork_choice(pe_engine* h, const pe_attestation& a, Resolved
     return PE_ATT_OK;
 }
 
-bool att_data_equal(const pe_attestation& a, const pe_attestation& b)
-{
-    return a.slot == b.slot && a.index == b.index && a.source_epoch == b.source_epoch &&
-           a.target_epoch == b.target_epoch && memcmp(a.beacon_block_root, b.beacon_block_root, 32) == 0 &&
-           memcmp(a.source_root, b.source_root, 32) == 0 && memcmp(a.target_root, b.target_root, 32) == 0;
-}
+// AttestationData (pe:689-697) is the first 128 bytes of the row, without padding
+static_assert(offsetof(pe_attestation, bits_offset) == 128, "pe_attestation: AttestationData must be the leading 128 bytes");
+bool att_data_equal(const pe_attestation& a, const pe_attestation& b) { return memcmp(&a, &b, 128) == 0; }
 
 int ensure_validator_arrays(pe_engine* h, uint64_t n)
 {
@@ -920,6 +932,9 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
                     h->d_weights.as<uint64_t>(), h->h_head.as<uint32_t>(), clear_direct);
     }
     HIP_TRY(h, hipGetLastError());
+    // a streaming pipeline's G1 sums go out now, ordered behind k_tree on the device: they start the moment the head
+    // is known, and their launch calls overlap the fork-choice kernels instead of following the poll below
+    if (h->streaming) PE_TRY(run_deferred(h));
     // k_tree's last act is a system-scope release store of the head index into this host-coherent word: polling it
     // sees the result a few microseconds before hipStreamSynchronize returns.  Bounded: after ~200 us (a hung or
     // faulted kernel) the stream sync takes over and reports the error.
@@ -1025,7 +1040,9 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
         hipEventCreateWithFlags(&h->arena[0].ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->arena[0].ev_side, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->arena[1].ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[1].ev_side, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->arena[1].ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[2].ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[2].ev_side, hipEventDisableTiming) != hipSuccess) {
         pe_engine_destroy(h);
         return PE_ERR_NO_DEVICE;
     }
@@ -1064,6 +1081,7 @@ void pe_engine_destroy(pe_engine* h)
         for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (hipEvent_t ev : h->g1_tune_ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->event_pool) (void)hipEventDestroy(ev);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
@@ -1501,7 +1519,7 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
                      h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(),
                      h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 0, expiry_slots_ptr(h),
-                     min_vote_slot(h));
+                     min_vote_slot(h), /*lean=*/h->pipelining ? 1 : 0);
     }
     lap.mark("head.1_launch_votes");
     uint32_t head;
@@ -2933,8 +2951,8 @@ int pe_pipeline_end_lagged(pe_engine* h)
     if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->fin_stream));  // the last kernel of the G1 chain runs there
     a.fenced = true;
     h->side_busy = false;   // accounted for by the fence from here on
-    h->cur ^= 1;
-    const int rc = complete_arena(h, h->cur);  // the pipeline before this one
+    h->cur = (h->cur + 1) % pe_engine::N_ARENAS;
+    const int rc = complete_arena(h, h->cur);  // the oldest pipeline still in flight (two back): its arena is reused next
     lap.mark("pipe.end_lagged_wait_previous");
     return rc;
 }
@@ -2944,6 +2962,12 @@ int pe_profile_enable(pe_engine* h, int on)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     h->profiling = on != 0;
+    if (h->profiling)
+        while (h->event_pool.size() < 4096) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            h->event_pool.push_back(e);
+        }
     return PE_OK;
 }
 static void prof_drain(pe_engine* h)
@@ -2955,8 +2979,8 @@ static void prof_drain(pe_engine* h)
         for (auto& ev : p.pending) {
             float ms = 0;
             if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { p.total_ms += ms; p.launches += 1; }
-            (void)hipEventDestroy(ev.first);
-            (void)hipEventDestroy(ev.second);
+            h->event_pool.push_back(ev.first);
+            h->event_pool.push_back(ev.second);
         }
         p.pending.clear();
     }

@@ -55,6 +55,11 @@ static bool first_use_on_this_device()
 constexpr int VOTES_WG = 512;  // 256 lanes: 21 us, 512: 15.8, 1024: 15.4 at 1 M validators / 64 workgroups
 constexpr int VOTES_PER_THREAD = 4;
 
+// QUADS = quads of validators in flight per lane and iteration.  2: the stand-alone get_head (63 VGPRs, fastest).
+// 1: the lean form for pipelined steps, where this kernel runs BESIDE k_g1_accumulate of the previous aggregate:
+// that kernel's two waves per SIMD hold 464 of the 512 registers, and only a wave of <= 48 fits into the rest and can
+// start before the accumulation's last workgroup retires.
+template <int QUADS>
 __global__ void __launch_bounds__(VOTES_WG)
 k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ eff_balance,
         const uint8_t* __restrict__ flags, uint64_t n_val, uint32_t filter_slashed,
@@ -69,13 +74,13 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
     uint32_t act_num = 0;
     const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
     const uint64_t stride = (uint64_t)gridDim.x * VOTES_WG;
-    // two quads (8 validators: 2 x (16 + 32 + 4) bytes of vector loads) in flight per lane per iteration
-    for (uint64_t q0 = (uint64_t)blockIdx.x * VOTES_WG + threadIdx.x; q0 < n_quads; q0 += 2 * stride) {
-        uint32_t vb[8];
-        unsigned long long bal[8];
-        uint32_t fl[8];
+    // QUADS quads (4 validators each: 16 + 32 + 4 bytes of vector loads) in flight per lane per iteration
+    for (uint64_t q0 = (uint64_t)blockIdx.x * VOTES_WG + threadIdx.x; q0 < n_quads; q0 += QUADS * stride) {
+        uint32_t vb[4 * QUADS];
+        unsigned long long bal[4 * QUADS];
+        uint32_t fl[4 * QUADS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < QUADS; ++u) {
             const uint64_t q = q0 + u * stride;
             const uint64_t v0 = q * VOTES_PER_THREAD;
             if (q < n_quads && v0 + 4 <= n_val) {  // arrays are 16-byte aligned and v0 % 4 == 0
@@ -105,7 +110,7 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4 * QUADS; ++k) {
             if (!(fl[k] & VAL_ACTIVE)) continue;
             act_bal += bal[k];
             act_num += 1;
@@ -140,7 +145,8 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
 
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx, uint32_t n_blocks,
-                  uint64_t* direct, VoteTotals* totals, int zero_first, const uint32_t* vote_slot, uint32_t min_vote_slot)
+                  uint64_t* direct, VoteTotals* totals, int zero_first, const uint32_t* vote_slot, uint32_t min_vote_slot,
+                  int lean)
 {
     if (zero_first) {  // caller-owned exchange buffer; the engine's own buffer is kept zeroed by k_tree
         (void)hipMemsetAsync(direct, 0, sizeof(uint64_t) * n_blocks, s);
@@ -162,12 +168,19 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
     if (forced) cap = (uint64_t)forced;
     if (blocks > cap) blocks = cap;
     if (first_use_on_this_device<0>()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(uint64_t) * TREE_MAX_BLOCKS));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(uint64_t) * TREE_MAX_BLOCKS));
     }
-    hipLaunchKernelGGL(k_votes, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
-                       eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
-                       reinterpret_cast<unsigned long long*>(direct), totals, vote_slot, min_vote_slot);
+    if (lean)
+        hipLaunchKernelGGL(k_votes<1>, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
+                           eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
+                           reinterpret_cast<unsigned long long*>(direct), totals, vote_slot, min_vote_slot);
+    else
+        hipLaunchKernelGGL(k_votes<2>, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
+                           eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
+                           reinterpret_cast<unsigned long long*>(direct), totals, vote_slot, min_vote_slot);
 }
 
 // ------------------------------------------------------------------ tree

@@ -244,6 +244,10 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
 
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x * G1_WG + tid;
+    // (s_setprio(3) here, to keep the guests of a pipelined step -- the previous aggregate's k_g1_finish, the next
+    // step's union / LMD / flag / vote kernels -- off this kernel's issue slots, was measured: no gain for the
+    // accumulation (0.315 ms either way: in a saturated stream of steps it runs at the chip's sustained clock, not at
+    // the boost clock an isolated launch sees, 0.278 ms) and k_g1_finish starved from 0.09 to 0.21 ms.  Dropped.)
     G1_STAMP(0);
     G1_WAVE_BEGIN();
 

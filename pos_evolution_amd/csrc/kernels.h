@@ -61,7 +61,7 @@ struct VoteTotals {            // one per K_votes workgroup (VOTES_MAX_WG slots)
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx,
                   uint32_t n_blocks, uint64_t* direct, VoteTotals* totals, int zero_first,
-                  const uint32_t* vote_slot = nullptr, uint32_t min_vote_slot = 0);
+                  const uint32_t* vote_slot = nullptr, uint32_t min_vote_slot = 0, int lean = 0);
 // Subtree sums (prefix scan over pre-order), viability, best child, pointer-jumping descent.
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,

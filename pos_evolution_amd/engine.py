@@ -143,7 +143,8 @@ class _Pipeline:
         e = self.e
         if self.lagged and exc_type is None:
             rc = e._lib.pe_pipeline_end_lagged(e._h)
-            e._lagged_keep = e._pipe_keep   # the previous lagged generation is complete now: drop its buffers
+            # lag depth 2: the generation two back is complete now, keep this one and the previous one alive
+            e._lagged_keep = [e._pipe_keep] + (e._lagged_keep or [])[:1]
         else:
             rc = e._lib.pe_pipeline_end(e._h)
             e._lagged_keep = None
@@ -184,7 +185,7 @@ class Engine:
         """Opt in to output-buffer reuse: the arrays the batch calls return come from a ring of `depth` buffer sets that
         advances at every pipeline exit, instead of fresh ``np.empty`` allocations (whose first touch page-faults: 50+ us
         per step for the 1 MB of rows and bits an epoch returns).  An array stays valid for depth - 1 further pipelines;
-        copy what must live longer.  depth >= 3 with lagged pipelines."""
+        copy what must live longer.  depth >= 4 with lagged pipelines (lag depth 2)."""
         self._ring = [dict() for _ in range(max(depth, 1))]
         self._ring_i = 0
 
@@ -223,8 +224,8 @@ class Engine:
         """``with engine.pipeline(): ...`` -- the batch calls inside return once their device work is enqueued
         (pe_pipeline_begin); their output arrays are complete when the block exits (pe_pipeline_end): one wait per
         step instead of one per call.  get_head() inside the block is still synchronous.
-        lagged=True (pe_pipeline_end_lagged): the block's outputs are complete when the NEXT pipeline block exits (or
-        at drain() / any other synchronous call) -- step N's G1 sums run while step N+1 is being prepared."""
+        lagged=True (pe_pipeline_end_lagged): the block's outputs are complete when the SECOND next lagged block exits
+        (or at drain() / any other synchronous call) -- step N's G1 sums run while step N+1 is being prepared."""
         return _Pipeline(self, lagged)
 
     def drain(self):
