@@ -5,13 +5,18 @@ A "step" = one epoch's pass of the hot path over one batch of synthetic input, p
     4 partial aggregates per committee (8192 rows) --pe_aggregate--> 2048 aggregates: bitfield union +
     aggregate pubkey (BLS12-381 G1 sum of ~1M validator points)        [A1, A2, A3]
     --pe_on_attestation_batch--> LMD latest-message update (~1M)       [A4, A5]
-    --pe_process_attestation_batch--> participation flags + numerators [A6]
     --pe_get_head--> weights from the 1M-entry vote table + descent    [H1-H6]
+    --pe_process_attestation_batch--> participation flags + numerators [A6]
 Every step targets a new epoch (fresh committee table, fresh votes, rotated participation), so no work is
 cached or skipped.  Inputs (registry, tree, committee tables) are resident in HBM before the timed region;
 the per-step attestation rows + bits (~1.7 MB) cross PCIe inside it, as the C ABI hands over host buffers.
+One GPU: the calls go through the pipelined C ABI (include/posevo.h): the aggregate's rows + bits stay on the
+device for the two handlers, and a step's G1 sums run on their own streams while the host prepares the next
+step; every step's outputs are complete (e.drain()) before the timed region closes.  --no-lag / --no-pipeline
+time the same step with one wait per step / per call.
 
-N > 1 (launched by torch.distributed.run): validators are range-sharded (weak scaling: 1M per GPU); the
+N > 1 (launched by torch.distributed.run): validators are range-sharded -- strong scaling by default (BASELINE
+configs[3]: the 1 048 576-validator registry over N GPUs), --scaling weak for a full registry per GPU; the
 exchange steps are one RCCL all-gather of G1 XYZZ partials (192 B per committee) and one all-reduce of per-block weights.
 
 Prints ONE JSON line on rank 0.
@@ -33,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guide: ~6290 GB/s achievable)
 def build_workload(e, args, rank, n_steps_total):
     import pos_evolution_amd.synth as synth
 
-    V, B, C, spe = args.validators, args.blocks, args.committees, 32
+    V, B, C, spe = args.validators_local, args.blocks, args.committees, 32
     seed = 4 + rank  # config 4 of BASELINE.json, per-rank registry
     tree = synth.random_tree(B, 4, "bushy")  # the tree is global: same on every rank
     e.store_init(0, 0, tree.roots[0].tobytes())
@@ -130,69 +135,193 @@ def run_step_sharded(e, w, st, sh):
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
-def cpu_baseline(w, st, target_seconds=12.0):
-    """The L1 C oracle ("port") timed on one host core over whole steps of the same workload."""
-    from oracle import cport
+def _flag_masks(w, st, rows):
+    """get_attestation_participation_flag_indices (Appendix A.9) per aggregate row of the step, computed here in plain
+    Python from the synthetic tree: the inputs of the C oracle's flag pass."""
     import pos_evolution_amd.synth as synth
 
-    tree, comm, atts, arena = w["tree"], st["comm"], st["atts"], st["arena"]
+    tree, spe = w["tree"], w["spe"]
+    ctx = st["ctx"]
+    tip = tree.roots.shape[0] - 1
+    cur_epoch = int(ctx.slot) // spe
+    masks = np.zeros(len(rows), dtype=np.uint8)
+    which = np.zeros(len(rows), dtype=np.uint8)
+    tgt_cache, head_cache = {}, {}
+    for k, a in enumerate(rows):
+        slot, ep = int(a["slot"]), int(a["target_epoch"])
+        delay = int(ctx.slot) - slot
+        if ep not in tgt_cache:
+            tgt_cache[ep] = tree.roots[synth.ancestor_at(tree, tip, ep * spe)].tobytes()
+        if slot not in head_cache:
+            head_cache[slot] = tree.roots[synth.ancestor_at(tree, tip, slot)].tobytes()
+        mt = a["target_root"].tobytes() == tgt_cache[ep]
+        mh = mt and a["beacon_block_root"].tobytes() == head_cache[slot]
+        masks[k] = (1 if delay <= 5 else 0) | (2 if mt and delay <= spe else 0) | (4 if mh and delay == 1 else 0)
+        which[k] = 0 if ep == cur_epoch else 1
+    return masks, which
+
+
+def cpu_step_inputs(w, st):
+    """Flat arrays of one step for the C oracle (built once, outside every timed region)."""
+    tree, comm, atts = w["tree"], st["comm"], st["atts"]
     spe = w["spe"]
     n_comm = comm.offsets.size - 1
     cps = n_comm // spe
-    V = w["bal"].size
     pos = ((atts["slot"] % spe) * cps + atts["index"]).astype(np.int64)
     order = np.argsort(pos, kind="stable")
     group_start = np.concatenate([[0], np.cumsum(np.bincount(pos, minlength=n_comm))]).astype(np.uint32)
     sizes = (comm.offsets[1:] - comm.offsets[:-1]).astype(np.uint32)
     out_off = np.concatenate([[0], np.cumsum((sizes + 7) // 8)]).astype(np.uint32)
     first = order[group_start[:-1]]
-    blk = np.array([int(np.nonzero((tree.roots == atts[i]["beacon_block_root"]).all(axis=1))[0][0]) for i in first],
-                   dtype=np.uint32)
-    vote_epoch = np.zeros(V, dtype=np.uint64)
-    vote_block = np.full(V, 0xFFFFFFFF, dtype=np.uint32)
-    pc, pp = np.zeros(V, dtype=np.uint8), np.zeros(V, dtype=np.uint8)
-    n_att = 0
-    t0 = time.perf_counter()
-    reps = 0
-    result = None
-    while True:
-        union, count = cport.bits_union(group_start, order.astype(np.uint32), atts["bits_offset"], arena, sizes,
-                                        out_off[:-1], int(out_off[-1]))
-        bits = np.unpackbits(union, bitorder="little")
-        idx_parts, offs = [], [0]
-        for c in range(n_comm):
-            sel = bits[8 * out_off[c]: 8 * out_off[c] + sizes[c]].astype(bool)
-            idx_parts.append(comm.members[comm.offsets[c]:comm.offsets[c + 1]][sel])
-            offs.append(offs[-1] + int(sel.sum()))
-        aggpk = cport.g1_sum_groups(w["pts"], np.concatenate(idx_parts), np.array(offs, dtype=np.uint32))
-        te = atts["target_epoch"][first] + reps
-        cport.update_latest_messages(comm.offsets[:-1], sizes, out_off[:-1], te, blk, union, comm.members, w["flags"],
-                                     vote_epoch, vote_block)
-        pp[:] = 0
-        num = cport.process_attestation_flags(comm.offsets[:-1], sizes, out_off[:-1], np.full(n_comm, 1, np.uint8),
-                                              np.ones(n_comm, np.uint8), union, comm.members, w["bal"], 10**9, 2264,
-                                              pc, pp)
-        head, weights = cport.get_head(tree.parent, np.ones(tree.parent.size, np.uint8), tree.roots, vote_block,
-                                       w["bal"], w["flags"], 0)
-        n_att += int(count.sum())
-        reps += 1
-        if result is None:
-            result = dict(aggpk=aggpk, count=count, head=tree.roots[head].tobytes(), weights=weights,
-                          vote_block=vote_block.copy())
-        if time.perf_counter() - t0 > target_seconds:
+    root_idx = {tree.roots[i].tobytes(): i for i in range(tree.roots.shape[0])}
+    blk = np.array([root_idx[atts[i]["beacon_block_root"].tobytes()] for i in first], dtype=np.uint32)
+    masks, which = _flag_masks(w, st, atts[first])
+    return dict(n_comm=n_comm, order=order.astype(np.uint32), group_start=group_start, sizes=sizes, out_off=out_off,
+                first=first, blk=blk, masks=masks, which=which, target_epoch=atts["target_epoch"][first].copy())
+
+
+def cpu_step(w, st, inp, mt, vote_epoch, vote_block, epoch_bump=0):
+    """One whole step on the CPU with the L1 C oracle: union + G1 sums + LMD + get_head + flags."""
+    from oracle import cport
+
+    tree, comm, arena = w["tree"], st["comm"], st["arena"]
+    n_comm, sizes, out_off = inp["n_comm"], inp["sizes"], inp["out_off"]
+    union, count = cport.bits_union(inp["group_start"], inp["order"], st["atts"]["bits_offset"], arena, sizes,
+                                    out_off[:-1], int(out_off[-1]), mt=mt)
+    aggpk = cport.g1_sum_attesters(comm.offsets[:-1], sizes, out_off[:-1], union, comm.members, w["pts"], mt=mt)
+    cport.update_latest_messages(comm.offsets[:-1], sizes, out_off[:-1], inp["target_epoch"] + epoch_bump, inp["blk"],
+                                 union, comm.members, w["flags"], vote_epoch, vote_block, mt=mt)
+    head, weights = cport.get_head(tree.parent, np.ones(tree.parent.size, np.uint8), tree.roots, vote_block,
+                                   w["bal"], w["flags"], 0, mt=mt)
+    pc, pp = np.zeros(w["bal"].size, dtype=np.uint8), np.zeros(w["bal"].size, dtype=np.uint8)
+    num = cport.process_attestation_flags(comm.offsets[:-1], sizes, out_off[:-1], inp["masks"], inp["which"], union,
+                                          comm.members, w["bal"], 10**9, int(st["ctx"].base_reward_per_increment),
+                                          pc, pp, mt=mt)
+    return dict(union=union, count=count, aggpk=aggpk, head=tree.roots[head].tobytes(), weights=weights,
+                vote_block=vote_block.copy(), numerators=num, part_cur=pc, part_prev=pp)
+
+
+def cpu_baseline(w, st, target_seconds=10.0):
+    """The L1 C oracle ("port") timed on the GPU box's host: whole steps of the timed workload on ONE core and, with
+    the OpenMP forms of the same loops, on ALL cores.  Bounded samples (~10 s each)."""
+    from oracle import cport
+
+    inp = cpu_step_inputs(w, st)
+    V = w["bal"].size
+    legs, result = {}, None
+    for name, mt in (("one_core", False), ("all_cores", True)):
+        if mt:  # the cores this process may run on (a container's CPU set can be smaller than the box)
+            cport.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        vote_epoch = np.zeros(V, dtype=np.uint64)
+        vote_block = np.full(V, 0xFFFFFFFF, dtype=np.uint32)
+        n_att, reps = 0, 0
+        t0 = time.perf_counter()
+        while True:
+            r = cpu_step(w, st, inp, mt, vote_epoch, vote_block, epoch_bump=reps)
+            n_att += int(r["count"].sum())
+            reps += 1
+            if result is None:
+                result = r
+            elif reps == 1:  # the all-cores leg's first step starts from the same empty table: same answers
+                for k in ("union", "count", "aggpk", "weights", "vote_block", "numerators"):
+                    assert np.array_equal(r[k], result[k]), f"all-cores oracle differs from the single-thread one: {k}"
+            if time.perf_counter() - t0 > target_seconds:
+                break
+        dt = time.perf_counter() - t0
+        legs[name] = dict(value=n_att / dt, steps=reps, seconds=dt, ms_per_step=dt / reps * 1e3,
+                          cores=(cport.max_threads() if mt else 1))
+    one = legs["one_core"]
+    return dict(value=one["value"], unit="attestations/s", cores=1, kind="port",
+                sample=f"{one['steps']} full steps (union + G1 sums + LMD + get_head + flags) of the timed workload, "
+                       f"oracle/posevo_oracle.c, single thread, {one['seconds']:.1f} s",
+                all_cores=dict(value=legs["all_cores"]["value"], unit="attestations/s", cores=legs["all_cores"]["cores"],
+                               ms_per_step=legs["all_cores"]["ms_per_step"],
+                               sample=f"{legs['all_cores']['steps']} full steps, the same loops under OpenMP "
+                                      f"(po_*_mt), {legs['all_cores']['seconds']:.1f} s"),
+                host_cores_available=os.cpu_count()), result
+
+
+def pyspec_c1_baseline(target_seconds=8.0):
+    """BASELINE configs[0]: 1 024 validators, 32 slots, one committee per slot -- the L0 oracle, i.e. the reference's
+    own pyspec text (oracle/_ref) on one host core: on_attestation throughput and get_head latency."""
+    from oracle import spec
+    from tests.scenario import new_world, slot_committee_members
+
+    w = new_world(1024, "mainnet")
+    anchor = w.store.justified_checkpoint.root
+    tip, n_att, t_att, t_head, n_head = anchor, 0, 0.0, 0.0, 0
+    t_start = time.perf_counter()
+    for slot in range(1, 33):
+        w.tick_to_slot(slot)
+        tip = w.block(tip, slot)
+        if slot >= 2:
+            voters = slot_committee_members(w.store, slot - 1)
+            atts = w.attestation_for(voters, w.store.blocks[tip].parent_root, slot - 1)
+            t = time.perf_counter()
+            for a in atts:
+                spec.on_attestation(w.store, a)
+            t_att += time.perf_counter() - t
+            n_att += len(voters)
+        t = time.perf_counter()
+        spec.get_head(w.store)
+        t_head += time.perf_counter() - t
+        n_head += 1
+        if time.perf_counter() - t_start > target_seconds and n_head >= 4:
             break
-    dt = time.perf_counter() - t0
-    return dict(value=n_att / dt, unit="attestations/s", cores=1, kind="port",
-                sample=f"{reps} full steps ({n_att} attestations: union + G1 sums + LMD + flags + get_head) of the "
-                       f"timed workload, oracle/posevo_oracle.c, single thread, {dt:.1f} s"), result
+    spec.use_preset("mainnet")
+    return dict(config="BASELINE configs[0]: 1024 validators, 32 slots, one committee of 32 per slot",
+                oracle=f"L0 = the reference's pyspec text ({spec.ORACLE_OF_RECORD})", cores=1,
+                on_attestation_attestations_per_s=(n_att / t_att) if t_att else None,
+                get_head_ms=t_head / n_head * 1e3, slots_run=n_head)
+
+
+def whole_step_check(pea, w, st, chk, device):
+    """Step 0 through a fresh engine (pipelined + resident, as timed) against the oracle's answers for the same step:
+    union bits, counts, every aggregate pubkey, the LMD table, the head, all per-block weights, the reward numerators
+    and both participation arrays."""
+    e2 = pea.Engine(device=device)
+    tree = w["tree"]
+    e2.store_init(0, 0, tree.roots[0].tobytes())
+    for i in range(1, tree.roots.shape[0]):
+        e2.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+    e2.set_validators(w["bal"], w["flags"], w["pts"])
+    e2.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
+    r = run_step_single(e2, w, st, pipelined=True, lagged=True)
+    e2.drain()
+    rows = r["rows"]
+    C = st["comm"].offsets.size - 1
+    cps = C // w["spe"]
+    pos = ((rows["slot"] % w["spe"]) * cps + rows["index"]).astype(np.int64)   # committee id of every aggregate row
+    inv = np.argsort(pos)                                                       # oracle arrays are in committee order
+    assert np.array_equal(pos[inv], np.arange(C)), "one aggregate per committee expected"
+    out = {}
+    agg = r["agg"]
+    union_e = np.concatenate([np.packbits(agg["bits"][g], bitorder="little") for g in inv])
+    out["union_bits"] = bool(np.array_equal(union_e, chk["union"]))
+    out["counts"] = bool(np.array_equal(agg["count"][inv], chk["count"]) and np.array_equal(r["count"][inv], chk["count"]))
+    out["aggregate_pubkeys"] = bool(np.array_equal(agg["aggpk96"][inv], chk["aggpk"]))
+    out["latest_messages"] = bool(np.array_equal(e2.latest_messages()[1], chk["vote_block"]))
+    out["head"] = r["head"] == chk["head"]
+    out["weights"] = bool(np.array_equal(e2.get_weights(), chk["weights"]))
+    out["reward_numerators"] = bool(np.array_equal(r["numerators"][inv], chk["numerators"]))
+    out["participation"] = bool(np.array_equal(e2.participation_get(0), chk["part_cur"]) and
+                                np.array_equal(e2.participation_get(1), chk["part_prev"]))
+    out["statuses_ok"] = bool((r["status"] == 0).all() and (r["pstatus"] == 0).all())
+    e2.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--validators", type=int, default=1 << 20, help="per GPU")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--validators", type=int, default=1 << 20,
+                    help="registry size: the whole job's with --scaling strong, per GPU with --scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = BASELINE configs[3] (the 1 048 576-validator registry range-sharded over the "
+                         "N GPUs, V/N validators and C committees x (V/N)/C local members per rank); weak = a full "
+                         "registry of --validators per GPU")
     ap.add_argument("--blocks", type=int, default=4096)
     ap.add_argument("--committees", type=int, default=2048)
     ap.add_argument("--parts", type=int, default=4, help="partial aggregates per committee")
@@ -231,6 +360,9 @@ def main():
 
     import pos_evolution_amd as pea
 
+    # validators this rank owns: the whole registry on one GPU; V/N (strong) or V (weak) of it on N
+    args.validators_local = args.validators // world if (world > 1 and args.scaling == "strong") else args.validators
+    assert args.validators_local % args.committees == 0, "validators per rank must be a multiple of the committee count"
     total = args.warmup + args.steps
     e = pea.Engine(device=local_rank, max_committee_tables=total + 1)
     w = build_workload(e, args, rank, total)
@@ -265,9 +397,11 @@ def main():
     t0 = time.perf_counter()
     last = None
     inflight = []
+    stamps = [t0]
     n_att_local = n_rejected = 0
     for s in range(args.warmup, total):
         inflight.append(step(w["steps"][s]))
+        stamps.append(time.perf_counter())
         if len(inflight) > 2:  # complete by now (a lagged step completes when the second next one's block exits)
             done = inflight.pop(0)
             n_att_local += int(done["count"].sum())
@@ -313,16 +447,21 @@ def main():
 
     # ---- roofline of the dominant kernel: k_g1_accumulate, algorithmic bytes per launch ----
     C = args.committees
+    VL = args.validators_local
     att_per_launch = n_att_local / args.steps
-    alg_bytes = 100.125 * att_per_launch + C * (96 + (args.validators / C) / 8)
+    alg_bytes = 100.125 * att_per_launch + C * (96 + (VL / C) / 8)
     acc = prof["g1_accumulate"]
     acc_ms = acc["total_ms"] / max(acc["launches"], 1)
     achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
-    traffic = None
+    # HBM bytes per launch from the PMC passes (tools/profile_round.sh): recorded per shape, quoted only for the shape
+    # that was measured
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_g1_accumulate_bytes_per_launch")
+            ent = json.load(open(tpath)).get("shapes", {}).get(f"{VL},{C},{args.blocks}")
+            if ent:
+                traffic, traffic_src = ent.get("k_g1_accumulate_bytes_per_launch"), ent.get("source")
         except Exception:
             traffic = None
     # VALU view of the same kernel: Montgomery products per launch against the measured chip ceiling
@@ -332,8 +471,19 @@ def main():
     valu_ach = products / (acc_ms * 1e-3) if acc_ms else 0.0
     votes = prof["votes"]
     votes_ms = votes["total_ms"] / max(votes["launches"], 1)
-    votes_bytes = 13.0 * args.validators + 32.0 * args.blocks
+    votes_bytes = 13.0 * VL + 32.0 * args.blocks
     kernel_ms = {k: (v["total_ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()}
+    per_step = np.diff(np.array(stamps)) * 1e3
+    V_total = VL * world
+    shape = ("BASELINE configs[3] shape" if (V_total, C, args.blocks) == (1 << 20, 2048, 4096)
+             else "BASELINE configs[4] shape" if (V_total, args.blocks) == (1 << 22, 8192)
+             else "BASELINE configs[2] shape" if (V_total, args.blocks) == (1 << 18, 4096)
+             else "custom shape")
+    scaling = "weak" if (world > 1 and args.scaling == "weak") else "strong"
+    mode = ("sharded, synchronous calls" if world > 1 else
+            "synchronous calls" if args.no_pipeline else
+            "pipelined calls (one wait per step)" if args.no_lag else
+            "streaming pipelines (pe_pipeline_begin_streaming / _end_lagged: a step's G1 sums overlap the next step)")
 
     out = {
         "metric": "attestations aggregated/sec + get_head() p50 latency at 1M validators",
@@ -344,26 +494,31 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "u32",
         "dtype_detail": "12 x u32 Montgomery limbs (381-bit Fp, exact integer arithmetic); u64 Gwei weights",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[3] shape" if (args.validators, C, args.blocks) == (1 << 20, 2048, 4096)
-                         else "BASELINE configs[4] shape" if (args.validators, args.blocks) == (1 << 22, 8192)
-                         else "BASELINE configs[2] shape" if (args.validators, args.blocks) == (1 << 18, 4096)
-                         else "custom shape") + f" on {world} GPU(s): {args.validators} validators/GPU, "
-                        f"{C} committees x {args.validators // C}, {args.parts} partial aggregates/committee, "
-                        f"99% participation, {args.blocks}-block tree, one epoch per step",
-            "validators_per_gpu": args.validators, "blocks": args.blocks, "committees": C,
-            "parallelism": f"validator-range shards x{world}" if world > 1 else "single GPU",
+            "workload": shape + f": {V_total} validators on {world} GPU(s) ({VL} per GPU), "
+                        f"{C} committees x {V_total // C}, {args.parts} partial aggregates/committee, "
+                        f"99% participation, {args.blocks}-block tree, one epoch per step: pe_aggregate (union + "
+                        f"aggregate pubkeys) -> pe_on_attestation_batch -> pe_get_head -> pe_process_attestation_batch",
+            "validators_total": V_total, "validators_per_gpu": VL, "blocks": args.blocks, "committees": C,
+            "parallelism": f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU",
+            "call_mode": mode,
+            "per_epoch_setup_outside_the_step": "pe_compute_committees (GPU swap-or-not shuffle + inverse committee "
+                                                "map) runs once per epoch when the workload is built, not in the step",
         },
+        "step_ms_p50": float(np.median(per_step)), "step_ms_min": float(per_step.min()),
+        "step_ms_p90": float(np.percentile(per_step, 90)),
+        "aggregation_budget": {"seconds": 4.0, "source": "pe:1536 (the last third of a 12 s slot)",
+                               "step_fraction_of_budget": dt / args.steps / 4.0},
         "get_head_p50_us": float(lat[len(lat) // 2]),
         "get_head_p99_us": float(lat[min(len(lat) - 1, int(len(lat) * 0.99))]),
         "roofline": {
             "kernel": "k_g1_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms, "launches": acc["launches"],
             "note": "integer-VALU bound (10 Montgomery products per 100 B gathered), not HBM bound: "
                     "see DESIGN.md; votes kernel below is the HBM-streaming one",
@@ -384,21 +539,12 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         base, chk = cpu_baseline(w, w["steps"][0])
         out["cpu_baseline"] = base
-        out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        # same-input cross-check of step 0's G1 aggregates against the oracle (not timed)
-        e2 = pea.Engine(device=local_rank)
-        st0 = w["steps"][0]
-        e2.store_init(0, 0, w["tree"].roots[0].tobytes())
-        e2.set_validators(w["bal"], w["flags"], w["pts"])
-        e2.set_committees(st0["epoch"], st0["comm"].offsets, st0["comm"].members)
-        agg = e2.aggregate(packed=(st0["atts"], st0["arena"]), want_aggregate_pubkeys=True)
-        import pos_evolution_amd.synth as synth
-        rows = agg["atts"]
-        cps = C // 32
-        pos = ((rows["slot"] % 32) * cps + rows["index"]).astype(np.int64)
-        out["checked_against_oracle"] = bool(np.array_equal(agg["aggpk96"], chk["aggpk"][pos]))
-        assert out["checked_against_oracle"], "GPU aggregate pubkeys differ from the oracle"
-        e2.close()
+        out["cpu_baseline"]["pyspec_c1"] = pyspec_c1_baseline()
+        # step 0 through a fresh engine, every output and the device state against the oracle's answers (not timed)
+        chk_out = whole_step_check(pea, w, w["steps"][0], chk, local_rank)
+        out["checked_against_oracle"] = bool(all(chk_out.values()))
+        out["oracle_check"] = chk_out
+        assert out["checked_against_oracle"], f"GPU step differs from the oracle: {chk_out}"
     if _BREAKDOWN is not None:
         out["host_breakdown_ms_per_step"] = {k: v / total * 1e3 for k, v in _BREAKDOWN.items()}
     print(json.dumps(out))

@@ -258,6 +258,9 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32]);
 /* get_latest_attesting_balance(store, root) for every block, in insertion order
  * (index 0 = anchor).  out must hold pe_num_blocks(h) entries. */
 int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n);
+/* The per-block weights the LAST head computation left behind (pe_get_head, or pe_head_from_weights on a reduced
+ * multi-GPU buffer), without recomputing them. */
+int pe_get_last_weights(pe_engine* h, uint64_t* out_weights, uint32_t n);
 
 /* on_attestation (pe:963-979, pe:1423-1428) x n, applied AS IF sequentially in
  * array order: validate_on_attestation (Appendix A.4), committee lookup
@@ -402,8 +405,10 @@ int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_block
  * points into a caller-owned DEVICE buffer; after an all-gather over ranks,
  * pe_g1_finish adds the n_ranks partials per group and normalises to affine. */
 #define PE_G1_PARTIAL_BYTES 192
+/* dev_partials_capacity: how many partials (groups) the caller's device buffer holds; a batch that forms more groups
+ * fails with PE_ERR_CAPACITY before anything is written. */
 int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups,
-                  void* dev_partials);
+                  void* dev_partials, uint32_t dev_partials_capacity);
 int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups,
                  uint8_t* out96);
 /* pe_aggregate whose aggregate pubkeys stay projective (XYZZ) partials of THIS shard's committee
@@ -414,7 +419,7 @@ int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
                          const uint8_t* bits_arena, uint64_t arena_len,
                          pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
                          uint8_t* out_bits_arena, uint64_t out_arena_cap, uint32_t* out_count,
-                         void* dev_partials);
+                         void* dev_partials, uint32_t dev_partials_capacity);
 
 /* ---- profiling hooks (bench.py roofline leg) ----------------------------- */
 /* When enabled, the engine brackets each launch of its kernels with HIP events on

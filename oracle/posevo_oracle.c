@@ -611,3 +611,186 @@ int po_g1_finish_partials(const uint8_t* gathered144, uint32_t n_ranks, uint32_t
     }
     return 0;
 }
+
+
+/* ======================================================================= */
+/* All-cores forms (OpenMP) for bench.py's cpu_baseline leg: the SAME loops  */
+/* split over independent units.  tests/test_oracle_cport.py holds them equal */
+/* to the single-thread functions above, which stay the checker of record.   */
+/* ======================================================================= */
+#ifdef _OPENMP
+#include <omp.h>
+int po_max_threads(void) { return omp_get_max_threads(); }
+void po_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+int po_max_threads(void) { return 1; }
+void po_set_threads(int n) { (void)n; }
+#endif
+
+/* groups are independent */
+void po_bits_union_mt(uint32_t n_groups, const uint32_t* group_start, const uint32_t* att_list,
+                      const uint32_t* att_bits_off, const uint8_t* arena, const uint32_t* group_n_bits,
+                      const uint32_t* out_bits_off, uint8_t* out_arena, uint32_t* out_count)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t g = 0; g < (int64_t)n_groups; ++g) {
+        const uint32_t gs[2] = {group_start[g], group_start[g + 1]};
+        po_bits_union(1, gs, att_list, att_bits_off, arena, group_n_bits + g, out_bits_off + g, out_arena,
+                      out_count ? out_count + g : 0);
+    }
+}
+
+int po_g1_sum_groups_mt(const uint8_t* points96, uint64_t n_points, const uint32_t* index,
+                        const uint32_t* offsets, uint32_t n_groups, uint8_t* out96)
+{
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t g = 0; g < (int64_t)n_groups; ++g) {
+        const uint32_t off[2] = {offsets[g], offsets[g + 1]};
+        const int r = po_g1_sum_groups(points96, n_points, index, off, 1, out96 + 96 * (size_t)g);
+        if (r) {
+#pragma omp atomic write
+            rc = r;
+        }
+    }
+    return rc;
+}
+
+/* Aggregate pubkey per attestation straight from its bits (get_attesting_indices + the sum of FastAggregateVerify,
+ * A.6/A.7, without materialising the index list): out[a] = sum of points[members[member_off[a] + i]] over set bits i. */
+int po_g1_sum_attesters(uint32_t n_att, const uint32_t* member_off, const uint32_t* n_bits, const uint32_t* bits_off,
+                        const uint8_t* arena, const uint32_t* members, const uint8_t* points96, uint64_t n_points,
+                        uint8_t* out96)
+{
+    for (uint32_t a = 0; a < n_att; ++a) {
+        const uint8_t* bits = arena + bits_off[a];
+        g1j acc;
+        g1j_set_inf(&acc);
+        for (uint32_t i = 0; i < n_bits[a]; ++i) {
+            if (!((bits[i >> 3] >> (i & 7)) & 1)) continue;
+            const uint64_t k = members[member_off[a] + i];
+            if (k >= n_points) return -1;
+            g1a q;
+            g1a_from_bytes96(&q, points96 + 96 * k);
+            g1j t;
+            g1j_add_affine(&t, &acc, &q);
+            acc = t;
+        }
+        g1j_to_bytes96(out96 + 96 * (size_t)a, &acc);
+    }
+    return 0;
+}
+int po_g1_sum_attesters_mt(uint32_t n_att, const uint32_t* member_off, const uint32_t* n_bits, const uint32_t* bits_off,
+                           const uint8_t* arena, const uint32_t* members, const uint8_t* points96, uint64_t n_points,
+                           uint8_t* out96)
+{
+    int rc = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t a = 0; a < (int64_t)n_att; ++a) {
+        const int r = po_g1_sum_attesters(1, member_off + a, n_bits + a, bits_off + a, arena, members, points96, n_points,
+                                          out96 + 96 * (size_t)a);
+        if (r) {
+#pragma omp atomic write
+            rc = r;
+        }
+    }
+    return rc;
+}
+
+/* PRECONDITION: the committees of the batch are pairwise disjoint (one aggregate per committee of a table that
+ * partitions the validators -- bench.py's step): attestations then touch disjoint validators and any order equals the
+ * sequential one. */
+void po_update_latest_messages_mt(uint32_t n_att, const uint32_t* member_off, const uint32_t* n_bits,
+                                  const uint32_t* bits_off, const uint64_t* target_epoch,
+                                  const uint32_t* block_idx, const uint8_t* arena, const uint32_t* members,
+                                  const uint8_t* val_flags, uint64_t* vote_epoch, uint32_t* vote_block)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < (int64_t)n_att; ++a)
+        po_update_latest_messages(1, member_off + a, n_bits + a, bits_off + a, target_epoch + a, block_idx + a, arena,
+                                  members, val_flags, vote_epoch, vote_block);
+}
+
+/* same precondition */
+void po_process_attestation_flags_mt(uint32_t n_att, const uint32_t* member_off, const uint32_t* n_bits,
+                                     const uint32_t* bits_off, const uint8_t* flag_mask, const uint8_t* which,
+                                     const uint8_t* arena, const uint32_t* members, const uint64_t* eff_balance,
+                                     uint64_t increment, uint64_t base_reward_per_increment,
+                                     uint8_t* participation_current, uint8_t* participation_previous,
+                                     uint64_t* out_numerators)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t a = 0; a < (int64_t)n_att; ++a)
+        po_process_attestation_flags(1, member_off + a, n_bits + a, bits_off + a, flag_mask + a, which + a, arena,
+                                     members, eff_balance, increment, base_reward_per_increment,
+                                     participation_current, participation_previous, out_numerators + a);
+}
+
+/* get_head with the O(V) vote scan split over validator ranges (one private weight array per thread, summed after);
+ * the O(B) tree part is the single-thread code. */
+int po_get_head_mt(uint32_t n_blocks, const uint32_t* parent, const uint8_t* leaf_ok, const uint8_t* roots,
+                   uint64_t n_val, const uint32_t* vote_block, const uint64_t* eff_balance,
+                   const uint8_t* flags, int filter_slashed, uint32_t justified_idx, uint32_t boost_idx,
+                   uint64_t slots_per_epoch, uint64_t boost_percent, uint64_t balance_increment,
+                   uint64_t* out_weights, uint32_t* out_head)
+{
+    if (n_blocks == 0 || justified_idx >= n_blocks) return -1;
+    int nt = po_max_threads();
+    if (nt < 1) nt = 1;
+    uint64_t* priv = (uint64_t*)calloc((size_t)nt * (n_blocks + 2), sizeof(uint64_t));
+    if (!priv) return -4;
+    int bad = 0;
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        uint64_t* w = priv + (size_t)t * (n_blocks + 2);
+        const uint64_t lo = n_val * (uint64_t)t / (uint64_t)T, hi = n_val * (uint64_t)(t + 1) / (uint64_t)T;
+        for (uint64_t v = lo; v < hi; ++v) {
+            const uint8_t f = flags[v];
+            if (!(f & PO_VAL_ACTIVE)) continue;
+            w[n_blocks] += eff_balance[v];
+            w[n_blocks + 1] += 1;
+            if (f & PO_VAL_EQUIVOCATING) continue;
+            if (filter_slashed && (f & PO_VAL_SLASHED)) continue;
+            const uint32_t b = vote_block[v];
+            if (b == PO_NONE) continue;
+            if (b >= n_blocks) { bad = 1; continue; }
+            w[b] += eff_balance[v];
+        }
+    }
+    if (bad) { free(priv); return -2; }
+    /* a synthetic one-validator-per-block registry carries the summed direct weights into the single-thread code */
+    uint64_t* bal = (uint64_t*)calloc((size_t)n_blocks + 1, sizeof(uint64_t));
+    uint32_t* vb = (uint32_t*)calloc((size_t)n_blocks + 1, sizeof(uint32_t));
+    uint8_t* fl = (uint8_t*)calloc((size_t)n_blocks + 1, 1);
+    if (!bal || !vb || !fl) { free(priv); free(bal); free(vb); free(fl); return -4; }
+    uint64_t total_active = 0, num_active = 0;
+    for (int t = 0; t < nt; ++t) {
+        const uint64_t* w = priv + (size_t)t * (n_blocks + 2);
+        for (uint32_t b = 0; b < n_blocks; ++b) bal[b] += w[b];
+        total_active += w[n_blocks];
+        num_active += w[n_blocks + 1];
+    }
+    free(priv);
+    for (uint32_t b = 0; b < n_blocks; ++b) { vb[b] = b; fl[b] = PO_VAL_ACTIVE; }
+    /* boost needs the true totals: compute the proposer score here and hand it over as one more "validator" */
+    uint64_t n_syn = n_blocks;
+    if (boost_idx != PO_NONE && num_active > 0) {
+        if (boost_idx >= n_blocks) { free(bal); free(vb); free(fl); return -3; }
+        if (total_active < balance_increment) total_active = balance_increment;
+        const uint64_t avg_balance = total_active / num_active;
+        const uint64_t committee_weight = (num_active / slots_per_epoch) * avg_balance;
+        bal[n_blocks] = (uint64_t)(((u128)committee_weight * boost_percent) / 100);
+        vb[n_blocks] = boost_idx;
+        fl[n_blocks] = PO_VAL_ACTIVE;
+        n_syn = n_blocks + 1;
+    }
+    const int rc = po_get_head(n_blocks, parent, leaf_ok, roots, n_syn, vb, bal, fl, 0, justified_idx, PO_NONE,
+                               slots_per_epoch, boost_percent, balance_increment, out_weights, out_head);
+    free(bal); free(vb); free(fl);
+    return rc;
+}

@@ -129,8 +129,9 @@ SIGNATURES = {
     "pe_votes_partial": (C.c_int, [_H, C.c_void_p, C.c_uint32]),
     "pe_head_from_weights": (C.c_int, [_H, C.c_void_p, C.c_uint32, _u8p]),
     "pe_aggregate_partial": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _attp,
-                                       _u32p, _u32p, _u8p, C.c_uint64, _u32p, C.c_void_p]),
-    "pe_g1_partial": (C.c_int, [_H, _u32p, _u32p, C.c_uint32, C.c_void_p]),
+                                       _u32p, _u32p, _u8p, C.c_uint64, _u32p, C.c_void_p, C.c_uint32]),
+    "pe_g1_partial": (C.c_int, [_H, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "pe_get_last_weights": (C.c_int, [_H, _u64p, C.c_uint32]),
     "pe_g1_finish": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, _u8p]),
     "pe_pipeline_begin": (C.c_int, [_H]),
     "pe_pipeline_end": (C.c_int, [_H]),

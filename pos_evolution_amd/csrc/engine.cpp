@@ -1543,6 +1543,16 @@ int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)
     return PE_OK;
 }
 
+int pe_get_last_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!out_weights || n != h->blocks.size() || !h->d_weights.p) return fail(h, PE_ERR_INVALID_ARG, "n must equal pe_num_blocks");
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out_weights, h->d_weights.p, 8ull * n, hipMemcpyDeviceToHost));
+    return PE_OK;
+}
+
 int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
 {
     int rc = need_init(h);
@@ -1915,7 +1925,8 @@ struct AggState {  // what the completion of one pe_aggregate needs after the wa
 static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                           uint64_t arena_len, const uint8_t* sig_points96, pe_attestation* out_atts,
                           uint32_t* out_n_groups, uint32_t* group_of, uint8_t* out_bits_arena, uint64_t out_arena_cap,
-                          uint8_t* out_sig96, uint8_t* out_aggpk96, uint32_t* out_count, void* dev_partials)
+                          uint8_t* out_sig96, uint8_t* out_aggpk96, uint32_t* out_count, void* dev_partials,
+                          uint32_t dev_partials_capacity = 0)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
@@ -1972,6 +1983,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     lo &= ~uint64_t(3);                              // keep the members' word alignment relative to the upload
     if (hi - lo >= 0xFFFFFFF0ull) return fail(h, PE_ERR_CAPACITY, "bit arena span exceeds 4 GiB");
     const uint32_t ng = (uint32_t)rep.size();
+    if (dev_partials && ng > dev_partials_capacity)  // before anything is launched: the buffer is the caller's
+        return fail(h, PE_ERR_CAPACITY, "dev_partials holds fewer groups than the batch forms");
     A.ng = ng;
     std::vector<uint32_t>& gstart = A.gstart;        // counting sort: members of group g, in input order
     std::vector<uint32_t>& order = A.order;
@@ -2252,11 +2265,13 @@ int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n, const uin
 
 int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                          uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
-                         uint8_t* out_bits_arena, uint64_t out_arena_cap, uint32_t* out_count, void* dev_partials)
+                         uint8_t* out_bits_arena, uint64_t out_arena_cap, uint32_t* out_count, void* dev_partials,
+                         uint32_t dev_partials_capacity)
 {
     if (!dev_partials) return PE_ERR_INVALID_ARG;
     return aggregate_impl(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of,
-                          out_bits_arena, out_arena_cap, nullptr, nullptr, out_count, dev_partials);
+                          out_bits_arena, out_arena_cap, nullptr, nullptr, out_count, dev_partials,
+                          dev_partials_capacity);
 }
 
 // ---------------------------------------------------------------- process_attestation
@@ -2594,9 +2609,11 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
     return g1_sum_common(h, d_pts, np, index, offsets, n_groups, out96, nullptr);
 }
 
-int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, void* dev_partials)
+int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, void* dev_partials,
+                  uint32_t dev_partials_capacity)
 {
     if (!h || !offsets || !dev_partials) return PE_ERR_INVALID_ARG;
+    if (n_groups > dev_partials_capacity) return fail(h, PE_ERR_CAPACITY, "dev_partials holds fewer than n_groups partials");
     PE_TRY(enter(h));
     if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
     if (n_groups == 0) return PE_OK;

@@ -319,6 +319,13 @@ class Engine:
         self._check(self._lib.pe_get_weights(self._h, _ptr(out, C.c_uint64), n))
         return out
 
+    def last_weights(self) -> np.ndarray:
+        """Per-block weights left behind by the last head computation (get_head / head_from_weights), not recomputed."""
+        n = self.num_blocks
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.pe_get_last_weights(self._h, _ptr(out, C.c_uint64), n))
+        return out
+
     def on_attestation_batch(self, rows=None, packed=None, want_aggregate_pubkeys=False):
         """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
@@ -489,8 +496,9 @@ class Engine:
         self._check(self._lib.pe_head_from_weights(self._h, C.c_void_p(dev_ptr), self.num_blocks, out))
         return bytes(out)
 
-    def aggregate_partial(self, dev_ptr: int, rows=None, packed=None):
-        """pe_aggregate with the aggregate pubkeys left as this shard's XYZZ partials (192 B each) at dev_ptr."""
+    def aggregate_partial(self, dev_ptr: int, rows=None, packed=None, capacity_groups: int = 0):
+        """pe_aggregate with the aggregate pubkeys left as this shard's XYZZ partials (192 B each) at dev_ptr, a device
+        buffer of capacity_groups partials (a batch forming more groups fails with PE_ERR_CAPACITY, nothing written)."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         out_atts = np.empty(max(n, 1), dtype=_ATT_DTYPE)
@@ -501,18 +509,18 @@ class Engine:
         self._check(self._lib.pe_aggregate_partial(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
                                                    _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
                                                    _ptr(out_arena, C.c_uint8), out_arena.size,
-                                                   _ptr(count, C.c_uint32), C.c_void_p(dev_ptr)))
+                                                   _ptr(count, C.c_uint32), C.c_void_p(dev_ptr), capacity_groups))
         g = n_groups.value
         if g:
             last = out_atts[g - 1]
             out_arena = out_arena[: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
         return dict(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena, count=count[:g])
 
-    def g1_partial(self, offsets, index, dev_ptr: int):
+    def g1_partial(self, offsets, index, dev_ptr: int, capacity_groups: int):
         off = np.ascontiguousarray(offsets, dtype=np.uint32)
         idx = None if index is None else np.ascontiguousarray(index, dtype=np.uint32)
         self._check(self._lib.pe_g1_partial(self._h, _ptr(idx, C.c_uint32), _ptr(off, C.c_uint32), off.size - 1,
-                                            C.c_void_p(dev_ptr)))
+                                            C.c_void_p(dev_ptr), capacity_groups))
 
     def g1_finish(self, dev_ptr: int, n_ranks: int, n_groups: int) -> np.ndarray:
         out = np.zeros((max(n_groups, 1), 96), dtype=np.uint8)

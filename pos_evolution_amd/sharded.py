@@ -74,9 +74,11 @@ class ShardedForkChoice:
         """pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.
         Every rank must pass attestations that form the SAME groups in the SAME order (group g of every rank =
         that rank's members of committee g)."""
-        res = self.engine.aggregate_partial(self._partial.data_ptr(), rows=rows, packed=packed)
+        # the engine refuses (PE_ERR_CAPACITY, before writing anything) a batch that forms more groups than the
+        # exchange buffers were sized for
+        res = self.engine.aggregate_partial(self._partial.data_ptr(), rows=rows, packed=packed,
+                                            capacity_groups=self.n_groups_max)
         g = res["n_groups"]
-        assert g <= self.n_groups_max
         part = self._partial[: g * self._pw]
         gathered = self._gathered[: self.world * g * self._pw]
         if self.dist.is_initialized():

@@ -1,0 +1,124 @@
+"""-m gpu: the whole step (aggregate -> on_attestation -> get_head -> process_attestation) at the BASELINE config
+shapes round 1 left without a G1 parity check, and the workload variations SURVEY.md 8(d) asks for (bit density
+50 % / 100 %, proposer boost on a leaf), against the C oracle -- through the same helpers bench.py's own
+cross-check uses, so the bench's "checked_against_oracle" and these tests cannot drift apart."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import bench
+import pos_evolution_amd as pea
+import pos_evolution_amd.synth as synth
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(e, n_val, n_comm, n_blocks, seed, density, parts, mixed=False, kind="bushy", shuffle=True):
+    spe = 32
+    tree = synth.random_tree(n_blocks, seed, kind)
+    e.store_init(0, 0, tree.roots[0].tobytes())
+    for i in range(1, n_blocks):
+        e.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+    bal = synth.balances(n_val, seed, mixed=mixed)
+    flags = synth.validator_flags(n_val, seed, inactive_frac=0.005)
+    pts = synth.registry_points(e, n_val)
+    e.set_validators(bal, flags, pts)
+    ep = int(tree.slot.max()) // spe + 1
+    if shuffle:   # the reference's swap-or-not shuffle on the GPU (pe:495-534), as the bench builds its tables
+        s = hashlib.sha256(b"shape" + seed.to_bytes(4, "little")).digest()
+        off, mem = e.compute_committees(ep, s, np.arange(n_val, dtype=np.uint32), n_comm, 90)
+        comm = synth.Committees(off, mem)
+    else:
+        comm = synth.random_committees(n_val, n_comm, seed)
+        e.set_committees(ep, comm.offsets, comm.members)
+    atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=seed, density=density, parts=parts,
+                                              source=(0, tree.roots[0].tobytes()), vote_recent=64)
+    w = dict(tree=tree, bal=bal, flags=flags, pts=pts, spe=spe)
+    st = dict(epoch=ep, comm=comm, atts=atts, arena=arena)
+    st["ctx"] = bench.state_ctx(w, ep)
+    w["steps"] = [st]
+    return w, st
+
+
+def _check_step(e, w, st, boost_root=None, pipelined=True):
+    inp = bench.cpu_step_inputs(w, st)
+    V = w["bal"].size
+    vote_epoch, vote_block = np.zeros(V, dtype=np.uint64), np.full(V, 0xFFFFFFFF, dtype=np.uint32)
+    want = bench.cpu_step(w, st, inp, False, vote_epoch, vote_block)
+    if boost_root is not None:   # the oracle's head / weights with the boost on that block
+        bi = next(i for i in range(w["tree"].roots.shape[0]) if w["tree"].roots[i].tobytes() == boost_root)
+        h, wts = cport.get_head(w["tree"].parent, np.ones(w["tree"].parent.size, np.uint8), w["tree"].roots,
+                                want["vote_block"], w["bal"], w["flags"], 0, boost_idx=bi)
+        want["head"], want["weights"] = w["tree"].roots[h].tobytes(), wts
+    r = bench.run_step_single(e, w, st, pipelined=pipelined, lagged=False)
+    rows = r["rows"]
+    C = st["comm"].offsets.size - 1
+    pos = ((rows["slot"] % 32) * (C // 32) + rows["index"]).astype(np.int64)
+    inv = np.argsort(pos)
+    assert np.array_equal(pos[inv], np.arange(C))
+    agg = r["agg"]
+    assert np.array_equal(agg["count"][inv], want["count"])
+    assert np.array_equal(np.concatenate([np.packbits(agg["bits"][g], bitorder="little") for g in inv]), want["union"])
+    assert np.array_equal(agg["aggpk96"][inv], want["aggpk"]), "aggregate pubkeys"
+    assert (r["status"] == 0).all() and (r["pstatus"] == 0).all()
+    assert np.array_equal(e.latest_messages()[1], want["vote_block"])
+    assert r["head"] == want["head"]
+    assert np.array_equal(e.get_weights(), want["weights"])
+    assert np.array_equal(r["numerators"][inv], want["numerators"])
+    assert np.array_equal(e.participation_get(0), want["part_cur"])
+    assert np.array_equal(e.participation_get(1), want["part_prev"])
+    return r, want, inv
+
+
+def test_config2_shape_65536_validators_64_committees_per_slot(engine_factory):
+    """BASELINE configs[1]: 65 536 validators, 64 committees per slot (2048 committees of 32), 2048-block tree."""
+    e = engine_factory()
+    w, st = _workload(e, 65536, 2048, 2048, seed=2, density=0.99, parts=4, kind="branchy")
+    _check_step(e, w, st)
+
+
+@pytest.mark.parametrize("density,parts", [(0.5, 4), (1.0, 1), (1.0, 4)])
+def test_bit_density_variations(engine_factory, density, parts):
+    """SURVEY.md 8(d) "also vary bit density {50 %, 99 %, 100 %}": 262 144 validators, 2048 committees of 128."""
+    e = engine_factory()
+    w, st = _workload(e, 262144, 2048, 512, seed=3, density=density, parts=parts)
+    r, want, _ = _check_step(e, w, st)
+    if density == 1.0:
+        assert int(want["count"].sum()) == 262144
+
+
+def test_proposer_boost_on_a_leaf(engine_factory):
+    """SURVEY.md 8(d) "boost {unset, set on a leaf}": the boost lands on a leaf (every ancestor gains the proposer
+    score, A.1); head and all weights against the oracle with the same boost."""
+    e = engine_factory()
+    w, st = _workload(e, 65536, 2048, 300, seed=5, density=0.9, parts=2)
+    tree = w["tree"]
+    is_parent = np.zeros(tree.parent.size, dtype=bool)
+    is_parent[tree.parent[1:]] = True
+    leaf = int(np.nonzero(~is_parent)[0][-3])
+    e.on_tick((st["epoch"] + 1) * 32 * 12)
+    e.set_proposer_boost(tree.roots[leaf].tobytes())
+    # run_step_single ticks to the same time again: no new slot, the boost stays (pe:943-944)
+    r, want, _ = _check_step(e, w, st, boost_root=tree.roots[leaf].tobytes())
+    plain, _ = cport.get_head(tree.parent, np.ones(tree.parent.size, np.uint8), tree.roots, want["vote_block"],
+                              w["bal"], w["flags"], 0)
+    assert np.array_equal(e.get_weights(), want["weights"])
+    assert want["weights"][leaf] > 0 and want["weights"][0] > 0
+
+
+def test_config5_shape_aggregate_2048_committees_of_2048_over_4m_registry(engine_factory):
+    """BASELINE configs[4]: 4 194 304 validators, EIP-7251-style mixed balances, 2048 committees of 2048 (the
+    MAX_VALIDATORS_PER_COMMITTEE of pe:715), 8192-block tree.  pe_aggregate's 2048 sums of ~2027 points each: EVERY
+    group against the closed form, the whole step (union, LMD, head, weights, flags, numerators and all 2048 aggregate
+    pubkeys) against the C oracle."""
+    e = engine_factory()
+    w, st = _workload(e, 1 << 22, 2048, 8192, seed=4, density=0.99, parts=4, mixed=True)
+    r, want, inv = _check_step(e, w, st)
+    agg, comm = r["agg"], st["comm"]
+    rows = agg["atts"]
+    pos = ((rows["slot"] % 32) * 64 + rows["index"]).astype(np.int64)
+    for g in range(agg["n_groups"]):
+        mem = comm.members[comm.offsets[pos[g]]:comm.offsets[pos[g] + 1]]
+        assert agg["aggpk96"][g].tobytes() == synth.registry_closed_form(mem[agg["bits"][g]]), g

@@ -83,7 +83,9 @@ def test_two_shards_on_one_gpu(engine_factory):
         _load(e, tree, bal[lo:hi], flags[lo:hi], pts[lo:hi], lc, epoch)
         la, larena = _local_attestations(atts, bit_rows, comm, lo, hi)
         part = torch.zeros(C * PW, dtype=torch.int32, device=dev)
-        res = e.aggregate_partial(part.data_ptr(), packed=(la, larena))
+        with pytest.raises(AssertionError):   # capacity is checked before anything is written (PE_ERR_CAPACITY)
+            e.aggregate_partial(part.data_ptr(), packed=(la, larena), capacity_groups=C - 1)
+        res = e.aggregate_partial(part.data_ptr(), packed=(la, larena), capacity_groups=C)
         torch.cuda.synchronize()
         assert res["n_groups"] == C
         gathered[r * C * PW:(r + 1) * C * PW] = part
@@ -101,12 +103,17 @@ def test_two_shards_on_one_gpu(engine_factory):
     assert np.array_equal(got_pk, ref["aggpk96"])
     for e in shards:
         assert e.head_from_weights(wsum.data_ptr()) == ref_head
-    assert np.array_equal(shards[0].get_weights() * 0 + 1, np.ones(B, dtype=np.uint64))  # shard-local call still works
-    # per-block weights of the reduced buffer = unsharded weights (read back through the tree kernel's output)
-    import ctypes as Cc
-    out = np.zeros(B, dtype=np.uint64)
-    shards[0].head_from_weights(wsum.data_ptr())
-    assert shards[0]._lib.pe_get_weights is not None
+    # per-block weights computed from the REDUCED buffer = the unsharded engine's weights, block for block (incl. the
+    # proposer boost, which needs the global active balance carried in the buffer's extra entries)
+    for e in shards:
+        e.head_from_weights(wsum.data_ptr())
+        assert np.array_equal(e.last_weights(), ref_w)
+    # a shard on its own weighs only its validators: the two local weight vectors (without boost) add up to the
+    # reduced one minus the boost it carries once
+    local = [e.get_weights() for e in shards]
+    boost_w = whole.get_weights() - ref_w   # zero: same store
+    assert not boost_w.any()
+    assert (local[0] <= ref_w).all() and (local[1] <= ref_w).all()
 
 
 def test_sharded_forkchoice_world_size_one(engine_factory):
@@ -140,7 +147,8 @@ def test_sharded_forkchoice_world_size_one(engine_factory):
             dist.destroy_process_group()
 
 
-def test_bench_two_ranks_dry_run_on_one_gpu():
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     """bench.py's N > 1 path end to end with two processes sharing this GPU (gloo, host-staged collectives): both ranks
     must reach the same head (bench.py asserts it) and rank 0 must print the contract's JSON line."""
     import json
@@ -150,10 +158,13 @@ def test_bench_two_ranks_dry_run_on_one_gpu():
     env = dict(os.environ, POSEVO_DIST_BACKEND="gloo", POSEVO_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--validators", "65536", "--blocks", "512", "--committees", "256", "--head-calls", "5", "--no-cpu-baseline"]
+           "--validators", "65536", "--blocks", "512", "--committees", "256", "--head-calls", "5", "--no-cpu-baseline",
+           "--scaling", scaling]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["parallelism"] == "validator-range shards x2"
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["parallelism"] == f"validator-range shards x2 ({scaling} scaling)"
+    per_gpu = 65536 // 2 if scaling == "strong" else 65536
+    assert d["config"]["validators_per_gpu"] == per_gpu and d["config"]["validators_total"] == 2 * per_gpu

@@ -130,3 +130,68 @@ def test_committee_slices_match_reference_example():
     perm = [spec.compute_shuffled_index(i, 100, seed) for i in range(100)]
     assert sorted(perm) == list(range(100))
     spec.use_preset("mainnet")
+
+
+def test_all_cores_forms_equal_single_thread():
+    """bench.py's cpu_baseline times the OpenMP forms (po_*_mt) on all host cores; they are the same loops split over
+    independent units and must return what the single-thread checker returns, bit for bit."""
+    import pos_evolution_amd.synth as synth
+    from tests import helpers as H
+    n_val, n_comm, spe = 6000, 64, 32
+    tree = synth.random_tree(200, 7, "bushy")
+    comm = synth.random_committees(n_val, n_comm, 7)
+    atts, arena, _ = synth.epoch_attestations(comm, tree, 9, spe, seed=7, density=0.8, parts=3)
+    bal = synth.balances(n_val, 7, mixed=True)
+    flags = synth.validator_flags(n_val, 7, inactive_frac=0.02)
+    flags[::97] |= 0x04
+    pts, _ = H.oracle_points(n_val)
+    cport.set_threads(4)
+    assert cport.max_threads() >= 1
+    # union
+    cps = n_comm // spe
+    pos = ((atts["slot"] % spe) * cps + atts["index"]).astype(np.int64)
+    order = np.argsort(pos, kind="stable").astype(np.uint32)
+    gstart = np.concatenate([[0], np.cumsum(np.bincount(pos, minlength=n_comm))]).astype(np.uint32)
+    sizes = (comm.offsets[1:] - comm.offsets[:-1]).astype(np.uint32)
+    out_off = np.concatenate([[0], np.cumsum((sizes + 7) // 8)]).astype(np.uint32)
+    u1, c1 = cport.bits_union(gstart, order, atts["bits_offset"], arena, sizes, out_off[:-1], int(out_off[-1]))
+    u2, c2 = cport.bits_union(gstart, order, atts["bits_offset"], arena, sizes, out_off[:-1], int(out_off[-1]), mt=True)
+    assert np.array_equal(u1, u2) and np.array_equal(c1, c2)
+    # G1 sums
+    idx = np.random.default_rng(7).integers(0, n_val, size=5000, dtype=np.uint32)
+    offs = np.sort(np.random.default_rng(8).integers(0, 5001, size=40)).astype(np.uint32)
+    offs[0], offs[-1] = 0, 5000
+    assert np.array_equal(cport.g1_sum_groups(pts, idx, offs), cport.g1_sum_groups(pts, idx, offs, mt=True))
+    # ... and straight from the bits (what bench.py's cpu_baseline times) = the index-list form
+    want = []
+    bits_all = np.unpackbits(u1, bitorder="little")
+    for c in range(n_comm):
+        sel = bits_all[8 * out_off[c]: 8 * out_off[c] + sizes[c]].astype(bool)
+        m = comm.members[comm.offsets[c]:comm.offsets[c + 1]][sel]
+        want.append(cport.g1_sum_groups(pts, m, np.array([0, m.size], dtype=np.uint32))[0])
+    for mt in (False, True):
+        got = cport.g1_sum_attesters(comm.offsets[:-1], sizes, out_off[:-1], u1, comm.members, pts, mt=mt)
+        assert np.array_equal(got, np.stack(want))
+    # LMD + flags on the aggregates (one per committee: pairwise disjoint, the mt forms' precondition)
+    blk = np.random.default_rng(9).integers(0, 200, size=n_comm, dtype=np.uint32)
+    te = np.full(n_comm, 9, dtype=np.uint64)
+    ve = [np.zeros(n_val, dtype=np.uint64) for _ in range(2)]
+    vb = [np.full(n_val, NONE32, dtype=np.uint32) for _ in range(2)]
+    for k, mt in enumerate((False, True)):
+        cport.update_latest_messages(comm.offsets[:-1], sizes, out_off[:-1], te, blk, u1, comm.members, flags, ve[k], vb[k], mt=mt)
+    assert np.array_equal(ve[0], ve[1]) and np.array_equal(vb[0], vb[1])
+    nums, parts = [], []
+    for mt in (False, True):
+        pc, pp = np.zeros(n_val, dtype=np.uint8), np.zeros(n_val, dtype=np.uint8)
+        nums.append(cport.process_attestation_flags(comm.offsets[:-1], sizes, out_off[:-1], np.full(n_comm, 7, np.uint8),
+                                                    (np.arange(n_comm) % 2).astype(np.uint8), u1, comm.members, bal,
+                                                    10**9, 321, pc, pp, mt=mt))
+        parts.append((pc, pp))
+    assert np.array_equal(nums[0], nums[1])
+    assert np.array_equal(parts[0][0], parts[1][0]) and np.array_equal(parts[0][1], parts[1][1])
+    # get_head incl. boost and equivocators
+    leaf_ok = (np.random.default_rng(3).random(200) > 0.1).astype(np.uint8)
+    for boost in (NONE32, 150):
+        h1, w1 = cport.get_head(tree.parent, leaf_ok, tree.roots, vb[0], bal, flags, 0, boost_idx=boost)
+        h2, w2 = cport.get_head(tree.parent, leaf_ok, tree.roots, vb[0], bal, flags, 0, boost_idx=boost, mt=True)
+        assert h1 == h2 and np.array_equal(w1, w2)

@@ -47,10 +47,11 @@ class OracleShardEngine:
         self.totals = (int(extra[:, 0].sum()), int(extra[:, 1].sum()))
         return self.tree.roots[head].tobytes()
 
-    def aggregate_partial(self, ptr, rows=None, packed=None):
+    def aggregate_partial(self, ptr, rows=None, packed=None, capacity_groups=0):
         from oracle import cport
         offs = self.comm.offsets
         g = offs.size - 1
+        assert g <= capacity_groups, "PE_ERR_CAPACITY"
         from pos_evolution_amd import _abi
         pb = _abi.PE_G1_PARTIAL_BYTES          # the exchange slot size; the oracle's Jacobian partial (144 B) sits in it
         out = cport.g1_partial_groups(self.pts, self.comm.members, offs)      # all bits set: whole committees
