@@ -210,8 +210,24 @@ def cpu_baseline(w, st, target_seconds=10.0):
     V = w["bal"].size
     legs, result = {}, None
     for name, mt in (("one_core", False), ("all_cores", True)):
-        if mt:  # the cores this process may run on (a container's CPU set can be smaller than the box)
-            cport.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        if mt:
+            # the cores this process may run on (a container's CPU set can be smaller than the box); the thread count is
+            # calibrated on a slice of the G1 sums, the dominant part: SMT siblings and the interpreter's own thread make
+            # "all logical CPUs" the slowest choice on the 256-thread hosts of this pool (profiles/r02_cpu_scaling.txt)
+            avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            comm = st["comm"]
+            sub = min(inp["n_comm"], 512)
+            ones = np.full(int(inp["out_off"][sub]), 0xFF, dtype=np.uint8)
+            best_t, best_dt = 1, None
+            for t in sorted({max(1, avail // d) for d in (1, 2, 4, 8)} | {min(avail, 64), min(avail, 32)}):
+                cport.set_threads(t)
+                t0 = time.perf_counter()
+                cport.g1_sum_attesters(comm.offsets[:sub], inp["sizes"][:sub], inp["out_off"][:sub], ones, comm.members,
+                                       w["pts"], mt=True)
+                d = time.perf_counter() - t0
+                if best_dt is None or d < best_dt:
+                    best_t, best_dt = t, d
+            cport.set_threads(best_t)
         vote_epoch = np.zeros(V, dtype=np.uint64)
         vote_block = np.full(V, 0xFFFFFFFF, dtype=np.uint32)
         n_att, reps = 0, 0

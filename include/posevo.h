@@ -421,6 +421,25 @@ int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
                          uint8_t* out_bits_arena, uint64_t out_arena_cap, uint32_t* out_count,
                          void* dev_partials, uint32_t dev_partials_capacity);
 
+/* ---- RCCL inside the engine: the exchange steps behind the C ABI ---------- */
+/* For clients without a collective library of their own (the cgo / bindgen / Panama bindings of INTEGRATION.md): the
+ * engine owns an RCCL communicator and issues the two collectives on its own stream, between its own kernels.
+ *   rank 0: pe_dist_unique_id(id); ship the 128 bytes to the other ranks (any side channel)
+ *   every rank: pe_dist_init(h, id, rank, world)      -- one process per GPU, one handle per process
+ *   pe_get_head_sharded   = pe_votes_partial -> ncclAllReduce(u64, sum, B + PE_EXCHANGE_EXTRA) -> pe_head_from_weights
+ *   pe_aggregate_sharded  = pe_aggregate_partial -> ncclAllGather(192 B x groups) -> pe_g1_finish
+ * librccl is loaded with dlopen at the first pe_dist_* call (the copy already in the process, e.g. torch's, else the
+ * ROCm installation's); single-GPU use never touches it. */
+#define PE_DIST_ID_BYTES 128
+int pe_dist_unique_id(uint8_t out_id[PE_DIST_ID_BYTES]);
+int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world);
+int pe_dist_destroy(pe_engine* h);
+int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32]);
+int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n,
+                         const uint8_t* bits_arena, uint64_t arena_len,
+                         pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                         uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count);
+
 /* ---- profiling hooks (bench.py roofline leg) ----------------------------- */
 /* When enabled, the engine brackets each launch of its kernels with HIP events on
  * the launch stream and accumulates per-kernel launch counts and durations. */

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libposevo.so")
 
 PE_OK = 0
 PE_ERR_NO_DEVICE = -2
+PE_ERR_CAPACITY = -10
+PE_ERR_STATE = -14
 NONE32 = 0xFFFFFFFF
 
 PE_VAL_ACTIVE, PE_VAL_SLASHED, PE_VAL_EQUIVOCATING, PE_VAL_ACTIVE_PREV = 0x01, 0x02, 0x04, 0x08
@@ -133,6 +135,12 @@ SIGNATURES = {
     "pe_g1_partial": (C.c_int, [_H, _u32p, _u32p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "pe_get_last_weights": (C.c_int, [_H, _u64p, C.c_uint32]),
     "pe_g1_finish": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, _u8p]),
+    "pe_dist_unique_id": (C.c_int, [_u8p]),
+    "pe_dist_init": (C.c_int, [_H, _u8p, C.c_int, C.c_int]),
+    "pe_dist_destroy": (C.c_int, [_H]),
+    "pe_get_head_sharded": (C.c_int, [_H, _u8p]),
+    "pe_aggregate_sharded": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _attp, _u32p, _u32p, _u8p,
+                                       C.c_uint64, _u8p, _u32p]),
     "pe_pipeline_begin": (C.c_int, [_H]),
     "pe_pipeline_end": (C.c_int, [_H]),
     "pe_pipeline_end_lagged": (C.c_int, [_H]),

@@ -14,6 +14,8 @@
 // There is NO CPU fallback: every hot-path entry point fails with PE_ERR_NO_DEVICE when
 // the HIP device is unavailable.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <array>
@@ -276,6 +278,11 @@ struct pe_engine {
     float g1_tune_best[2] = {1e30f, 1e30f};
     uint32_t g1_target_slots = 0;   // 0 = undecided
     hipEvent_t g1_tune_ev[2] = {nullptr, nullptr};
+
+    // ---- RCCL inside the engine (pe_dist_*): one communicator per handle, collectives on the engine's stream ----
+    ncclComm_t comm = nullptr;
+    int dist_rank = 0, dist_world = 1;
+    DevBuf d_xchg, d_xpart, d_xgather;  // weights exchange | this rank's G1 partials | all ranks' partials
 
     // ---- profiling ----
     bool profiling = false;
@@ -957,6 +964,56 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
 
 }  // namespace
 
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names)
+            if ((x.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // one already in the process (torch's)
+        if (!x.lib)
+            for (const char* n : names)
+                if ((x.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!x.lib) return x;
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.lib, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.lib, "ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(x.lib, "ncclAllReduce"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.lib, "ncclAllGather"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.lib, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.lib, "ncclGroupEnd"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.lib, "ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllReduce && x.AllGather && x.GroupStart && x.GroupEnd;
+        return x;
+    }();
+    return r;
+}
+int rccl_fail(pe_engine* h, ncclResult_t r, const char* what)
+{
+    const char* msg = rccl().GetErrorString ? rccl().GetErrorString(r) : "RCCL error";
+    return fail(h, PE_ERR_NO_DEVICE, std::string(what) + ": " + msg);
+}
+#define RCCL_TRY(h, expr)                                          \
+    do {                                                           \
+        ncclResult_t _r = (expr);                                  \
+        if (_r != ncclSuccess) return rccl_fail((h), _r, #expr);   \
+    } while (0)
+static_assert(sizeof(ncclUniqueId) == PE_DIST_ID_BYTES, "PE_DIST_ID_BYTES must be sizeof(ncclUniqueId)");
+}  // namespace
+
 // ====================================================================== C ABI
 extern "C" {
 
@@ -1059,6 +1116,10 @@ void pe_engine_destroy(pe_engine* h)
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+    h->d_xchg.release();
+    h->d_xpart.release();
+    h->d_xgather.release();
     for (auto& a : h->arena) {
         a.d_res_bits.release();
         a.d_res_info.release();
@@ -2922,6 +2983,87 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
     if (br) memcpy(br, h->best_justified.root.data(), 32);
     if (boost) memcpy(boost, h->boost_root.data(), 32);
     return PE_OK;
+}
+
+// ---------------------------------------------------------------- RCCL inside the C ABI
+// librccl is resolved at run time (dlopen): a process that already carries one -- torch ships its own -- shares it, a
+// plain C / Go / Rust client gets the ROCm installation's.  No link-time dependency: single-GPU users never load it.
+int pe_dist_unique_id(uint8_t out_id[PE_DIST_ID_BYTES])
+{
+    if (!out_id) return PE_ERR_INVALID_ARG;
+    if (!rccl().ok) return PE_ERR_NO_DEVICE;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return PE_ERR_NO_DEVICE;
+    memcpy(out_id, &id, sizeof(id));
+    return PE_OK;
+}
+
+int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world)
+{
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (!rccl().ok) return fail(h, PE_ERR_NO_DEVICE, "librccl could not be loaded (dlopen librccl.so.1)");
+    if (h->comm) return fail(h, PE_ERR_STATE, "pe_dist_init: this handle already has a communicator");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    RCCL_TRY(h, rccl().CommInitRank(&h->comm, world, uid, rank));
+    h->dist_rank = rank;
+    h->dist_world = world;
+    return PE_OK;
+}
+
+int pe_dist_destroy(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (h->comm) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)rccl().CommDestroy(h->comm);
+        h->comm = nullptr;
+    }
+    h->dist_world = 1;
+    h->dist_rank = 0;
+    return PE_OK;
+}
+
+// get_head over all shards: this shard's direct weights -> ONE all-reduce(sum, u64) of B + PE_EXCHANGE_EXTRA words on
+// the engine's stream -> subtree sums + descent on every rank (same root everywhere; integer sums are order-free).
+int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    if (!out_root) return PE_ERR_INVALID_ARG;
+    if (!h->comm) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
+    const uint32_t nb = (uint32_t)h->blocks.size();
+    const size_t words = (size_t)nb + PE_EXCHANGE_EXTRA;
+    HIP_TRY(h, h->d_xchg.ensure(words * 8));
+    rc = pe_votes_partial(h, h->d_xchg.p, nb);
+    if (rc) return rc;
+    RCCL_TRY(h, rccl().AllReduce(h->d_xchg.p, h->d_xchg.p, words, ncclUint64, ncclSum, h->comm, h->stream));
+    return pe_head_from_weights(h, h->d_xchg.p, nb, out_root);
+}
+
+// pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.  Every rank passes attestations
+// that form the SAME groups in the SAME order (group g of every rank = that rank's members of committee g); the
+// XYZZ partials (192 B per group) are all-gathered and every rank runs the finishing add + normalisation.
+int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
+                         uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                         uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count)
+{
+    if (!h || !out_n_groups || !out_aggpk96) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (!h->comm) return fail(h, PE_ERR_STATE, "pe_aggregate_sharded: call pe_dist_init first");
+    if (n == 0) { *out_n_groups = 0; return PE_OK; }
+    HIP_TRY(h, h->d_xpart.ensure((size_t)PE_G1_PARTIAL_BYTES * n));
+    HIP_TRY(h, h->d_xgather.ensure((size_t)PE_G1_PARTIAL_BYTES * n * (size_t)h->dist_world));
+    int rc = aggregate_impl(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of, out_bits_arena,
+                            out_arena_cap, nullptr, nullptr, out_count, h->d_xpart.p, n);
+    if (rc) return rc;
+    const uint32_t ng = *out_n_groups;
+    if (ng == 0) return PE_OK;
+    RCCL_TRY(h, rccl().AllGather(h->d_xpart.p, h->d_xgather.p, (size_t)ng * (PE_G1_PARTIAL_BYTES / 4), ncclUint32,
+                                 h->comm, h->stream));
+    return pe_g1_finish(h, h->d_xgather.p, (uint32_t)h->dist_world, ng, out_aggpk96);
 }
 
 // ---------------------------------------------------------------- pipelined calls

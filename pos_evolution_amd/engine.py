@@ -486,6 +486,52 @@ class Engine:
                                         _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
         return out[:n_groups]
 
+    # -- multi-GPU exchange inside the C ABI (RCCL owned by the engine) -------
+    def dist_unique_id(self) -> bytes:
+        """rank 0: the 128-byte RCCL unique id to ship to the other ranks (pe_dist_unique_id)."""
+        out = (C.c_uint8 * 128)()
+        rc = self._lib.pe_dist_unique_id(out)
+        if rc != _abi.PE_OK:
+            raise EngineError(rc, "pe_dist_unique_id: librccl not available")
+        return bytes(out)
+
+    def dist_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._lib.pe_dist_init(self._h, buf, rank, world))
+
+    def dist_destroy(self):
+        self._check(self._lib.pe_dist_destroy(self._h))
+
+    def get_head_sharded(self) -> bytes:
+        """get_head over all shards through the engine's own RCCL communicator (one all-reduce on its stream)."""
+        out = (C.c_uint8 * 32)()
+        self._check(self._lib.pe_get_head_sharded(self._h, out))
+        return bytes(out)
+
+    def aggregate_sharded(self, rows=None, packed=None):
+        """pe_aggregate over all shards (one all-gather of the XYZZ partials inside): rank-local unions, global
+        aggregate pubkeys."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        m = max(n, 1)
+        out_atts = np.empty(m, dtype=_ATT_DTYPE)
+        n_groups = C.c_uint32(0)
+        group_of = np.empty(m, dtype=np.uint32)
+        out_arena = np.empty(max(arena.size, 1), dtype=np.uint8)
+        out_pk = np.empty((m, 96), dtype=np.uint8)
+        count = np.empty(m, dtype=np.uint32)
+        self._check(self._lib.pe_aggregate_sharded(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
+                                                   _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
+                                                   _ptr(out_arena, C.c_uint8), out_arena.size,
+                                                   _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
+        g = n_groups.value
+        if g:
+            last = out_atts[g - 1]
+            out_arena = out_arena[: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
+        return AggregateResult(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena, sig96=None,
+                               sig192=None, aggpk96=out_pk[:g], count=count[:g])
+
     # -- multi-GPU exchange -------------------------------------------------
     def votes_partial(self, dev_ptr: int):
         """dev_ptr: device buffer of num_blocks + PE_EXCHANGE_EXTRA u64 (weights | per-workgroup active totals)."""

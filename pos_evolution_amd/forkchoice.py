@@ -77,6 +77,13 @@ class Store:
         self.hash_tree_root = hash_tree_root
         self.equivocating_indices = set()   # host mirror of pe:897 (the engine holds the per-validator bit)
         self.blocks: Dict[bytes, object] = {}  # root -> the caller's block object (pe:898)
+        # get_latest_attesting_balance reads checkpoint_states[store.justified_checkpoint] on EVERY call (Appendix A.1);
+        # the engine holds ONE registry view.  Which checkpoint it belongs to is tracked here, and get_head refuses
+        # to weigh votes with another checkpoint's balances (on_block / on_tick / set_checkpoints can move
+        # justified_checkpoint).  checkpoint_state_provider(checkpoint) -> state, when set, is asked for the missing
+        # state instead (a client has it materialised by the time the checkpoint is justified).
+        self.balances_checkpoint: Optional[Checkpoint] = None
+        self.checkpoint_state_provider: Optional[Callable] = None
 
     # -- the spec's fields ---------------------------------------------------
     @property
@@ -115,9 +122,23 @@ class Store:
                 for i in np.nonzero(block != _abi.NONE32)[0]}
 
     # -- inputs the pyspec derives from states the engine does not hold -----------
+    def ensure_justified_state(self):
+        """The engine's balances must be those of checkpoint_states[justified_checkpoint] (A.1)."""
+        jc = self.justified_checkpoint
+        if self.balances_checkpoint == jc:
+            return
+        if self.checkpoint_state_provider is not None:
+            self.set_justified_state(self.checkpoint_state_provider(jc))
+            return
+        raise EngineError(_abi.PE_ERR_STATE,
+                          f"justified checkpoint moved to epoch {jc.epoch} but the engine still holds the balances of "
+                          f"{self.balances_checkpoint}: call store.set_justified_state(checkpoint_states[justified_checkpoint]) "
+                          "or set store.checkpoint_state_provider")
+
     def set_justified_state(self, state, slots_per_epoch: Optional[int] = None):
         """checkpoint_states[justified_checkpoint] (Appendix A.1): balances/activity feeding the weights,
-        and the pubkeys feeding the G1 sums."""
+        and the pubkeys feeding the G1 sums.  Records that the engine's view now belongs to the store's current
+        justified checkpoint."""
         spe = slots_per_epoch or int(self.engine.cfg.slots_per_epoch)
         epoch = int(state.slot) // spe
         n = len(state.validators)
@@ -138,6 +159,7 @@ class Store:
             self.engine.set_validators(bal, flags, pk)
             if pk48 is not None:
                 self.engine.set_pubkeys_compressed(pk48)
+        self.balances_checkpoint = self.justified_checkpoint
 
     def set_committees(self, epoch: int, committees: Sequence[Sequence[int]]):
         """get_beacon_committee(state, slot, index) for every (slot, index) of ``epoch``, in committee-id
@@ -238,7 +260,9 @@ def get_indexed_attestation(store: Store, attestation):
 
 
 def get_head(store: Store) -> bytes:
-    """pe:1102-1116"""
+    """pe:1102-1116.  Raises (AssertionError) when the justified checkpoint has moved and the balances of its state
+    have not been handed over (Store.ensure_justified_state)."""
+    store.ensure_justified_state()
     return store.engine.get_head()
 
 
@@ -284,19 +308,36 @@ class StateBinding:
         self.state.previous_epoch_participation[:] = [int(x) for x in self.engine.participation_get(1)]
 
 
-_bindings: Dict[int, StateBinding] = {}
+_BINDING_ATTR = "_posevo_state_binding"
 
 
 def bind_state(engine: Engine, state, chain_tip_root: bytes, base_reward_per_increment: int) -> StateBinding:
+    """The binding lives ON the state object (not in a table keyed by id(state), which would leak and could hand a
+    recycled id a stale binding); ``unbind_state`` drops it."""
     b = StateBinding(engine, state, chain_tip_root, base_reward_per_increment)
-    _bindings[id(state)] = b
+    object.__setattr__(state, _BINDING_ATTR, b)
     return b
 
 
-def process_attestation(state, attestation, *, get_beacon_proposer_index: Optional[Callable] = None) -> None:
-    """pe:722-754.  ``state`` must have been bound with ``bind_state``."""
-    b = _bindings.get(id(state))
+def unbind_state(state) -> None:
+    if getattr(state, _BINDING_ATTR, None) is not None:
+        object.__setattr__(state, _BINDING_ATTR, None)
+
+
+def _binding(state) -> Optional[StateBinding]:
+    b = getattr(state, _BINDING_ATTR, None)
+    return b if b is not None and b.state is state else None   # a copy of a bound state is not bound
+
+
+def process_attestation(state, attestation, *, get_beacon_proposer_index: Optional[Callable] = None,
+                        proposer_index: Optional[int] = None) -> None:
+    """pe:722-754.  ``state`` must have been bound with ``bind_state``.  The proposer that earns the reward
+    (pe:754) is ``get_beacon_proposer_index(state)`` or the explicit ``proposer_index``: one of them is required --
+    crediting a default validator would silently corrupt ``state.balances``."""
+    b = _binding(state)
     assert b is not None, "process_attestation: bind_state(engine, state, ...) first"
+    assert get_beacon_proposer_index is not None or proposer_index is not None, \
+        "process_attestation: pass get_beacon_proposer_index or proposer_index (pe:754)"
     status, numerators = b.engine.process_attestation_batch(b.ctx(), [_att_row(attestation)])
     if status[0] != 0:
         raise EngineError(int(status[0]), "process_attestation: " + _abi.ATT_STATUS_NAMES.get(int(status[0]), "?"))
@@ -304,7 +345,7 @@ def process_attestation(state, attestation, *, get_beacon_proposer_index: Option
     # Reward proposer (pe:752-754)
     proposer_reward_denominator = (WEIGHT_DENOMINATOR - PROPOSER_WEIGHT) * WEIGHT_DENOMINATOR // PROPOSER_WEIGHT
     proposer_reward = int(numerators[0]) // proposer_reward_denominator
-    proposer = get_beacon_proposer_index(state) if get_beacon_proposer_index else 0
+    proposer = int(proposer_index) if proposer_index is not None else int(get_beacon_proposer_index(state))
     state.balances[proposer] += proposer_reward
     state._last_proposer_reward_numerator = int(numerators[0])
 
@@ -349,7 +390,7 @@ def weigh_justification_and_finalization(state, total_active_balance: int, previ
 def process_justification_and_finalization(state, *, get_block_root: Callable) -> None:
     """pe:791-802.  ``state`` must have been bound with ``bind_state`` (its participation arrays live on the GPU);
     the three balance sums come from one streaming kernel over the working-state registry view."""
-    b = _bindings.get(id(state))
+    b = _binding(state)
     assert b is not None, "process_justification_and_finalization: bind_state(engine, state, ...) first"
     spe = int(b.engine.cfg.slots_per_epoch)
     if int(state.slot) // spe <= GENESIS_EPOCH + 1:

@@ -15,6 +15,10 @@ LMD updates and participation flags are local to the shard that owns the validat
 The exchange buffers are torch tensors (plumbing: device memory + collectives); the engine reads and writes them
 through raw device pointers on the SAME stream torch issues the collectives on, so no host synchronisation sits
 between kernels and collectives.
+
+``use_engine_rccl=True`` is the thin face of the C ABI's own exchange (pe_dist_init / pe_get_head_sharded /
+pe_aggregate_sharded, include/posevo.h): the engine owns the RCCL communicator and issues the collectives between its
+kernels on its own stream; torch.distributed only carries the 128-byte unique id to the other ranks.
 """
 from __future__ import annotations
 
@@ -24,13 +28,14 @@ from . import _abi
 
 
 class ShardedForkChoice:
-    def __init__(self, engine, n_groups_max: int = 2048, group=None, device=None):
+    def __init__(self, engine, n_groups_max: int = 2048, group=None, device=None, use_engine_rccl: bool = False):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
         self.engine = engine
         self.group = group
+        self.use_engine_rccl = use_engine_rccl
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if device is None:
@@ -41,6 +46,12 @@ class ShardedForkChoice:
         self._partial = torch.zeros(n_groups_max * self._pw, dtype=torch.int32, device=device)
         self._gathered = torch.zeros(self.world * n_groups_max * self._pw, dtype=torch.int32, device=device)
         self.n_groups_max = n_groups_max
+        if use_engine_rccl:
+            ids = [engine.dist_unique_id() if self.rank == 0 else None]
+            if dist.is_initialized() and self.world > 1:
+                dist.broadcast_object_list(ids, src=0, group=group)
+            engine.dist_init(ids[0], self.rank, self.world)
+            return
         if device.type == "cuda":
             # engine kernels and RCCL ordered on one (non-null) stream
             if torch.cuda.current_stream().cuda_stream == 0:
@@ -55,6 +66,8 @@ class ShardedForkChoice:
 
     def get_head(self) -> bytes:
         """get_head (pe:1102-1116) over all shards; every rank returns the same root."""
+        if self.use_engine_rccl:
+            return self.engine.get_head_sharded()
         buf = self._weights_buffer()
         self.engine.votes_partial(buf.data_ptr())
         if self.dist.is_initialized():  # also with world == 1: keeps the RCCL path exercised on one GPU
@@ -74,6 +87,8 @@ class ShardedForkChoice:
         """pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.
         Every rank must pass attestations that form the SAME groups in the SAME order (group g of every rank =
         that rank's members of committee g)."""
+        if self.use_engine_rccl:
+            return self.engine.aggregate_sharded(rows=rows, packed=packed)
         # the engine refuses (PE_ERR_CAPACITY, before writing anything) a batch that forms more groups than the
         # exchange buffers were sized for
         res = self.engine.aggregate_partial(self._partial.data_ptr(), rows=rows, packed=packed,

@@ -301,6 +301,40 @@ def justified_checkpoint_promotion_on_tick(mk):
     assert w.store.justified_checkpoint == just2
 
 
+def justified_state_balances_follow_the_checkpoint(mk):
+    """get_latest_attesting_balance weighs votes with checkpoint_states[store.justified_checkpoint] (Appendix A.1):
+    when on_block moves the justified checkpoint, effective balances and activity of the NEW justified state count.
+    (the engine holds one registry view; the mirror must be handed the new state -- World.check does,
+    and pos_evolution_amd.forkchoice.get_head refuses to run on the old one.)"""
+    w = mk(64)
+    anchor = w.store.justified_checkpoint.root
+    spe = spec.SLOTS_PER_EPOCH
+    w.tick_to_slot(1)
+    b1 = w.block(anchor, 1)
+    # the chain's state at b1 differs from genesis: half the validators at 16 ETH, a few exited before epoch 1
+    st = w.store.block_states[b1]
+    for i, v in enumerate(st.validators):
+        if i % 2 == 0:
+            v.effective_balance = 16 * ETH
+        if i % 7 == 3:
+            v.exit_epoch = 1
+    w.tick_to_slot(spe)
+    just = spec.Checkpoint(1, b1)
+    good = w.block(b1, spe, scripted=(just, spec.Checkpoint(0, anchor)), graffiti=b"good")
+    assert w.store.justified_checkpoint == just
+    w.tick_to_slot(spe + 1, offset=spec.SECONDS_PER_SLOT - 1)
+    other = w.block(b1, spe + 1, scripted=(just, spec.Checkpoint(0, anchor)), graffiti=b"other")
+    w.tick_to_slot(spe + 3)
+    voters = slot_committee_members(w.store, spe + 2)   # epoch-1 committees: from the justified state's active set
+    jstate = w.store.checkpoint_states[just]
+    assert all(spec.is_active_validator(jstate.validators[v], 1) for v in voters)
+    w.vote(voters, other, spe + 2)
+    want = sum(jstate.validators[v].effective_balance for v in voters)
+    assert want != len(voters) * 32 * ETH
+    assert spec.get_latest_attesting_balance(w.store, other) == want
+    assert w.head() == other
+
+
 def rlmd_ghost_vote_expiry(mk):
     """[VARIANT pe:1585-1596, pe:1549] vote expiry period eta: only latest messages from the most recent eta slots
     count.  A heavier but stale branch loses to a lighter fresh one; eta = 0 is the reference's LMD-GHOST."""
@@ -333,5 +367,5 @@ ALL = [
     genesis_head, chain_no_attestations, split_tie_breaker_no_attestations, shorter_chain_but_heavier_weight,
     lmd_walkthrough_five_validators, lmd_rule_first_seen_and_strictly_later, proposer_boost_correct_head,
     ex_ante_reorg_arithmetic, discard_equivocations, invalid_handlers_leave_store_untouched, filtered_block_tree,
-    justified_checkpoint_promotion_on_tick, rlmd_ghost_vote_expiry,
+    justified_checkpoint_promotion_on_tick, justified_state_balances_follow_the_checkpoint, rlmd_ghost_vote_expiry,
 ]

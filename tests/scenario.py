@@ -67,7 +67,11 @@ class World:
         jc = self.store.justified_checkpoint
         if jc not in self.store.checkpoint_states:
             spec.store_target_checkpoint_state(self.store, jc)
-            if self.mirror is not None:
+        # the engine holds one registry view: hand it the justified state's whenever the checkpoint it belongs to is
+        # no longer the store's (also when on_attestation had materialised that checkpoint state earlier)
+        if self.mirror is not None:
+            have = self.mirror.balances_checkpoint
+            if have is None or (have.epoch, bytes(have.root)) != (jc.epoch, bytes(jc.root)):
                 self.mirror.set_justified_state(self.store.checkpoint_states[jc])
 
     def check(self):

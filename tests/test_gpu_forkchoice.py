@@ -136,6 +136,8 @@ def test_process_attestation_vs_literal_oracle(engine_factory):
         m_ok = True
         try:
             fc.process_attestation(mstate, att, get_beacon_proposer_index=spec.get_beacon_proposer_index)
+            with pytest.raises(AssertionError):   # the proposer (pe:754) is never defaulted
+                fc.process_attestation(mstate, att)
         except AssertionError:
             m_ok = False
         assert ok == m_ok
@@ -188,3 +190,33 @@ def test_justification_and_finalization_vs_literal_oracle(engine_factory):
         assert mst.current_justified_checkpoint == st.current_justified_checkpoint
         assert mst.previous_justified_checkpoint == st.previous_justified_checkpoint
         assert mst.finalized_checkpoint == st.finalized_checkpoint
+
+
+def test_get_head_refuses_a_stale_justified_state(engine_factory):
+    """on_block can move store.justified_checkpoint; the reference then weighs votes with THAT checkpoint's
+    state (A.1).  The mirror tracks which checkpoint the engine's balances belong to: get_head raises until the new
+    state is handed over -- directly or through store.checkpoint_state_provider."""
+    import pos_evolution_amd.forkchoice as fc
+    from pos_evolution_amd import EngineError
+    w = new_world(64, "minimal", engine_factory=engine_factory)
+    anchor = w.store.justified_checkpoint.root
+    spe = spec.SLOTS_PER_EPOCH
+    w.tick_to_slot(1)
+    b1 = w.block(anchor, 1)
+    for i, v in enumerate(w.store.block_states[b1].validators):
+        v.effective_balance = (8 + i % 3) * 10**9
+    spec.on_tick(w.store, w.store.genesis_time + spe * spec.SECONDS_PER_SLOT)
+    fc.on_tick(w.mirror, w.store.genesis_time + spe * spec.SECONDS_PER_SLOT)
+    just = spec.Checkpoint(1, b1)
+    blk = spec.BeaconBlock(slot=spe, parent_root=b1, body=spec.BeaconBlockBody(graffiti=b"j"))
+    signed = spec.SignedBeaconBlock(message=blk, scripted_checkpoints=(just, spec.Checkpoint(0, anchor)))
+    spec.on_block(w.store, signed)
+    fc.on_block(w.mirror, signed, w.store.block_states[spec.hash_tree_root(blk)])
+    assert w.mirror.justified_checkpoint.epoch == 1
+    with pytest.raises(EngineError):
+        fc.get_head(w.mirror)
+    spec.store_target_checkpoint_state(w.store, just)
+    w.mirror.checkpoint_state_provider = lambda cp: w.store.checkpoint_states[spec.Checkpoint(cp.epoch, spec.Root(cp.root))]
+    assert fc.get_head(w.mirror) == bytes(spec.get_head(w.store))
+    assert w.mirror.balances_checkpoint == w.mirror.justified_checkpoint
+    w.check()

@@ -147,6 +147,38 @@ def test_sharded_forkchoice_world_size_one(engine_factory):
             dist.destroy_process_group()
 
 
+def test_engine_owned_rccl_world_size_one(engine_factory):
+    """The C ABI's own exchange (pe_dist_init / pe_get_head_sharded / pe_aggregate_sharded): the engine loads librccl,
+    owns the communicator and issues ncclAllReduce / ncclAllGather on its stream.  One rank here (one GPU per box):
+    results must equal the unsharded calls; the N > 1 arithmetic is what test_two_shards_on_one_gpu checks."""
+    V, C = 20000, 64
+    tree, bal, flags, comm = _workload(V=V, C=C, seed=23)
+    e = engine_factory()
+    pts = synth.registry_points(e, V)
+    epoch = int(tree.slot.max()) // 32 + 1
+    _load(e, tree, bal, flags, pts, comm, epoch)
+    atts, arena, _ = synth.epoch_attestations(comm, tree, epoch, 32, seed=7, density=0.9, parts=3)
+    ref = e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+    with pytest.raises(AssertionError):
+        e.get_head_sharded()                      # PE_ERR_STATE before pe_dist_init
+    e.dist_init(e.dist_unique_id(), 0, 1)
+    got = e.aggregate_sharded(packed=(atts, arena))
+    assert got["n_groups"] == ref["n_groups"]
+    assert np.array_equal(got["aggpk96"], ref["aggpk96"])
+    assert np.array_equal(got["out_arena"], ref["out_arena"]) and np.array_equal(got["count"], ref["count"])
+    st, _, _ = e.on_attestation_batch(packed=(ref["atts"], ref["out_arena"]))
+    assert (st == 0).all()
+    assert e.get_head_sharded() == e.get_head()
+    assert np.array_equal(e.last_weights(), e.get_weights())
+    # the thin Python face of the same path
+    from pos_evolution_amd.sharded import ShardedForkChoice
+    e.dist_destroy()
+    sh = ShardedForkChoice(e, n_groups_max=C, use_engine_rccl=True)
+    assert sh.get_head() == e.get_head()
+    assert np.array_equal(sh.aggregate(packed=(atts, arena))["aggpk96"], ref["aggpk96"])
+    e.dist_destroy()
+
+
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     """bench.py's N > 1 path end to end with two processes sharing this GPU (gloo, host-staged collectives): both ranks
