@@ -704,7 +704,8 @@ void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan, uint
 {
     uint64_t total = 0;
     for (uint32_t g = 0; g < n_groups; ++g) total += size_of(g);
-    const uint32_t k = (uint32_t)std::max<uint64_t>(4, (total + target_slots - 1) / target_slots);
+    static const uint32_t min_k = [] { const char* e = getenv("POSEVO_G1_MIN_K"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 4u; }();
+    const uint32_t k = (uint32_t)std::max<uint64_t>(min_k, (total + target_slots - 1) / target_slots);
     uint32_t cursor = 0, outp = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {
         G1Group& d = out[g];

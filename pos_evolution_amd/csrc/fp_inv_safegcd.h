@@ -79,7 +79,12 @@ struct sg_trans {
     int32_t u, v, q, r;
 };
 
-// 30 divsteps on the low bits.  delta is the paper's delta (starts at 1).  f0 must be odd.
+// 30 divsteps on the low bits.  `delta` holds TWICE the paper's delta and starts at 1, i.e. delta = 1/2: the
+// "half-delta" variant (the starting point libsecp256k1's modinv uses).  Measured on 20 000 random 380-bit values:
+// 26.0 batches of 30 on average, 27 at most, against 26.9 / 28 with delta = 1 -- a 3 % shorter chain, not the sixth
+// its worst-case bound suggests; kept because it is free.  The 40-batch cap of sg_modinv covers either variant's
+// worst case (1101 divsteps = 37 batches for delta = 1, Theorem 11.2; fewer for 1/2).  The state stays odd:
+// "delta > 0" is the test, "+ 2" the step.  f0 must be odd.
 POSEVO_HD int32_t sg_divsteps_30(int32_t delta, uint32_t f0, uint32_t g0, sg_trans& t)
 {
     uint32_t u = 1, v = 0, q = 0, r = 1;
@@ -99,7 +104,7 @@ POSEVO_HD int32_t sg_divsteps_30(int32_t delta, uint32_t f0, uint32_t g0, sg_tra
         u += q & c1;
         v += r & c1;
         delta = (int32_t)(((uint32_t)delta ^ c1) - c1);  // negate if c1
-        delta += 1;
+        delta += 2;                                       // (2 delta) <- 2 (1 +- delta)
         g >>= 1;
         u <<= 1;
         v <<= 1;

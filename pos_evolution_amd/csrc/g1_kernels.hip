@@ -453,6 +453,11 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
+    // 32 waves of one long dependent chain each (the inversion).  In a stream of pipelined steps they run beside the
+    // next aggregate's k_g1_accumulate and stretch from 90 to ~360 us (profiles/r02_timeline.txt): every instruction
+    // of the chain queues behind the multi-cycle v_mad_u64_u32 of two older waves on its SIMD.  s_setprio(3) here was
+    // measured and changes nothing (the wait is for the ALU, not for the arbiter); the pipeline's lag depth of two
+    // absorbs it (the finish stream keeps up as long as a launch stays under the step period).
     uint32_t first, n_parts, stride;
     if (groups) {  // single-GPU: the group's workgroup partials are consecutive
         const G1Group d = groups[g];

@@ -10,3 +10,10 @@ extern "C" int host_modinv_many(uint32_t* out, const uint32_t* x, int n)
     }
     return worst;
 }
+extern "C" long host_modinv_total_batches(const uint32_t* x, int n)
+{
+    long total = 0;
+    uint32_t out[12];
+    for (int i = 0; i < n; ++i) total += posevo::sg_modinv(out, x + 12 * i, posevo::SG_PINV30);
+    return total;
+}

@@ -1,6 +1,7 @@
 // g1_phases.hip -- where does k_g1_accumulate spend its time?  Stamps wall_clock64() (100 MHz) in every workgroup at:
 // start, end of wave 0's accumulation, after the first barrier (all waves accumulated), after each tree level.
-// Workload = the bench's pubkey leg: 2048 groups x 512 members, k = 8 -> 64 tasks per group, all bits set.
+// Workload = the bench's pubkey leg: 2048 groups x 512 members, k = 8 -> 64 tasks per group, all bits set
+// (usage: g1_phases [k [members_per_group]]: 64 / 128 members = the per-GPU shard of configs[3] on 8 / 4 GPUs).
 // Build (in tools/): hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPOSEVO_G1_PHASE_TIMING -I../pos_evolution_amd/csrc -o g1_phases g1_phases.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -15,7 +16,7 @@ using namespace posevo;
 
 int main(int argc, char** argv)
 {
-    const uint32_t n_groups = 2048, size = 512, k = argc > 1 ? atoi(argv[1]) : 8;
+    const uint32_t n_groups = 2048, k = argc > 1 ? atoi(argv[1]) : 8, size = argc > 2 ? atoi(argv[2]) : 512;
     const uint32_t n_pts = n_groups * size;
     std::vector<uint32_t> pts((size_t)G1_ROW_WORDS * n_pts), members(n_pts);
     std::mt19937 rng(1);

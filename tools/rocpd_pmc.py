@@ -12,7 +12,7 @@ rows = db.execute("select kernel_name, dispatch_id, sum(value) from counters_col
                   "group by kernel_name, dispatch_id", (sys.argv[2],)).fetchall()
 agg = {}
 for name, _, v in rows:
-    short = name.split("(")[0].replace("posevo::", "")
+    short = name.split("(")[0].replace("posevo::", "").replace("void ", "")
     agg.setdefault(short, []).append(v)
 out = {}
 for k, vals in agg.items():
