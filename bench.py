@@ -397,11 +397,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if ex is None and not args.no_pipeline:
+        e.reuse_outputs(4)  # a streaming caller reuses its output buffers; results are consumed two steps behind
     for s in range(args.warmup):
         step(w["steps"][s])
     e.drain()
-    if ex is None and not args.no_pipeline:
-        e.reuse_outputs(4)  # a streaming caller reuses its output buffers; results are consumed two steps behind
     e.profile_enable(True)
     e.profile_reset()
     # Python's cyclic collector is paused over the timed steps: with torch loaded a full collection walks ~10^6

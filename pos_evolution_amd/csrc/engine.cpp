@@ -2220,7 +2220,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
                 HIP_TRY(h, hipEventRecord(h->ev_fork, ms_));
                 HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
                 // a second aggregate in the SAME pipeline shares this arena's d_partials with the first one's finish
-                if (arena->side_used) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
+                static const bool serial_finish = [] { const char* e = getenv("POSEVO_G1_SERIAL_FINISH"); return e && atoi(e) != 0; }();
+                if (arena->side_used || (serial_finish && h->side_ever)) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
             } else {
                 g1_stream_guard(h, gs);
             }
@@ -3073,6 +3074,24 @@ int pe_pipeline_begin(pe_engine* h)
     if (!h) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     PE_TRY(complete_arena(h, h->cur));  // a lagged pipeline in the other arena stays in flight
+    // Steps of a stream look alike: size this (idle) arena like the largest one now, instead of growing it call by call
+    // inside the pipeline -- a growth there waits for everything enqueued and re-allocates pinned memory (milliseconds).
+    {
+        pe_engine::PipeArena& a = h->A();
+        size_t stage = 0, out = 0, bits = 0, info = 0, part = 0;
+        for (auto& o : h->arena) {
+            stage = std::max(stage, std::min(o.d_stage.cap, o.h_stage.cap));
+            out = std::max(out, std::min(o.d_outblk.cap, o.h_pin.cap));
+            bits = std::max(bits, o.d_res_bits.cap);
+            info = std::max(info, o.d_res_info.cap);
+            part = std::max(part, o.d_partials.cap);
+        }
+        if (stage) { HIP_TRY(h, a.d_stage.ensure(stage)); HIP_TRY(h, a.h_stage.ensure(stage)); }
+        if (out) { HIP_TRY(h, a.d_outblk.ensure(out)); HIP_TRY(h, a.h_pin.ensure(out)); }
+        if (bits) HIP_TRY(h, a.d_res_bits.ensure(bits));
+        if (info) HIP_TRY(h, a.d_res_info.ensure(info));
+        if (part) HIP_TRY(h, a.d_partials.ensure(part));
+    }
     h->pipelining = true;
     return PE_OK;
 }
