@@ -55,7 +55,7 @@ def build_workload(e, args, rank, n_steps_total):
         # the epoch's committees: the reference's swap-or-not shuffle (pe:495-534, 90 rounds) run on the GPU
         import hashlib
         ep_seed = hashlib.sha256(b"bench-seed" + seed.to_bytes(8, "little") + ep.to_bytes(8, "little")).digest()
-        off, mem = e.compute_committees(ep, ep_seed, np.arange(V, dtype=np.uint32), C, 90)
+        off, mem = e.compute_committees(ep, ep_seed, V, C, 90)   # every validator active: the identity index set
         comm = synth.Committees(off, mem)
         atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=seed, density=0.99, parts=args.parts,
                                                   source=(0, tree.roots[0].tobytes()), vote_recent=64,

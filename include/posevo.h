@@ -211,8 +211,9 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees,
  * compute_shuffled_index (pe:513-534, swap-or-not, shuffle_round_count rounds of SHA-256) for every committee
  * of the epoch: committee c = [active_indices[shuffled(i)] for i in [n*c/count, n*(c+1)/count)], count =
  * n_committees.  seed = get_seed(state, epoch, DOMAIN_BEACON_ATTESTER) (pe:481-486) and the active set are the
- * caller's (state accessors).  Registers the table for `epoch` like pe_set_committees; out_offsets
- * (n_committees + 1) and out_members (n_active) are optional copies of the result. */
+ * caller's (state accessors); active_indices NULL = validators 0 .. n_active - 1 (every validator active).  Registers
+ * the table for `epoch` like pe_set_committees and KEEPS IT ON THE DEVICE; out_offsets (n_committees + 1) and
+ * out_members (n_active) are optional copies of the result (NULL: nothing is read back). */
 int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
                           uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
                           uint32_t* out_offsets, uint32_t* out_members);
@@ -333,11 +334,17 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points,
 
 /* BLSPubkey wire format (Validator.pubkey: BLSPubkey, pe:37): 48 bytes, big-endian x, flag bits in the leading byte
  * (bit 7 compressed, bit 6 infinity, bit 5 y > (p-1)/2).  Decompression runs on the GPU (one square root per key);
- * status[i]: 0 ok, 1 malformed encoding (flag bits, x >= p), 2 x is not on the curve.  No subgroup check.
+ * status[i]: 0 ok, 1 malformed encoding (flag bits, x >= p), 2 x is not on the curve.  Subgroup: pe_g1_key_validate.
  *   pe_g1_decompress          48-byte keys -> 96-byte uncompressed affine (the format pe_set_validators takes)
  *   pe_set_pubkeys_compressed decompress straight into the registry of the n validators already loaded;
  *                             any status != 0 fails the call (PE_ERR_INVALID_ARG) and leaves no pubkeys loaded
  *   pe_g1_compress            96-byte affine -> 48-byte compressed (serialisation only: host, no handle) */
+/* KeyValidate (FastAggregateVerify validates every pubkey before summing them, Appendix A.7; call sites pe:736, pe:976):
+ * beyond "decodes to a curve point" (pe_g1_decompress / pe_set_pubkeys_compressed) a key must not be the identity and
+ * must lie in the prime-order subgroup, r * P == infinity -- one 255-bit scalar multiplication per key on the GPU.
+ * points96: n uncompressed points, or NULL = the n pubkeys of the registry as loaded.
+ * status[i]: 0 valid, 3 not in the subgroup, 4 identity.  An optional once-per-registry-load pass (~65 ms per 1 M keys). */
+int pe_g1_key_validate(pe_engine* h, const uint8_t* points96, uint64_t n, int32_t* status);
 int pe_g1_decompress(pe_engine* h, const uint8_t* in48, uint64_t n, uint8_t* out96, int32_t* status);
 int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48, int32_t* status);
 int pe_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48);

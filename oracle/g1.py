@@ -85,6 +85,41 @@ def mul(k, pt):
     return acc
 
 
+def mul_unreduced(k, pt):
+    """k * pt WITHOUT reducing k mod r: the curve E(Fp) has points outside the prime-order subgroup (cofactor
+    0x396c8c005555e1568c00aaab0000aaab), for which r * pt != infinity."""
+    acc = None
+    base = pt
+    while k:
+        if k & 1:
+            acc = add(acc, base)
+        base = double(base)
+        k >>= 1
+    return acc
+
+
+def in_subgroup(pt) -> bool:
+    """The subgroup part of KeyValidate (IETF BLS draft 2.5): r * P == infinity."""
+    return mul_unreduced(R_ORDER, pt) is None
+
+
+def key_validate(pt) -> bool:
+    """KeyValidate: a curve point, not the identity, in the subgroup."""
+    return pt is not None and is_on_curve(pt) and in_subgroup(pt)
+
+
+def curve_point_from_x(x0: int):
+    """The first x >= x0 with x^3 + 4 a square, and the smaller root y (p = 3 mod 4): almost surely OUTSIDE the
+    subgroup -- test input for KeyValidate."""
+    x = x0 % P
+    while True:
+        rhs = (x * x * x + B_COEFF) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs:
+            return (x, min(y, P - y))
+        x += 1
+
+
 def sum_points(points):
     acc = None
     for pt in points:

@@ -116,6 +116,7 @@ SIGNATURES = {
     "pe_get_latest_message_slots": (C.c_int, [_H, _u32p, C.c_uint64]),
     "pe_set_latest_messages": (C.c_int, [_H, C.c_uint64, _u64p, _u32p, _u32p]),
     "pe_set_best_justified": (C.c_int, [_H, C.c_uint64, _u8p]),
+    "pe_g1_key_validate": (C.c_int, [_H, _u8p, C.c_uint64, _i32p]),
     "pe_g1_decompress": (C.c_int, [_H, _u8p, C.c_uint64, _u8p, _i32p]),
     "pe_set_pubkeys_compressed": (C.c_int, [_H, C.c_uint64, _u8p, _i32p]),
     "pe_g1_compress": (C.c_int, [_u8p, C.c_uint64, _u8p]),

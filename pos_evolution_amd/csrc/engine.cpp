@@ -1495,19 +1495,33 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
                           uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
                           uint32_t* out_offsets, uint32_t* out_members)
 {
-    if (!h || !seed || (n_active && !active_indices)) return PE_ERR_INVALID_ARG;
+    if (!h || !seed) return PE_ERR_INVALID_ARG;
     PE_TRY(enter(h));
+    HostLap lap(&h->trace);
     if (n_committees == 0 || n_committees % h->cfg.slots_per_epoch != 0)
         return fail(h, PE_ERR_INVALID_ARG, "n_committees must be a positive multiple of SLOTS_PER_EPOCH");
     if (shuffle_round_count > 255) return fail(h, PE_ERR_INVALID_ARG, "shuffle_round_count is a uint8 in the spec");
-    {   // the active set: distinct validator indices (get_active_validator_indices is increasing)
-        std::vector<uint8_t> seen(h->n_val, 0);
-        for (uint32_t i = 0; i < n_active; ++i) {
+    // active_indices NULL = every validator 0 .. n_active - 1 is active (get_active_validator_indices of a registry
+    // without pending or exited validators): nothing to validate, nothing to upload
+    const bool identity = active_indices == nullptr;
+    if (identity) {
+        if (n_active > h->n_val) return fail(h, PE_ERR_INVALID_ARG, "n_active exceeds the registry");
+    } else {   // the active set: distinct validator indices (get_active_validator_indices is increasing)
+        bool increasing = true;
+        for (uint32_t i = 0; i < n_active && increasing; ++i) {
             if (active_indices[i] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "active index out of range");
-            if (seen[active_indices[i]]) return fail(h, PE_ERR_INVALID_ARG, "duplicate active index");
-            seen[active_indices[i]] = 1;
+            if (i && active_indices[i] <= active_indices[i - 1]) increasing = false;
+        }
+        if (!increasing) {  // not sorted: the general distinctness check
+            std::vector<uint8_t> seen(h->n_val, 0);
+            for (uint32_t i = 0; i < n_active; ++i) {
+                if (active_indices[i] >= h->n_val) return fail(h, PE_ERR_INVALID_ARG, "active index out of range");
+                if (seen[active_indices[i]]) return fail(h, PE_ERR_INVALID_ARG, "duplicate active index");
+                seen[active_indices[i]] = 1;
+            }
         }
     }
+    lap.mark("comm.1_validate");
     std::vector<uint32_t> offsets(n_committees + 1);
     for (uint32_t c = 0; c <= n_committees; ++c)
         offsets[c] = (uint32_t)(((uint64_t)n_active * c) / n_committees);  // start/end of pe:502-503
@@ -1523,14 +1537,14 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
     }
     const uint32_t nb = (n_active + 255) / 256;
     Stage st(h);
-    PE_TRY(st.reserve(64 + 4ull * n_active + 4ull * (n_committees + 1) + 1024));
+    PE_TRY(st.reserve(64 + (identity ? 0 : 4ull * n_active) + 4ull * (n_committees + 1) + 1024));
     const size_t off_seed = st.alloc(32);
-    const size_t off_idx = st.alloc(4ull * n_active + 4);
+    const size_t off_idx = st.alloc(identity ? 4 : 4ull * n_active + 4);
     const size_t off_offs = st.alloc(4ull * (n_committees + 1));
     uint32_t* sw = st.host<uint32_t>(off_seed);
     for (int i = 0; i < 8; ++i)
         sw[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
-    if (n_active) memcpy(st.host<uint32_t>(off_idx), active_indices, 4ull * n_active);
+    if (!identity && n_active) memcpy(st.host<uint32_t>(off_idx), active_indices, 4ull * n_active);
     memcpy(st.host<uint32_t>(off_offs), offsets.data(), 4ull * (n_committees + 1));
     HIP_TRY(h, t->d_members.ensure(std::max<size_t>(64, 4ull * n_active)));
     HIP_TRY(h, t->d_offsets.ensure(4ull * (n_committees + 1)));
@@ -1539,7 +1553,7 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
     uint32_t* d_source = h->d_tmp_be.as<uint32_t>();
     uint32_t* d_pivots = d_source + 8ull * nb * shuffle_round_count;
     launch_shuffle(h->stream, st.dev<uint32_t>(off_seed), n_active, shuffle_round_count, d_source, d_pivots,
-                   st.dev<uint32_t>(off_idx), t->d_members.as<uint32_t>());
+                   identity ? nullptr : st.dev<uint32_t>(off_idx), t->d_members.as<uint32_t>());
     HIP_TRY(h, hipMemcpyAsync(t->d_offsets.p, st.dev<uint32_t>(off_offs), 4ull * (n_committees + 1),
                               hipMemcpyDeviceToDevice, h->stream));
     if (h->n_val) {
@@ -1549,9 +1563,19 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
                                  t->d_inv_comm.as<uint32_t>(), t->d_inv_pos.as<uint32_t>(), h->n_val);
     }
     HIP_TRY(h, hipGetLastError());
-    if (out_members && n_active)
-        HIP_TRY(h, hipMemcpyAsync(out_members, t->d_members.p, 4ull * n_active, hipMemcpyDeviceToHost, h->stream));
+    lap.mark("comm.2_launch");
+    // the table stays on the device; the members come back only on request, through the pinned block (a pageable
+    // 4 MB device-to-host copy is staged by the runtime in small pieces: ~2 ms against 0.3)
+    OutBlock ob(h);
+    size_t off_mem = 0;
+    if (out_members && n_active) {
+        off_mem = ob.alloc(4ull * n_active);
+        PE_TRY(ob.ensure());
+        HIP_TRY(h, hipMemcpyAsync(ob.host<uint32_t>(off_mem), t->d_members.p, 4ull * n_active, hipMemcpyDeviceToHost, h->stream));
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    lap.mark("comm.3_wait");
+    if (out_members && n_active) memcpy(out_members, ob.host<uint32_t>(off_mem), 4ull * n_active);
     if (out_offsets) memcpy(out_offsets, offsets.data(), 4ull * (n_committees + 1));
     t->epoch = epoch;
     t->n_committees = n_committees;
@@ -1559,6 +1583,7 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
     t->is_partition = true;  // a permutation of distinct indices, sliced
     t->n_val_at_load = h->n_val;
     t->stamp = ++h->table_stamp;
+    lap.mark("comm.4_outputs");
     return PE_OK;
 }
 
@@ -2748,6 +2773,33 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
     if (rc) return rc;
     if (n_bad) return fail(h, PE_ERR_INVALID_ARG, std::to_string(n_bad) + " pubkeys do not decode to curve points (see status[])");
     h->have_points = true;
+    return PE_OK;
+}
+
+// KeyValidate (Appendix A.7: FastAggregateVerify validates every pubkey): points96 NULL = the registry as loaded.
+int pe_g1_key_validate(pe_engine* h, const uint8_t* points96, uint64_t n, int32_t* status)
+{
+    if (!h || (n && !status)) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n == 0) return PE_OK;
+    const uint32_t* d_pts;
+    if (points96) {
+        if (n >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "too many points");
+        HIP_TRY(h, h->d_tmp_be.ensure(96ull * n));
+        HIP_TRY(h, h->d_tmp_points.ensure(4ull * G1_ROW_WORDS * n + 4ull * n));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n, hipMemcpyHostToDevice, h->stream));
+        launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
+        d_pts = h->d_tmp_points.as<uint32_t>();
+    } else {
+        if (!h->have_points || n != h->n_val) return fail(h, PE_ERR_STATE, "pe_g1_key_validate: no pubkeys loaded / n differs from the registry");
+        d_pts = h->d_points.as<uint32_t>();
+    }
+    HIP_TRY(h, h->d_out96.ensure(4ull * n));
+    int32_t* d_st = h->d_out96.as<int32_t>();
+    launch_g1_key_validate(h->stream, d_pts, n, d_st);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(status, d_st, 4ull * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return PE_OK;
 }
 

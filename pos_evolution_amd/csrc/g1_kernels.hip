@@ -132,6 +132,49 @@ void launch_g1_decompress(hipStream_t s, const uint8_t* in48, uint64_t n, uint32
                        out_be96, status);
 }
 
+// ---------------------------------------------------------------- KeyValidate
+// FastAggregateVerify = KeyValidate each pubkey first (IETF BLS draft 2.5): a valid curve point, not the
+// identity, and in the prime-order subgroup: r * P == infinity.  One lane per key: 254 doublings + one mixed add per set
+// bit of r (MSB first; the scalar is a constant, so the branch is uniform) ~ 3.5 k Montgomery products per key -- a
+// once-per-registry-load pass (1 M keys ~ 65 ms of the chip).  status: 0 ok, 3 not in the subgroup, 4 identity.
+__constant__ uint32_t G1_R_ORDER_BE_WORDS[8] = {0x73eda753u, 0x299d7d48u, 0x3339d808u, 0x09a1d805u,
+                                                0x53bda402u, 0xfffe5bfeu, 0xffffffffu, 0x00000001u};
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_g1_key_validate(const uint32_t* __restrict__ pts, uint64_t n, int32_t* __restrict__ status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* row = pts + (uint64_t)G1_ROW_WORDS * i;
+    fp px, py;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        px.l[j] = row[j];
+        py.l[j] = row[12 + j];
+    }
+    if (fp_is_zero(px) && fp_is_zero(py)) {  // (0, 0) encodes infinity in the table
+        status[i] = 4;
+        return;
+    }
+    g1x acc;
+    acc.x = px;
+    acc.y = py;
+    fp_set_one(acc.zz);
+    fp_set_one(acc.zzz);
+    // bit 254 (the top bit of r) is the initial value; bits 253 .. 0 follow
+    for (int b = 253; b >= 0; --b) {
+        acc = g1x_double(acc);
+        const uint32_t w = G1_R_ORDER_BE_WORDS[7 - (b >> 5)];
+        if ((w >> (b & 31)) & 1u) g1x_add_affine(acc, px, py, false);
+    }
+    status[i] = g1x_is_inf(acc) ? 0 : 3;
+}
+
+void launch_g1_key_validate(hipStream_t s, const uint32_t* points_mont, uint64_t n, int32_t* status)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_g1_key_validate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, points_mont, n, status);
+}
+
 // ---------------------------------------------------------------- accumulate
 __device__ __forceinline__ void load_point(fp& x, fp& y, const uint32_t* __restrict__ pts, uint32_t idx)
 {

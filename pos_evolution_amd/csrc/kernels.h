@@ -124,6 +124,9 @@ void launch_state_view_from_registry(hipStream_t s, const uint8_t* flags, const 
 void launch_g1_decompress(hipStream_t s, const uint8_t* in48, uint64_t n, uint32_t* out_mont24, uint8_t* out_be96,
                           int32_t* status);
 
+// KeyValidate's subgroup part over Montgomery rows (128-byte rows): status 0 ok, 3 r*P != infinity, 4 identity
+void launch_g1_key_validate(hipStream_t s, const uint32_t* points_mont, uint64_t n, int32_t* status);
+
 // G2 (g2_kernels.hip): same group descriptors, points as 48 Montgomery words [x0 x1 y0 y1], partials 96 words
 void launch_g2_convert(hipStream_t s, const uint8_t* be192, uint32_t* mont48, uint64_t n);
 void launch_g2_accumulate(hipStream_t s, const uint32_t* points_mont48, const uint32_t* members,

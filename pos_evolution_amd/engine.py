@@ -298,14 +298,19 @@ class Engine:
     def compute_committees(self, epoch: int, seed: bytes, active_indices, n_committees: int,
                            shuffle_round_count: int = 90, want_result: bool = True):
         """compute_committee / compute_shuffled_index (pe:495-534) for the whole epoch on the GPU; registers the
-        table for `epoch`.  -> (offsets uint32[C+1], members uint32[n_active]) when want_result."""
-        act = np.ascontiguousarray(active_indices, dtype=np.uint32)
-        off = np.zeros(n_committees + 1, dtype=np.uint32) if want_result else None
-        mem = np.zeros(max(act.size, 1), dtype=np.uint32) if want_result else None
-        self._check(self._lib.pe_compute_committees(self._h, epoch, _root(seed), _ptr(act, C.c_uint32), act.size,
+        table for `epoch` (it stays on the device).  active_indices: the index array, or an int n meaning validators
+        0 .. n - 1.  -> (offsets uint32[C+1], members uint32[n_active]) when want_result, else nothing is read back."""
+        if isinstance(active_indices, (int, np.integer)):   # "every validator 0 .. n - 1 is active": nothing to upload
+            act, n_act = None, int(active_indices)
+        else:
+            act = np.ascontiguousarray(active_indices, dtype=np.uint32)
+            n_act = act.size
+        off = np.empty(n_committees + 1, dtype=np.uint32) if want_result else None
+        mem = np.empty(max(n_act, 1), dtype=np.uint32) if want_result else None
+        self._check(self._lib.pe_compute_committees(self._h, epoch, _root(seed), _ptr(act, C.c_uint32), n_act,
                                                     n_committees, shuffle_round_count, _ptr(off, C.c_uint32),
                                                     _ptr(mem, C.c_uint32)))
-        return (off, mem[:act.size]) if want_result else None
+        return (off, mem[:n_act]) if want_result else None
 
     # -- hot path ---------------------------------------------------------
     def get_head(self) -> bytes:
@@ -438,6 +443,18 @@ class Engine:
         self._check(self._lib.pe_g1_sum(self._h, _ptr(pts, C.c_uint8), n_points, _ptr(idx, C.c_uint32),
                                         _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
         return out[:n_groups]
+
+    def g1_key_validate(self, points96=None) -> np.ndarray:
+        """KeyValidate (A.7): status per key -- 0 valid, 3 not in the prime-order subgroup, 4 identity.  points96 None =
+        the registry's pubkeys as loaded."""
+        if points96 is None:
+            n, p = self.num_validators, None
+        else:
+            p = np.ascontiguousarray(points96, dtype=np.uint8).reshape(-1, 96)
+            n = p.shape[0]
+        status = np.empty(max(n, 1), dtype=np.int32)
+        self._check(self._lib.pe_g1_key_validate(self._h, _ptr(p, C.c_uint8), n, _ptr(status, C.c_int32)))
+        return status[:n]
 
     def g1_decompress(self, keys48):
         """48-byte compressed BLSPubkeys (pe:37) -> (96-byte uncompressed (n, 96), status int32[n])."""

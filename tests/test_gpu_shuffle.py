@@ -72,3 +72,26 @@ def test_million_validator_epoch_is_a_partition_and_drives_on_attestation(engine
     assert (status == 0).all()
     _, blk = e.latest_messages()
     assert (blk != 0xFFFFFFFF).sum() == count.sum()
+
+
+def test_compute_committees_identity_active_set_and_no_readback(engine_factory):
+    """active_indices = n ("validators 0 .. n - 1 are active") must give the table of the explicit index array, and
+    want_result=False keeps it on the device: a following aggregation resolves against it."""
+    import pos_evolution_amd as pea
+    n, count, rounds = 30000, 64, 90
+    seed = spec.sha256(b"identity")
+    a = engine_factory()
+    b = engine_factory()
+    for e in (a, b):
+        e.set_validators(np.full(n, 32 * 10**9, dtype=np.uint64), np.ones(n, dtype=np.uint8))
+    off_a, mem_a = a.compute_committees(3, seed, np.arange(n, dtype=np.uint32), count, rounds)
+    off_b, mem_b = b.compute_committees(3, seed, n, count, rounds)
+    assert np.array_equal(off_a, off_b) and np.array_equal(mem_a, mem_b)
+    assert sorted(mem_b.tolist()) == list(range(n))
+    assert b.compute_committees(4, seed, n, count, rounds, want_result=False) is None
+    # an unsorted or duplicated active set is still validated
+    with pytest.raises(pea.EngineError):
+        a.compute_committees(5, seed, np.array([1, 1, 2], dtype=np.uint32), 32, rounds)
+    perm = np.random.default_rng(1).permutation(n).astype(np.uint32)
+    off_p, mem_p = a.compute_committees(6, seed, perm, count, rounds)
+    assert np.array_equal(mem_p, perm[mem_a])      # members[i] = indices[shuffled(i)]

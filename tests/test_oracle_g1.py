@@ -126,3 +126,19 @@ def test_c_abi_compress_matches_oracle():
     out = np.zeros(48 * len(pts), dtype=np.uint8)
     assert lib.pe_g1_compress(raw.ctypes.data_as(C.POINTER(C.c_uint8)), len(pts), out.ctypes.data_as(C.POINTER(C.c_uint8))) == 0
     assert out.tobytes() == b"".join(g1.compress(p) for p in pts)
+
+
+def test_key_validate_oracle():
+    """KeyValidate (A.7): subgroup points pass, the identity and points of E(Fp) outside the r-torsion fail; the
+    cofactor clears any curve point into the subgroup."""
+    H_COFACTOR = 0x396C8C005555E1568C00AAAB0000AAAB
+    assert g1.key_validate(g1.G) and g1.key_validate(g1.mul(0xDEADBEEF, g1.G))
+    assert not g1.key_validate(None)
+    outside = 0
+    for x0 in (1, 2, 1000, 2**200):
+        pt = g1.curve_point_from_x(x0)
+        assert g1.is_on_curve(pt)
+        if not g1.in_subgroup(pt):
+            outside += 1
+        assert g1.in_subgroup(g1.mul_unreduced(H_COFACTOR, pt))
+    assert outside == 4
