@@ -459,7 +459,8 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n,
 #define PE_KERNEL_BITS_UNION    6
 #define PE_KERNEL_G2_ACCUMULATE 7
 #define PE_KERNEL_G2_NORMALISE  8
-#define PE_KERNEL_COUNT         9
+#define PE_KERNEL_G1_TREE       9   /* the LDS tree over the lane partials: its own kernel since round 2 */
+#define PE_KERNEL_COUNT         10
 int pe_profile_enable(pe_engine* h, int on);
 int pe_profile_reset(pe_engine* h);
 int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms);

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libposevo.so")
+# POSEVO_LIB_PATH: another build of the same sources (kernel-variant experiments, tools/); the default is the in-tree library
+LIB_PATH = os.environ.get("POSEVO_LIB_PATH") or os.path.join(_HERE, "libposevo.so")
 
 PE_OK = 0
 PE_ERR_NO_DEVICE = -2
@@ -23,9 +24,9 @@ PE_G1_PARTIAL_BYTES = 192
 PE_EXCHANGE_EXTRA = 512
 (PE_KERNEL_G1_ACCUMULATE, PE_KERNEL_G1_NORMALISE, PE_KERNEL_VOTES, PE_KERNEL_TREE, PE_KERNEL_LMD,
  PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_G2_ACCUMULATE, PE_KERNEL_G2_NORMALISE,
- PE_KERNEL_COUNT) = range(10)
+ PE_KERNEL_G1_TREE, PE_KERNEL_COUNT) = range(11)
 KERNEL_NAMES = ["g1_accumulate", "g1_normalise", "votes", "tree", "lmd", "participation", "bits_union",
-                "g2_accumulate", "g2_normalise"]
+                "g2_accumulate", "g2_normalise", "g1_tree"]
 
 ATT_STATUS_NAMES = {
     0: "ok", 1: "target epoch not current or previous", 2: "target epoch != epoch(slot)",

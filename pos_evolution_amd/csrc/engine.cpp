@@ -229,7 +229,7 @@ struct pe_engine {
     size_t last_table = 0;  // index of the table find_table returned last
 
     // ---- scratch ----
-    DevBuf d_partials, d_out96, d_tmp_points, d_tmp_be;
+    DevBuf d_partials, d_lane_partials, d_out96, d_tmp_points, d_tmp_be;
 
     // ---- pipelined calls (pe_pipeline_begin / _end): one wait per step instead of one per call ----
     // A batch call lays out its inputs at stage_cursor / its outputs at out_cursor of the current arena, enqueues
@@ -241,7 +241,7 @@ struct pe_engine {
         DevBuf d_stage, d_outblk;         // H2D staging block | device output block
         PinBuf h_stage, h_pin;            // their pinned host mirrors (h_pin is host-coherent: kernels write into it)
         DevBuf d_res_bits, d_res_info;    // resident hand-over: OR-ed bit words | {popcount, overlap} per group
-        DevBuf d_partials;                // accumulate -> finish hand-over of this arena's pipelined aggregate
+        DevBuf d_partials, d_lane_partials;  // tree -> finish | accumulate -> tree hand-over of this arena's pipelined aggregate
         size_t stage_cursor = 0, out_cursor = 0;
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr;  // recorded by pe_pipeline_end_lagged
@@ -756,26 +756,35 @@ void g1_stream_guard(pe_engine* h, hipStream_t s)
 }
 
 // Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
-// fin != s: the finish kernel goes to its own stream behind an event (a pipelined aggregate: it then overlaps the next
-// aggregate's accumulation); partials: the scratch the two kernels hand over through (per arena when pipelined).
+// fin != s: the tree and finish kernels go to their own stream behind an event (a pipelined aggregate: they then overlap
+// the next aggregate's accumulation); partials / lane_partials: the scratch the kernels hand over through (per arena
+// when pipelined).
 int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
-                      hipStream_t s = nullptr, hipStream_t fin = nullptr, DevBuf* partials = nullptr)
+                      hipStream_t s = nullptr, hipStream_t fin = nullptr, DevBuf* partials = nullptr,
+                      DevBuf* lane_partials = nullptr)
 {
     if (plan.n_groups == 0) return PE_OK;
     if (!s) s = h->stream;
     if (!fin) fin = s;
     if (!partials) partials = &h->d_partials;
+    if (!lane_partials) lane_partials = &h->d_lane_partials;
     PE_TRY(ensure_quiesced(h, *partials,
                            std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
+    const size_t lane_bytes = (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan.n_slots + G1_WG - 1) / G1_WG);
+    PE_TRY(ensure_quiesced(h, *lane_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, lane_bytes)));
     {
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s);
         launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             partials->as<uint32_t>());
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>());
     }
     if (fin != s) {
         HIP_TRY(h, hipEventRecord(h->ev_acc, s));
         HIP_TRY(h, hipStreamWaitEvent(fin, h->ev_acc, 0));
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G1_TREE, fin);
+        launch_g1_tree(fin, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>());
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_NORMALISE, fin);
@@ -1125,6 +1134,7 @@ void pe_engine_destroy(pe_engine* h)
         a.d_res_bits.release();
         a.d_res_info.release();
         a.d_partials.release();
+        a.d_lane_partials.release();
         a.d_stage.release();
         a.d_outblk.release();
         a.h_stage.release();
@@ -1135,7 +1145,7 @@ void pe_engine_destroy(pe_engine* h)
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
                       &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head,
-                      &h->d_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
+                      &h->d_partials, &h->d_lane_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
         b->release();
     for (auto& t : h->tables) { t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release(); }
     h->h_head.release();
@@ -2261,7 +2271,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
                 }
             }
             int rc = launch_g1_planned(h, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, gs,
-                                       on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr);
+                                       on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr,
+                                       on_side ? &arena->d_lane_partials : nullptr);
             if (rc) return rc;
             if (arm >= 0) (void)hipEventRecord(h->g1_tune_ev[1], on_side ? h->fin_stream : gs);
             if (on_side) {
@@ -2276,6 +2287,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
             // scratch sizes are settled now, while nothing of the launch is in flight
             PE_TRY(ensure_quiesced(h, arena->d_partials,
                                    std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
+            PE_TRY(ensure_quiesced(h, arena->d_lane_partials,
+                                   (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
             h->deferred.push_back(launch_g1);
         } else {
             int rc = launch_g1();
@@ -3130,19 +3143,21 @@ int pe_pipeline_begin(pe_engine* h)
     // inside the pipeline -- a growth there waits for everything enqueued and re-allocates pinned memory (milliseconds).
     {
         pe_engine::PipeArena& a = h->A();
-        size_t stage = 0, out = 0, bits = 0, info = 0, part = 0;
+        size_t stage = 0, out = 0, bits = 0, info = 0, part = 0, lane = 0;
         for (auto& o : h->arena) {
             stage = std::max(stage, std::min(o.d_stage.cap, o.h_stage.cap));
             out = std::max(out, std::min(o.d_outblk.cap, o.h_pin.cap));
             bits = std::max(bits, o.d_res_bits.cap);
             info = std::max(info, o.d_res_info.cap);
             part = std::max(part, o.d_partials.cap);
+            lane = std::max(lane, o.d_lane_partials.cap);
         }
         if (stage) { HIP_TRY(h, a.d_stage.ensure(stage)); HIP_TRY(h, a.h_stage.ensure(stage)); }
         if (out) { HIP_TRY(h, a.d_outblk.ensure(out)); HIP_TRY(h, a.h_pin.ensure(out)); }
         if (bits) HIP_TRY(h, a.d_res_bits.ensure(bits));
         if (info) HIP_TRY(h, a.d_res_info.ensure(info));
         if (part) HIP_TRY(h, a.d_partials.ensure(part));
+        if (lane) HIP_TRY(h, a.d_lane_partials.ensure(lane));
     }
     h->pipelining = true;
     return PE_OK;

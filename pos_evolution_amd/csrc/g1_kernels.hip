@@ -276,76 +276,124 @@ __device__ unsigned long long g1_wave_info[3 * 4 * 4096];  // per wave: HW_ID | 
 #ifndef POSEVO_G1_WAVES_PER_EU
 #define POSEVO_G1_WAVES_PER_EU 2
 #endif
+// The sum of one launch runs in THREE kernels since round 2:
+//   k_g1_accumulate  per-lane XYZZ accumulation of k gathered points (mixed adds): throughput-bound, at the VALU issue
+//                    floor; writes one partial per lane slot, limb-major per workgroup (coalesced);
+//   k_g1_tree        the compacting pairwise tree over each workgroup's 256 partials (LDS, two- and four-lane
+//                    cooperative adds): latency-bound, a level is one full add deep;
+//   k_g1_finish      adds the few workgroup partials of a wide group and normalises.
+// Fused (round 1) the tree of the younger workgroup of every CU ran exposed at the end of the launch (45-70 us at < 50 %
+// lane use).  Split, the tree is a short kernel of its own that -- in a stream of pipelined steps -- runs on the finish
+// stream BESIDE the next aggregate's accumulation, which leaves it the issue slots a latency-bound kernel needs: the
+// accumulation alone is the step's critical path.  Stand-alone (synchronous calls) the two launches cost what the
+// fused one did.
+// Slot -> (output slot of its block, block size): shared by the two kernels.
+__device__ __forceinline__ void g1_slot_block(const G1Group* __restrict__ groups, uint32_t n_groups, uint32_t n_slots,
+                                              uint32_t slot, uint32_t& my_out, uint32_t& my_size, G1Group& d, uint32_t& t)
+{
+    my_out = NONE32;
+    my_size = 0;
+    t = 0;
+    if (slot >= n_slots) return;
+    const uint32_t g = find_group(groups, n_groups, slot);
+    d = groups[g];
+    t = slot - d.slot_base;
+    const bool wide = d.log2_block > 8;                  // group spans whole workgroups
+    const uint32_t block_slots = d.n_tasks == 0 ? 0u
+                               : wide ? ((d.n_tasks + G1_WG - 1) / G1_WG) * G1_WG : (1u << d.log2_block);
+    if (t < block_slots) {  // inside the group's padded block (padding lanes carry infinity)
+        my_size = wide ? (uint32_t)G1_WG : (1u << d.log2_block);
+        my_out = d.out_base + (wide ? (t >> 8) : 0u);
+    }
+}
+
+// lane partials in HBM: word k of lane `tid` of workgroup `wg` at ((wg * 48 + k) * 256 + tid): a wave's 64 lanes write
+// 256 contiguous bytes per word
+__device__ __forceinline__ void lane_store_x(uint32_t* __restrict__ buf, uint32_t wg, int tid, const g1x& p)
+{
+    uint32_t* b = buf + (size_t)wg * G1X_WORDS * G1_WG + tid;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        b[(0 + k) * G1_WG] = p.x.l[k];
+        b[(12 + k) * G1_WG] = p.y.l[k];
+        b[(24 + k) * G1_WG] = p.zz.l[k];
+        b[(36 + k) * G1_WG] = p.zzz.l[k];
+    }
+}
+
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
 k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ members,
                 const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
-                uint32_t n_slots, uint32_t* __restrict__ wg_partials)
+                uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 48*256 partial words + 2*256 block info
-    uint32_t* lds_out = lds + G1X_WORDS * G1_WG;  // output slot of the block a partial belongs to
-    uint32_t* lds_sz = lds_out + G1_WG;           // current block size (0 = empty / retired)
-
     const int tid = threadIdx.x;
     const uint32_t slot = blockIdx.x * G1_WG + tid;
-    // (s_setprio(3) here, to keep the guests of a pipelined step -- the previous aggregate's k_g1_finish, the next
-    // step's union / LMD / flag / vote kernels -- off this kernel's issue slots, was measured: no gain for the
-    // accumulation (0.315 ms either way: in a saturated stream of steps it runs at the chip's sustained clock, not at
-    // the boost clock an isolated launch sees, 0.278 ms) and k_g1_finish starved from 0.09 to 0.21 ms.  Dropped.)
     G1_STAMP(0);
     G1_WAVE_BEGIN();
 
     g1x acc;
     g1x_set_inf(acc);
-    uint32_t my_out = NONE32, my_size = 0;
-
-    if (slot < n_slots) {
-        const uint32_t g = find_group(groups, n_groups, slot);
-        const G1Group d = groups[g];
-        const uint32_t t = slot - d.slot_base;
-        const bool wide = d.log2_block > 8;                  // group spans whole workgroups
-        const uint32_t block_slots = d.n_tasks == 0 ? 0u
-                                   : wide ? ((d.n_tasks + G1_WG - 1) / G1_WG) * G1_WG : (1u << d.log2_block);
-        if (t < block_slots) {  // inside the group's padded block (padding lanes carry infinity)
-            my_size = wide ? (uint32_t)G1_WG : (1u << d.log2_block);
-            my_out = d.out_base + (wide ? (t >> 8) : 0u);
-        }
-        if (t < d.n_tasks) {
-            const uint32_t first = t * d.k;
-            const uint32_t count = min(d.k, d.n_members - first);
-            // gather + mixed adds; the next point's loads are issued before the current add
-            fp qx, qy, nx, ny;
-            bool have = false, nhave = false;
-            auto fetch = [&](uint32_t j, fp& ox, fp& oy) -> bool {
-                const uint32_t i = first + j;
-                if (d.bits_word != NONE32) {
-                    const uint32_t w = bit_arena[d.bits_word + (i >> 5)];
-                    if (!((w >> (i & 31)) & 1u)) return false;
-                }
-                const uint32_t idx = members ? members[d.member_start + i] : d.member_start + i;
-                load_point(ox, oy, pts, idx);
-                return true;
-            };
-            if (count > 0) have = fetch(0, qx, qy);
-            for (uint32_t j = 0; j < count; ++j) {
-                nhave = false;
-                if (j + 1 < count) nhave = fetch(j + 1, nx, ny);
-                if (have) {
-                    const bool q_inf = fp_is_zero(qx) && fp_is_zero(qy);  // (0,0) encodes infinity in the table
-                    g1x_add_affine(acc, qx, qy, q_inf);
-                }
-                qx = nx; qy = ny; have = nhave;
+    uint32_t my_out, my_size, t;
+    G1Group d;
+    g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
+    if (slot < n_slots && t < d.n_tasks) {
+        const uint32_t first = t * d.k;
+        const uint32_t count = min(d.k, d.n_members - first);
+        // gather + mixed adds; the next point's loads are issued before the current add
+        fp qx, qy, nx, ny;
+        bool have = false, nhave = false;
+        auto fetch = [&](uint32_t j, fp& ox, fp& oy) -> bool {
+            const uint32_t i = first + j;
+            if (d.bits_word != NONE32) {
+                const uint32_t w = bit_arena[d.bits_word + (i >> 5)];
+                if (!((w >> (i & 31)) & 1u)) return false;
             }
+            const uint32_t idx = members ? members[d.member_start + i] : d.member_start + i;
+            load_point(ox, oy, pts, idx);
+            return true;
+        };
+        if (count > 0) have = fetch(0, qx, qy);
+        for (uint32_t j = 0; j < count; ++j) {
+            nhave = false;
+            if (j + 1 < count) nhave = fetch(j + 1, nx, ny);
+            if (have) {
+                const bool q_inf = fp_is_zero(qx) && fp_is_zero(qy);  // (0,0) encodes infinity in the table
+                g1x_add_affine(acc, qx, qy, q_inf);
+            }
+            qx = nx; qy = ny; have = nhave;
         }
     }
-    // ---- workgroup tree over the 256 partials.  Level with n pairs: lanes 2w, 2w+1 add pair w together
-    // (g1x_add_pair: 7 dependent products instead of 14), results compact into slot w. ----
     G1_STAMP(1);
     G1_WAVE_END();
-    if (my_size == 1) {  // single-task group: done
-        global_store_x(wg_partials + (size_t)G1X_WORDS * my_out, acc);
-        my_size = 0;
+    if (my_size == 1) global_store_x(wg_partials + (size_t)G1X_WORDS * my_out, acc);  // single-task group: done
+    lane_store_x(lane_partials, blockIdx.x, tid, acc);
+}
+
+#ifndef POSEVO_G1_TREE_WAVES_PER_EU
+#define POSEVO_G1_TREE_WAVES_PER_EU 2
+#endif
+// Two waves per SIMD: 226 VGPRs, no scratch.  The three-wave build (168 VGPRs, 288 B of scratch per lane) would fit
+// beside the two waves of the NEXT aggregate's k_g1_accumulate and start while that one runs; measured back to back on
+// one box it loses anyway -- alone 59 vs 51 us, in the streaming step 0.114 vs 0.093 ms and the finish behind it
+// 0.14 vs 0.086 ms, step 0.396-0.404 vs 0.381-0.389 ms (gpurun_out/r02r_*, summary in profiles/README.md).
+__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_TREE_WAVES_PER_EU, POSEVO_G1_TREE_WAVES_PER_EU)))
+k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups, uint32_t n_groups,
+          uint32_t n_slots, uint32_t* __restrict__ wg_partials)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 48*256 partial words + 2*256 block info
+    uint32_t* lds_out = lds + G1X_WORDS * G1_WG;  // output slot of the block a partial belongs to
+    uint32_t* lds_sz = lds_out + G1_WG;           // current block size (0 = empty / retired)
+    const int tid = threadIdx.x;
+    const uint32_t slot = blockIdx.x * G1_WG + tid;
+    uint32_t my_out, my_size, t;
+    G1Group d;
+    g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
+    if (my_size == 1) my_size = 0;  // written by k_g1_accumulate
+    {
+        const uint32_t* b = lane_partials + (size_t)blockIdx.x * G1X_WORDS * G1_WG + tid;
+#pragma unroll
+        for (int k = 0; k < G1X_WORDS; ++k) lds[k * G1_WG + tid] = b[k * G1_WG];
     }
-    lds_store_x(lds, tid, acc);
     lds_out[tid] = my_out;
     lds_sz[tid] = my_size;
     __syncthreads();
@@ -479,13 +527,22 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
 
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
-                          uint32_t* wg_partials48)
+                          uint32_t* lane_partials, uint32_t* wg_partials48)
+{
+    if (n_groups == 0 || n_slots == 0) return;
+    const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
+    hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), 0, s, points_mont24, members, bit_arena,
+                       groups, n_groups, n_slots, lane_partials, wg_partials48);
+}
+
+void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
+                    uint32_t n_slots, uint32_t* wg_partials48)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     const size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), lds_bytes, s, points_mont24, members, bit_arena,
-                       groups, n_groups, n_slots, wg_partials48);
+    hipLaunchKernelGGL(k_g1_tree, dim3(blocks), dim3(G1_WG), lds_bytes, s, lane_partials, groups, n_groups, n_slots,
+                       wg_partials48);
 }
 
 // ---------------------------------------------------------------- finish

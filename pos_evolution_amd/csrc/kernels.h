@@ -34,10 +34,15 @@ struct G1Group {
 // ---- G1 ----
 // 96-byte big-endian uncompressed affine -> 24 u32 Montgomery limbs (x | y); infinity -> all zero.
 void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uint64_t n);
-// Per-lane XYZZ accumulation + LDS tree; writes one 48-u32 XYZZ partial (192 bytes) per (group, workgroup).
+// Per-lane XYZZ accumulation of k gathered points: one partial per lane slot into lane_partials (limb-major per
+// workgroup: ceil(n_slots / 256) * 256 * 192 bytes); single-task groups are written straight to wg_partials48.
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups,
-                          uint32_t n_slots, uint32_t* wg_partials48);
+                          uint32_t n_slots, uint32_t* lane_partials, uint32_t* wg_partials48);
+// The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
+// (group, workgroup) into wg_partials48.
+void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
+                    uint32_t n_slots, uint32_t* wg_partials48);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
 // g when first == null), then either write the XYZZ sum (48 u32) or normalise to 96-byte affine.
 void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,

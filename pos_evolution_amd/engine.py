@@ -101,6 +101,9 @@ _ATT_DTYPE = np.dtype([
 ])  # == synth.ATT_DTYPE == struct pe_attestation (144 bytes)
 
 
+_I32, _U32, _U64, _U8 = np.dtype(np.int32), np.dtype(np.uint32), np.dtype(np.uint64), np.dtype(np.uint8)
+
+
 class _Resident:
     """Sentinel for ``packed=(rows, RESIDENT)``: the rows are rows of the last ``aggregate`` result and their OR-ed
     bits are used where pe_aggregate left them on the device (PE_BITS_RESIDENT, include/posevo.h)."""
@@ -189,15 +192,19 @@ class Engine:
         self._ring = [dict() for _ in range(max(depth, 1))]
         self._ring_i = 0
 
-    def _out(self, name, shape, dtype):
+    def _outs(self, key, specs):
+        """The output arrays of one call and their addresses: ``specs`` = ((shape, dtype) or None, ...).  With
+        reuse_outputs() the set comes from the ring slot of the current pipeline -- one dict lookup instead of one
+        allocation and one address computation per array (a step makes ~20 pointer arguments)."""
         if self._ring is None:
-            return np.empty(shape, dtype=dtype)
+            arrs = tuple(None if sp is None else np.empty(sp[0], dtype=sp[1]) for sp in specs)
+            return arrs, tuple(_ptr(a) for a in arrs)
         d = self._ring[self._ring_i]
-        key = (name, shape if isinstance(shape, tuple) else (shape,), np.dtype(dtype).str)
-        a = d.get(key)
-        if a is None:
-            a = d[key] = np.zeros(shape, dtype=dtype)  # zeros: touch the pages once, here
-        return a
+        hit = d.get((key, specs))
+        if hit is None:
+            arrs = tuple(None if sp is None else np.zeros(sp[0], dtype=sp[1]) for sp in specs)  # zeros: touch the pages here
+            hit = d[(key, specs)] = (arrs, tuple(_ptr(a) for a in arrs))
+        return hit
 
     def _keep(self, *buffers):
         """Inside a pipeline the engine writes into these buffers at pe_pipeline_end: keep them alive until then."""
@@ -335,14 +342,15 @@ class Engine:
         """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        status = self._out("att.status", max(n, 1), np.int32)
-        count = self._out("att.count", max(n, 1), np.uint32)
-        agg = self._out("att.aggpk", (max(n, 1), 96), np.uint8) if want_aggregate_pubkeys else None
+        m = max(n, 1)
+        (status, count, agg), (p_status, p_count, p_agg) = self._outs(
+            "att", ((m, _I32), (m, _U32), ((m, 96), _U8) if want_aggregate_pubkeys else None))
         arena_p = _abi.PE_BITS_RESIDENT if arena is RESIDENT else _ptr(arena, C.c_uint8)
-        self._keep(arr, status, count, agg)
-        self._check(self._lib.pe_on_attestation_batch(self._h, _att_ptr(arr), n, arena_p, arena.size,
-                                                      _ptr(status, C.c_int32), _ptr(agg, C.c_uint8),
-                                                      _ptr(count, C.c_uint32)))
+        if self._pipe_keep is not None:
+            self._pipe_keep.append((arr, status, count, agg))
+        rc = self._lib.pe_on_attestation_batch(self._h, _att_ptr(arr), n, arena_p, arena.size, p_status, p_agg, p_count)
+        if rc:
+            self._check(rc)
         return status[:n], (agg[:n] if agg is not None else None), count[:n]
 
     def get_indexed_attestations(self, rows=None, packed=None):
@@ -366,26 +374,26 @@ class Engine:
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
-        out_atts = self._out("agg.atts", m, _ATT_DTYPE)  # output buffers: written by the engine, never read before that
-        n_groups = C.c_uint32(0)
-        group_of = self._out("agg.group_of", m, np.uint32)
-        out_arena = self._out("agg.arena", max(arena.size, 1), np.uint8)
         sig = None
         if sig_points96 is not None:
             sig = np.ascontiguousarray(sig_points96, dtype=np.uint8)
             assert sig.size == 96 * n
-        out_sig = self._out("agg.sig", (m, 96), np.uint8) if sig is not None else None
-        out_pk = self._out("agg.pk", (m, 96), np.uint8) if want_aggregate_pubkeys else None
-        count = self._out("agg.count", m, np.uint32)
-        self._keep(arr, arena, sig, out_atts, group_of, out_arena, out_sig, out_pk, count)
-        self._check(self._lib.pe_aggregate(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size, _ptr(sig, C.c_uint8),
-                                           _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
-                                           _ptr(out_arena, C.c_uint8), out_arena.size, _ptr(out_sig, C.c_uint8),
-                                           _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
+        # output buffers: written by the engine, never read before that.  "tail" receives (offset, n_bits) of the last
+        # group's bits through two of the row fields the C side fills in, read back as plain u32s below
+        (out_atts, group_of, out_arena, out_sig, out_pk, count), (p_atts, p_gof, p_arena, p_sig, p_pk, p_count) = self._outs(
+            "agg", ((m, _ATT_DTYPE), (m, _U32), (max(arena.size, 1), _U8), ((m, 96), _U8) if sig is not None else None,
+                    ((m, 96), _U8) if want_aggregate_pubkeys else None, (m, _U32)))
+        n_groups = C.c_uint32(0)
+        if self._pipe_keep is not None:
+            self._pipe_keep.append((arr, arena, sig, out_atts, group_of, out_arena, out_sig, out_pk, count))
+        rc = self._lib.pe_aggregate(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size, _ptr(sig, C.c_uint8),
+                                    p_atts, C.byref(n_groups), p_gof, p_arena, out_arena.size, p_sig, p_pk, p_count)
+        if rc:
+            self._check(rc)
         g = n_groups.value
         if g:  # the groups' unions are laid out back to back: hand back only the written part of the arena
-            last = out_atts[g - 1]
-            out_arena = out_arena[: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
+            tail = out_atts.view(np.uint32).reshape(-1, 36)[g - 1]   # u32 words 32 / 33 of a row: bits_offset, n_bits
+            out_arena = out_arena[: int(tail[32]) + (int(tail[33]) + 7) // 8]
         sig192 = None
         if sig_points192 is not None:
             s2 = np.ascontiguousarray(sig_points192, dtype=np.uint8)
@@ -401,13 +409,15 @@ class Engine:
         """-> (status int32[n], proposer_reward_numerator uint64[n])."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
-        status = self._out("proc.status", max(n, 1), np.int32)
-        num = self._out("proc.num", max(n, 1), np.uint64)
+        m = max(n, 1)
+        (status, num), (p_status, p_num) = self._outs("proc", ((m, _I32), (m, _U64)))
         arena_p = _abi.PE_BITS_RESIDENT if arena is RESIDENT else _ptr(arena, C.c_uint8)
-        self._keep(arr, status, num)
-        self._check(self._lib.pe_process_attestation_batch(self._h, C.byref(state_ctx), _att_ptr(arr), n,
-                                                           arena_p, arena.size,
-                                                           _ptr(status, C.c_int32), _ptr(num, C.c_uint64)))
+        if self._pipe_keep is not None:
+            self._pipe_keep.append((arr, status, num))
+        rc = self._lib.pe_process_attestation_batch(self._h, C.byref(state_ctx), _att_ptr(arr), n, arena_p, arena.size,
+                                                    p_status, p_num)
+        if rc:
+            self._check(rc)
         return status[:n], num[:n]
 
     def participation_set(self, which: int, flags):

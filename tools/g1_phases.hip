@@ -33,26 +33,33 @@ int main(int argc, char** argv)
         d.slot_base = g << l2; d.out_base = g; d.bits_word = NONE32;
     }
     const uint32_t n_slots = n_groups << l2;
-    uint32_t *d_pts, *d_members, *d_partials;
+    uint32_t *d_pts, *d_members, *d_partials, *d_lane;
     G1Group* d_groups;
     CHECK(hipMalloc(&d_pts, pts.size() * 4));
     CHECK(hipMalloc(&d_members, members.size() * 4));
     CHECK(hipMalloc(&d_groups, sizeof(G1Group) * n_groups));
     CHECK(hipMalloc(&d_partials, 192ull * n_groups));
+    CHECK(hipMalloc(&d_lane, 192ull * G1_WG * ((n_slots + G1_WG - 1) / G1_WG)));
     CHECK(hipMemcpy(d_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_members, members.data(), members.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_groups, groups.data(), sizeof(G1Group) * n_groups, hipMemcpyHostToDevice));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    float ms = 0;
-    for (int rep = 0; rep < 5; ++rep) {
+    hipEvent_t em;
+    CHECK(hipEventCreate(&em));
+    float ms = 0, ms_acc = 0;
+    for (int rep = 0; rep < 5; ++rep) {  // the two kernels of a sum, back to back (k_g1_finish is not part of this tool)
         CHECK(hipEventRecord(e0, 0));
-        launch_g1_accumulate(0, d_pts, d_members, nullptr, d_groups, n_groups, n_slots, d_partials);
+        launch_g1_accumulate(0, d_pts, d_members, nullptr, d_groups, n_groups, n_slots, d_lane, d_partials);
+        CHECK(hipEventRecord(em, 0));
+        launch_g1_tree(0, d_lane, d_groups, n_groups, n_slots, d_partials);
         CHECK(hipEventRecord(e1, 0));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms, e0, e1));
+        CHECK(hipEventElapsedTime(&ms_acc, e0, em));
     }
+    printf("k_g1_accumulate %.1f us + k_g1_tree %.1f us (events)\n", ms_acc * 1e3, (ms - ms_acc) * 1e3);
     const uint32_t wgs = (n_slots + G1_WG - 1) / G1_WG;
     std::vector<unsigned long long> st(16 * 4096);
     CHECK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g1_phase_stamps), st.size() * 8));
