@@ -123,7 +123,26 @@ def run_step_single(e, w, st, pipelined=True, lagged=True):
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
 
 
+def run_step_sharded_pipelined(e, w, st, lagged=True):
+    """The sharded step through the engine's own RCCL communicator (pe_dist_init): kernels, the all-gather of the G1
+    partials and the all-reduce of the vote weights are enqueued on the engine's stream, the unions are handed on
+    resident, and the host waits once per step (two steps behind when lagged)."""
+    from pos_evolution_amd import RESIDENT
+
+    ep = st["epoch"]
+    e.on_tick((ep + 1) * w["spe"] * 12)
+    e.participation_rotate()
+    with e.pipeline(lagged=lagged):
+        agg = e.aggregate_sharded(packed=(st["atts"], st["arena"]))   # all-gather of C x 192 B XYZZ partials inside
+        rows = agg["atts"]
+        status, _, count = e.on_attestation_batch(packed=(rows, RESIDENT))
+        head = e.get_head_sharded()                                   # all-reduce of (B + 512) x 8 B inside
+        st2, num = e.process_attestation_batch(st["ctx"], packed=(rows, RESIDENT))
+    return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
+
+
 def run_step_sharded(e, w, st, sh):
+    """The sharded step with torch.distributed carrying the two collectives (synchronous calls)."""
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
@@ -344,6 +363,9 @@ def main():
     ap.add_argument("--mixed-balances", action="store_true")
     ap.add_argument("--head-calls", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded-mode", choices=["engine", "torch"], default="engine",
+                    help="N > 1: collectives issued by the engine on its own stream inside pipelined calls (engine), "
+                         "or by torch.distributed between synchronous calls (torch)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one wait per call instead of one per step (A/B of the pipelined C ABI)")
     ap.add_argument("--no-lag", action="store_true",
@@ -383,11 +405,29 @@ def main():
     e = pea.Engine(device=local_rank, max_committee_tables=total + 1)
     w = build_workload(e, args, rank, total)
     ex = None
+    engine_rccl = False
     if dist is not None:
         from pos_evolution_amd.sharded import ShardedForkChoice
-        ex = ShardedForkChoice(e, n_groups_max=args.committees)
+        if args.sharded_mode == "engine" and backend == "nccl" and not args.no_pipeline:
+            try:  # the engine's own communicator; torch.distributed only carries the 128-byte id
+                ex = ShardedForkChoice(e, n_groups_max=args.committees, use_engine_rccl=True)
+                engine_rccl = True
+            except Exception as err:  # e.g. no librccl to dlopen: the torch-carried exchange does the same job
+                print(f"[bench] engine-owned RCCL unavailable ({err}); using torch.distributed", file=sys.stderr)
+                ok = torch.tensor([0], device="cuda")
+            else:
+                ok = torch.tensor([1], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same path
+            if int(ok[0]) == 0:
+                if engine_rccl:
+                    e.dist_destroy()
+                ex, engine_rccl = None, False
+        if ex is None:
+            ex = ShardedForkChoice(e, n_groups_max=args.committees)
 
     def step(st):
+        if engine_rccl:
+            return run_step_sharded_pipelined(e, w, st, lagged=not args.no_lag)
         return run_step_sharded(e, w, st, ex) if ex else run_step_single(e, w, st, pipelined=not args.no_pipeline,
                                                                          lagged=not args.no_lag)
 
@@ -397,7 +437,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if ex is None and not args.no_pipeline:
+    if (ex is None or engine_rccl) and not args.no_pipeline:
         e.reuse_outputs(4)  # a streaming caller reuses its output buffers; results are consumed two steps behind
     for s in range(args.warmup):
         step(w["steps"][s])
@@ -481,8 +521,9 @@ def main():
         except Exception:
             traffic = None
     # VALU view of the same kernel: Montgomery products per launch against the measured chip ceiling
-    # (tools/fpbench: 57 G products/s at the kernel's 2 waves/SIMD): 10 per mixed add, 14 per tree add
-    products = 10.0 * att_per_launch + 14.0 * max(att_per_launch / 8.0 - C, 0.0)
+    # (tools/fpbench: 57 G products/s at the kernel's 2 waves/SIMD): 10 per mixed add (the 14-product tree adds run in
+    # k_g1_tree since the kernel was split)
+    products = 10.0 * att_per_launch
     valu_peak = 57.0e9
     valu_ach = products / (acc_ms * 1e-3) if acc_ms else 0.0
     votes = prof["votes"]
@@ -496,7 +537,8 @@ def main():
              else "BASELINE configs[2] shape" if (V_total, args.blocks) == (1 << 18, 4096)
              else "custom shape")
     scaling = "weak" if (world > 1 and args.scaling == "weak") else "strong"
-    mode = ("sharded, synchronous calls" if world > 1 else
+    mode = ("sharded, pipelined calls, collectives issued by the engine (pe_dist_init)" if engine_rccl else
+            "sharded, synchronous calls, collectives through torch.distributed" if world > 1 else
             "synchronous calls" if args.no_pipeline else
             "pipelined calls (one wait per step)" if args.no_lag else
             "streaming pipelines (pe_pipeline_begin_streaming / _end_lagged: a step's G1 sums overlap the next step)")

@@ -1650,12 +1650,10 @@ int pe_get_last_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)
     return PE_OK;
 }
 
-int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
+static int votes_partial_impl(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
 {
-    int rc = need_init(h);
-    if (rc) return rc;
     if (!dev_buf_u64 || n_blocks != h->blocks.size()) return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
-    rc = refresh_tree(h);
+    int rc = refresh_tree(h);
     if (rc) return rc;
     uint64_t* buf = static_cast<uint64_t*>(dev_buf_u64);
     {
@@ -1668,13 +1666,11 @@ int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
     return PE_OK;
 }
 
-int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32])
+static int head_from_weights_impl(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32])
 {
-    int rc = need_init(h);
-    if (rc) return rc;
     if (!dev_buf_u64 || !out_root || n_blocks != h->blocks.size())
         return fail(h, PE_ERR_INVALID_ARG, "n_blocks mismatch");
-    rc = refresh_tree(h);
+    int rc = refresh_tree(h);
     if (rc) return rc;
     uint64_t* buf = const_cast<uint64_t*>(static_cast<const uint64_t*>(dev_buf_u64));
     uint32_t head;
@@ -1682,6 +1678,20 @@ int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_block
     if (rc) return rc;
     memcpy(out_root, h->blocks[head].root.data(), 32);
     return PE_OK;
+}
+
+int pe_votes_partial(pe_engine* h, void* dev_buf_u64, uint32_t n_blocks)
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    return votes_partial_impl(h, dev_buf_u64, n_blocks);
+}
+
+int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_blocks, uint8_t out_root[32])
+{
+    int rc = need_init(h);
+    if (rc) return rc;
+    return head_from_weights_impl(h, dev_buf_u64, n_blocks, out_root);
 }
 
 // ---------------------------------------------------------------- on_attestation
@@ -2023,7 +2033,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
                           uint64_t arena_len, const uint8_t* sig_points96, pe_attestation* out_atts,
                           uint32_t* out_n_groups, uint32_t* group_of, uint8_t* out_bits_arena, uint64_t out_arena_cap,
                           uint8_t* out_sig96, uint8_t* out_aggpk96, uint32_t* out_count, void* dev_partials,
-                          uint32_t dev_partials_capacity = 0)
+                          uint32_t dev_partials_capacity = 0, bool partials_may_defer = false)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
@@ -2244,7 +2254,9 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         const G1Group* d_groups = st.dev<G1Group>(off_g1);
         uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
         uint32_t* jac = static_cast<uint32_t*>(dev_partials);
-        const bool defer = on_side && h->streaming;
+        // streaming pipelines launch the sums behind the step's fork-choice kernels (run_tree / pe_pipeline_end_lagged):
+        // on the side stream, or -- partials for the engine's own exchange -- on the engine's stream itself
+        const bool defer = (on_side || (dev_partials && partials_may_defer && h->stream == h->own_stream)) && h->streaming;
         if (defer) tune_arm = -1;  // the autotune's event pair assumes launch and read-back in one call
         auto launch_g1 = [h, arena, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, on_side, gs, tune_arm]() -> int {
             hipStream_t ms_ = h->stream;
@@ -2285,10 +2297,10 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         };
         if (defer) {
             // scratch sizes are settled now, while nothing of the launch is in flight
-            PE_TRY(ensure_quiesced(h, arena->d_partials,
-                                   std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
-            PE_TRY(ensure_quiesced(h, arena->d_lane_partials,
-                                   (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
+            DevBuf& dp = on_side ? arena->d_partials : h->d_partials;
+            DevBuf& dl = on_side ? arena->d_lane_partials : h->d_lane_partials;
+            PE_TRY(ensure_quiesced(h, dp, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
+            PE_TRY(ensure_quiesced(h, dl, (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
             h->deferred.push_back(launch_g1);
         } else {
             int rc = launch_g1();
@@ -3097,40 +3109,68 @@ int pe_dist_destroy(pe_engine* h)
 // the engine's stream -> subtree sums + descent on every rank (same root everywhere; integer sums are order-free).
 int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
 {
-    int rc = need_init(h);
+    // inside a pipeline the call is ordered behind the enqueued batch calls on the stream, like pe_get_head
+    int rc = need_init(h, /*flush=*/!(h && h->pipelining));
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
     if (!h->comm) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
     const uint32_t nb = (uint32_t)h->blocks.size();
     const size_t words = (size_t)nb + PE_EXCHANGE_EXTRA;
-    HIP_TRY(h, h->d_xchg.ensure(words * 8));
-    rc = pe_votes_partial(h, h->d_xchg.p, nb);
+    PE_TRY(ensure_quiesced(h, h->d_xchg, words * 8));
+    rc = votes_partial_impl(h, h->d_xchg.p, nb);
     if (rc) return rc;
     RCCL_TRY(h, rccl().AllReduce(h->d_xchg.p, h->d_xchg.p, words, ncclUint64, ncclSum, h->comm, h->stream));
-    return pe_head_from_weights(h, h->d_xchg.p, nb, out_root);
+    return head_from_weights_impl(h, h->d_xchg.p, nb, out_root);
 }
 
 // pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.  Every rank passes attestations
 // that form the SAME groups in the SAME order (group g of every rank = that rank's members of committee g); the
 // XYZZ partials (192 B per group) are all-gathered and every rank runs the finishing add + normalisation.
+// Inside a pipeline nothing here waits: kernels, the all-gather and the finish are enqueued on the engine's stream, the
+// unions stay resident for PE_BITS_RESIDENT hand-over, and the outputs are complete at pe_pipeline_end.
 int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                          uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
                          uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count)
 {
     if (!h || !out_n_groups || !out_aggpk96) return PE_ERR_INVALID_ARG;
-    PE_TRY(enter(h));
+    (void)hipSetDevice(h->device);
+    if (!h->pipelining) PE_TRY(flush_pending(h));
     if (!h->comm) return fail(h, PE_ERR_STATE, "pe_aggregate_sharded: call pe_dist_init first");
     if (n == 0) { *out_n_groups = 0; return PE_OK; }
-    HIP_TRY(h, h->d_xpart.ensure((size_t)PE_G1_PARTIAL_BYTES * n));
-    HIP_TRY(h, h->d_xgather.ensure((size_t)PE_G1_PARTIAL_BYTES * n * (size_t)h->dist_world));
+    PE_TRY(ensure_quiesced(h, h->d_xpart, (size_t)PE_G1_PARTIAL_BYTES * n));
+    PE_TRY(ensure_quiesced(h, h->d_xgather, (size_t)PE_G1_PARTIAL_BYTES * n * (size_t)h->dist_world));
     int rc = aggregate_impl(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of, out_bits_arena,
-                            out_arena_cap, nullptr, nullptr, out_count, h->d_xpart.p, n);
+                            out_arena_cap, nullptr, nullptr, out_count, h->d_xpart.p, n, /*partials_may_defer=*/true);
     if (rc) return rc;
     const uint32_t ng = *out_n_groups;
     if (ng == 0) return PE_OK;
-    RCCL_TRY(h, rccl().AllGather(h->d_xpart.p, h->d_xgather.p, (size_t)ng * (PE_G1_PARTIAL_BYTES / 4), ncclUint32,
-                                 h->comm, h->stream));
-    return pe_g1_finish(h, h->d_xgather.p, (uint32_t)h->dist_world, ng, out_aggpk96);
+    Stage st(h);
+    OutBlock ob(h);
+    const size_t off_pk = ob.alloc(96ull * ng);
+    PE_TRY(ob.ensure());
+    uint8_t* pin_pk = ob.host<uint8_t>(off_pk);
+    // all-gather of the ranks' partials, then the finishing add + normalisation, written straight into the pinned
+    // block.  In a streaming pipeline the partials' kernels were deferred behind the step's fork-choice kernels; the
+    // exchange follows them (every rank runs the same calls, so the collectives are issued in the same order everywhere)
+    auto exchange = [h, ng, pin_pk]() -> int {
+        RCCL_TRY(h, rccl().AllGather(h->d_xpart.p, h->d_xgather.p, (size_t)ng * (PE_G1_PARTIAL_BYTES / 4), ncclUint32,
+                                     h->comm, h->stream));
+        {
+            ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
+            launch_g1_finish(h->stream, h->d_xgather.as<uint32_t>(), nullptr, ng, (uint32_t)h->dist_world, ng, pin_pk, nullptr);
+        }
+        HIP_TRY(h, hipGetLastError());
+        return PE_OK;
+    };
+    if (!h->deferred.empty()) h->deferred.push_back(exchange);
+    else PE_TRY(exchange());
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off_pk, ng, out_aggpk96]() -> int {
+        memcpy(out_aggpk96, h->arena[ai].h_pin.as<uint8_t>() + base + off_pk, 96ull * ng);
+        return PE_OK;
+    };
+    return finish_call(h, st, ob, complete);
 }
 
 // ---------------------------------------------------------------- pipelined calls

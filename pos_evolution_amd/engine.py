@@ -538,24 +538,23 @@ class Engine:
 
     def aggregate_sharded(self, rows=None, packed=None):
         """pe_aggregate over all shards (one all-gather of the XYZZ partials inside): rank-local unions, global
-        aggregate pubkeys."""
+        aggregate pubkeys.  Inside a pipeline() block nothing waits; the unions can be handed on as RESIDENT."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
-        out_atts = np.empty(m, dtype=_ATT_DTYPE)
+        (out_atts, group_of, out_arena, out_pk, count), (p_atts, p_gof, p_arena, p_pk, p_count) = self._outs(
+            "aggsh", ((m, _ATT_DTYPE), (m, _U32), (max(arena.size, 1), _U8), ((m, 96), _U8), (m, _U32)))
         n_groups = C.c_uint32(0)
-        group_of = np.empty(m, dtype=np.uint32)
-        out_arena = np.empty(max(arena.size, 1), dtype=np.uint8)
-        out_pk = np.empty((m, 96), dtype=np.uint8)
-        count = np.empty(m, dtype=np.uint32)
-        self._check(self._lib.pe_aggregate_sharded(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
-                                                   _att_ptr(out_atts), C.byref(n_groups), _ptr(group_of, C.c_uint32),
-                                                   _ptr(out_arena, C.c_uint8), out_arena.size,
-                                                   _ptr(out_pk, C.c_uint8), _ptr(count, C.c_uint32)))
+        if self._pipe_keep is not None:
+            self._pipe_keep.append((arr, arena, out_atts, group_of, out_arena, out_pk, count))
+        rc = self._lib.pe_aggregate_sharded(self._h, _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size, p_atts,
+                                            C.byref(n_groups), p_gof, p_arena, out_arena.size, p_pk, p_count)
+        if rc:
+            self._check(rc)
         g = n_groups.value
         if g:
-            last = out_atts[g - 1]
-            out_arena = out_arena[: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
+            tail = out_atts.view(np.uint32).reshape(-1, 36)[g - 1]   # u32 words 32 / 33 of a row: bits_offset, n_bits
+            out_arena = out_arena[: int(tail[32]) + (int(tail[33]) + 7) // 8]
         return AggregateResult(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena, sig96=None,
                                sig192=None, aggpk96=out_pk[:g], count=count[:g])
 

@@ -200,3 +200,74 @@ def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     assert d["config"]["parallelism"] == f"validator-range shards x2 ({scaling} scaling)"
     per_gpu = 65536 // 2 if scaling == "strong" else 65536
     assert d["config"]["validators_per_gpu"] == per_gpu and d["config"]["validators_total"] == 2 * per_gpu
+
+
+@pytest.mark.parametrize("lagged", [False, True])
+def test_engine_owned_rccl_pipelined_step_world_size_one(engine_factory, lagged):
+    """The sharded step as bench.py runs it for N > 1: pe_aggregate_sharded, the handlers on the resident unions and
+    pe_get_head_sharded inside pipelined calls, nothing waiting between them.  One rank: every output must equal the
+    unsharded synchronous calls on a twin engine."""
+    import pos_evolution_amd as pea
+    from pos_evolution_amd._abi import pe_state_ctx
+
+    V, C = 20000, 64
+    tree, bal, flags, comm = _workload(V=V, C=C, seed=24)
+    epoch = int(tree.slot.max()) // 32 + 1
+    atts, arena, _ = synth.epoch_attestations(comm, tree, epoch, 32, seed=8, density=0.9, parts=3,
+                                              source=(0, tree.roots[0].tobytes()))
+    ctx = pe_state_ctx()
+    ctx.slot = (epoch + 1) * 32
+    ctx.chain_tip_root[:] = tree.roots[tree.roots.shape[0] - 1].tobytes()
+    ctx.current_justified_root[:] = tree.roots[0].tobytes()
+    ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+    ctx.base_reward_per_increment = 357
+    engines = []
+    for _ in range(2):
+        e = engine_factory()
+        pts = synth.registry_points(e, V)
+        _load(e, tree, bal, flags, pts, comm, epoch)
+        engines.append(e)
+    ref_e, e = engines
+    ref = ref_e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+    ref_st, _, ref_cnt = ref_e.on_attestation_batch(packed=(ref["atts"], ref["out_arena"]))
+    ref_head = ref_e.get_head()
+    ref_pst, ref_num = ref_e.process_attestation_batch(ctx, packed=(ref["atts"], ref["out_arena"]))
+
+    e.dist_init(e.dist_unique_id(), 0, 1)
+    for rep in range(3):   # several steps in flight when lagged; the repeats change nothing (same votes, flags already set)
+        with e.pipeline(lagged=lagged):
+            got = e.aggregate_sharded(packed=(atts, arena))
+            st, _, cnt = e.on_attestation_batch(packed=(got["atts"], pea.RESIDENT))
+            head = e.get_head_sharded()
+            pst, num = e.process_attestation_batch(ctx, packed=(got["atts"], pea.RESIDENT))
+        if rep == 0:
+            first = (got, st, cnt, head, pst, num)
+    e.drain()
+    got, st, cnt, head, pst, num = first
+    assert got["n_groups"] == ref["n_groups"]
+    assert np.array_equal(got["aggpk96"], ref["aggpk96"])
+    assert np.array_equal(got["out_arena"], ref["out_arena"]) and np.array_equal(got["count"], ref["count"])
+    assert np.array_equal(st, ref_st) and np.array_equal(cnt, ref_cnt)
+    assert head == ref_head
+    assert np.array_equal(pst, ref_pst) and np.array_equal(num, ref_num)
+    assert (ref_st == 0).all() and (ref_pst == 0).all() and int(ref_num.sum()) > 0
+    assert np.array_equal(e.get_weights(), ref_e.get_weights())
+    e.dist_destroy()
+
+
+def test_bench_engine_rccl_path_one_rank():
+    """bench.py's default N > 1 step (collectives issued by the engine inside pipelined calls) driven with ONE rank
+    over RCCL: the same code path the 2/4/8-GPU runs take, minus the peers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEVO_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3",
+           "--validators", "65536", "--blocks", "512", "--committees", "256", "--head-calls", "5", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "collectives issued by the engine" in d["config"]["call_mode"]
