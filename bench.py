@@ -409,7 +409,7 @@ def main():
     if dist is not None:
         from pos_evolution_amd.sharded import ShardedForkChoice
         if args.sharded_mode == "engine" and backend == "nccl" and not args.no_pipeline:
-            try:  # the engine's own communicator; torch.distributed only carries the 128-byte id
+            try:  # the engine's own communicator; torch.distributed only carries the 256-byte id
                 ex = ShardedForkChoice(e, n_groups_max=args.committees, use_engine_rccl=True)
                 engine_rccl = True
             except Exception as err:  # e.g. no librccl to dlopen: the torch-carried exchange does the same job

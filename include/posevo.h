@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 2
+#define PE_ABI_VERSION 3
 
 typedef struct pe_engine pe_engine;
 
@@ -430,14 +430,20 @@ int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
 
 /* ---- RCCL inside the engine: the exchange steps behind the C ABI ---------- */
 /* For clients without a collective library of their own (the cgo / bindgen / Panama bindings of INTEGRATION.md): the
- * engine owns an RCCL communicator and issues the two collectives on its own stream, between its own kernels.
- *   rank 0: pe_dist_unique_id(id); ship the 128 bytes to the other ranks (any side channel)
+ * engine owns its RCCL communicators and issues the two collectives on its own streams, between its own kernels.
+ *   rank 0: pe_dist_unique_id(id); ship the PE_DIST_ID_BYTES to the other ranks (any side channel)
  *   every rank: pe_dist_init(h, id, rank, world)      -- one process per GPU, one handle per process
  *   pe_get_head_sharded   = pe_votes_partial -> ncclAllReduce(u64, sum, B + PE_EXCHANGE_EXTRA) -> pe_head_from_weights
  *   pe_aggregate_sharded  = pe_aggregate_partial -> ncclAllGather(192 B x groups) -> pe_g1_finish
+ * The id holds two ncclUniqueIds: the all-reduce and the all-gather have a communicator each, because inside a
+ * pipeline the G1 chain of a step (partials -> all-gather -> finish) runs on the engine's finishing stream beside the
+ * next step's fork-choice kernels and their all-reduce, and one communicator must not be driven from two streams.
+ * Both calls may be made inside pe_pipeline_begin(_streaming) ... _end(_lagged): nothing then waits except the poll
+ * for the head; pe_aggregate_sharded's unions are handed on with PE_BITS_RESIDENT like pe_aggregate's, its outputs are
+ * complete where the pipeline's are.  Every rank must make the same sequence of calls (collectives pair up by order).
  * librccl is loaded with dlopen at the first pe_dist_* call (the copy already in the process, e.g. torch's, else the
  * ROCm installation's); single-GPU use never touches it. */
-#define PE_DIST_ID_BYTES 128
+#define PE_DIST_ID_BYTES 256
 int pe_dist_unique_id(uint8_t out_id[PE_DIST_ID_BYTES]);
 int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world);
 int pe_dist_destroy(pe_engine* h);

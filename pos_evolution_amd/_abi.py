@@ -22,6 +22,7 @@ PE_VAL_ACTIVE, PE_VAL_SLASHED, PE_VAL_EQUIVOCATING, PE_VAL_ACTIVE_PREV = 0x01, 0
 PE_ATT_FLAG_SIGNATURE_VALID, PE_ATT_FLAG_FROM_BLOCK = 0x1, 0x2
 PE_G1_PARTIAL_BYTES = 192
 PE_EXCHANGE_EXTRA = 512
+PE_DIST_ID_BYTES = 256
 (PE_KERNEL_G1_ACCUMULATE, PE_KERNEL_G1_NORMALISE, PE_KERNEL_VOTES, PE_KERNEL_TREE, PE_KERNEL_LMD,
  PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_G2_ACCUMULATE, PE_KERNEL_G2_NORMALISE,
  PE_KERNEL_G1_TREE, PE_KERNEL_COUNT) = range(11)

@@ -280,7 +280,10 @@ struct pe_engine {
     hipEvent_t g1_tune_ev[2] = {nullptr, nullptr};
 
     // ---- RCCL inside the engine (pe_dist_*): one communicator per handle, collectives on the engine's stream ----
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr, comm_g1 = nullptr;  // get_head's all-reduce (engine stream) | the G1 partials' all-gather
+    uint32_t xchg_blocks = 0;                       // block count / registry size d_xchg was last laid out for
+    uint64_t xchg_nval = 0;
+    bool last_agg_on_side = false;                  // the last aggregate's G1 chain went to the side / finishing streams
     int dist_rank = 0, dist_world = 1;
     DevBuf d_xchg, d_xpart, d_xgather;  // weights exchange | this rank's G1 partials | all ranks' partials
 
@@ -1021,7 +1024,7 @@ int rccl_fail(pe_engine* h, ncclResult_t r, const char* what)
         ncclResult_t _r = (expr);                                  \
         if (_r != ncclSuccess) return rccl_fail((h), _r, #expr);   \
     } while (0)
-static_assert(sizeof(ncclUniqueId) == PE_DIST_ID_BYTES, "PE_DIST_ID_BYTES must be sizeof(ncclUniqueId)");
+static_assert(2 * sizeof(ncclUniqueId) == PE_DIST_ID_BYTES, "PE_DIST_ID_BYTES must hold two ncclUniqueIds");
 }  // namespace
 
 // ====================================================================== C ABI
@@ -1127,6 +1130,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+    if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
     h->d_xchg.release();
     h->d_xpart.release();
     h->d_xgather.release();
@@ -2231,7 +2235,10 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     // pipelined + host outputs: the G1 sums run on the side stream, beside the fork-choice kernels of the calls that
     // follow (they only need the union).  Sharded partials stay on the main stream, where the caller's collective is.
     static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
-    const bool on_side = want_pk && !dev_partials && h->pipelining && side_ok && h->side_stream && h->stream == h->own_stream;
+    // (partials for the engine's own exchange follow the same route; partials for a caller's collective never do)
+    const bool on_side = want_pk && (!dev_partials || partials_may_defer) && h->pipelining && side_ok && h->side_stream &&
+                         h->stream == h->own_stream;
+    h->last_agg_on_side = on_side;
     hipStream_t gs = on_side ? h->side_stream : ms;
     // a previous aggregate of THIS pipeline may still read the arena's d_res_* on the side stream
     if (h->A().side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
@@ -2254,9 +2261,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         const G1Group* d_groups = st.dev<G1Group>(off_g1);
         uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
         uint32_t* jac = static_cast<uint32_t*>(dev_partials);
-        // streaming pipelines launch the sums behind the step's fork-choice kernels (run_tree / pe_pipeline_end_lagged):
-        // on the side stream, or -- partials for the engine's own exchange -- on the engine's stream itself
-        const bool defer = (on_side || (dev_partials && partials_may_defer && h->stream == h->own_stream)) && h->streaming;
+        // streaming pipelines launch the sums behind the step's fork-choice kernels (run_tree / pe_pipeline_end_lagged)
+            const bool defer = on_side && h->streaming;
         if (defer) tune_arm = -1;  // the autotune's event pair assumes launch and read-back in one call
         auto launch_g1 = [h, arena, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, on_side, gs, tune_arm]() -> int {
             hipStream_t ms_ = h->stream;
@@ -2297,10 +2303,10 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         };
         if (defer) {
             // scratch sizes are settled now, while nothing of the launch is in flight
-            DevBuf& dp = on_side ? arena->d_partials : h->d_partials;
-            DevBuf& dl = on_side ? arena->d_lane_partials : h->d_lane_partials;
-            PE_TRY(ensure_quiesced(h, dp, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
-            PE_TRY(ensure_quiesced(h, dl, (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
+            PE_TRY(ensure_quiesced(h, arena->d_partials,
+                                   std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
+            PE_TRY(ensure_quiesced(h, arena->d_lane_partials,
+                                   (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
             h->deferred.push_back(launch_g1);
         } else {
             int rc = launch_g1();
@@ -3071,9 +3077,11 @@ int pe_dist_unique_id(uint8_t out_id[PE_DIST_ID_BYTES])
 {
     if (!out_id) return PE_ERR_INVALID_ARG;
     if (!rccl().ok) return PE_ERR_NO_DEVICE;
-    ncclUniqueId id;
-    if (rccl().GetUniqueId(&id) != ncclSuccess) return PE_ERR_NO_DEVICE;
-    memcpy(out_id, &id, sizeof(id));
+    for (int k = 0; k < 2; ++k) {  // one communicator per stream that carries collectives (see pe_dist_init)
+        ncclUniqueId id;
+        if (rccl().GetUniqueId(&id) != ncclSuccess) return PE_ERR_NO_DEVICE;
+        memcpy(out_id + k * sizeof(id), &id, sizeof(id));
+    }
     return PE_OK;
 }
 
@@ -3083,9 +3091,20 @@ int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int
     PE_TRY(enter(h));
     if (!rccl().ok) return fail(h, PE_ERR_NO_DEVICE, "librccl could not be loaded (dlopen librccl.so.1)");
     if (h->comm) return fail(h, PE_ERR_STATE, "pe_dist_init: this handle already has a communicator");
+    // Two communicators: the all-reduce of get_head travels on the engine's stream, the all-gather of the G1
+    // partials on the finishing stream of the G1 chain (beside the next step's fork-choice kernels).  One communicator
+    // must not be driven from two streams at once; two of them may.
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     RCCL_TRY(h, rccl().CommInitRank(&h->comm, world, uid, rank));
+    memcpy(&uid, id + sizeof(uid), sizeof(uid));
+    ncclResult_t r2 = rccl().CommInitRank(&h->comm_g1, world, uid, rank);
+    if (r2 != ncclSuccess) {
+        (void)rccl().CommDestroy(h->comm);
+        h->comm = nullptr;
+        h->comm_g1 = nullptr;
+        return rccl_fail(h, r2, "ncclCommInitRank (aggregation communicator)");
+    }
     h->dist_rank = rank;
     h->dist_world = world;
     return PE_OK;
@@ -3097,8 +3116,10 @@ int pe_dist_destroy(pe_engine* h)
     PE_TRY(enter(h));
     if (h->comm) {
         (void)hipStreamSynchronize(h->stream);
+        if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
         (void)rccl().CommDestroy(h->comm);
-        h->comm = nullptr;
+        if (h->comm_g1) (void)rccl().CommDestroy(h->comm_g1);
+        h->comm = h->comm_g1 = nullptr;
     }
     h->dist_world = 1;
     h->dist_rank = 0;
@@ -3116,11 +3137,40 @@ int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
     if (!h->comm) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
     const uint32_t nb = (uint32_t)h->blocks.size();
     const size_t words = (size_t)nb + PE_EXCHANGE_EXTRA;
-    PE_TRY(ensure_quiesced(h, h->d_xchg, words * 8));
-    rc = votes_partial_impl(h, h->d_xchg.p, nb);
+    if (words * 8 > h->d_xchg.cap) {  // the engine's own exchange buffer is self-cleaning, like pe_get_head's: zero it once
+        PE_TRY(ensure_quiesced(h, h->d_xchg, words * 8));
+        HIP_TRY(h, hipMemsetAsync(h->d_xchg.p, 0, h->d_xchg.cap, h->stream));
+        h->xchg_blocks = 0;
+    }
+    if (h->xchg_blocks != nb || h->xchg_nval != h->n_val) {
+        // the block count changed (the totals sit at a different offset now) or the registry did (a different number
+        // of k_votes workgroups store totals; slots none of them writes must read zero)
+        HIP_TRY(h, hipMemsetAsync(h->d_xchg.p, 0, h->d_xchg.cap, h->stream));
+        h->xchg_blocks = nb;
+        h->xchg_nval = h->n_val;
+    }
+    HostLap lap(&h->trace);
+    rc = refresh_tree(h);
     if (rc) return rc;
+    uint64_t* buf = h->d_xchg.as<uint64_t>();
+    {
+        ProfScope ps(h, PE_KERNEL_VOTES);
+        // no memsets (k_tree zeroes the weights it read; the totals are plain per-workgroup stores), and inside a
+        // pipeline the lean form that fits beside a running k_g1_accumulate
+        launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
+                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), nb, buf,
+                     reinterpret_cast<VoteTotals*>(buf + nb), 0, expiry_slots_ptr(h), min_vote_slot(h),
+                     /*lean=*/h->pipelining ? 1 : 0);
+    }
+    HIP_TRY(h, hipGetLastError());
+    lap.mark("dist.votes_launch");
     RCCL_TRY(h, rccl().AllReduce(h->d_xchg.p, h->d_xchg.p, words, ncclUint64, ncclSum, h->comm, h->stream));
-    return head_from_weights_impl(h, h->d_xchg.p, nb, out_root);
+    lap.mark("dist.all_reduce_enqueue");
+    uint32_t head;
+    rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + nb), /*clear_direct=*/1, &head);
+    if (rc == PE_OK) memcpy(out_root, h->blocks[head].root.data(), 32);
+    lap.mark("dist.tree_wait");
+    return rc;
 }
 
 // pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.  Every rank passes attestations
@@ -3152,14 +3202,19 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
     // all-gather of the ranks' partials, then the finishing add + normalisation, written straight into the pinned
     // block.  In a streaming pipeline the partials' kernels were deferred behind the step's fork-choice kernels; the
     // exchange follows them (every rank runs the same calls, so the collectives are issued in the same order everywhere)
-    auto exchange = [h, ng, pin_pk]() -> int {
+    const bool on_side = h->last_agg_on_side;
+    auto exchange = [h, ng, pin_pk, on_side]() -> int {
+        HostLap lap(&h->trace);
+        hipStream_t xs = on_side ? h->fin_stream : h->stream;  // where this aggregate's partials were produced
         RCCL_TRY(h, rccl().AllGather(h->d_xpart.p, h->d_xgather.p, (size_t)ng * (PE_G1_PARTIAL_BYTES / 4), ncclUint32,
-                                     h->comm, h->stream));
+                                     h->comm_g1, xs));
+        lap.mark("dist.all_gather_enqueue");
         {
-            ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
-            launch_g1_finish(h->stream, h->d_xgather.as<uint32_t>(), nullptr, ng, (uint32_t)h->dist_world, ng, pin_pk, nullptr);
+            ProfScope ps(h, PE_KERNEL_G1_NORMALISE, xs);
+            launch_g1_finish(xs, h->d_xgather.as<uint32_t>(), nullptr, ng, (uint32_t)h->dist_world, ng, pin_pk, nullptr);
         }
         HIP_TRY(h, hipGetLastError());
+        if (on_side) HIP_TRY(h, hipEventRecord(h->ev_join, xs));  // the end of this arena's G1 chain moved
         return PE_OK;
     };
     if (!h->deferred.empty()) h->deferred.push_back(exchange);

@@ -515,16 +515,16 @@ class Engine:
 
     # -- multi-GPU exchange inside the C ABI (RCCL owned by the engine) -------
     def dist_unique_id(self) -> bytes:
-        """rank 0: the 128-byte RCCL unique id to ship to the other ranks (pe_dist_unique_id)."""
-        out = (C.c_uint8 * 128)()
+        """rank 0: the PE_DIST_ID_BYTES (two RCCL unique ids) to ship to the other ranks (pe_dist_unique_id)."""
+        out = (C.c_uint8 * _abi.PE_DIST_ID_BYTES)()
         rc = self._lib.pe_dist_unique_id(out)
         if rc != _abi.PE_OK:
             raise EngineError(rc, "pe_dist_unique_id: librccl not available")
         return bytes(out)
 
     def dist_init(self, unique_id: bytes, rank: int, world: int):
-        assert len(unique_id) == 128
-        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        assert len(unique_id) == _abi.PE_DIST_ID_BYTES
+        buf = (C.c_uint8 * _abi.PE_DIST_ID_BYTES).from_buffer_copy(unique_id)
         self._check(self._lib.pe_dist_init(self._h, buf, rank, world))
 
     def dist_destroy(self):

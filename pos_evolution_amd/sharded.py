@@ -18,7 +18,7 @@ between kernels and collectives.
 
 ``use_engine_rccl=True`` is the thin face of the C ABI's own exchange (pe_dist_init / pe_get_head_sharded /
 pe_aggregate_sharded, include/posevo.h): the engine owns the RCCL communicator and issues the collectives between its
-kernels on its own stream; torch.distributed only carries the 128-byte unique id to the other ranks.
+kernels on its own stream; torch.distributed only carries the 256-byte id (two RCCL unique ids) to the other ranks.
 """
 from __future__ import annotations
 

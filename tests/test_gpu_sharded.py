@@ -170,6 +170,17 @@ def test_engine_owned_rccl_world_size_one(engine_factory):
     assert (st == 0).all()
     assert e.get_head_sharded() == e.get_head()
     assert np.array_equal(e.last_weights(), e.get_weights())
+    # the exchange buffer is self-cleaning and laid out for one block count / registry size: change both
+    for k in range(3):
+        tip = tree.roots[tree.roots.shape[0] - 1].tobytes() if k == 0 else new_root
+        new_root = bytes([0xA0 + k]) * 32
+        e.add_block(new_root, tip, int(tree.slot.max()) + 1 + k, (0, tree.roots[0].tobytes()), (0, tree.roots[0].tobytes()))
+        assert e.get_head_sharded() == e.get_head()
+        assert np.array_equal(e.last_weights(), e.get_weights())
+    e.set_validators(bal[: V // 2], flags[: V // 2], pts[: V // 2])
+    assert e.get_head_sharded() == e.get_head()
+    assert np.array_equal(e.last_weights(), e.get_weights())
+    e.set_validators(bal, flags, pts)
     # the thin Python face of the same path
     from pos_evolution_amd.sharded import ShardedForkChoice
     e.dist_destroy()
