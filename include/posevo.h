@@ -321,6 +321,14 @@ int pe_participation_rotate(pe_engine* h);
  * get_previous_epoch(state)).  Until this is called the engine uses the pe_set_validators data for both. */
 #define PE_VAL_ACTIVE_PREV 0x08u
 int pe_state_set_validators(pe_engine* h, uint64_t n, const uint64_t* effective_balance, const uint8_t* flags);
+/* Read-backs for checkpoint / resume (pe_store_init drops committee tables, the working-state view and participation
+ * with the store; a restart hands them back).  *out_is_set = 0: the view still mirrors pe_set_validators. */
+int pe_state_get_validators(pe_engine* h, uint64_t n, uint64_t* out_effective_balance, uint8_t* out_flags, int* out_is_set);
+/* Epochs of the committee tables held (out_epochs NULL: count only), and one table: out_offsets u32[n_committees + 1],
+ * out_members u32[offsets[n_committees]] (either may be NULL; *out_n_committees is always written). */
+int pe_get_committee_epochs(pe_engine* h, uint64_t* out_epochs, uint32_t cap, uint32_t* out_n);
+int pe_get_committees(pe_engine* h, uint64_t epoch, uint32_t* out_n_committees, uint32_t* out_offsets,
+                      uint32_t offsets_cap, uint32_t* out_members, uint64_t members_cap);
 /* The balance sums of process_justification_and_finalization (pe:791-802) over the working state and the engine's
  * participation arrays: out[0] = get_total_active_balance(state), out[1] = previous_target_balance,
  * out[2] = current_target_balance (each max(EFFECTIVE_BALANCE_INCREMENT, sum), Appendix A.1).  The caller feeds

@@ -111,6 +111,9 @@ SIGNATURES = {
     "pe_participation_get": (C.c_int, [_H, C.c_int, _u8p, C.c_uint64]),
     "pe_participation_rotate": (C.c_int, [_H]),
     "pe_state_set_validators": (C.c_int, [_H, C.c_uint64, _u64p, _u8p]),
+    "pe_state_get_validators": (C.c_int, [_H, C.c_uint64, _u64p, _u8p, C.c_void_p]),
+    "pe_get_committee_epochs": (C.c_int, [_H, _u64p, C.c_uint32, _u32p]),
+    "pe_get_committees": (C.c_int, [_H, C.c_uint64, _u32p, _u32p, C.c_uint32, _u32p, C.c_uint64]),
     "pe_ffg_balances": (C.c_int, [_H, _u64p]),
     "pe_g1_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
     "pe_get_block": (C.c_int, [_H, C.c_uint32, _u8p, _u32p, _u64p, _u64p, _u8p, _u64p, _u8p]),

@@ -2644,6 +2644,61 @@ int pe_state_set_validators(pe_engine* h, uint64_t n, const uint64_t* effective_
     return PE_OK;
 }
 
+// Read-back of the working-state view (checkpoint / resume): *out_is_set = 0 while the view still mirrors the registry.
+int pe_state_get_validators(pe_engine* h, uint64_t n, uint64_t* out_effective_balance, uint8_t* out_flags, int* out_is_set)
+{
+    if (!h || !out_is_set || (n && (!out_effective_balance || !out_flags))) return PE_ERR_INVALID_ARG;
+    if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_state_get_validators: n differs from the registry size");
+    PE_TRY(enter(h));
+    *out_is_set = h->state_view_set ? 1 : 0;
+    if (n && h->d_sbalance.p && h->d_sflags.p) {
+        HIP_TRY(h, hipMemcpyAsync(out_effective_balance, h->d_sbalance.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(out_flags, h->d_sflags.p, n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return PE_OK;
+}
+
+// The committee tables the handle holds: epochs first (out_epochs NULL: count only), then one table at a time.
+int pe_get_committee_epochs(pe_engine* h, uint64_t* out_epochs, uint32_t cap, uint32_t* out_n)
+{
+    if (!h || !out_n) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    uint32_t k = 0;
+    for (auto& t : h->tables) {
+        if (!t.n_committees) continue;
+        if (out_epochs) {
+            if (k >= cap) return fail(h, PE_ERR_CAPACITY, "pe_get_committee_epochs: more tables than cap");
+            out_epochs[k] = t.epoch;
+        }
+        ++k;
+    }
+    *out_n = k;
+    return PE_OK;
+}
+int pe_get_committees(pe_engine* h, uint64_t epoch, uint32_t* out_n_committees, uint32_t* out_offsets,
+                      uint32_t offsets_cap, uint32_t* out_members, uint64_t members_cap)
+{
+    if (!h || !out_n_committees) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    CommitteeTable* t = find_table(h, epoch);
+    if (!t) return fail(h, PE_ERR_NO_COMMITTEES, "no committee table for the epoch");
+    *out_n_committees = t->n_committees;
+    if (out_offsets) {
+        if (offsets_cap < t->n_committees + 1) return fail(h, PE_ERR_CAPACITY, "pe_get_committees: offsets_cap too small");
+        memcpy(out_offsets, t->offsets.data(), 4ull * (t->n_committees + 1));
+    }
+    if (out_members) {  // the members live on the device (a table computed by pe_compute_committees never left it)
+        const uint64_t total = t->offsets.empty() ? 0 : t->offsets.back();
+        if (members_cap < total) return fail(h, PE_ERR_CAPACITY, "pe_get_committees: members_cap too small");
+        if (total) {
+            HIP_TRY(h, hipMemcpyAsync(out_members, t->d_members.p, 4ull * total, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+        }
+    }
+    return PE_OK;
+}
+
 int pe_ffg_balances(pe_engine* h, uint64_t out[3])
 {
     if (!h || !out) return PE_ERR_INVALID_ARG;

@@ -627,10 +627,36 @@ class Engine:
         return ep[:n], bi[:n]
 
     # -- checkpoint / resume ------------------------------------------------
+    def state_validators(self):
+        """-> (effective_balance u64[n], flags u8[n], is_set): the working-state view process_attestation and the FFG
+        sums read (pe_state_set_validators); is_set False while it still mirrors the registry."""
+        n = self.num_validators
+        bal, flags, is_set = np.zeros(max(n, 1), dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint8), C.c_int(0)
+        self._check(self._lib.pe_state_get_validators(self._h, n, _ptr(bal), _ptr(flags), C.byref(is_set)))
+        return bal[:n], flags[:n], bool(is_set.value)
+
+    def committee_epochs(self):
+        n = C.c_uint32(0)
+        self._check(self._lib.pe_get_committee_epochs(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint64)
+        self._check(self._lib.pe_get_committee_epochs(self._h, _ptr(out), n.value, C.byref(n)))
+        return [int(x) for x in out[: n.value]]
+
+    def committees(self, epoch: int):
+        """-> (offsets u32[C + 1], members u32[total]) of the table held for `epoch` (set or computed on the GPU)."""
+        nc = C.c_uint32(0)
+        self._check(self._lib.pe_get_committees(self._h, epoch, C.byref(nc), None, 0, None, 0))
+        offsets = np.zeros(nc.value + 1, dtype=np.uint32)
+        self._check(self._lib.pe_get_committees(self._h, epoch, C.byref(nc), _ptr(offsets), offsets.size, None, 0))
+        members = np.zeros(max(int(offsets[-1]), 1), dtype=np.uint32)
+        self._check(self._lib.pe_get_committees(self._h, epoch, C.byref(nc), None, 0, _ptr(members), int(offsets[-1])))
+        return offsets, members[: int(offsets[-1])]
+
     def export_state(self) -> dict:
         """The store's dynamic state as flat arrays (SURVEY.md 5 "checkpoint / resume"): scalars, the block table in
-        insertion order, validator flags (incl. the equivocating bit), latest messages, participation flags.  The
-        registry itself (balances, pubkeys) is the caller's input and is passed again to import_state."""
+        insertion order, validator flags (incl. the equivocating bit), latest messages, participation flags, the
+        committee tables and the working-state view.  The registry itself (balances, pubkeys) is the caller's input and
+        is passed again to import_state."""
         nb, nv = self.num_blocks, self.num_validators
         roots = np.zeros((nb, 32), dtype=np.uint8)
         parent = np.zeros(nb, dtype=np.uint32)
@@ -650,7 +676,10 @@ class Engine:
             self._check(self._lib.pe_get_validator_flags(self._h, _ptr(flags), nv))
             self._check(self._lib.pe_get_latest_message_slots(self._h, _ptr(lm_slot), nv))
         ep, bi = self.latest_messages()
-        return dict(scalars=self.store_scalars(), roots=roots, parent=parent, slot=slot, post_justified_epoch=pj_e,
+        sbal, sflags, s_set = self.state_validators()
+        return dict(committees={e: self.committees(e) for e in self.committee_epochs()},
+                    state_view=(sbal.copy(), sflags.copy()) if s_set else None,
+                    scalars=self.store_scalars(), roots=roots, parent=parent, slot=slot, post_justified_epoch=pj_e,
                     post_justified_root=pj_r, post_finalized_epoch=pf_e, post_finalized_root=pf_r, flags=flags[:nv],
                     lm_epoch=ep.copy(), lm_block=bi.copy(), lm_slot=lm_slot[:nv],
                     participation=(self.participation_get(0), self.participation_get(1)))
@@ -679,6 +708,10 @@ class Engine:
         self.set_proposer_boost(sc["proposer_boost_root"])
         self.participation_set(0, st["participation"][0])
         self.participation_set(1, st["participation"][1])
+        for epoch, (offsets, members) in sorted(st.get("committees", {}).items()):
+            self.set_committees(epoch, offsets, members)
+        if st.get("state_view") is not None:
+            self.state_set_validators(*st["state_view"])
 
     def store_scalars(self) -> dict:
         t, g, je, fe, be = (C.c_uint64(0) for _ in range(5))

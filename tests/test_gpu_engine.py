@@ -480,8 +480,16 @@ def test_export_import_state_round_trip(engine_factory):
     a.set_proposer_boost(tree.roots[n_blocks - 1].tobytes())
     a.participation_set(0, rng.integers(0, 8, size=n_val).astype(np.uint8))
     a.participation_set(1, rng.integers(0, 8, size=n_val).astype(np.uint8))
+    # the working-state view (what process_attestation / the FFG sums read) differs from the justified state's registry
+    sbal = synth.balances(n_val, 93, True)
+    sflags = synth.validator_flags(n_val, 93, inactive_frac=0.03, slashed_frac=0.02)
+    a.state_set_validators(sbal, sflags)
+    # one table computed on the GPU (its members never left the device), besides the host-provided one of _install_votes
+    Ec = int(tree.slot.max()) // spe + 3
+    a.compute_committees(Ec, bytes(range(32)), n_val, 64, 10, want_result=False)
 
     st = a.export_state()
+    assert st["state_view"] is not None and Ec in st["committees"] and len(st["committees"]) >= 2
     b = engine_factory(**cfg)
     b.import_state(st, bal)
     assert b.store_scalars() == a.store_scalars()
@@ -489,10 +497,15 @@ def test_export_import_state_round_trip(engine_factory):
     for k, v in st.items():
         if k == "scalars":
             continue
-        if k == "participation":
-            assert all(np.array_equal(x, y) for x, y in zip(v, st_b[k]))
+        if k in ("participation", "state_view"):
+            assert all(np.array_equal(x, y) for x, y in zip(v, st_b[k])), k
+        elif k == "committees":
+            assert sorted(v) == sorted(st_b[k])
+            for ep in v:
+                assert all(np.array_equal(x, y) for x, y in zip(v[ep], st_b[k][ep])), ep
         else:
             assert np.array_equal(v, st_b[k]), k
+    assert a.ffg_balances() == b.ffg_balances()
     assert np.array_equal(a.get_weights(), b.get_weights()) and a.get_head() == b.get_head()
 
     # both keep evolving identically: a later epoch's attestations, then time moves on until votes start to expire

@@ -1,0 +1,148 @@
+"""-m gpu: the awkward corners of pipelined / streaming calls: a failing call inside a pipeline, staging blocks that
+have to grow while work is enqueued, store mutations between streaming pipelines, a handle destroyed or re-initialised
+with pipelines in flight.  The reference point is always a twin engine driven with synchronous calls."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import pos_evolution_amd as pea
+import pos_evolution_amd.synth as synth
+from pos_evolution_amd._abi import pe_state_ctx
+from tests.test_gpu_pipeline import _same_results, _step_sync, _world
+
+pytestmark = pytest.mark.gpu
+
+
+def _step_streaming(w, lagged=True):
+    e = w["e"]
+    with e.pipeline(lagged=lagged):
+        agg = e.aggregate(packed=(w["atts"], w["arena"]), want_aggregate_pubkeys=True)
+        status, _, count = e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+        head = e.get_head()
+        pst, num = e.process_attestation_batch(w["ctx"], packed=(agg["atts"], pea.RESIDENT))
+    return agg, status, count, pst, num, head
+
+
+def test_failing_call_inside_a_pipeline_leaves_the_rest_intact(engine_factory):
+    """A call that is refused inside a pipeline (rows that are not rows of the resident aggregate) changes nothing; the
+    calls around it complete as usual."""
+    wa = _world(engine_factory, 12000, 64, seed=31)
+    wb = _world(engine_factory, 12000, 64, seed=31)
+    ra = _step_sync(wa)
+    e = wb["e"]
+    with e.pipeline():
+        agg = e.aggregate(packed=(wb["atts"], wb["arena"]), want_aggregate_pubkeys=True)
+        foreign = wb["atts"][:5].copy()
+        foreign["bits_offset"] += 3           # no group of the aggregate starts there
+        with pytest.raises(AssertionError) as ei:
+            e.on_attestation_batch(packed=(foreign, pea.RESIDENT))
+        assert ei.value.status == -1   # PE_ERR_INVALID_ARG
+        status, _, count = e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+        pst, num = e.process_attestation_batch(wb["ctx"], packed=(agg["atts"], pea.RESIDENT))
+        head = e.get_head()
+    _same_results(ra, (agg, status, count, pst, num, head))
+    # the same inside a streaming pipeline, where the G1 launch is deferred behind get_head
+    for w in (wa, wb):
+        w["e"].participation_rotate()
+    ra = _step_sync(wa)
+    with e.pipeline(lagged=True):
+        agg = e.aggregate(packed=(wb["atts"], wb["arena"]), want_aggregate_pubkeys=True)
+        with pytest.raises(AssertionError):
+            e.on_attestation_batch(packed=(foreign, pea.RESIDENT))
+        status, _, count = e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+        head = e.get_head()
+        pst, num = e.process_attestation_batch(wb["ctx"], packed=(agg["atts"], pea.RESIDENT))
+    e.drain()
+    _same_results(ra, (agg, status, count, pst, num, head))
+    assert np.array_equal(wa["e"].get_weights(), e.get_weights())
+    assert np.array_equal(wa["e"].participation_get(0), e.participation_get(0))
+
+
+def test_staging_blocks_grow_while_streaming(engine_factory):
+    """Streaming pipelines whose batches grow from one step to the next: the pinned staging / output blocks and the
+    resident buffers are re-allocated with earlier steps still in flight.  Every step equals the synchronous twin."""
+    n_val, spe = 60000, 32
+    worlds = [_world(engine_factory, n_val, 64, seed=41), _world(engine_factory, n_val, 64, seed=41)]
+    tree = worlds[0]["tree"]
+    out = [[], []]
+    for k, (n_comm, parts) in enumerate([(32, 1), (64, 2), (256, 3), (2048, 4), (64, 1), (1024, 6)]):
+        ep = worlds[0]["epoch"] + k
+        seed = hashlib.sha256(b"grow%d" % k).digest()
+        for w in worlds:   # an engine keeps a handful of tables: each epoch's is computed right before its step
+            off, mem = w["e"].compute_committees(ep, seed, n_val, n_comm, 8)
+        comm = synth.Committees(off, mem)
+        atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=41 + k, density=0.9, parts=parts,
+                                                  source=(0, tree.roots[0].tobytes()))
+        ctx = pe_state_ctx()
+        ctx.slot = (ep + 1) * spe
+        ctx.chain_tip_root[:] = tree.roots[-1].tobytes()
+        ctx.current_justified_root[:] = tree.roots[0].tobytes()
+        ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+        ctx.base_reward_per_increment = 300 + k
+        for which, w in enumerate(worlds):
+            e = w["e"]
+            e.on_tick((ep + 1) * spe * 12)
+            e.participation_rotate()
+            wk = dict(e=e, atts=atts, arena=arena, ctx=ctx)
+            out[which].append(_step_sync(wk) if which == 0 else _step_streaming(wk))
+    worlds[1]["e"].drain()
+    for a, b in zip(*out):
+        _same_results(a, b)
+        assert (b[1] == 0).all() and (b[3] == 0).all()
+    assert np.array_equal(worlds[0]["e"].get_weights(), worlds[1]["e"].get_weights())
+
+
+def test_store_mutations_between_streaming_pipelines(engine_factory):
+    """on_block / on_tick / proposer boost / equivocation marks / a balance refresh between streaming pipelines: the
+    ones that touch device state first complete what is in flight (they are synchronous entry points), the host-only
+    ones (on_tick, the boost root) do not need to, and the next step sees the new store -- exactly as with synchronous
+    calls."""
+    n_val, n_comm, spe = 20000, 64, 32
+    worlds = [_world(engine_factory, n_val, n_comm, seed=51), _world(engine_factory, n_val, n_comm, seed=51)]
+    tree = worlds[0]["tree"]
+    tip = tree.roots[-1].tobytes()
+    heads = [[], []]
+    for which, w in enumerate(worlds):
+        e = w["e"]
+        step = _step_sync if which == 0 else _step_streaming
+        res = [step(w)]
+        new1 = b"\x51" * 32
+        e.on_block(new1, tip, int(tree.slot.max()) + 1, (0, tree.roots[0].tobytes()), (0, tree.roots[0].tobytes()))
+        e.set_proposer_boost(new1)
+        e.participation_rotate()
+        res.append(step(w))
+        e.mark_equivocating(np.arange(0, n_val, 97))
+        bal2 = w["bal"].copy()
+        bal2[::3] = 17_000_000_000
+        e.set_balances(bal2, w["flags"])
+        e.participation_rotate()
+        res.append(step(w))
+        e.on_tick((w["epoch"] + 1) * spe * 12 + 12)   # a new slot: the boost is cleared (pe:943-944)
+        e.participation_rotate()
+        res.append(step(w))
+        if which == 1:
+            e.drain()
+        heads[which] = res
+    for a, b in zip(*heads):
+        _same_results(a, b)
+    assert np.array_equal(worlds[0]["e"].get_weights(), worlds[1]["e"].get_weights())
+
+
+def test_destroy_and_reinit_with_pipelines_in_flight(engine_factory):
+    """A handle closed, or its store re-initialised, while streaming pipelines are still in flight: no hang, no crash,
+    and the outputs of the steps already issued are complete (closing a handle drains it first)."""
+    w = _world(engine_factory, 30000, 128, seed=61)
+    twin = _world(engine_factory, 30000, 128, seed=61)
+    ref = _step_sync(twin)
+    e = w["e"]
+    got = [_step_streaming(w) for _ in range(3)]   # same votes each time; flags are set by the first step only
+    e.store_init(0, int(w["tree"].slot[0]), w["tree"].roots[0].tobytes())   # synchronous: completes what is in flight
+    _same_results(ref, got[0])
+    with pytest.raises(AssertionError):
+        e.on_attestation_batch(packed=(got[0][0]["atts"], pea.RESIDENT))   # the resident aggregate went with the store
+    # ... and a handle that is simply closed with work in flight
+    w2 = _world(engine_factory, 30000, 128, seed=61)
+    got2 = [_step_streaming(w2) for _ in range(2)]
+    w2["e"].close()
+    _same_results(ref, got2[0])
