@@ -64,6 +64,16 @@ def build_workload(e, args, rank, n_steps_total):
     w = dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe)
     for st in steps:  # the working state's context of each step is an input like the attestations: built up front
         st["ctx"] = state_ctx(w, st["epoch"])
+    if not args.host_arena:
+        # the contract's headline condition: inputs resident in HBM when the timed region starts.  The aggregation bits
+        # (the only input the host never reads) go to the device; the attestation rows stay host memory, the host
+        # groups and validates them.  --host-arena times the hand-over from pageable host memory instead.
+        import torch
+        from pos_evolution_amd import DeviceArena
+        for st in steps:
+            t = torch.from_numpy(st["arena"]).cuda()
+            st["arena_in"] = DeviceArena(t.data_ptr(), t.numel(), keep=t)
+        torch.cuda.synchronize()
     return w
 
 
@@ -113,7 +123,8 @@ def run_step_single(e, w, st, pipelined=True, lagged=True):
     # lagged: this step's outputs are complete when the NEXT step's block exits (the last one at e.drain(), inside the
     # timed region): the G1 sums of step N run on the second stream while the host prepares step N+1
     with e.pipeline(lagged=lagged):
-        agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
+        agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st.get("arena_in", st["arena"])),
+                     want_aggregate_pubkeys=True)
         rows = agg["atts"]
         status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, RESIDENT))
         # fork choice first (the head depends on the LMD update only), then the state transition's flag pass: the
@@ -133,7 +144,7 @@ def run_step_sharded_pipelined(e, w, st, lagged=True):
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
     with e.pipeline(lagged=lagged):
-        agg = e.aggregate_sharded(packed=(st["atts"], st["arena"]))   # all-gather of C x 192 B XYZZ partials inside
+        agg = e.aggregate_sharded(packed=(st["atts"], st.get("arena_in", st["arena"])))   # all-gather of C x 192 B partials inside
         rows = agg["atts"]
         status, _, count = e.on_attestation_batch(packed=(rows, RESIDENT))
         head = e.get_head_sharded()                                   # all-reduce of (B + 512) x 8 B inside
@@ -366,6 +377,8 @@ def main():
     ap.add_argument("--sharded-mode", choices=["engine", "torch"], default="engine",
                     help="N > 1: collectives issued by the engine on its own stream inside pipelined calls (engine), "
                          "or by torch.distributed between synchronous calls (torch)")
+    ap.add_argument("--host-arena", action="store_true",
+                    help="hand the aggregation bits over from pageable host memory (PCIe-inclusive) instead of HBM")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one wait per call instead of one per step (A/B of the pipelined C ABI)")
     ap.add_argument("--no-lag", action="store_true",
@@ -565,6 +578,9 @@ def main():
             "validators_total": V_total, "validators_per_gpu": VL, "blocks": args.blocks, "committees": C,
             "parallelism": f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU",
             "call_mode": mode,
+            "inputs": ("attestation rows in host memory (grouped and validated by the host inside the timed step); "
+                       + ("aggregation bits in pageable host memory, copied over PCIe inside the timed step"
+                          if args.host_arena else "aggregation bits resident in HBM before the timed region")),
             "per_epoch_setup_outside_the_step": "pe_compute_committees (GPU swap-or-not shuffle + inverse committee "
                                                 "map) runs once per epoch when the workload is built, not in the step",
         },

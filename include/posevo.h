@@ -292,7 +292,11 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
  * over the OR-ed bits (needs the epoch's committee table; NULL out to skip).
  *   out_atts[g]   : the group's data, bits_offset into out_bits_arena
  *   group_of[i]   : group index of input attestation i (nullable)
- * Capacities: out_atts has room for n rows, out_bits_arena for out_arena_cap bytes. */
+ * Capacities: out_atts has room for n rows, out_bits_arena for out_arena_cap bytes.
+ * bits_arena may lie in pageable host memory (copied during the call), in pinned host memory or in device memory
+ * (hipMalloc of the engine's device): the latter two are picked up by the copy engine without a pass on the host, and
+ * must stay unchanged until the call's outputs are complete (inside a pipeline: until the pipeline's are).  The same
+ * holds for pe_aggregate_partial and pe_aggregate_sharded.  The attestation rows are always host memory. */
 int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n,
                  const uint8_t* bits_arena, uint64_t arena_len, const uint8_t* sig_points96,
                  pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,

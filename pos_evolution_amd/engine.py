@@ -27,11 +27,23 @@ class EngineError(AssertionError):
 _c_char = C.c_char
 
 
+class DeviceArena:
+    """A bit arena that already lies in device memory (or pinned host memory): ``ptr`` = its address, ``size`` = bytes.
+    pe_aggregate copies it with the copy engine instead of passing over it on the host; keep it unchanged (and ``keep``,
+    the owning object, alive) until the call's outputs are complete."""
+    __slots__ = ("ptr", "size", "keep")
+
+    def __init__(self, ptr: int, size: int, keep=None):
+        self.ptr, self.size, self.keep = int(ptr), int(size), keep
+
+
 def _ptr(a, ctype=None):
     """Address of a C-contiguous numpy buffer (None stays NULL).  c_char.from_buffer + addressof is the cheapest route
     ctypes offers; read-only or empty arrays take the slower ndarray.ctypes path."""
     if a is None:
         return None
+    if a.__class__ is DeviceArena:
+        return a.ptr
     try:
         return C.addressof(_c_char.from_buffer(a))
     except (TypeError, ValueError, BufferError):

@@ -316,3 +316,34 @@ def test_unaligned_member_offsets_in_the_arena(engine_factory):
     for g, size in enumerate(sizes):
         assert np.array_equal(res["bits"][g], want[g]), size
         assert res["count"][g] == want[g].sum()
+
+
+def test_arena_in_device_or_pinned_memory(engine_factory):
+    """pe_aggregate with the members' bits lying in device memory, in pinned host memory, or at an odd offset inside a
+    device allocation: same result as from pageable host memory, synchronous and inside a streaming pipeline."""
+    import torch
+    w = _world(engine_factory, 20000, 64, seed=77, density=0.7, parts=3)
+    e = w["e"]
+    ref = e.aggregate(packed=(w["atts"], w["arena"]), want_aggregate_pubkeys=True)
+    dev = torch.from_numpy(w["arena"]).cuda()
+    pin = torch.from_numpy(w["arena"]).pin_memory()
+    shifted = torch.zeros(w["arena"].size + 64, dtype=torch.uint8, device="cuda")
+    shifted[13:13 + w["arena"].size] = dev
+    atts13 = w["atts"].copy()
+    atts13["bits_offset"] += 13
+    torch.cuda.synchronize()
+    cases = [(w["atts"], pea.DeviceArena(dev.data_ptr(), dev.numel(), keep=dev)),
+             (w["atts"], pea.DeviceArena(pin.data_ptr(), pin.numel(), keep=pin)),
+             (atts13, pea.DeviceArena(shifted.data_ptr(), shifted.numel(), keep=shifted))]
+    for atts, arena in cases:
+        got = e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+        for k in ("out_arena", "count", "aggpk96", "group_of"):
+            assert np.array_equal(got[k], ref[k]), k
+        with e.pipeline(lagged=True):
+            got = e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+            status, _, count = e.on_attestation_batch(packed=(got["atts"], pea.RESIDENT))
+            e.get_head()
+        e.drain()
+        for k in ("out_arena", "count", "aggpk96", "group_of"):
+            assert np.array_equal(got[k], ref[k]), k
+        assert (status == 0).all() and np.array_equal(count, ref["count"])
