@@ -787,7 +787,8 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_TREE, fin);
-        launch_g1_tree(fin, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>());
+        launch_g1_tree(fin, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
+                       /*one_per_cu=*/fin != s ? 1 : 0);  // on its own stream it meets the next step's k_tree: leave it room
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_NORMALISE, fin);
@@ -949,7 +950,8 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
         // the head index lands directly in host-coherent pinned memory: no D2H copy, just the stream sync
         launch_tree(h->stream, tree_dev(h), d_direct, d_totals, 0, 0, 0, h->h_pos_of_idx[just_idx], boost_pos,
                     h->cfg.slots_per_epoch, h->cfg.proposer_score_boost, h->cfg.effective_balance_increment,
-                    h->d_weights.as<uint64_t>(), h->h_head.as<uint32_t>(), clear_direct);
+                    h->d_weights.as<uint64_t>(), h->h_head.as<uint32_t>(), clear_direct,
+                    /*lean=*/h->pipelining ? 1 : 0);  // inside a pipeline: the shape that fits beside an accumulation
     }
     HIP_TRY(h, hipGetLastError());
     // a streaming pipeline's G1 sums go out now, ordered behind k_tree on the device: they start the moment the head
@@ -2030,6 +2032,7 @@ struct AggState {  // what the completion of one pe_aggregate needs after the wa
     uint32_t* out_count = nullptr;
     uint32_t ng = 0;
     size_t base = 0, off_obits = 0, off_oinfo = 0, off_opk = 0, off_osig = 0;
+    size_t packed_bytes = 0;  // > 0: the word-aligned unions in the pinned block ARE the caller's byte-packed layout
     int tune_arm = -1;
 };
 
@@ -2066,6 +2069,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     std::vector<uint32_t>& gof = A.gof;
     std::vector<uint32_t>& rep = A.rep;             // rep[g] = first attestation of group g
     std::vector<uint32_t> gcount;
+    std::vector<uint32_t> boff(n);                  // bits_offset per row, compact: the later passes never re-read the rows
+    std::vector<uint32_t>& gvalid = A.all_valid;    // AND of the members' signature verdicts
     gof.resize(n);
     uint64_t lo = ~0ull, hi = 0;                    // byte span of the arena this call reads
     for (uint32_t i = 0; i < n; ++i) {
@@ -2081,6 +2086,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
                 table[slot] = g;
                 rep.push_back(i);
                 gcount.push_back(0);
+                gvalid.push_back(PE_ATT_FLAG_SIGNATURE_VALID);
                 break;
             }
             const pe_attestation& r = atts[rep[g]];
@@ -2089,6 +2095,8 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         }
         gof[i] = g;
         gcount[g] += 1;
+        gvalid[g] &= atts[i].flags;
+        boff[i] = atts[i].bits_offset;
     }
     if (lo > hi) lo = hi = 0;
     lo &= ~uint64_t(3);                              // keep the members' word alignment relative to the upload
@@ -2168,7 +2176,6 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     uint32_t* ubytes = st.host<uint32_t>(off_ub);
     A.out_byte_off.resize(ng);
     A.out_word.resize(ng);
-    A.all_valid.resize(ng);
     {
         uint32_t ow = 0, obytes = 0;
         for (uint32_t g = 0; g < ng; ++g) {
@@ -2180,11 +2187,9 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
             ow += (atts[rep[g]].n_bits + 31) / 32;
             A.out_byte_off[g] = obytes;
             obytes += (atts[rep[g]].n_bits + 7) / 8;
-            uint32_t all_valid = PE_ATT_FLAG_SIGNATURE_VALID;
-            for (uint32_t k = gstart[g]; k < gstart[g + 1]; ++k) all_valid &= atts[order[k]].flags;
-            A.all_valid[g] = all_valid;
         }
-        for (uint32_t k = 0; k < n; ++k) ubytes[k] = (uint32_t)(atts[order[k]].bits_offset - lo);
+        const uint32_t lo32 = (uint32_t)lo;          // bits_offset is 32 bits wide, so is every offset at or below it
+        for (uint32_t k = 0; k < n; ++k) ubytes[k] = boff[order[k]] - lo32;
     }
     lap.mark("agg.2c_union_groups");
     // resident outputs: the OR-ed bits and {popcount, overlap} stay on the device for the calls that follow
@@ -2366,6 +2371,11 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     A.off_opk = off_opk;
     A.off_osig = off_osig;
     A.tune_arm = tune_arm;
+    {   // every union a whole number of words (committee sizes that are multiples of 32), except possibly the last one?
+        bool same = true;
+        for (uint32_t g = 0; g < ng && same; ++g) same = A.out_byte_off[g] == 4ull * A.out_word[g];
+        A.packed_bytes = same ? (size_t)out_bytes : 0;
+    }
     const int ai = h->cur;
     auto complete = [h, stp, info_p, ai]() -> int {
         AggState& S = *stp;
@@ -2379,9 +2389,10 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         }
         const uint8_t* obits = pin + S.off_obits;
         const uint32_t* oinfo = reinterpret_cast<const uint32_t*>(pin + S.off_oinfo);
+        if (S.packed_bytes) memcpy(S.out_bits_arena, obits, S.packed_bytes);  // one copy instead of one per group
         for (uint32_t g = 0; g < S.ng; ++g) {
             const uint32_t nb = S.out_atts[g].n_bits;
-            memcpy(S.out_bits_arena + S.out_byte_off[g], obits + 4ull * S.out_word[g], (nb + 7) / 8);
+            if (!S.packed_bytes) memcpy(S.out_bits_arena + S.out_byte_off[g], obits + 4ull * S.out_word[g], (nb + 7) / 8);
             if (S.out_count) S.out_count[g] = oinfo[2 * g];
             if (oinfo[2 * g + 1]) {
                 // members overlap: the summed signature counts a validator twice while bits and pubkey count it

@@ -37,19 +37,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-// Function attributes are per device: one flag per (kernel tag, device) so that a process driving several GPUs
-// through several handles opts every device in.
-template <int TAG>
-static bool first_use_on_this_device()
-{
-    static bool done[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return true;
-    if (done[dev]) return false;
-    done[dev] = true;
-    return true;
-}
+// The kernels in front of a head (union, LMD, votes, tree) are latency-critical guests beside the long G1 kernels of
+// the previous step; the SIMD's issue arbiter serves the oldest wave first, i.e. the G1 kernel's.  Raising their wave
+// priority puts them first (POSEVO_FC_PRIO=0 builds without it, for comparison).
+#ifndef POSEVO_FC_PRIO_LEVEL
+#define POSEVO_FC_PRIO_LEVEL 3
+#endif
+#if POSEVO_FC_PRIO_LEVEL > 0
+#define POSEVO_FC_PRIO() __builtin_amdgcn_s_setprio(POSEVO_FC_PRIO_LEVEL)
+#else
+#define POSEVO_FC_PRIO() ((void)0)
+#endif
 
 // ------------------------------------------------------------------ votes
 constexpr int VOTES_WG = 512;  // 256 lanes: 21 us, 512: 15.8, 1024: 15.4 at 1 M validators / 64 workgroups
@@ -66,6 +64,7 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
         const uint32_t* __restrict__ pos_of_idx, uint32_t n_blocks, unsigned long long* __restrict__ direct,
         VoteTotals* __restrict__ totals, const uint32_t* __restrict__ vote_slot, uint32_t min_vote_slot)
 {
+    POSEVO_FC_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];  // n_blocks bins, by insertion index
     for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) hist[b] = 0;
     __syncthreads();
@@ -194,7 +193,7 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
 // LDS index skew: thread t owns items PER*t .. PER*t+PER-1, i.e. a lane stride of PER elements = a PER-way (u32) bank
 // conflict on every own-item access.  i -> i + i/PER turns the stride into PER+1 (odd): conflict-free.
 template <int PER>
-__device__ __forceinline__ uint32_t SKT(uint32_t i) { return PER == 1 ? i : i + i / PER; }
+__host__ __device__ __forceinline__ uint32_t SKT(uint32_t i) { return PER == 1 ? i : i + i / PER; }
 // largest skewed index over the shapes in use: 8192 blocks at PER = 8 (PER = 4 only serves n <= 4096)
 constexpr uint32_t TREE_LDS_ENTRIES = TREE_MAX_BLOCKS + 2 + ((TREE_MAX_BLOCKS + 2) >> 3) + 1;
 
@@ -229,23 +228,29 @@ __device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_TH
     __syncthreads();
 }
 
-template <int TREE_WG, int TREE_PER_THREAD>
+// LEAN: the form that fits beside a running k_g1_accumulate (two waves of 168 VGPRs per SIMD leave 176 registers per
+// SIMD lane; a 512-lane workgroup = two waves per SIMD of 64 here).  Parent, rank and block index are loaded where they
+// are used instead of up front -- three more round trips to L2, ~6 us -- so only pipelined calls use it.
+// lds_entries: skewed index range of this launch (the host sizes the dynamic LDS for the block count at hand, not for
+// the 8192-block maximum: 82 KB at 4096 blocks leaves room for another kernel's workgroup on the CU).
+template <int TREE_WG, int TREE_PER_THREAD, bool LEAN = false>
 __global__ void __launch_bounds__(TREE_WG)
-k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* __restrict__ totals,
+k_tree(TreeDev tree, uint32_t lds_entries, unsigned long long* __restrict__ direct, const VoteTotals* __restrict__ totals,
        unsigned long long ov_balance, unsigned long long ov_num, int use_override, uint32_t justified_pos,
        uint32_t boost_pos, unsigned long long slots_per_epoch, unsigned long long boost_percent,
        unsigned long long balance_increment, unsigned long long* __restrict__ weights_by_idx,
        uint32_t* __restrict__ head_idx, int clear_direct)
 {
+    POSEVO_FC_PRIO();
     // LDS plan (n <= 8192, skewed indices):  S u64 (later bestW) | L u32 (later bestRank) | jump u32 | scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // u64 regions first so that every 64-bit LDS access (ds_*_b64, ds_add_u64, ds_max_u64) is 8-byte aligned
     unsigned long long* S = reinterpret_cast<unsigned long long*>(smem);
-    unsigned long long* wave_tot64 = S + TREE_LDS_ENTRIES;   // 16 waves
+    unsigned long long* wave_tot64 = S + lds_entries;         // 16 waves
     unsigned long long* tot = wave_tot64 + 16;                // 2 words
     uint32_t* L = reinterpret_cast<uint32_t*>(tot + 2);
-    uint32_t* jump = L + TREE_LDS_ENTRIES;
-    uint32_t* wave_tot32 = jump + TREE_LDS_ENTRIES;           // 16 waves
+    uint32_t* jump = L + lds_entries;
+    uint32_t* wave_tot32 = jump + lds_entries;                // 16 waves
 
     const uint32_t n = tree.n;
     const int tid = threadIdx.x;
@@ -262,9 +267,11 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
         sz[k] = in ? tree.size[i] : 0u;
         w_item[k] = in ? direct[i] : 0ull;
         l_item[k] = (in && tree.leaf_ok[i]) ? 1u : 0u;
-        par_g[k] = in ? tree.parent[i] : NONE32;
-        rk_g[k] = in ? tree.rank[i] + 1 : 0u;  // 0 = "no viable child yet"
-        idx_g[k] = in ? tree.idx_of_pos[i] : 0u;
+        if (!LEAN) {
+            par_g[k] = in ? tree.parent[i] : NONE32;
+            rk_g[k] = in ? tree.rank[i] + 1 : 0u;  // 0 = "no viable child yet"
+            idx_g[k] = in ? tree.idx_of_pos[i] : 0u;
+        }
     }
     unsigned long long t_bal = 0, t_num = 0;
     if (boost_pos != NONE32 && !use_override) {
@@ -320,7 +327,7 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
         if (i < n) {
             W[k] = S[SK(i + sz[k])] - S[SK(i)];
             if (L[SK(i + sz[k])] - L[SK(i)] > 0) viable |= 1u << k;
-            weights_by_idx[idx_g[k]] = W[k];
+            weights_by_idx[LEAN ? tree.idx_of_pos[i] : idx_g[k]] = W[k];
         }
     }
     __syncthreads();
@@ -336,11 +343,19 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
     uint32_t par[TREE_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k) {
-        par[k] = ((viable >> k) & 1u) ? par_g[k] : NONE32;
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        par[k] = ((viable >> k) & 1u) ? (LEAN ? tree.parent[i] : par_g[k]) : NONE32;  // viable => i < n
         if (par[k] != NONE32) atomicMax(&bestW[SK(par[k])], W[k]);
     }
     __syncthreads();
     // pass 2: among the heaviest, the lexicographically highest root
+    if (LEAN) {
+#pragma unroll
+        for (int k = 0; k < TREE_PER_THREAD; ++k) {
+            const uint32_t i = tid * TREE_PER_THREAD + k;
+            rk_g[k] = par[k] != NONE32 ? tree.rank[i] + 1 : 0u;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k)
         if (par[k] != NONE32 && W[k] == bestW[SK(par[k])]) atomicMax(&bestRank[SK(par[k])], rk_g[k]);
@@ -373,32 +388,37 @@ k_tree(TreeDev tree, unsigned long long* __restrict__ direct, const VoteTotals* 
         __hip_atomic_store(head_idx, tree.idx_of_pos[jump[SK(justified_pos)]], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <int WG, int PER>
-static void launch_tree_shape(hipStream_t s, size_t lds, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
+template <int WG, int PER, bool LEAN = false>
+static void launch_tree_shape(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                               uint64_t ovb, uint64_t ovn, int use_override, uint32_t justified_pos, uint32_t boost_pos,
                               uint64_t slots_per_epoch, uint64_t boost_percent, uint64_t balance_increment,
                               uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
 {
-    if (first_use_on_this_device<1000 + WG + PER>()) {  // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<WG, PER>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    constexpr size_t lds_max = sizeof(uint64_t) * (TREE_LDS_ENTRIES + 18) + sizeof(uint32_t) * (2 * TREE_LDS_ENTRIES + 16);
+    if (first_use_on_this_device<1000 + WG + PER + (LEAN ? 5000 : 0)>()) {  // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<WG, PER, LEAN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     }
-    hipLaunchKernelGGL((k_tree<WG, PER>), dim3(1), dim3(WG), lds, s, tree, reinterpret_cast<unsigned long long*>(direct),
-                       totals, (unsigned long long)ovb, (unsigned long long)ovn, use_override, justified_pos, boost_pos,
-                       (unsigned long long)slots_per_epoch, (unsigned long long)boost_percent,
-                       (unsigned long long)balance_increment, reinterpret_cast<unsigned long long*>(weights_by_idx),
-                       head_idx, clear_direct);
+    // skewed index of the last entry (n) of this shape, + 1, rounded up to keep the u32 regions 16-byte aligned
+    const uint32_t entries = std::min<uint32_t>(TREE_LDS_ENTRIES, ((SKT<PER>(tree.n + 1) + 2) + 3u) & ~3u);
+    const size_t lds = sizeof(uint64_t) * ((size_t)entries + 18) + sizeof(uint32_t) * (2 * (size_t)entries + 16);
+    hipLaunchKernelGGL((k_tree<WG, PER, LEAN>), dim3(1), dim3(WG), lds, s, tree, entries,
+                       reinterpret_cast<unsigned long long*>(direct), totals, (unsigned long long)ovb,
+                       (unsigned long long)ovn, use_override, justified_pos, boost_pos, (unsigned long long)slots_per_epoch,
+                       (unsigned long long)boost_percent, (unsigned long long)balance_increment,
+                       reinterpret_cast<unsigned long long*>(weights_by_idx), head_idx, clear_direct);
 }
 
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
                  uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
-                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
+                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct, int lean)
 {
-    const size_t lds = sizeof(uint64_t) * (TREE_LDS_ENTRIES + 18) + sizeof(uint32_t) * (2 * TREE_LDS_ENTRIES + 16);
-#define POSEVO_TREE_ARGS s, lds, tree, direct, totals, totals_override_balance, totals_override_num, use_override, justified_pos, \
+#define POSEVO_TREE_ARGS s, tree, direct, totals, totals_override_balance, totals_override_num, use_override, justified_pos, \
         boost_pos, slots_per_epoch, boost_percent, balance_increment, weights_by_idx, head_idx, clear_direct
-    if (tree.n <= 1024) launch_tree_shape<1024, 1>(POSEVO_TREE_ARGS);
+    if (tree.n <= 1024) launch_tree_shape<1024, 1>(POSEVO_TREE_ARGS);  // 40 VGPRs x 4 waves per SIMD: lean as it is
+    else if (lean && tree.n <= 2048) launch_tree_shape<512, 4, true>(POSEVO_TREE_ARGS);
+    else if (lean && tree.n <= 4096) launch_tree_shape<512, 8, true>(POSEVO_TREE_ARGS);
     else if (tree.n <= 2048) launch_tree_shape<1024, 2>(POSEVO_TREE_ARGS);
     else if (tree.n <= 4096) launch_tree_shape<1024, 4>(POSEVO_TREE_ARGS);
     else launch_tree_shape<1024, 8>(POSEVO_TREE_ARGS);
@@ -479,6 +499,7 @@ k_lmd_validator_major(const AttRow* __restrict__ rows, const uint32_t* __restric
                       uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot,
                       const uint32_t* __restrict__ gates)
 {
+    POSEVO_FC_PRIO();
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_val) return;
     const uint32_t c = inv_comm[v];
@@ -721,6 +742,7 @@ k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uin
              const uint8_t* __restrict__ bit_arena, uint32_t* __restrict__ out_arena,
              uint32_t* __restrict__ out_info, uint32_t* __restrict__ host_arena, uint32_t* __restrict__ host_info)
 {
+    POSEVO_FC_PRIO();
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_groups) return;
     const int lane = threadIdx.x & 63;

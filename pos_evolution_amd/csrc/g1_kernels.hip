@@ -535,12 +535,23 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const ui
                        groups, n_groups, n_slots, lane_partials, wg_partials48);
 }
 
+// one_per_cu: ask for 77 KB of LDS instead of the 50 KB the kernel uses, so that a CU holds ONE of its workgroups and
+// keeps 83 KB free.  In a streaming pipeline the tree of step N runs when the accumulation of step N retires -- which
+// is when the fork-choice kernels of step N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096 blocks) then
+// found no CU with room until this kernel had drained: +60 us on every get_head (profiles/r02_timeline_tree_collision.txt).
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
-                    uint32_t n_slots, uint32_t* wg_partials48)
+                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
-    const size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
+    size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
+    if (one_per_cu) {
+        constexpr size_t padded = 77 * 1024;
+        if (first_use_on_this_device<77>())
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)padded);
+        lds_bytes = padded;
+    }
     hipLaunchKernelGGL(k_g1_tree, dim3(blocks), dim3(G1_WG), lds_bytes, s, lane_partials, groups, n_groups, n_slots,
                        wg_partials48);
 }

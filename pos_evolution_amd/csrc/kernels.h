@@ -7,6 +7,20 @@
 
 namespace posevo {
 
+// Function attributes (the opt-in to > 64 KiB of dynamic LDS) are per device: one flag per (kernel tag, device), so that
+// a process driving several GPUs through several handles opts every device in.
+template <int TAG>
+static bool first_use_on_this_device()
+{
+    static bool done[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 // Registry / point-table rows: 24 Montgomery words (x | y) padded to 32 = 128 bytes, so that a gathered point is
 // exactly one 128-byte memory line (96-byte rows straddle two lines half of the time: PMC showed 2x the
@@ -42,7 +56,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const ui
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
 // (group, workgroup) into wg_partials48.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
-                    uint32_t n_slots, uint32_t* wg_partials48);
+                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
 // g when first == null), then either write the XYZZ sum (48 u32) or normalise to 96-byte affine.
 void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
@@ -71,7 +85,8 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
                  uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
-                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct);
+                 uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct,
+                 int lean = 0);
 
 // One resolved attestation (device row).
 struct AttRow {
