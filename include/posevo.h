@@ -289,7 +289,9 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
  * ordered by first appearance).  Per group: aggregation_bits = OR of the members'
  * bits; signature = sum of the members' signature points (sig_points96, 96 B per
  * input attestation, nullable); aggregate pubkey = sum of pubkey[committee[i]]
- * over the OR-ed bits (needs the epoch's committee table; NULL out to skip).
+ * over the OR-ed bits (needs the committee table of every target epoch in the batch;
+ * NULL out to skip).  A batch may span target epochs (an epoch boundary); only the
+ * partial / sharded forms below want one target epoch per call.
  *   out_atts[g]   : the group's data, bits_offset into out_bits_arena
  *   group_of[i]   : group index of input attestation i (nullable)
  * Capacities: out_atts has room for n rows, out_bits_arena for out_arena_cap bytes.

@@ -1700,6 +1700,15 @@ int pe_head_from_weights(pe_engine* h, const void* dev_buf_u64, uint32_t n_block
     return head_from_weights_impl(h, dev_buf_u64, n_blocks, out_root);
 }
 
+// The handlers and pe_get_indexed_attestations re-pack the caller's bits on the host: device memory would fault there.
+static bool bits_on_device(const uint8_t* bits_arena)
+{
+    hipPointerAttribute_t pa;
+    if (hipPointerGetAttributes(&pa, bits_arena) == hipSuccess) return pa.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    return false;
+}
+
 // ---------------------------------------------------------------- on_attestation
 // Rows handed over resident (bits_arena == PE_BITS_RESIDENT): which group of the last pe_aggregate is this row?
 static bool find_resident(const pe_engine* h, const pe_attestation& a, uint32_t* g_out, uint32_t guess)
@@ -1730,6 +1739,8 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
     if (n == 0) return PE_OK;
     const bool resident = bits_arena == PE_BITS_RESIDENT;
     if (resident && !h->res_valid) return fail(h, PE_ERR_STATE, "PE_BITS_RESIDENT: no pe_aggregate result is resident");
+    if (!resident && bits_on_device(bits_arena))
+        return fail(h, PE_ERR_INVALID_ARG, "bits in device memory: hand them over through pe_aggregate + PE_BITS_RESIDENT");
     HostLap lap(&h->trace);
     // ---- sizes first: the staging block must not move once pointers into it exist ----
     uint64_t word_bound = 0;
@@ -1946,6 +1957,7 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
     PE_TRY(enter(h));
     out_offsets[0] = 0;
     if (n == 0) return PE_OK;
+    if (bits_on_device(bits_arena)) return fail(h, PE_ERR_INVALID_ARG, "bits in device memory: only pe_aggregate reads them there");
     uint64_t word_bound = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
@@ -2032,6 +2044,7 @@ struct AggState {  // what the completion of one pe_aggregate needs after the wa
     uint32_t* out_count = nullptr;
     uint32_t ng = 0;
     size_t base = 0, off_obits = 0, off_oinfo = 0, off_opk = 0, off_osig = 0;
+    size_t off_opkx = 0;      // aggregate pubkeys of the groups of further committee tables (compacted)
     size_t packed_bytes = 0;  // > 0: the word-aligned unions in the pinned block ARE the caller's byte-packed layout
     int tune_arm = -1;
 };
@@ -2118,14 +2131,22 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     // ---- resolve committees (aggregate pubkey) ----
     std::vector<Resolved> gres(want_pk ? ng : 0);
     CommitteeTable* table_pk = nullptr;
+    auto xgroups_p = std::make_shared<std::vector<uint32_t>>();  // groups whose committee table is not the first one's
+    std::vector<uint32_t>& xgroups = *xgroups_p;
     if (want_pk) {
         for (uint32_t g = 0; g < ng; ++g) {
             const pe_attestation& a = atts[rep[g]];
             CommitteeTable* t = find_table(h, a.target_epoch);
             if (!t) return fail(h, PE_ERR_NO_COMMITTEES, "no committee table for a group's target epoch");
-            if (table_pk && t != table_pk)
-                return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate: one target epoch per call when aggregate pubkeys are requested");
-            table_pk = t;
+            if (table_pk && t != table_pk) {
+                // a batch around an epoch boundary: the groups of the first table go through the main launch, the
+                // others through one (synchronous-stream) launch per further table -- see "further tables" below
+                if (dev_partials)
+                    return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate_partial / _sharded: one target epoch per call");
+                xgroups.push_back(g);
+            } else {
+                table_pk = t;
+            }
             const uint64_t cps = t->n_committees / h->cfg.slots_per_epoch;
             if (a.index >= cps) return fail(h, PE_ERR_INVALID_ARG, "committee index out of range");
             const uint64_t pos = (a.slot % h->cfg.slots_per_epoch) * cps + a.index;
@@ -2145,7 +2166,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     if (out_bytes > out_arena_cap) return fail(h, PE_ERR_CAPACITY, "output bit arena too small");
     const size_t span = (size_t)(hi - lo);
     Stage st(h);
-    PE_TRY(st.reserve(span + 64 + sizeof(UnionGroup) * (size_t)ng + 4ull * n + 2 * sizeof(G1Group) * (size_t)ng +
+    PE_TRY(st.reserve(span + 64 + sizeof(UnionGroup) * (size_t)ng + 4ull * n + 3 * sizeof(G1Group) * (size_t)ng +
                       4ull * n + 8192));
     const size_t off_arena = st.alloc(span + 16);
     const size_t off_ug = st.alloc(sizeof(UnionGroup) * (size_t)ng);
@@ -2153,6 +2174,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     const size_t off_g1 = st.alloc(sizeof(G1Group) * (size_t)ng);
     const size_t off_g1s = st.alloc(sizeof(G1Group) * (size_t)ng);
     const size_t off_idx = st.alloc(4ull * n);
+    const size_t off_g1x = xgroups.empty() ? 0 : st.alloc(sizeof(G1Group) * xgroups.size());
     // the caller's bits travel as they are (one copy into the pinned block): k_bits_union reads the members at
     // their byte offsets, masks the tail of the last word and never needs re-packed words
     lap.mark("agg.2a_resolve_reserve");
@@ -2200,6 +2222,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     const size_t off_oinfo = ob.alloc(8ull * ng);
     const size_t off_opk = out_aggpk96 ? ob.alloc(96ull * ng) : 0;
     const size_t off_osig = out_sig96 ? ob.alloc(96ull * ng) : 0;
+    const size_t off_opkx = (out_aggpk96 && !xgroups.empty()) ? ob.alloc(96ull * xgroups.size()) : 0;
     PE_TRY(ob.ensure());
     G1Plan plan_pk, plan_sig;
     int tune_arm = -1;  // >= 0: this call is an autotune trial of shape `tune_arm`
@@ -2224,10 +2247,29 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
                 target = tune_arm ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
             }
         }
-        plan_g1(ng, [&](uint32_t g) { return gres[g].size; }, gr, &plan_pk, G1_WG, target);
+        plan_g1(ng, [&](uint32_t g) { return gres[g].table == table_pk ? gres[g].size : 0u; }, gr, &plan_pk, G1_WG, target);
         for (uint32_t g = 0; g < ng; ++g) {
-            gr[g].member_start = table_pk->offsets[gres[g].pos];
+            gr[g].member_start = gres[g].table == table_pk ? table_pk->offsets[gres[g].pos] : 0u;
             gr[g].bits_word = A.out_word[g];  // the OR-ed bits, device resident: no round trip
+        }
+    }
+    // further tables: their groups (kept in group order, contiguous per table) get descriptor arrays of their own
+    struct XSeg { CommitteeTable* table; uint32_t begin, end; G1Plan plan; };
+    std::vector<XSeg> xsegs;
+    if (!xgroups.empty()) {
+        std::stable_sort(xgroups.begin(), xgroups.end(), [&](uint32_t x, uint32_t y) { return gres[x].table < gres[y].table; });
+        G1Group* grx = st.host<G1Group>(off_g1x);
+        for (uint32_t b = 0; b < xgroups.size();) {
+            uint32_t e = b + 1;
+            while (e < xgroups.size() && gres[xgroups[e]].table == gres[xgroups[b]].table) ++e;
+            XSeg sg{gres[xgroups[b]].table, b, e, G1Plan()};
+            plan_g1(e - b, [&](uint32_t k) { return gres[xgroups[b + k]].size; }, grx + b, &sg.plan);
+            for (uint32_t k = b; k < e; ++k) {
+                grx[k].member_start = sg.table->offsets[gres[xgroups[k]].pos];
+                grx[k].bits_word = A.out_word[xgroups[k]];
+            }
+            xsegs.push_back(sg);
+            b = e;
         }
     }
     if (out_sig96) {
@@ -2262,7 +2304,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
     // (partials for the engine's own exchange follow the same route; partials for a caller's collective never do)
     const bool on_side = want_pk && (!dev_partials || partials_may_defer) && h->pipelining && side_ok && h->side_stream &&
-                         h->stream == h->own_stream;
+                         h->stream == h->own_stream && xgroups.empty();
     h->last_agg_on_side = on_side;
     hipStream_t gs = on_side ? h->side_stream : ms;
     // a previous aggregate of THIS pipeline may still read the arena's d_res_* on the side stream
@@ -2344,6 +2386,14 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
             int rc = launch_g1();
             if (rc) return rc;
         }
+        for (const XSeg& sg : xsegs) {  // further tables: same stream, same scratch, one after the other
+            g1_stream_guard(h, ms);
+            int rc = launch_g1_planned(h, d_points, sg.table->d_members.as<uint32_t>(), d_union,
+                                       st.dev<G1Group>(off_g1x) + sg.begin, sg.plan,
+                                       out_aggpk96 ? ob.host<uint8_t>(off_opkx) + 96ull * sg.begin : nullptr, nullptr, ms);
+            if (rc) return rc;
+            sg.table->stamp = ++h->table_stamp;
+        }
         lap.mark("agg.3d_g1_launch");
         table_pk->stamp = ++h->table_stamp;
     }
@@ -2370,6 +2420,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     A.off_oinfo = off_oinfo;
     A.off_opk = off_opk;
     A.off_osig = off_osig;
+    A.off_opkx = off_opkx;
     A.tune_arm = tune_arm;
     {   // every union a whole number of words (committee sizes that are multiples of 32), except possibly the last one?
         bool same = true;
@@ -2377,7 +2428,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         A.packed_bytes = same ? (size_t)out_bytes : 0;
     }
     const int ai = h->cur;
-    auto complete = [h, stp, info_p, ai]() -> int {
+    auto complete = [h, stp, info_p, ai, xgroups_p]() -> int {
         AggState& S = *stp;
         const uint8_t* pin = h->arena[ai].h_pin.as<uint8_t>() + S.base;
         if (S.tune_arm >= 0) {
@@ -2402,6 +2453,9 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
         }
         info_p->assign(oinfo, oinfo + 2 * (size_t)S.ng);
         if (S.out_aggpk96) memcpy(S.out_aggpk96, pin + S.off_opk, 96ull * S.ng);
+        if (S.out_aggpk96)  // groups of further tables: their sums were computed compacted, per table
+            for (size_t k = 0; k < xgroups_p->size(); ++k)
+                memcpy(S.out_aggpk96 + 96ull * (*xgroups_p)[k], pin + S.off_opkx + 96ull * k, 96);
         if (S.out_sig96) memcpy(S.out_sig96, pin + S.off_osig, 96ull * S.ng);
         return PE_OK;
     };
@@ -2442,6 +2496,8 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     if (n == 0) return PE_OK;
     const bool resident = bits_arena == PE_BITS_RESIDENT;
     if (resident && !h->res_valid) return fail(h, PE_ERR_STATE, "PE_BITS_RESIDENT: no pe_aggregate result is resident");
+    if (!resident && bits_on_device(bits_arena))
+        return fail(h, PE_ERR_INVALID_ARG, "bits in device memory: hand them over through pe_aggregate + PE_BITS_RESIDENT");
     uint32_t tip;
     if (!find_block(h, to_root(st->chain_tip_root), &tip)) return fail(h, PE_ERR_UNKNOWN_ROOT, "chain tip unknown");
     const uint64_t spe = h->cfg.slots_per_epoch;

@@ -347,3 +347,59 @@ def test_arena_in_device_or_pinned_memory(engine_factory):
         for k in ("out_arena", "count", "aggpk96", "group_of"):
             assert np.array_equal(got[k], ref[k]), k
         assert (status == 0).all() and np.array_equal(count, ref["count"])
+    # the handlers re-pack host bits: device memory is refused, not dereferenced
+    dev_arena = cases[0][1]
+    for call in (lambda: e.on_attestation_batch(packed=(ref["atts"], dev_arena)),
+                 lambda: e.process_attestation_batch(w["ctx"], packed=(ref["atts"], dev_arena)),
+                 lambda: e.get_indexed_attestations(packed=(ref["atts"], dev_arena))):
+        with pytest.raises(AssertionError) as ei:
+            call()
+        assert ei.value.status == -1
+
+
+def test_aggregate_across_two_target_epochs(engine_factory):
+    """A batch around an epoch boundary: attestations of two target epochs (two committee tables) in one pe_aggregate
+    with aggregate pubkeys, rows interleaved.  Every group must equal what per-epoch calls give, synchronously and
+    inside a streaming pipeline (where such a batch stays on the engine's stream)."""
+    n_val, n_comm, spe = 20000, 64, 32
+    w = _world(engine_factory, n_val, n_comm, seed=88, density=0.8, parts=2)
+    e, tree, ep = w["e"], w["tree"], w["epoch"]
+    comm2 = synth.random_committees(n_val, n_comm, 89)
+    e.set_committees(ep + 1, comm2.offsets, comm2.members)
+    e.on_tick((ep + 2) * spe * 12)
+    atts2, arena2, _ = synth.epoch_attestations(comm2, tree, ep + 1, spe, seed=89, density=0.6, parts=3,
+                                                source=(0, tree.roots[0].tobytes()))
+    ref1 = e.aggregate(packed=(w["atts"], w["arena"]), want_aggregate_pubkeys=True)
+    ref2 = e.aggregate(packed=(atts2, arena2), want_aggregate_pubkeys=True)
+    both = np.concatenate([w["atts"], atts2])
+    both["bits_offset"][len(w["atts"]):] += w["arena"].size
+    arena = np.concatenate([w["arena"], arena2])
+    order = np.random.default_rng(3).permutation(len(both))
+    both = both[order].copy()
+
+    def key(row):
+        return (int(row["target_epoch"]), int(row["slot"]), int(row["index"]), row["beacon_block_root"].tobytes())
+
+    want = {}
+    for ref in (ref1, ref2):
+        for g in range(ref["n_groups"]):
+            want[key(ref["atts"][g])] = (ref["aggpk96"][g].tobytes(), int(ref["count"][g]), ref["bits"][g])
+
+    def check(got):
+        assert got["n_groups"] == ref1["n_groups"] + ref2["n_groups"] == len(want)
+        for g in range(got["n_groups"]):
+            pk, cnt, bits = want[key(got["atts"][g])]
+            assert got["aggpk96"][g].tobytes() == pk and int(got["count"][g]) == cnt
+            assert np.array_equal(got["bits"][g], bits)
+
+    check(e.aggregate(packed=(both, arena), want_aggregate_pubkeys=True))
+    with e.pipeline(lagged=True):
+        got = e.aggregate(packed=(both, arena), want_aggregate_pubkeys=True)
+        status, _, count = e.on_attestation_batch(packed=(got["atts"], pea.RESIDENT))
+        head = e.get_head()
+    e.drain()
+    check(got)
+    # the clock stands in epoch ep + 2: the rows of epoch ep + 1 are "previous epoch" votes, those of ep are too old
+    newer = got["atts"]["target_epoch"] == ep + 1
+    assert (status[newer] == 0).all() and (status[~newer] != 0).all() and newer.any() and (~newer).any()
+    assert np.array_equal(count[newer], got["count"][newer]) and (count[~newer] == 0).all() and len(head) == 32
