@@ -247,7 +247,9 @@ int pe_pipeline_begin_streaming(pe_engine* h);
  * any order, fields other than flags unchanged): their OR-ed bits are used where pe_aggregate left them in HBM --
  * nothing is re-packed or re-uploaded, and it works inside a pipeline where out_bits_arena is not filled yet.  Rows
  * whose members overlapped (PE_ATT_FLAG_OVERLAPPING_BITS) are rejected with PE_ATT_BAD_SIGNATURE; len(aggregation_bits)
- * must equal the committee length. */
+ * must equal the committee length.  A row that is not a row of the last pe_aggregate -- e.g. one of an earlier
+ * aggregate of the same pipeline, which a later one replaced -- fails the call with PE_ERR_INVALID_ARG (rows are
+ * recognised by bits_offset, n_bits and a fold of their AttestationData), nothing applied. */
 #define PE_BITS_RESIDENT ((const uint8_t*)(uintptr_t)1)
 
 /* ---- the hot path ------------------------------------------------------ */

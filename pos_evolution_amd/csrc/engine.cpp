@@ -262,7 +262,9 @@ struct pe_engine {
     bool streaming = false;             // pe_pipeline_begin_streaming: G1 launches are deferred to the pipeline's end
     std::vector<std::function<int()>> deferred;  // ... these
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
-    struct ResGroup { uint32_t byte_off, n_bits, word, sig_valid; };
+    // tag: a fold of the group's AttestationData -- a row handed over as resident must BE a row of the resident aggregate,
+    // not merely sit at the same offset as one (two aggregates of equal shape lay their unions out alike)
+    struct ResGroup { uint32_t byte_off, n_bits, word, sig_valid, tag; };
     std::vector<ResGroup> res_groups;     // sorted by byte_off (= group order)
     std::shared_ptr<std::vector<uint32_t>> res_info_host;  // copy of d_res_info, filled when that aggregate completes
     bool res_valid = false;
@@ -1711,12 +1713,21 @@ static bool bits_on_device(const uint8_t* bits_arena)
 
 // ---------------------------------------------------------------- on_attestation
 // Rows handed over resident (bits_arena == PE_BITS_RESIDENT): which group of the last pe_aggregate is this row?
+static inline uint32_t att_data_tag(const pe_attestation& a)
+{
+    uint32_t r0, r1;
+    memcpy(&r0, a.beacon_block_root, 4);
+    memcpy(&r1, a.target_root, 4);
+    return (uint32_t)a.slot * 0x9E3779B1u ^ (uint32_t)a.index * 0x85EBCA6Bu ^ (uint32_t)a.target_epoch * 0xC2B2AE35u ^ r0 ^
+           (r1 << 1);
+}
 static bool find_resident(const pe_engine* h, const pe_attestation& a, uint32_t* g_out, uint32_t guess)
 {
     if (!h->res_valid) return false;
     const auto& rg = h->res_groups;
-    if (guess < rg.size() && rg[guess].byte_off == a.bits_offset && rg[guess].n_bits == a.n_bits) {  // rows in group order
-        *g_out = guess;
+    const uint32_t tag = att_data_tag(a);
+    if (guess < rg.size() && rg[guess].byte_off == a.bits_offset && rg[guess].n_bits == a.n_bits && rg[guess].tag == tag) {
+        *g_out = guess;  // rows in group order
         return true;
     }
     size_t lo = 0, hi = rg.size();
@@ -1725,7 +1736,7 @@ static bool find_resident(const pe_engine* h, const pe_attestation& a, uint32_t*
         if (rg[mid].byte_off < a.bits_offset) lo = mid + 1; else hi = mid;
     }
     for (; lo < rg.size() && rg[lo].byte_off == a.bits_offset; ++lo)
-        if (rg[lo].n_bits == a.n_bits) { *g_out = (uint32_t)lo; return true; }
+        if (rg[lo].n_bits == a.n_bits && rg[lo].tag == tag) { *g_out = (uint32_t)lo; return true; }
     return false;
 }
 
@@ -2290,7 +2301,7 @@ static int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, 
     *out_n_groups = ng;
     h->res_groups.resize(ng);
     for (uint32_t g = 0; g < ng; ++g)
-        h->res_groups[g] = {A.out_byte_off[g], atts[rep[g]].n_bits, A.out_word[g], A.all_valid[g]};
+        h->res_groups[g] = {A.out_byte_off[g], atts[rep[g]].n_bits, A.out_word[g], A.all_valid[g], att_data_tag(atts[rep[g]])};
     auto info_p = std::make_shared<std::vector<uint32_t>>();
     h->res_info_host = info_p;
     h->res_valid = true;

@@ -146,3 +146,47 @@ def test_destroy_and_reinit_with_pipelines_in_flight(engine_factory):
     got2 = [_step_streaming(w2) for _ in range(2)]
     w2["e"].close()
     _same_results(ref, got2[0])
+
+
+@pytest.mark.parametrize("lagged", [False, True])
+def test_two_aggregates_in_one_pipeline(engine_factory, lagged):
+    """Two pe_aggregate calls inside one pipeline (the slots of an epoch in two halves): the second replaces the first as
+    the resident aggregate, both share the arena's G1 scratch on the side stream, and each one's rows are handed to the
+    handlers right after it.  Outputs equal the synchronous calls on a twin engine."""
+    wa = _world(engine_factory, 30000, 128, seed=71, density=0.85, parts=2)
+    wb = _world(engine_factory, 30000, 128, seed=71, density=0.85, parts=2)
+    first = wa["atts"]["slot"] % 32 < 16
+    halves = []
+    for mask in (first, ~first):
+        halves.append(np.ascontiguousarray(wa["atts"][mask]))
+    ref = []
+    ea = wa["e"]
+    for atts in halves:
+        agg = ea.aggregate(packed=(atts, wa["arena"]), want_aggregate_pubkeys=True)
+        st, _, cnt = ea.on_attestation_batch(packed=(agg["atts"], agg["out_arena"]))
+        ref.append((agg, st, cnt))
+    ref_head = ea.get_head()
+    e = wb["e"]
+    got = []
+    for rep in range(2):   # twice: the second round re-uses arenas that have two completions each
+        got = []
+        with e.pipeline(lagged=lagged):
+            for atts in halves:
+                agg = e.aggregate(packed=(atts, wb["arena"]), want_aggregate_pubkeys=True)
+                st, _, cnt = e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+                got.append((agg, st, cnt))
+            head = e.get_head()
+        e.drain()
+    for (ra, rs, rc), (ga, gs, gc) in zip(ref, got):
+        assert ga["n_groups"] == ra["n_groups"]
+        for k in ("aggpk96", "count", "out_arena", "group_of"):
+            assert np.array_equal(ga[k], ra[k]), k
+        assert np.array_equal(gs, rs) and np.array_equal(gc, rc) and (gs == 0).all()
+    assert head == ref_head
+    assert np.array_equal(e.get_weights(), ea.get_weights())
+    # the first aggregate is no longer resident once the second one was made
+    with pytest.raises(AssertionError):
+        with e.pipeline():
+            a1 = e.aggregate(packed=(halves[0], wb["arena"]), want_aggregate_pubkeys=True)
+            e.aggregate(packed=(halves[1], wb["arena"]), want_aggregate_pubkeys=True)
+            e.on_attestation_batch(packed=(a1["atts"], pea.RESIDENT))
