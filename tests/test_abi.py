@@ -93,3 +93,22 @@ def test_header_is_plain_c_and_cxx(tmp_path):
                            "-Wl,-rpath," + libdir])
     env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     assert subprocess.call([str(exe)], env=env) == 0
+
+
+def test_example_c_client_builds_against_the_header(tmp_path):
+    """examples/step_client.c (the whole step through the C ABI) compiles warning-free as C99 against include/posevo.h
+    and links against the library; without a GPU it must stop at pe_engine_create, not crash."""
+    import subprocess
+    libdir = os.path.join(ROOT, "pos_evolution_amd")
+    exe = tmp_path / "step_client"
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-Wall", "-Wextra", "-Werror", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "step_client.c"), "-o", str(exe),
+                           "-L", libdir, "-lposevo", "-Wl,-rpath," + libdir])
+    wl = tmp_path / "w.bin"
+    import struct
+    wl.write_bytes(struct.pack("<8Q", 0x30764F5645534F50, 0, 32, 1, 0, 32, 0, 0) + bytes(32 + 4 + 8))
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe), str(wl), "sync"], env=env, capture_output=True, text=True)
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode == 1 and "pe_engine_create" in out.stderr
