@@ -283,6 +283,7 @@ struct pe_engine {
 
     // ---- RCCL inside the engine (pe_dist_*): one communicator per handle, collectives on the engine's stream ----
     ncclComm_t comm = nullptr, comm_g1 = nullptr;  // get_head's all-reduce (engine stream) | the G1 partials' all-gather
+    int early_rc = PE_OK;                           // status of a completion run ahead of its pipeline end (complete_oldest_if_ready)
     uint32_t xchg_blocks = 0;                       // block count / registry size d_xchg was last laid out for
     uint64_t xchg_nval = 0;
     bool last_agg_on_side = false;                  // the last aggregate's G1 chain went to the side / finishing streams
@@ -396,10 +397,27 @@ int complete_arena(pe_engine* h, int ai)
     }
     return rc;
 }
+// A streaming pipeline's pe_get_head has ~25 us to spare between launching k_tree and seeing the head: spend them on
+// the completion (copy-out of ~330 KB) of the oldest lagged pipeline, if the device is already through with it --
+// pe_pipeline_end_lagged would otherwise do that work after this step's calls.  A failing completion is reported by the
+// next call that completes pipelines.
+void complete_oldest_if_ready(pe_engine* h)
+{
+    const int ai = (h->cur + 1) % pe_engine::N_ARENAS;
+    pe_engine::PipeArena& a = h->arena[ai];
+    if (!a.fenced || a.pending.empty()) return;
+    if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess)) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+        return;
+    }
+    const int rc = complete_arena(h, ai);
+    if (rc && !h->early_rc) h->early_rc = rc;
+}
 // Everything: the lagged arena first (it is the older one), then the current one.
 int flush_pending(pe_engine* h)
 {
-    int rc = PE_OK;
+    int rc = h->early_rc;
+    h->early_rc = PE_OK;
     for (int k = 1; k <= pe_engine::N_ARENAS; ++k) {  // oldest first, the current one last
         const int r = complete_arena(h, (h->cur + k) % pe_engine::N_ARENAS);
         if (r && !rc) rc = r;
@@ -958,7 +976,10 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
     HIP_TRY(h, hipGetLastError());
     // a streaming pipeline's G1 sums go out now, ordered behind k_tree on the device: they start the moment the head
     // is known, and their launch calls overlap the fork-choice kernels instead of following the poll below
-    if (h->streaming) PE_TRY(run_deferred(h));
+    if (h->streaming) {
+        PE_TRY(run_deferred(h));
+        complete_oldest_if_ready(h);
+    }
     // k_tree's last act is a system-scope release store of the head index into this host-coherent word: polling it
     // sees the result a few microseconds before hipStreamSynchronize returns.  Bounded: after ~200 us (a hung or
     // faulted kernel) the stream sync takes over and reports the error.
@@ -3453,7 +3474,9 @@ int pe_pipeline_end_lagged(pe_engine* h)
     a.fenced = true;
     h->side_busy = false;   // accounted for by the fence from here on
     h->cur = (h->cur + 1) % pe_engine::N_ARENAS;
-    const int rc = complete_arena(h, h->cur);  // the oldest pipeline still in flight (two back): its arena is reused next
+    int rc = complete_arena(h, h->cur);  // the oldest pipeline still in flight (two back): its arena is reused next
+    if (!rc) rc = h->early_rc;           // ... unless pe_get_head found it ready and completed it already
+    h->early_rc = PE_OK;
     lap.mark("pipe.end_lagged_wait_previous");
     return rc;
 }
