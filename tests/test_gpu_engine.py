@@ -98,6 +98,13 @@ def test_get_head_vs_oracle(engine_factory, n_val, n_blocks, kind, boost, mixed)
     w_e = e.get_weights()
     assert np.array_equal(w_e, w_o)
     assert e.get_head() == tree.roots[head_o].tobytes()
+    # inside pipelined calls get_head runs its lean shapes (k_votes<1>; k_tree<512, 4> / <512, 8> from 1025 to 4096
+    # blocks): same head, same per-block weights
+    for lagged in (False, True):
+        with e.pipeline(lagged=lagged):
+            assert e.get_head() == tree.roots[head_o].tobytes()
+        e.drain()
+        assert np.array_equal(e.last_weights(), w_o)
 
 
 def _install_votes(e, tree, comm, vote):
