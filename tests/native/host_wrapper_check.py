@@ -1,0 +1,116 @@
+"""Run by tests/test_host_wrapper.py in a subprocess with POSEVO_LIB_PATH pointing at a STUB of libposevo.so (every
+entry point of include/posevo.h present, none of them computing anything): what is checked here is the host logic of the
+Python package above the C ABI -- argument marshalling, the output-set ring, pipeline book-keeping, the pyspec-level
+guards of forkchoice.py -- which needs no GPU."""
+import ctypes as C
+import sys
+import types
+
+import numpy as np
+
+import pos_evolution_amd as pea
+import pos_evolution_amd.forkchoice as fc
+import pos_evolution_amd.synth as synth
+from pos_evolution_amd import _abi
+
+lib = _abi.load()
+log = (C.c_char * 65536).in_dll(lib, "stub_log")
+
+
+def calls():
+    names = bytes(log.value).decode().split()
+    lib.stub_reset()
+    return names
+
+
+# ---- pack_attestations: rows -> 144-byte records + one bit arena ----
+rows = [pea.AttRow(slot=5, index=1, beacon_block_root=b"\x11" * 32, source_epoch=0, source_root=b"\x00" * 32,
+                   target_epoch=0, target_root=b"\x22" * 32, bits=[True, False, True] + [False] * 9 + [True],
+                   signature_valid=True, is_from_block=False),
+        pea.AttRow(slot=6, index=0, beacon_block_root=b"\x33" * 32, source_epoch=0, source_root=b"\x00" * 32,
+                   target_epoch=0, target_root=b"\x22" * 32, bits=[False] * 7 + [True], signature_valid=False,
+                   is_from_block=True)]
+arr, arena = pea.pack_attestations(rows)
+view = np.frombuffer(arr, dtype=synth.ATT_DTYPE, count=2)
+assert list(view["n_bits"]) == [13, 8] and list(view["bits_offset"]) == [0, 2]
+assert bytes(arena[:3]) == bytes([0b00000101, 0b00010000, 0b10000000])
+assert list(view["flags"]) == [_abi.PE_ATT_FLAG_SIGNATURE_VALID, _abi.PE_ATT_FLAG_FROM_BLOCK]
+assert view["beacon_block_root"][1].tobytes() == b"\x33" * 32 and int(view["slot"][0]) == 5
+
+# ---- Engine: create / call order / output-set ring / pipelines ----
+e = pea.Engine()
+assert calls()[:1] == ["pe_engine_create"]
+atts = np.zeros(8, dtype=synth.ATT_DTYPE)
+atts["n_bits"], atts["bits_offset"] = 64, np.arange(8) * 8
+bits = np.zeros(64, dtype=np.uint8)
+ctx = _abi.pe_state_ctx()
+
+
+def step(lagged):
+    with e.pipeline(lagged=lagged):
+        agg = e.aggregate(packed=(atts, bits), want_aggregate_pubkeys=True)
+        st, _, cnt = e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+        head = e.get_head()
+        pst, num = e.process_attestation_batch(ctx, packed=(agg["atts"], pea.RESIDENT))
+    return agg, st, cnt, pst, num, head
+
+
+r = step(False)
+assert calls() == ["pe_pipeline_begin", "pe_aggregate", "pe_on_attestation_batch", "pe_get_head",
+                   "pe_process_attestation_batch", "pe_pipeline_end"]
+assert r[0]["n_groups"] == 2 and len(r[0]["atts"]) == 2 and r[0]["aggpk96"].shape == (2, 96)   # the stub forms n / 4 groups
+assert r[0]["out_arena"].size == 8 + 8            # trimmed to the last group's bits (stub: offsets 0 and 8, 64 bits each)
+r = step(True)
+assert calls() == ["pe_pipeline_begin_streaming", "pe_aggregate", "pe_on_attestation_batch", "pe_get_head",
+                   "pe_process_attestation_batch", "pe_pipeline_end_lagged"]
+# without reuse_outputs every call gets fresh arrays; with a ring of depth d the arrays of pipeline k return at k + d
+a1, a2 = step(True), step(True)
+assert a1[1].ctypes.data != a2[1].ctypes.data
+e.reuse_outputs(3)
+ring = [step(True) for _ in range(7)]
+addr = [x[1].ctypes.data for x in ring]
+assert len(set(addr[:3])) == 3 and addr[3:6] == addr[:3] and addr[6] == addr[0]
+assert all(ring[k][0]["aggpk96"].ctypes.data == ring[k + 3][0]["aggpk96"].ctypes.data for k in range(4))
+e.drain()
+assert "pe_pipeline_end" in calls()
+# a DeviceArena travels as its address; the host-repacking calls never see one from the wrapper's own paths
+dev = pea.DeviceArena(0xDEAD0000, 64)
+with e.pipeline():
+    e.aggregate(packed=(atts, dev))
+lib.stub_last_arena.restype = C.c_size_t
+assert lib.stub_last_arena() == 0xDEAD0000
+
+# ---- error mapping: a failing status raises EngineError carrying it ----
+lib.stub_fail_next(-10)
+try:
+    e.get_head()
+    raise SystemExit("expected EngineError")
+except pea.EngineError as err:
+    assert err.status == -10 and isinstance(err, AssertionError)
+
+# ---- forkchoice.py guards ----
+store = fc.Store(e)
+store.balances_checkpoint = fc.Checkpoint(3, b"\x01" * 32)      # the engine's balances belong to another checkpoint
+try:
+    fc.get_head(store)
+    raise SystemExit("get_head must refuse balances of another justified state")
+except pea.EngineError as err:
+    assert err.status == _abi.PE_ERR_STATE
+seen = []
+state = types.SimpleNamespace(slot=64, validators=[types.SimpleNamespace(effective_balance=32 * 10**9, activation_epoch=0,
+                                                                        exit_epoch=2**64 - 1, slashed=False, pubkey=None)] * 4)
+store.checkpoint_state_provider = lambda cp: (seen.append(cp), state)[1]
+lib.stub_reset()
+assert len(fc.get_head(store)) == 32 and len(seen) == 1
+assert "pe_set_validators" in calls() and store.balances_checkpoint == store.justified_checkpoint
+fc.get_head(store)
+assert len(seen) == 1                                            # provider asked once per justified checkpoint
+# process_attestation: unbound state / missing proposer are refused before anything reaches the engine
+st2 = types.SimpleNamespace()
+for kwargs in ({}, {"proposer_index": 0}):
+    try:
+        fc.process_attestation(st2, object(), **kwargs)
+        raise SystemExit("process_attestation must refuse an unbound state")
+    except AssertionError:
+        pass
+print("host wrapper ok")
