@@ -113,4 +113,16 @@ for kwargs in ({}, {"proposer_index": 0}):
         raise SystemExit("process_attestation must refuse an unbound state")
     except AssertionError:
         pass
+# ---- sharded.py over the engine's own collectives: id from rank 0, init, then the two sharded calls ----
+from pos_evolution_amd.sharded import ShardedForkChoice
+lib.stub_reset()
+sh = ShardedForkChoice(e, n_groups_max=4, use_engine_rccl=True)
+assert calls() == ["pe_dist_unique_id", "pe_dist_init"]
+assert len(sh.get_head()) == 32
+with e.pipeline(lagged=True):
+    res = sh.aggregate(packed=(atts, bits))
+    e.on_attestation_batch(packed=(res["atts"], pea.RESIDENT))
+    sh.get_head()
+assert calls() == ["pe_get_head_sharded", "pe_pipeline_begin_streaming", "pe_aggregate_sharded", "pe_on_attestation_batch",
+                   "pe_get_head_sharded", "pe_pipeline_end_lagged"]
 print("host wrapper ok")
