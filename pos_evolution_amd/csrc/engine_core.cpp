@@ -1,0 +1,413 @@
+// engine_core.cpp -- lifecycle of the handle, completion of batch calls (arenas, pipelines), profiling hooks.
+//
+// There is NO CPU fallback: every hot-path entry point fails with PE_ERR_NO_DEVICE when the HIP device is unavailable.
+#include "engine_internal.h"
+
+using namespace posevo;
+
+namespace posevo {
+
+// ------------------------------------------------------------------ errors
+int fail(pe_engine* h, int code, const std::string& msg)
+{
+    if (h) h->last_error = msg;
+    return code;
+}
+int hip_fail(pe_engine* h, hipError_t e, const char* what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    return fail(h, e == hipErrorOutOfMemory ? PE_ERR_OOM : PE_ERR_NO_DEVICE, m);
+}
+
+// ------------------------------------------------------------------ completion of batch calls
+// Launches a streaming pipeline held back (the G1 sums of its pe_aggregate): issue them now.
+int run_deferred(pe_engine* h)
+{
+    if (h->deferred.empty()) return PE_OK;
+    std::vector<std::function<int()>> todo;
+    todo.swap(h->deferred);
+    int rc = PE_OK;
+    for (auto& f : todo) {
+        const int r = f();
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+// Wait for what the batch calls put into one arena, then run their completions in call order.
+int complete_arena(pe_engine* h, int ai)
+{
+    pe_engine::PipeArena& a = h->arena[ai];
+    if (a.pending.empty() && !a.fenced && a.stage_cursor == 0 && a.out_cursor == 0) return PE_OK;
+    if (ai == h->cur) PE_TRY(run_deferred(h));  // deferred launches belong to the arena the calls are going into
+    hipError_t e = hipSuccess;
+    if (a.fenced) {  // a lagged pipeline: its end was marked on both streams
+        e = hipEventSynchronize(a.ev_main);
+        if (a.side_used) {
+            hipError_t e2 = hipEventSynchronize(a.ev_side);
+            if (e == hipSuccess) e = e2;
+        }
+    } else {         // the arena the calls are still going into
+        e = hipStreamSynchronize(h->stream);
+        if (h->side_busy) {
+            hipError_t e2 = hipStreamSynchronize(h->side_stream);
+            if (e == hipSuccess) e = e2;
+            e2 = hipStreamSynchronize(h->fin_stream);
+            if (e == hipSuccess) e = e2;
+            h->side_busy = false;
+        }
+    }
+    std::vector<std::function<int()>> todo;
+    todo.swap(a.pending);
+    a.stage_cursor = a.out_cursor = 0;
+    a.fenced = a.side_used = false;
+    if (e != hipSuccess) return hip_fail(h, e, "waiting for the enqueued batch calls");
+    int rc = PE_OK;
+    for (auto& f : todo) {
+        const int r = f();
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+// A streaming pipeline's pe_get_head has ~25 us to spare between launching k_tree and seeing the head: spend them on
+// the completion (copy-out of ~330 KB) of the oldest lagged pipeline, if the device is already through with it --
+// pe_pipeline_end_lagged would otherwise do that work after this step's calls.  A failing completion is reported by the
+// next call that completes pipelines.
+void complete_oldest_if_ready(pe_engine* h)
+{
+    const int ai = (h->cur + 1) % pe_engine::N_ARENAS;
+    pe_engine::PipeArena& a = h->arena[ai];
+    if (!a.fenced || a.pending.empty()) return;
+    if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess)) {
+        (void)hipGetLastError();  // hipErrorNotReady is not an error here
+        return;
+    }
+    const int rc = complete_arena(h, ai);
+    if (rc && !h->early_rc) h->early_rc = rc;
+}
+// Everything: the lagged arena first (it is the older one), then the current one.
+int flush_pending(pe_engine* h)
+{
+    int rc = h->early_rc;
+    h->early_rc = PE_OK;
+    for (int k = 1; k <= pe_engine::N_ARENAS; ++k) {  // oldest first, the current one last
+        const int r = complete_arena(h, (h->cur + k) % pe_engine::N_ARENAS);
+        if (r && !rc) rc = r;
+    }
+    return rc;
+}
+
+// Register a batch call's completion.  Outside a pipeline: wait now and run it (the call is synchronous, as
+// include/posevo.h promises).  Inside one: advance the cursors and return; pe_pipeline_end waits once.
+int finish_call(pe_engine* h, const Stage& st, const OutBlock& ob, std::function<int()> complete, bool force_sync)
+{
+    h->A().pending.push_back(std::move(complete));
+    h->A().stage_cursor = st.end();
+    h->A().out_cursor = ob.end();
+    if (!h->pipelining || force_sync) return flush_pending(h);
+    return PE_OK;
+}
+
+// A device buffer other enqueued work may still read: wait for that work before re-allocating it.
+int ensure_quiesced(pe_engine* h, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return PE_OK;
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, b.ensure(bytes));
+    return PE_OK;
+}
+
+// Entry of a call that is not part of the pipelined hot path: complete whatever the batch calls left enqueued.
+int enter(pe_engine* h)
+{
+    (void)hipSetDevice(h->device);
+    return flush_pending(h);
+}
+int need_init(pe_engine* h, bool flush)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    if (!h->initialised) return fail(h, PE_ERR_STATE, "store not initialised: call pe_store_init first");
+    (void)hipSetDevice(h->device);
+    return flush ? flush_pending(h) : PE_OK;
+}
+
+}  // namespace posevo
+
+extern "C" {
+
+uint32_t pe_abi_version(void) { return PE_ABI_VERSION; }
+
+void pe_config_default(pe_config* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->slots_per_epoch = 32;
+    c->seconds_per_slot = 12;
+    c->intervals_per_slot = 3;
+    c->safe_slots_to_update_justified = 8;
+    c->proposer_score_boost = 40;
+    c->effective_balance_increment = 1000000000ull;
+    c->min_attestation_inclusion_delay = 1;
+    c->max_validators_per_committee = 2048;
+    c->filter_slashed = 0;
+    c->device = -1;
+}
+
+const char* pe_strerror(int status)
+{
+    switch (status) {
+        case PE_OK: return "ok";
+        case PE_ERR_INVALID_ARG: return "invalid argument";
+        case PE_ERR_NO_DEVICE: return "no HIP device / HIP runtime failure";
+        case PE_ERR_OOM: return "out of memory";
+        case PE_ERR_UNKNOWN_PARENT: return "on_block: parent block unknown";
+        case PE_ERR_FUTURE_BLOCK: return "on_block: block is from the future";
+        case PE_ERR_NOT_AFTER_FINALIZED: return "on_block: block slot not after the finalized slot";
+        case PE_ERR_NOT_FINALIZED_DESCENDANT: return "on_block: block does not descend from the finalized checkpoint";
+        case PE_ERR_DUPLICATE_BLOCK: return "block already in the store";
+        case PE_ERR_UNKNOWN_ROOT: return "unknown root";
+        case PE_ERR_CAPACITY: return "capacity exceeded";
+        case PE_ERR_NO_COMMITTEES: return "no committee table for the epoch";
+        case PE_ERR_NOT_SLASHABLE: return "attestation data not slashable";
+        case PE_ERR_INVALID_INDEXED: return "invalid indexed attestation";
+        case PE_ERR_STATE: return "call sequence error";
+        default: return "unknown status";
+    }
+}
+const char* pe_last_error(const pe_engine* h) { return h ? h->last_error.c_str() : ""; }
+
+int pe_engine_create(const pe_config* cfg, pe_engine** out)
+{
+    if (!out) return PE_ERR_INVALID_ARG;
+    *out = nullptr;
+    pe_config c;
+    if (cfg) c = *cfg; else pe_config_default(&c);
+    if (c.slots_per_epoch == 0 || c.seconds_per_slot == 0 || c.intervals_per_slot == 0 ||
+        c.effective_balance_increment == 0)
+        return PE_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return PE_ERR_NO_DEVICE;  // no CPU fallback
+    int dev = c.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return PE_ERR_NO_DEVICE;
+    }
+    if (dev >= ndev) return PE_ERR_INVALID_ARG;
+    if (hipSetDevice(dev) != hipSuccess) return PE_ERR_NO_DEVICE;
+    pe_engine* h = new (std::nothrow) pe_engine();
+    if (!h) return PE_ERR_OOM;
+    h->cfg = c;
+    h->device = dev;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return PE_ERR_NO_DEVICE;
+    }
+    h->stream = h->own_stream;
+    // Pipelined steps run three things at once: the fork-choice kernels of step N+1, k_g1_accumulate of step N and
+    // k_g1_finish of step N-1/N, each on its own stream.  (CU-masked streams -- a private CU partition for the
+    // latency-sized fork-choice kernels -- were measured and dropped: hipExtStreamCreateWithCUMask with 16 / 32 / 48
+    // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
+    const bool ok_streams = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess &&
+                            hipStreamCreateWithFlags(&h->fin_stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok_streams ||
+        hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[0].ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[0].ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[1].ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[1].ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[2].ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[2].ev_side, hipEventDisableTiming) != hipSuccess) {
+        pe_engine_destroy(h);
+        return PE_ERR_NO_DEVICE;
+    }
+    h->tables.reserve(c.max_committee_tables ? c.max_committee_tables : 4u);
+    *out = h;
+    return PE_OK;
+}
+
+void pe_engine_destroy(pe_engine* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)flush_pending(h);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
+    if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
+    h->d_xchg.release();
+    h->d_xpart.release();
+    h->d_xgather.release();
+    for (auto& a : h->arena) {
+        a.d_res_bits.release();
+        a.d_res_info.release();
+        a.d_partials.release();
+        a.d_lane_partials.release();
+        a.d_stage.release();
+        a.d_outblk.release();
+        a.h_stage.release();
+        a.h_pin.release();
+        if (a.ev_main) (void)hipEventDestroy(a.ev_main);
+        if (a.ev_side) (void)hipEventDestroy(a.ev_side);
+    }
+    for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
+                      &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
+                      &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head,
+                      &h->d_partials, &h->d_lane_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
+        b->release();
+    for (auto& t : h->tables) { t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release(); }
+    h->h_head.release();
+    for (auto& p : h->prof)
+        for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (hipEvent_t ev : h->g1_tune_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->event_pool) (void)hipEventDestroy(ev);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->fin_stream) (void)hipStreamDestroy(h->fin_stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->trace.on && h->g1_tune_calls)
+        fprintf(stderr, "[posevo host] accumulate autotune: 131072 slots %.3f ms, 65536 slots %.3f ms -> %u\n",
+                h->g1_tune_best[0], h->g1_tune_best[1], h->g1_target_slots);
+    if (h->trace.on)
+        for (auto& kv : h->trace.acc) {
+            std::vector<float> v = kv.second.all;
+            std::sort(v.begin(), v.end());
+            fprintf(stderr, "[posevo host] %-30s calls %5llu  avg %8.1f  min %8.1f  p50 %8.1f  max %8.1f us\n",
+                    kv.first.c_str(), (unsigned long long)kv.second.n, kv.second.sum / kv.second.n, kv.second.mn,
+                    v.empty() ? 0.0 : (double)v[v.size() / 2], kv.second.mx);
+        }
+    delete h;
+}
+
+int pe_set_stream(pe_engine* h, void* hip_stream)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- pipelined calls
+int pe_pipeline_begin(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    PE_TRY(complete_arena(h, h->cur));  // a lagged pipeline in the other arena stays in flight
+    // Steps of a stream look alike: size this (idle) arena like the largest one now, instead of growing it call by call
+    // inside the pipeline -- a growth there waits for everything enqueued and re-allocates pinned memory (milliseconds).
+    {
+        pe_engine::PipeArena& a = h->A();
+        size_t stage = 0, out = 0, bits = 0, info = 0, part = 0, lane = 0;
+        for (auto& o : h->arena) {
+            stage = std::max(stage, std::min(o.d_stage.cap, o.h_stage.cap));
+            out = std::max(out, std::min(o.d_outblk.cap, o.h_pin.cap));
+            bits = std::max(bits, o.d_res_bits.cap);
+            info = std::max(info, o.d_res_info.cap);
+            part = std::max(part, o.d_partials.cap);
+            lane = std::max(lane, o.d_lane_partials.cap);
+        }
+        if (stage) { HIP_TRY(h, a.d_stage.ensure(stage)); HIP_TRY(h, a.h_stage.ensure(stage)); }
+        if (out) { HIP_TRY(h, a.d_outblk.ensure(out)); HIP_TRY(h, a.h_pin.ensure(out)); }
+        if (bits) HIP_TRY(h, a.d_res_bits.ensure(bits));
+        if (info) HIP_TRY(h, a.d_res_info.ensure(info));
+        if (part) HIP_TRY(h, a.d_partials.ensure(part));
+        if (lane) HIP_TRY(h, a.d_lane_partials.ensure(lane));
+    }
+    h->pipelining = true;
+    return PE_OK;
+}
+int pe_pipeline_end(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    h->pipelining = false;
+    h->streaming = false;
+    HostLap lap(&h->trace);
+    const int rc = flush_pending(h);
+    lap.mark("pipe.end_wait_outputs");
+    return rc;
+}
+
+int pe_pipeline_begin_streaming(pe_engine* h)
+{
+    const int rc = pe_pipeline_begin(h);
+    if (rc == PE_OK) h->streaming = true;
+    return rc;
+}
+
+int pe_pipeline_end_lagged(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    h->pipelining = false;
+    h->streaming = false;
+    HostLap lap(&h->trace);
+    PE_TRY(run_deferred(h));  // the step's G1 sums start now, behind its fork-choice kernels
+    lap.mark("pipe.end_lagged_launch_g1");
+    pe_engine::PipeArena& a = h->A();
+    // mark the end of this pipeline on both streams; its completions run when the NEXT lagged end (or any
+    // synchronous call) has waited for the marks
+    HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
+    if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->fin_stream));  // the last kernel of the G1 chain runs there
+    a.fenced = true;
+    h->side_busy = false;   // accounted for by the fence from here on
+    h->cur = (h->cur + 1) % pe_engine::N_ARENAS;
+    int rc = complete_arena(h, h->cur);  // the oldest pipeline still in flight (two back): its arena is reused next
+    if (!rc) rc = h->early_rc;           // ... unless pe_get_head found it ready and completed it already
+    h->early_rc = PE_OK;
+    lap.mark("pipe.end_lagged_wait_previous");
+    return rc;
+}
+
+// ---------------------------------------------------------------- profiling
+int pe_profile_enable(pe_engine* h, int on)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    h->profiling = on != 0;
+    if (h->profiling)
+        while (h->event_pool.size() < 4096) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            h->event_pool.push_back(e);
+        }
+    return PE_OK;
+}
+static void prof_drain(pe_engine* h)
+{
+    (void)flush_pending(h);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    for (auto& p : h->prof) {
+        for (auto& ev : p.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { p.total_ms += ms; p.launches += 1; }
+            h->event_pool.push_back(ev.first);
+            h->event_pool.push_back(ev.second);
+        }
+        p.pending.clear();
+    }
+}
+int pe_profile_reset(pe_engine* h)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    prof_drain(h);
+    for (auto& p : h->prof) { p.launches = 0; p.total_ms = 0; }
+    return PE_OK;
+}
+int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms)
+{
+    if (!h || kernel < 0 || kernel >= PE_KERNEL_COUNT) return PE_ERR_INVALID_ARG;
+    prof_drain(h);
+    if (launches) *launches = h->prof[kernel].launches;
+    if (total_ms) *total_ms = h->prof[kernel].total_ms;
+    return PE_OK;
+}
+
+
+}  // extern "C"

@@ -1,0 +1,350 @@
+// engine_g1.cpp -- G1 sums: planning + launch of the three-kernel sum (accumulate / tree / finish); plain G1 and G2
+// sums over caller-chosen groups; the BLSPubkey / BLSSignature wire formats (pe:37, pe:717).
+#include "engine_internal.h"
+
+using namespace posevo;
+
+namespace posevo {
+
+// G1 work of one pe_aggregate may run on the side stream (pipelined calls): anything else that is about to use the
+// shared G1 scratch (d_partials) on another stream first waits for it.
+void g1_stream_guard(pe_engine* h, hipStream_t s)
+{
+    // ev_join marks the end of the last G1 launch on the side stream (a lagged pipeline may still be running it);
+    // waiting on a completed event costs nothing
+    if (h->side_ever && s != h->side_stream && s != h->fin_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+}
+
+// Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
+// fin != s: the tree and finish kernels go to their own stream behind an event (a pipelined aggregate: they then overlap
+// the next aggregate's accumulation); partials / lane_partials: the scratch the kernels hand over through (per arena
+// when pipelined).
+int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
+                      const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
+                      hipStream_t s, hipStream_t fin, DevBuf* partials, DevBuf* lane_partials)
+{
+    if (plan.n_groups == 0) return PE_OK;
+    if (!s) s = h->stream;
+    if (!fin) fin = s;
+    if (!partials) partials = &h->d_partials;
+    if (!lane_partials) lane_partials = &h->d_lane_partials;
+    PE_TRY(ensure_quiesced(h, *partials,
+                           std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
+    const size_t lane_bytes = (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan.n_slots + G1_WG - 1) / G1_WG);
+    PE_TRY(ensure_quiesced(h, *lane_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, lane_bytes)));
+    {
+        ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s);
+        launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>());
+    }
+    if (fin != s) {
+        HIP_TRY(h, hipEventRecord(h->ev_acc, s));
+        HIP_TRY(h, hipStreamWaitEvent(fin, h->ev_acc, 0));
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G1_TREE, fin);
+        launch_g1_tree(fin, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
+                       /*one_per_cu=*/fin != s ? 1 : 0);  // on its own stream it meets the next step's k_tree: leave it room
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G1_NORMALISE, fin);
+        launch_g1_finish(fin, partials->as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac);
+    }
+    HIP_TRY(h, hipGetLastError());
+    return PE_OK;
+}
+
+}  // namespace posevo
+
+extern "C" {
+
+// ---------------------------------------------------------------- plain G1 sums
+// Shared by pe_g1_sum / pe_g1_partial: groups over an optional index list, staged and launched.
+static int g1_sum_common(pe_engine* h, const uint32_t* d_pts, uint64_t n_pts, const uint32_t* index,
+                         const uint32_t* offsets, uint32_t n_groups, uint8_t* out96_host, uint32_t* dev_jac)
+{
+    const uint32_t total = offsets[n_groups];
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
+    if (index) {
+        for (uint32_t j = 0; j < total; ++j)
+            if (index[j] >= n_pts) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
+    } else if (total > n_pts) {
+        return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
+    }
+    Stage st(h);
+    PE_TRY(st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
+    const size_t off_g = st.alloc(sizeof(G1Group) * (size_t)n_groups);
+    const size_t off_i = st.alloc(4ull * total + 4);
+    G1Group* gr = st.host<G1Group>(off_g);
+    G1Plan plan;
+    plan_g1(n_groups, [&](uint32_t g) { return offsets[g + 1] - offsets[g]; }, gr, &plan);
+    for (uint32_t g = 0; g < n_groups; ++g) gr[g].member_start = offsets[g];
+    if (index) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
+    OutBlock ob(h);
+    const size_t off_o = out96_host ? ob.alloc(96ull * n_groups) : 0;
+    PE_TRY(ob.ensure());
+    HIP_TRY(h, st.upload());
+    int rc = launch_g1_planned(h, d_pts, index ? st.dev<uint32_t>(off_i) : nullptr, nullptr, st.dev<G1Group>(off_g), plan,
+                               out96_host ? ob.dev<uint8_t>(off_o) : nullptr, dev_jac);
+    if (rc) return rc;
+    if (out96_host) HIP_TRY(h, ob.download());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (out96_host) memcpy(out96_host, ob.host<uint8_t>(off_o), 96ull * n_groups);
+    return PE_OK;
+}
+
+int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const uint32_t* index, const uint32_t* offsets,
+              uint32_t n_groups, uint8_t* out96)
+{
+    if (!h || !offsets || !out96) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n_groups == 0) return PE_OK;
+    const uint32_t* d_pts;
+    uint64_t np;
+    if (points96) {
+        if (n_points >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "too many points");
+        HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(96, 96ull * n_points)));
+        HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(128, 4ull * G1_ROW_WORDS * n_points)));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n_points, hipMemcpyHostToDevice, h->stream));
+        launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
+        d_pts = h->d_tmp_points.as<uint32_t>();
+        np = n_points;
+    } else {
+        if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
+        d_pts = h->d_points.as<uint32_t>();
+        np = h->n_val;
+    }
+    return g1_sum_common(h, d_pts, np, index, offsets, n_groups, out96, nullptr);
+}
+
+int pe_g1_partial(pe_engine* h, const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, void* dev_partials,
+                  uint32_t dev_partials_capacity)
+{
+    if (!h || !offsets || !dev_partials) return PE_ERR_INVALID_ARG;
+    if (n_groups > dev_partials_capacity) return fail(h, PE_ERR_CAPACITY, "dev_partials holds fewer than n_groups partials");
+    PE_TRY(enter(h));
+    if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
+    if (n_groups == 0) return PE_OK;
+    return g1_sum_common(h, h->d_points.as<uint32_t>(), h->n_val, index, offsets, n_groups, nullptr,
+                         static_cast<uint32_t*>(dev_partials));
+}
+
+int pe_g1_finish(pe_engine* h, const void* dev_gathered, uint32_t n_ranks, uint32_t n_groups, uint8_t* out96)
+{
+    if (!h || !dev_gathered || !out96 || n_ranks == 0) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n_groups == 0) return PE_OK;
+    HIP_TRY(h, h->d_out96.ensure(96ull * n_groups));
+    {
+        ProfScope ps(h, PE_KERNEL_G1_NORMALISE);
+        launch_g1_finish(h->stream, static_cast<const uint32_t*>(dev_gathered), nullptr, n_groups, n_ranks, n_groups,
+                         h->d_out96.as<uint8_t>(), nullptr);
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, h->A().h_pin.ensure(96ull * n_groups));
+    HIP_TRY(h, hipMemcpyAsync(h->A().h_pin.p, h->d_out96.p, 96ull * n_groups, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out96, h->A().h_pin.p, 96ull * n_groups);
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- BLSPubkey wire format (8(f) rank 3)
+static int g1_decompress_common(pe_engine* h, const uint8_t* in48, uint64_t n, uint32_t* d_mont24, uint8_t* out96,
+                                int32_t* status, uint64_t* n_bad)
+{
+    const uint64_t chunk = 1ull << 20;
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, (48ull + 96ull + 4ull) * std::min(chunk, n))));
+    *n_bad = 0;
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const uint64_t m = std::min(chunk, n - base);
+        uint8_t* d_in = h->d_tmp_be.as<uint8_t>();
+        uint8_t* d_out = d_in + 48ull * m;
+        int32_t* d_st = reinterpret_cast<int32_t*>(d_out + 96ull * m);
+        HIP_TRY(h, hipMemcpyAsync(d_in, in48 + 48ull * base, 48ull * m, hipMemcpyHostToDevice, h->stream));
+        launch_g1_decompress(h->stream, d_in, m, d_mont24 ? d_mont24 + (uint64_t)G1_ROW_WORDS * base : nullptr, out96 ? d_out : nullptr, d_st);
+        HIP_TRY(h, hipGetLastError());
+        if (out96) HIP_TRY(h, hipMemcpyAsync(out96 + 96ull * base, d_out, 96ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(status + base, d_st, 4ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        for (uint64_t i = 0; i < m; ++i) *n_bad += status[base + i] != 0;
+    }
+    return PE_OK;
+}
+
+int pe_g1_decompress(pe_engine* h, const uint8_t* in48, uint64_t n, uint8_t* out96, int32_t* status)
+{
+    if (!h || (n && (!in48 || !out96 || !status))) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n == 0) return PE_OK;
+    uint64_t n_bad = 0;
+    return g1_decompress_common(h, in48, n, nullptr, out96, status, &n_bad);
+}
+
+int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48, int32_t* status)
+{
+    if (!h || (n && (!pubkeys48 || !status))) return PE_ERR_INVALID_ARG;
+    if (n != h->n_val) return fail(h, PE_ERR_INVALID_ARG, "pe_set_pubkeys_compressed: n differs from the registry size");
+    PE_TRY(enter(h));
+    if (n == 0) return PE_OK;
+    HIP_TRY(h, h->d_points.ensure(4ull * G1_ROW_WORDS * n));
+    h->have_points = false;
+    uint64_t n_bad = 0;
+    int rc = g1_decompress_common(h, pubkeys48, n, h->d_points.as<uint32_t>(), nullptr, status, &n_bad);
+    if (rc) return rc;
+    if (n_bad) return fail(h, PE_ERR_INVALID_ARG, std::to_string(n_bad) + " pubkeys do not decode to curve points (see status[])");
+    h->have_points = true;
+    return PE_OK;
+}
+
+// KeyValidate (Appendix A.7: FastAggregateVerify validates every pubkey): points96 NULL = the registry as loaded.
+int pe_g1_key_validate(pe_engine* h, const uint8_t* points96, uint64_t n, int32_t* status)
+{
+    if (!h || (n && !status)) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n == 0) return PE_OK;
+    const uint32_t* d_pts;
+    if (points96) {
+        if (n >= 0xFFFFFFFFull) return fail(h, PE_ERR_CAPACITY, "too many points");
+        HIP_TRY(h, h->d_tmp_be.ensure(96ull * n));
+        HIP_TRY(h, h->d_tmp_points.ensure(4ull * G1_ROW_WORDS * n + 4ull * n));
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n, hipMemcpyHostToDevice, h->stream));
+        launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
+        d_pts = h->d_tmp_points.as<uint32_t>();
+    } else {
+        if (!h->have_points || n != h->n_val) return fail(h, PE_ERR_STATE, "pe_g1_key_validate: no pubkeys loaded / n differs from the registry");
+        d_pts = h->d_points.as<uint32_t>();
+    }
+    HIP_TRY(h, h->d_out96.ensure(4ull * n));
+    int32_t* d_st = h->d_out96.as<int32_t>();
+    launch_g1_key_validate(h->stream, d_pts, n, d_st);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(status, d_st, 4ull * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PE_OK;
+}
+
+int pe_g2_decompress(pe_engine* h, const uint8_t* in96, uint64_t n, uint8_t* out192, int32_t* status)
+{
+    if (!h || (n && (!in96 || !out192 || !status))) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    const uint64_t chunk = 1ull << 19;
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, (96ull + 192ull + 4ull) * std::min(chunk, std::max<uint64_t>(n, 1)))));
+    for (uint64_t base = 0; base < n; base += chunk) {
+        const uint64_t m = std::min(chunk, n - base);
+        uint8_t* d_in = h->d_tmp_be.as<uint8_t>();
+        uint8_t* d_out = d_in + 96ull * m;
+        int32_t* d_st = reinterpret_cast<int32_t*>(d_out + 192ull * m);
+        HIP_TRY(h, hipMemcpyAsync(d_in, in96 + 96ull * base, 96ull * m, hipMemcpyHostToDevice, h->stream));
+        launch_g2_decompress(h->stream, d_in, m, nullptr, d_out, d_st);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(out192 + 192ull * base, d_out, 192ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(status + base, d_st, 4ull * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return PE_OK;
+}
+
+// Serialisation only (flag bits from a 48-byte comparison); no device work, no handle.
+int pe_g1_compress(const uint8_t* in96, uint64_t n, uint8_t* out48)
+{
+    if (n && (!in96 || !out48)) return PE_ERR_INVALID_ARG;
+    static const uint8_t HALF_BE[48] = {  // (p - 1) / 2, big-endian
+        0x0d, 0x00, 0x88, 0xf5, 0x1c, 0xbf, 0xf3, 0x4d, 0x25, 0x8d, 0xd3, 0xdb, 0x21, 0xa5, 0xd6, 0x6b,
+        0xb2, 0x3b, 0xa5, 0xc2, 0x79, 0xc2, 0x89, 0x5f, 0xb3, 0x98, 0x69, 0x50, 0x7b, 0x58, 0x7b, 0x12,
+        0x0f, 0x55, 0xff, 0xff, 0x58, 0xa9, 0xff, 0xff, 0xdc, 0xff, 0x7f, 0xff, 0xff, 0xff, 0xd5, 0x55};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t* p = in96 + 96 * i;
+        uint8_t* o = out48 + 48 * i;
+        if (p[0] & 0x40) {
+            memset(o, 0, 48);
+            o[0] = 0xC0;
+            continue;
+        }
+        memcpy(o, p, 48);
+        o[0] = (uint8_t)((o[0] & 0x1f) | 0x80 | (memcmp(p + 48, HALF_BE, 48) > 0 ? 0x20 : 0));
+    }
+    return PE_OK;
+}
+
+int pe_g2_compress(const uint8_t* in192, uint64_t n, uint8_t* out96)
+{
+    if (n && (!in192 || !out96)) return PE_ERR_INVALID_ARG;
+    static const uint8_t HALF_BE[48] = {
+        0x0d, 0x00, 0x88, 0xf5, 0x1c, 0xbf, 0xf3, 0x4d, 0x25, 0x8d, 0xd3, 0xdb, 0x21, 0xa5, 0xd6, 0x6b,
+        0xb2, 0x3b, 0xa5, 0xc2, 0x79, 0xc2, 0x89, 0x5f, 0xb3, 0x98, 0x69, 0x50, 0x7b, 0x58, 0x7b, 0x12,
+        0x0f, 0x55, 0xff, 0xff, 0x58, 0xa9, 0xff, 0xff, 0xdc, 0xff, 0x7f, 0xff, 0xff, 0xff, 0xd5, 0x55};
+    static const uint8_t ZERO48[48] = {0};
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t* p = in192 + 192 * i;
+        uint8_t* o = out96 + 96 * i;
+        if (p[0] & 0x40) {
+            memset(o, 0, 96);
+            o[0] = 0xC0;
+            continue;
+        }
+        memcpy(o, p, 96);  // x.c1 | x.c0
+        const uint8_t* y1 = p + 96;
+        const uint8_t* y0 = p + 144;
+        const bool larger = memcmp(y1, ZERO48, 48) != 0 ? memcmp(y1, HALF_BE, 48) > 0 : memcmp(y0, HALF_BE, 48) > 0;
+        o[0] = (uint8_t)((o[0] & 0x1f) | 0x80 | (larger ? 0x20 : 0));
+    }
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- plain G2 sums (8(f) rank 3)
+int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const uint32_t* index, const uint32_t* offsets,
+              uint32_t n_groups, uint8_t* out192)
+{
+    if (!h || !offsets || !out192 || (n_points && !points192)) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n_groups == 0) return PE_OK;
+    if (n_points >= 0xFFFFFFFFull / 48) return fail(h, PE_ERR_CAPACITY, "too many points");
+    const uint32_t total = offsets[n_groups];
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
+    if (index) {
+        for (uint32_t j = 0; j < total; ++j)
+            if (index[j] >= n_points) return fail(h, PE_ERR_INVALID_ARG, "point index out of range");
+    } else if (total > n_points) {
+        return fail(h, PE_ERR_INVALID_ARG, "offsets exceed the number of points");
+    }
+    HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(192, 192ull * n_points)));
+    HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(192, 192ull * n_points)));
+    if (n_points) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points192, 192ull * n_points, hipMemcpyHostToDevice, h->stream));
+        launch_g2_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
+    }
+    Stage st(h);
+    PE_TRY(st.reserve(sizeof(G1Group) * (size_t)n_groups + 4ull * total + 4096));
+    const size_t off_g = st.alloc(sizeof(G1Group) * (size_t)n_groups);
+    const size_t off_i = st.alloc(4ull * total + 4);
+    G1Group* gr = st.host<G1Group>(off_g);
+    G1Plan plan;
+    plan_g1(n_groups, [&](uint32_t g) { return offsets[g + 1] - offsets[g]; }, gr, &plan, G2_WG_SLOTS,
+            G1_TARGET_LANES / 2);
+    for (uint32_t g = 0; g < n_groups; ++g) gr[g].member_start = offsets[g];
+    if (index) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
+    OutBlock ob(h);
+    const size_t off_o = ob.alloc(192ull * n_groups);
+    PE_TRY(ob.ensure());
+    HIP_TRY(h, st.upload());
+    HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(384, 384ull * plan.n_partials)));
+    {
+        ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE);
+        launch_g2_accumulate(h->stream, h->d_tmp_points.as<uint32_t>(), index ? st.dev<uint32_t>(off_i) : nullptr,
+                             st.dev<G1Group>(off_g), plan.n_groups, plan.n_slots, h->d_partials.as<uint32_t>());
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G2_NORMALISE);
+        launch_g2_finish(h->stream, h->d_partials.as<uint32_t>(), st.dev<G1Group>(off_g), plan.n_groups,
+                         ob.dev<uint8_t>(off_o));
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, ob.download());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    memcpy(out192, ob.host<uint8_t>(off_o), 192ull * n_groups);
+    return PE_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
 // kernels.h -- host-callable launch wrappers around the HIP kernels (internal interface
-// between engine.cpp and the *.hip translation units; NOT the public ABI -- that is
+// between engine_*.cpp and the *.hip translation units; NOT the public ABI -- that is
 // include/posevo.h).
 #pragma once
 #include <hip/hip_runtime.h>
