@@ -650,10 +650,15 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
     for (uint32_t g = 0; g < ng; ++g)
         h->res_groups[g] = {A.out_byte_off[g], atts[rep[g]].n_bits, A.out_word[g], A.all_valid[g], att_data_tag(atts[rep[g]])};
     auto info_p = std::make_shared<std::vector<uint32_t>>();
-    h->res_info_host = info_p;
-    h->res_valid = true;
-    h->res_arena = h->cur;
-    ++h->res_generation;
+    // the resident hand-over is published at the end, when every enqueue below has succeeded: a failing launch or copy
+    // must not leave res_valid pointing at unions that were never computed, nor a deferred launch at a staging region
+    // whose cursor never advanced
+    h->res_valid = false;
+    const size_t deferred_before = h->deferred.size();
+    struct Unwind {
+        pe_engine* h; size_t keep; bool armed = true;
+        ~Unwind() { if (armed) { h->res_valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
+    } unwind{h, deferred_before};
     lap.mark("agg.2e_out_rows");
     // ---- device ----
     hipStream_t ms = h->stream;
@@ -665,7 +670,11 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
                          h->stream == h->own_stream && xgroups.empty();
     h->last_agg_on_side = on_side;
     hipStream_t gs = on_side ? h->side_stream : ms;
-    // a previous aggregate of THIS pipeline may still read the arena's d_res_* on the side stream
+    // A previous aggregate of THIS pipeline reads the arena's d_res_bits / d_res_info from its G1 launch.  In a streaming
+    // pipeline that launch may still sit in h->deferred (nothing has read the unions yet): issue it now, so that the
+    // ev_join wait below orders this call's k_bits_union -- which rewrites the arena's resident words from word 0 --
+    // behind the earlier chain (without this the first aggregate's pubkeys were summed over the second's unions).
+    if (!h->deferred.empty()) PE_TRY(run_deferred(h));
     if (h->A().side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
     if (arena_kind == 0) {
         HIP_TRY(h, st.upload());
@@ -817,6 +826,11 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         if (S.out_sig96) memcpy(S.out_sig96, pin + S.off_osig, 96ull * S.ng);
         return PE_OK;
     };
+    unwind.armed = false;
+    h->res_info_host = info_p;
+    h->res_valid = true;
+    h->res_arena = h->cur;
+    ++h->res_generation;
     HostLap lap2(&h->trace);
     const int rc = finish_call(h, st, ob, complete, /*force_sync=*/out_sig96 != nullptr);
     lap2.mark("agg.4_wait_outputs");

@@ -135,6 +135,14 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
         totals[blockIdx.x].total_active_balance = wg_tot[0];
         totals[blockIdx.x].num_active = wg_tot[1];
     }
+    // The slots no workgroup of THIS launch owns must read zero: after an in-place all-reduce they hold the other ranks'
+    // sums of the previous round (ranks with unequal shards launch different grids), and a shrinking registry leaves
+    // stale partials behind (the sharded head double-counted them).  Workgroup 0 clears them: no memset.
+    if (blockIdx.x == 0)
+        for (uint32_t j = gridDim.x + threadIdx.x; j < (uint32_t)VOTES_MAX_WG; j += VOTES_WG) {
+            totals[j].total_active_balance = 0;
+            totals[j].num_active = 0;
+        }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) {
         const unsigned long long w = hist[b];

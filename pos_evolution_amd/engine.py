@@ -150,8 +150,13 @@ class _Pipeline:
     def __enter__(self):
         e = self.e
         # a lagged pipeline still in flight stays in flight
+        if self.lagged and e._ring is not None and len(e._ring) < 4:
+            # outputs of lagged pipeline k are written at the exit of k + 2: a set handed out again before k + 3 would
+            # never be stable to read
+            raise ValueError("reuse_outputs(depth) must be >= 4 with lagged pipelines (lag depth 2)")
         e._check((e._lib.pe_pipeline_begin_streaming if self.lagged else e._lib.pe_pipeline_begin)(e._h))
         e._pipe_keep = []
+        e._ring_ord = {}
         return e
 
     def __exit__(self, exc_type, exc, tb):
@@ -194,15 +199,19 @@ class Engine:
         self._lagged_keep = None
         self._ring = None
         self._ring_i = 0
+        self._ring_ord = {}
 
     # -- plumbing ---------------------------------------------------------
-    def reuse_outputs(self, depth: int = 3):
+    def reuse_outputs(self, depth: int = 4):
         """Opt in to output-buffer reuse: the arrays the batch calls return come from a ring of `depth` buffer sets that
-        advances at every pipeline exit, instead of fresh ``np.empty`` allocations (whose first touch page-faults: 50+ us
-        per step for the 1 MB of rows and bits an epoch returns).  An array stays valid for depth - 1 further pipelines;
-        copy what must live longer.  depth >= 4 with lagged pipelines (lag depth 2)."""
+        advances at every pipeline exit (and after every batch call made outside a pipeline), instead of fresh
+        ``np.empty`` allocations (whose first touch page-faults: 50+ us per step for the 1 MB of rows and bits an epoch
+        returns).  An array stays valid for depth - 1 further pipelines / synchronous calls; copy what must live longer.
+        Two calls of the same kind inside ONE pipeline get distinct sets (keyed by their ordinal in the pipeline).
+        depth >= 4 with lagged pipelines (lag depth 2: entering one with a shallower ring raises)."""
         self._ring = [dict() for _ in range(max(depth, 1))]
         self._ring_i = 0
+        self._ring_ord = {}
 
     def _outs(self, key, specs):
         """The output arrays of one call and their addresses: ``specs`` = ((shape, dtype) or None, ...).  With
@@ -212,10 +221,20 @@ class Engine:
             arrs = tuple(None if sp is None else np.empty(sp[0], dtype=sp[1]) for sp in specs)
             return arrs, tuple(_ptr(a) for a in arrs)
         d = self._ring[self._ring_i]
-        hit = d.get((key, specs))
+        if self._pipe_keep is None:
+            # a synchronous call: its results are complete at return, the next call gets the next set
+            k = (key, specs, 0)
+            self._ring_i = (self._ring_i + 1) % len(self._ring)
+        else:
+            # inside a pipeline every call's buffers are written at the pipeline's end: the n-th call of a kind gets
+            # the n-th set of this ring slot (two aggregates of one pipeline must not share their outputs)
+            o = self._ring_ord.get((key, specs), 0)
+            self._ring_ord[(key, specs)] = o + 1
+            k = (key, specs, o)
+        hit = d.get(k)
         if hit is None:
             arrs = tuple(None if sp is None else np.zeros(sp[0], dtype=sp[1]) for sp in specs)  # zeros: touch the pages here
-            hit = d[(key, specs)] = (arrs, tuple(_ptr(a) for a in arrs))
+            hit = d[k] = (arrs, tuple(_ptr(a) for a in arrs))
         return hit
 
     def _keep(self, *buffers):

@@ -67,11 +67,33 @@ assert calls() == ["pe_pipeline_begin_streaming", "pe_aggregate", "pe_on_attesta
 a1, a2 = step(True), step(True)
 assert a1[1].ctypes.data != a2[1].ctypes.data
 e.reuse_outputs(3)
-ring = [step(True) for _ in range(7)]
+try:                                    # lag depth 2: a set handed out again before k + 3 is never stable to read
+    step(True)
+    raise SystemExit("a lagged pipeline must refuse a ring shallower than 4")
+except ValueError:
+    pass
+e.reuse_outputs()                       # default depth 4
+ring = [step(True) for _ in range(9)]
 addr = [x[1].ctypes.data for x in ring]
-assert len(set(addr[:3])) == 3 and addr[3:6] == addr[:3] and addr[6] == addr[0]
-assert all(ring[k][0]["aggpk96"].ctypes.data == ring[k + 3][0]["aggpk96"].ctypes.data for k in range(4))
+assert len(set(addr[:4])) == 4 and addr[4:8] == addr[:4] and addr[8] == addr[0]
+assert all(ring[k][0]["aggpk96"].ctypes.data == ring[k + 4][0]["aggpk96"].ctypes.data for k in range(5))
 e.drain()
+# two calls of one kind inside ONE pipeline get distinct output sets (they aliased), and the pair returns
+# with the ring slot
+def two_aggregates():
+    with e.pipeline():
+        x = e.aggregate(packed=(atts, bits), want_aggregate_pubkeys=True)
+        y = e.aggregate(packed=(atts, bits), want_aggregate_pubkeys=True)
+    return x, y
+pairs = [two_aggregates() for _ in range(5)]
+for x, y in pairs:
+    assert x["aggpk96"].ctypes.data != y["aggpk96"].ctypes.data and x["atts"].ctypes.data != y["atts"].ctypes.data
+assert pairs[0][0]["aggpk96"].ctypes.data == pairs[4][0]["aggpk96"].ctypes.data
+assert pairs[0][1]["aggpk96"].ctypes.data == pairs[4][1]["aggpk96"].ctypes.data
+# synchronous calls outside a pipeline advance the ring too: consecutive results do not alias
+s1 = e.aggregate(packed=(atts, bits), want_aggregate_pubkeys=True)
+s2 = e.aggregate(packed=(atts, bits), want_aggregate_pubkeys=True)
+assert s1["aggpk96"].ctypes.data != s2["aggpk96"].ctypes.data
 assert "pe_pipeline_end" in calls()
 # a DeviceArena travels as its address; the host-repacking calls never see one from the wrapper's own paths
 dev = pea.DeviceArena(0xDEAD0000, 64)

@@ -140,3 +140,21 @@ def test_typed_uint_to_bytes_widths():
     assert spec.uint_to_bytes(spec.uint64(7)) == (7).to_bytes(8, "little") == spec.uint_to_bytes(7)
     assert spec.hash(b"abc") == hashlib.sha256(b"abc").digest()
     assert spec.hash((1, 2)) == hash((1, 2))
+
+
+def test_generated_file_is_verified_against_committed_pins_before_exec():
+    """oracle/_ref/ is git-ignored and regenerated from a file outside the repository; overlay() executes it
+    only if every section hashes to its committed pin."""
+    from oracle import ref_extract as r
+
+    pins = r.committed_pins()
+    assert pins is not None and "stitched_sha256" in pins["pinned"]["on_attestation"]
+    if not r.available():
+        pytest.skip("oracle/_ref/ not generated here")
+    text = open(r.FENCES_PY, encoding="utf-8").read()
+    assert r.verify_generated(text, pins) is None
+    assert r.verify_generated(text.replace("store.time", "store.time ", 1), pins) is not None      # one byte changed
+    assert r.verify_generated("import os\n" + text, pins) == "code before the first pinned section"
+    assert r.verify_generated(text + "\n# ==== extra  pe:1-2 ====\nprint(1)\n", pins) is not None   # unpinned section
+    bad = dict(pins, markdown_sha256="0" * 64)
+    assert r.verify_generated(text, bad) is None  # sections are what is executed; the markdown hash gates generate()
