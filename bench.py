@@ -65,14 +65,17 @@ def build_workload(e, args, rank, n_steps_total):
     for st in steps:  # the working state's context of each step is an input like the attestations: built up front
         st["ctx"] = state_ctx(w, st["epoch"])
     if not args.host_arena:
-        # the contract's headline condition: inputs resident in HBM when the timed region starts.  The aggregation bits
-        # (the only input the host never reads) go to the device; the attestation rows stay host memory, the host
-        # groups and validates them.  --host-arena times the hand-over from pageable host memory instead.
+        # the contract's headline condition: inputs resident in HBM when the timed region starts -- the aggregation bits
+        # and (unless --host-rows) the attestation rows, which are then grouped, resolved and validated on the device
+        # (PE_ROWS_RESIDENT).  --host-arena / --host-rows time the hand-over from host memory instead.
         import torch
-        from pos_evolution_amd import DeviceArena
+        from pos_evolution_amd import DeviceArena, DeviceRows
         for st in steps:
             t = torch.from_numpy(st["arena"]).cuda()
             st["arena_in"] = DeviceArena(t.data_ptr(), t.numel(), keep=t)
+            if not args.host_rows:
+                r = torch.from_numpy(st["atts"].view(np.uint8).reshape(-1)).cuda()
+                st["rows_in"] = DeviceRows(r.data_ptr(), len(st["atts"]), keep=r)
         torch.cuda.synchronize()
     return w
 
@@ -107,11 +110,21 @@ def run_step_single(e, w, st, pipelined=True, lagged=True):
     rows + OR-ed bits stay on the device for the two handlers (PE_BITS_RESIDENT), get_head polls its head word, and
     pe_pipeline_end waits ONCE for every output (include/posevo.h "pipelined calls").  Same results either way
     (tests/test_gpu_pipeline.py)."""
-    from pos_evolution_amd import RESIDENT
+    from pos_evolution_amd import RESIDENT, ROWS_RESIDENT
 
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
+    if "rows_in" in st and pipelined:
+        # rows + bits resident in HBM: the host enqueues a fixed sequence of launches and reads nothing of the rows
+        cap = st["comm"].offsets.size - 1   # one AttestationData per committee in this workload: groups <= committees
+        with e.pipeline(lagged=lagged):
+            agg = _timed("aggregate", e.aggregate, packed=(st["rows_in"], st["arena_in"]), want_aggregate_pubkeys=True)
+            status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
+            head = _timed("get_head", e.get_head)
+            st2, num = _timed("process_attestation", e.process_attestation_batch, st["ctx"],
+                              packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
+        return dict(agg=agg, rows=None, status=status, count=count, pstatus=st2, numerators=num, head=head)
     if not pipelined:
         agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
         rows = agg["atts"]
@@ -334,7 +347,7 @@ def whole_step_check(pea, w, st, chk, device):
     e2.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
     r = run_step_single(e2, w, st, pipelined=True, lagged=True)
     e2.drain()
-    rows = r["rows"]
+    rows = r["agg"]["atts"]
     C = st["comm"].offsets.size - 1
     cps = C // w["spe"]
     pos = ((rows["slot"] % w["spe"]) * cps + rows["index"]).astype(np.int64)   # committee id of every aggregate row
@@ -344,17 +357,52 @@ def whole_step_check(pea, w, st, chk, device):
     agg = r["agg"]
     union_e = np.concatenate([np.packbits(agg["bits"][g], bitorder="little") for g in inv])
     out["union_bits"] = bool(np.array_equal(union_e, chk["union"]))
-    out["counts"] = bool(np.array_equal(agg["count"][inv], chk["count"]) and np.array_equal(r["count"][inv], chk["count"]))
+    out["counts"] = bool(np.array_equal(agg["count"][inv], chk["count"]) and np.array_equal(r["count"][:C][inv], chk["count"]))
     out["aggregate_pubkeys"] = bool(np.array_equal(agg["aggpk96"][inv], chk["aggpk"]))
     out["latest_messages"] = bool(np.array_equal(e2.latest_messages()[1], chk["vote_block"]))
     out["head"] = r["head"] == chk["head"]
     out["weights"] = bool(np.array_equal(e2.get_weights(), chk["weights"]))
-    out["reward_numerators"] = bool(np.array_equal(r["numerators"][inv], chk["numerators"]))
+    out["reward_numerators"] = bool(np.array_equal(r["numerators"][:C][inv], chk["numerators"]))
     out["participation"] = bool(np.array_equal(e2.participation_get(0), chk["part_cur"]) and
                                 np.array_equal(e2.participation_get(1), chk["part_prev"]))
     out["statuses_ok"] = bool((r["status"] == 0).all() and (r["pstatus"] == 0).all())
     e2.close()
     return out
+
+
+def step_digest(r):
+    """sha256 over everything one step hands back: head, statuses, counts, reward numerators, the aggregate rows, the
+    OR-ed bits, the aggregate pubkeys, the grouping."""
+    import hashlib
+
+    agg = r["agg"]
+    g = int(agg["n_groups"])
+    h = hashlib.sha256()
+    h.update(r["head"])
+    for a in (r["status"][:g], r["count"][:g], r["pstatus"][:g], r["numerators"][:g], agg["atts"][:g], agg["out_arena"],
+              agg["aggpk96"][:g], agg["count"][:g], agg["group_of"]):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.digest()
+
+
+def replay_and_verify(pea, w, device, results, total):
+    """Every step of the run (warm-up included: the store state carries over) again on a fresh engine with SYNCHRONOUS
+    calls over HOST rows -- the path the -m gpu tests hold against the oracle call by call -- and the digest of each
+    step's outputs compared with what the timed run returned.  -> number of steps whose outputs are identical."""
+    e2 = pea.Engine(device=device, max_committee_tables=total + 1)
+    tree = w["tree"]
+    e2.store_init(0, 0, tree.roots[0].tobytes())
+    for i in range(1, tree.roots.shape[0]):
+        e2.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+    e2.set_validators(w["bal"], w["flags"], w["pts"])
+    same = []
+    for s, st in enumerate(w["steps"][:total]):
+        e2.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
+        host_st = {k: v for k, v in st.items() if k not in ("rows_in", "arena_in")}
+        r = run_step_single(e2, w, host_st, pipelined=False)
+        same.append(step_digest(r) == step_digest(results[s]))
+    e2.close()
+    return same
 
 
 def main():
@@ -379,6 +427,11 @@ def main():
                          "or by torch.distributed between synchronous calls (torch)")
     ap.add_argument("--host-arena", action="store_true",
                     help="hand the aggregation bits over from pageable host memory (PCIe-inclusive) instead of HBM")
+    ap.add_argument("--host-rows", action="store_true",
+                    help="attestation rows in host memory: grouped and validated by the host inside the timed step (the "
+                         "round-2 path) instead of resident in HBM and handled on the device")
+    ap.add_argument("--no-verify-steps", action="store_true",
+                    help="skip the replay that checks every timed step's outputs (steps_verified)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one wait per call instead of one per step (A/B of the pipelined C ABI)")
     ap.add_argument("--no-lag", action="store_true",
@@ -450,10 +503,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    verify = ex is None and not args.no_pipeline and not args.no_verify_steps
     if (ex is None or engine_rccl) and not args.no_pipeline:
-        e.reuse_outputs(4)  # a streaming caller reuses its output buffers; results are consumed two steps behind
+        # a streaming caller reuses its output buffers (results are consumed two steps behind); to verify every timed
+        # step afterwards the ring is as deep as the run, allocated and touched before the clock starts
+        e.reuse_outputs(total + 2 if verify else 4)
+    kept = []
     for s in range(args.warmup):
-        step(w["steps"][s])
+        kept.append(step(w["steps"][s]))
+        if s == 0:
+            e.drain()
+            e.fill_ring()
     e.drain()
     e.profile_enable(True)
     e.profile_reset()
@@ -470,6 +530,8 @@ def main():
     n_att_local = n_rejected = 0
     for s in range(args.warmup, total):
         inflight.append(step(w["steps"][s]))
+        if verify:
+            kept.append(inflight[-1])
         stamps.append(time.perf_counter())
         if len(inflight) > 2:  # complete by now (a lagged step completes when the second next one's block exits)
             done = inflight.pop(0)
@@ -578,7 +640,10 @@ def main():
             "validators_total": V_total, "validators_per_gpu": VL, "blocks": args.blocks, "committees": C,
             "parallelism": f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU",
             "call_mode": mode,
-            "inputs": ("attestation rows in host memory (grouped and validated by the host inside the timed step); "
+            "inputs": (("attestation rows in host memory (grouped and validated by the host inside the timed step); "
+                        if (args.host_rows or args.host_arena or world > 1) else
+                        "attestation rows resident in HBM before the timed region (grouped, resolved and validated on "
+                        "the device: PE_ROWS_RESIDENT); ")
                        + ("aggregation bits in pageable host memory, copied over PCIe inside the timed step"
                           if args.host_arena else "aggregation bits resident in HBM before the timed region")),
             "per_epoch_setup_outside_the_step": "pe_compute_committees (GPU swap-or-not shuffle + inverse committee "
@@ -610,6 +675,15 @@ def main():
         },
         "kernel_avg_ms": kernel_ms,
     }
+    if verify:
+        # every step's outputs (kept in the deep ring) against a synchronous host-row replay, after the clock stopped
+        same = replay_and_verify(pea, w, local_rank, kept, total)
+        out["steps_verified"] = int(sum(same[args.warmup:]))
+        out["steps_verified_detail"] = ("sha256 of each timed step's outputs (head, statuses, counts, numerators, aggregate "
+                                        "rows, OR-ed bits, aggregate pubkeys, grouping) == the same step replayed with "
+                                        "synchronous host-row calls on a fresh engine; warm-up steps replayed too: "
+                                        f"{int(sum(same[:args.warmup]))}/{args.warmup} identical")
+        assert out["steps_verified"] == args.steps, f"timed steps differ from their synchronous replay: {same}"
     if not args.no_cpu_baseline and world == 1:
         base, chk = cpu_baseline(w, w["steps"][0])
         out["cpu_baseline"] = base

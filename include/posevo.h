@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 3
+#define PE_ABI_VERSION 4
 
 typedef struct pe_engine pe_engine;
 
@@ -251,6 +251,29 @@ int pe_pipeline_begin_streaming(pe_engine* h);
  * aggregate of the same pipeline, which a later one replaced -- fails the call with PE_ERR_INVALID_ARG (rows are
  * recognised by bits_offset, n_bits and a fold of their AttestationData), nothing applied. */
 #define PE_BITS_RESIDENT ((const uint8_t*)(uintptr_t)1)
+/* Rows resident on the device: the host off the step's critical path.
+ * pe_aggregate accepts `atts` in DEVICE memory (hipMalloc of the engine's device, 16-byte aligned; the bits as above).
+ * The host then reads nothing of the rows: grouping by AttestationData (pe:689-697), committee resolution
+ * (get_beacon_committee's index arithmetic, Appendix A.6), validate_on_attestation (Appendix A.4, called at pe:970) and
+ * the asserts of process_attestation (pe:724-730) all run on the device, and EVERY output of the call -- out_atts,
+ * *out_n_groups, group_of, bits, counts, aggregate pubkeys -- is complete when a synchronous call returns / when the
+ * pipeline's outputs are (nothing is host-derived any more).  Capacities are the caller's bounds: out_atts, group_of,
+ * out_count, out_aggpk96 hold n entries (groups <= rows).  The handlers then take
+ *     pe_on_attestation_batch(h, PE_ROWS_RESIDENT, cap, PE_BITS_RESIDENT, 0, status, NULL, out_count)
+ *     pe_process_attestation_batch(h, state, PE_ROWS_RESIDENT, cap, PE_BITS_RESIDENT, 0, status, out_numerators)
+ * = on_attestation / process_attestation over every group of that aggregate, in group order; cap = entries of the
+ * status / count / numerator arrays (entries past the groups formed read 0; fewer entries than groups: PE_ERR_CAPACITY
+ * at completion, nothing applied).  Statuses and results equal those of the host-row path.  Restrictions of this mode:
+ *   - committees are resolved against the tables of the store's CURRENT and PREVIOUS epoch (the only targets
+ *     validate_on_attestation admits for gossip attestations; a from-block row with an older target reads
+ *     PE_ATT_NO_COMMITTEE_TABLE -- hand such rows over from host memory), and both tables must partition the registry
+ *     (a real shuffling does; pe_compute_committees tables always do);
+ *   - the store's clock and tables stay unchanged between pe_aggregate and its handlers (else PE_ERR_STATE);
+ *   - a failing aggregate (bits outside the arena, no committee table / index out of range / len(aggregation_bits) !=
+ *     len(committee) when aggregate pubkeys are asked for, output arena too small) forms NO groups: its error is returned
+ *     where its outputs complete, and the handlers behind it apply nothing;
+ *   - signature points (sig_points96) and the partial / sharded forms take host rows. */
+#define PE_ROWS_RESIDENT ((const pe_attestation*)(uintptr_t)1)
 
 /* ---- the hot path ------------------------------------------------------ */
 /* get_head (pe:1102-1116): full recomputation from the V-entry vote table:
@@ -300,7 +323,8 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
  * bits_arena may lie in pageable host memory (copied during the call), in pinned host memory or in device memory
  * (hipMalloc of the engine's device): the latter two are picked up by the copy engine without a pass on the host, and
  * must stay unchanged until the call's outputs are complete (inside a pipeline: until the pipeline's are).  The same
- * holds for pe_aggregate_partial and pe_aggregate_sharded.  The attestation rows are always host memory. */
+ * holds for pe_aggregate_partial and pe_aggregate_sharded.  The attestation rows are host memory, or -- pe_aggregate
+ * only -- device memory: see PE_ROWS_RESIDENT above. */
 int pe_aggregate(pe_engine* h, const pe_attestation* atts, uint32_t n,
                  const uint8_t* bits_arena, uint64_t arena_len, const uint8_t* sig_points96,
                  pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,

@@ -11,6 +11,7 @@ the thin Python host layer above it:
 Import never falls back to a CPU implementation: without the built library it raises.
 """
 from . import _abi
-from .engine import RESIDENT, AttRow, DeviceArena, Engine, EngineError, pack_attestations
+from .engine import RESIDENT, ROWS_RESIDENT, AttRow, DeviceArena, DeviceRows, Engine, EngineError, pack_attestations
 
-__all__ = ["Engine", "EngineError", "AttRow", "DeviceArena", "pack_attestations", "RESIDENT", "_abi"]
+__all__ = ["Engine", "EngineError", "AttRow", "DeviceArena", "DeviceRows", "pack_attestations", "RESIDENT", "ROWS_RESIDENT",
+           "_abi"]

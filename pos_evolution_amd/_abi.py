@@ -156,6 +156,7 @@ SIGNATURES = {
     "pe_profile_get": (C.c_int, [_H, C.c_int, _u64p, _P(C.c_double)]),
 }
 
+PE_ROWS_RESIDENT = 1  # include/posevo.h: "every group of the last pe_aggregate over rows in device memory"
 PE_BITS_RESIDENT = 1  # the address include/posevo.h defines as "bits are where the last pe_aggregate left them"
 PE_ATT_FLAG_OVERLAPPING_BITS = 0x4
 

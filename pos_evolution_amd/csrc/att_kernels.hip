@@ -1,0 +1,707 @@
+// att_kernels.hip -- attestation rows resident in device memory: what the host does per row in engine_attest.cpp,
+// done on the device so that the host only enqueues launches (the host paced the step).
+//
+//   k_att_ingest          one lane per input row: hash the 128-byte AttestationData (pe:689-697) + len(aggregation_bits),
+//                         insert into an open-addressing table in HBM; a slot's value is the SMALLEST row index of its
+//                         class (atomicMin), i.e. the row of first appearance -- the grouping rule of pe_aggregate
+//                         ("attestations with identical AttestationData and n_bits form one group, groups ordered by
+//                         first appearance").
+//   k_att_plan            one workgroup: group ids by a prefix count over the representatives, committee resolution
+//                         (get_beacon_committee's index arithmetic, A.6) against the store's current / previous
+//                         epoch tables, offsets of the unions (prefix sums), member counts, the G1 plan, the
+//                         rows-per-committee lists the handlers walk.  Writes the very descriptor arrays the host
+//                         path uploads (UnionGroup, G1Group), so k_bits_union / k_g1_* run unchanged.
+//   k_att_members         one lane per input row: group_of[], the group's member list, AND of the signature verdicts,
+//                         the output rows; clears the hash table for the next call.
+//   k_att_validate_fc     validate_on_attestation (A.4, called at pe:970) + is_valid_indexed_attestation's structural
+//                         part per group: root -> block lookups in a device hash table, the LMD/FFG consistency walk
+//                         (at most SLOTS_PER_EPOCH parent steps once the two slot checks passed), one AttRow + one
+//                         pe_att_status per group.
+//   k_att_validate_state  the asserts of process_attestation (pe:724-730) and
+//                         get_attestation_participation_flag_indices (A.9) per group.
+//   k_lmd_vm_tables       update_latest_messages (pe:1435-1441), validator-major, both candidate tables in one launch.
+//   k_participation_tables the flag loop of pe:745-749, one wave per committee, rows of a committee in batch order.
+//
+// Integer / byte work, latency- and HBM-bound: no MFMA.
+#include <cstdlib>
+#include "kernels.h"
+
+namespace posevo {
+
+namespace {
+
+constexpr uint32_t VAL_EQUIVOCATING_BIT = 0x04u;
+constexpr uint32_t FLAG_SIG_VALID = 0x1u, FLAG_FROM_BLOCK = 0x2u;
+// pe_att_status values (include/posevo.h)
+constexpr int32_t ST_OK = 0, ST_EPOCH_TIME = 1, ST_EPOCH_SLOT = 2, ST_UNKNOWN_TARGET = 3, ST_UNKNOWN_BLOCK = 4,
+                  ST_BLOCK_AFTER_SLOT = 5, ST_TARGET_NOT_ANCESTOR = 6, ST_SLOT_NOT_PAST = 7, ST_NO_TABLE = 8,
+                  ST_INDEX_RANGE = 9, ST_BITS_LENGTH = 10, ST_EMPTY = 11, ST_BAD_SIGNATURE = 12, ST_INCLUSION = 13,
+                  ST_SOURCE = 14;
+// -pe_status values reported through AttPlan::error
+constexpr uint32_t ERR_INVALID_ARG = 1, ERR_CAPACITY = 10, ERR_NO_COMMITTEES = 11;
+
+// a pe_attestation is 9 x 16 bytes: [0] slot, index  [1-2] beacon_block_root  [3] source_epoch, source_root[0:8]
+// [4] source_root[8:24]  [5] source_root[24:32], target_epoch  [6-7] target_root  [8] bits_offset, n_bits, flags, reserved
+struct Row9 { uint4 q[9]; };
+__device__ __forceinline__ void load_row(Row9& r, const uint4* __restrict__ rows, uint32_t i)
+{
+    const uint4* p = rows + (size_t)9 * i;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.q[k] = p[k];
+}
+__device__ __forceinline__ unsigned long long u64_of(uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; }
+__device__ __forceinline__ unsigned long long row_slot(const Row9& r) { return u64_of(r.q[0].x, r.q[0].y); }
+__device__ __forceinline__ unsigned long long row_index(const Row9& r) { return u64_of(r.q[0].z, r.q[0].w); }
+__device__ __forceinline__ unsigned long long row_source_epoch(const Row9& r) { return u64_of(r.q[3].x, r.q[3].y); }
+__device__ __forceinline__ unsigned long long row_target_epoch(const Row9& r) { return u64_of(r.q[5].z, r.q[5].w); }
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h, uint32_t v)
+{
+    h ^= v;
+    h *= 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
+__device__ __forceinline__ uint32_t att_hash(const Row9& r)
+{
+    uint32_t h = 0x85EBCA6Bu ^ r.q[8].y;  // n_bits is part of the key
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h = mix32(h, r.q[k].x);
+        h = mix32(h, r.q[k].y);
+        h = mix32(h, r.q[k].z);
+        h = mix32(h, r.q[k].w);
+    }
+    return h;
+}
+__device__ __forceinline__ bool same4(const uint4& a, const uint4& b)
+{
+    return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) == 0;
+}
+
+// exclusive prefix sum over the 1024 lanes of the single planning workgroup; *total = sum over the block
+template <typename T>
+__device__ __forceinline__ T block_scan_1024(T v, T* wave_tot /* 16 entries of LDS */, T* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();  // wave_tot may still be read by the previous scan
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const T t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ ingest: hash + insert
+__global__ void __launch_bounds__(256)
+k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t mask,
+             uint32_t* __restrict__ slot_of, unsigned long long arena_len, AttPlan* __restrict__ plan)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Row9 r;
+    load_row(r, rows, i);
+    const uint32_t b0 = r.q[8].x, nb = r.q[8].y;
+    // "attestation bits exceed the arena" / "target epoch must fit 32 bits" of the host path: the whole call fails
+    if ((unsigned long long)b0 + (nb + 7) / 8 > arena_len || row_target_epoch(r) >= 0xFFFFFFFEull) atomicMax(&plan->error, ERR_INVALID_ARG);
+    uint32_t h = att_hash(r) & mask;
+    for (;;) {
+        const uint32_t prev = atomicCAS(&tab[h], ATT_EMPTY, i);
+        if (prev == ATT_EMPTY) break;  // first of its class to arrive here
+        const uint4* q = rows + (size_t)9 * prev;   // any row of the slot's class: they all carry the same data
+        bool eq = q[8].y == nb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) eq = eq && same4(q[k], r.q[k]);
+        if (eq) {
+            atomicMin(&tab[h], i);  // the slot keeps the row of first appearance
+            break;
+        }
+        h = (h + 1) & mask;
+    }
+    slot_of[i] = h;
+}
+
+void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t tab_mask, uint32_t* slot_of,
+                       uint64_t arena_len, AttPlan* plan)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_att_ingest, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
+                       tab_mask, slot_of, (unsigned long long)arena_len, plan);
+}
+
+// ------------------------------------------------------------------ plan: one workgroup
+constexpr int PLAN_WG = 1024;
+
+__global__ void __launch_bounds__(PLAN_WG)
+k_att_plan(AttPlanArgs a)
+{
+    __shared__ uint32_t wt32[16];
+    __shared__ unsigned long long wt64[16];
+    __shared__ uint32_t s_max_size, s_not_aligned, s_err, s_rows_t[2];
+    const uint4* rows = static_cast<const uint4*>(a.rows);
+    const uint32_t n = a.n;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_max_size = 0; s_not_aligned = 0; s_err = a.plan->error; s_rows_t[0] = 0; s_rows_t[1] = 0; }
+    __syncthreads();
+    const bool dead = s_err != 0;  // ingest refused a row: nothing downstream may touch the bits
+
+    // ---- 1. representatives -> group ids in order of first appearance
+    uint32_t ng = 0;
+    for (uint32_t base = 0; base < n; base += PLAN_WG) {
+        const uint32_t i = base + tid;
+        uint32_t rep = NONE32;
+        if (i < n) {
+            rep = a.tab[a.slot_of[i]];
+            a.rep_of[i] = rep;
+        }
+        const uint32_t is_rep = (i < n && rep == i) ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t pos = block_scan_1024<uint32_t>(is_rep, wt32, &tot);
+        if (is_rep) {
+            a.gid_of_row[i] = ng + pos;
+            a.rep_row[ng + pos] = i;
+        }
+        ng += tot;
+    }
+    if (dead) ng = 0;
+    __syncthreads();  // rep_row / gid_of_row are re-read below by other lanes (workgroup-scope visibility)
+
+    // ---- 2. per group: committee resolution, union offsets (prefix sums over words and bytes)
+    const unsigned long long spe = a.tables.slots_per_epoch;
+    uint32_t word_base = 0, byte_base = 0;
+    unsigned long long total_members = 0;
+    for (uint32_t base = 0; base < ng; base += PLAN_WG) {
+        const uint32_t g = base + tid;
+        uint32_t words = 0, bytes = 0, nbits = 0, size = 0, table = NONE32, pos = 0, mbase = 0, rep = 0;
+        int32_t st = ST_OK;
+        if (g < ng) {
+            rep = a.rep_row[g];
+            const uint4* p = rows + (size_t)9 * rep;
+            const uint4 q0 = p[0], q5 = p[5], q8 = p[8];
+            const unsigned long long slot = u64_of(q0.x, q0.y), index = u64_of(q0.z, q0.w), tep = u64_of(q5.z, q5.w);
+            nbits = q8.y;
+            words = (nbits + 31) >> 5;
+            bytes = (nbits + 7) >> 3;
+            // get_beacon_committee(state, slot, index) (A.6) against the table of the target epoch
+            if (a.tables.t[0].valid && a.tables.t[0].epoch == tep) table = 0;
+            else if (a.tables.t[1].valid && a.tables.t[1].epoch == tep) table = 1;
+            if (table == NONE32) st = ST_NO_TABLE;
+            else {
+                const TableDev& t = a.tables.t[table];
+                const unsigned long long cps = t.n_committees / spe;
+                if (index >= cps) st = ST_INDEX_RANGE;
+                else {
+                    pos = (uint32_t)((slot % spe) * cps + index);
+                    mbase = t.offsets[pos];
+                    size = t.offsets[pos + 1] - mbase;
+                    if (nbits != size) st = ST_BITS_LENGTH;  // len(aggregation_bits) == len(committee), pe:730
+                }
+            }
+            if (st != ST_OK && a.want_pk)  // the host path fails the whole aggregate here (engine_attest.cpp)
+                atomicMax(&s_err, st == ST_NO_TABLE ? ERR_NO_COMMITTEES : ERR_INVALID_ARG);
+            if (st == ST_OK) {
+                atomicMax(&s_max_size, size);
+                atomicAdd(&s_rows_t[table], 1u);
+            }
+        }
+        uint32_t tw, tb;
+        const uint32_t ow = block_scan_1024<uint32_t>(words, wt32, &tw);
+        const uint32_t ob = block_scan_1024<uint32_t>(bytes, wt32, &tb);
+        unsigned long long tm;
+        (void)block_scan_1024<unsigned long long>(st == ST_OK ? (unsigned long long)size : 0ull, wt64, &tm);
+        total_members += tm;
+        if (g < ng) {
+            AttGroup& G = a.grp[g];
+            G.rep = rep;
+            G.n_atts = 0;
+            G.cursor = 0;
+            G.n_bits = nbits;
+            G.out_word = word_base + ow;
+            G.out_byte = byte_base + ob;
+            G.table = st == ST_NO_TABLE ? NONE32 : table;
+            G.pos = pos;
+            G.size = size;
+            G.member_base = mbase;
+            G.sig_valid = FLAG_SIG_VALID;
+            G.status_agg = (uint32_t)st;
+            // word layout == byte layout as long as every union but the last one is a whole number of words
+            if (g + 1 < ng && bytes != 4 * words) atomicOr(&s_not_aligned, 1u);
+        }
+        word_base += tw;
+        byte_base += tb;
+    }
+    __syncthreads();
+
+    // ---- 3. members per group
+    for (uint32_t i = tid; i < n && ng; i += PLAN_WG) atomicAdd(&a.grp[a.gid_of_row[a.rep_of[i]]].n_atts, 1u);
+    __syncthreads();
+
+    // ---- 4. list offsets, union + G1 descriptors
+    // one block size for every group: k members per lane, blocks of BL = 2^L lanes, group g at slot g * BL.  k follows
+    // from the largest committee so that its tasks fill a block exactly or nearly (sizes that differ by one -- 511 / 512
+    // members -- would otherwise put half of the lanes of every block to sleep)
+    uint32_t k = a.min_k, L = 0;
+    {
+        const uint32_t max_size = s_max_size;
+        const unsigned long long k0 = max((unsigned long long)a.min_k, (total_members + a.target_slots - 1) / a.target_slots);
+        uint32_t tasks = (uint32_t)((max_size + k0 - 1) / k0);
+        if (tasks > (uint32_t)G1_WG) tasks = G1_WG;
+        while ((1u << L) < tasks) ++L;
+        while (L > 0 && ((unsigned long long)ng << L) > a.slot_cap) --L;  // bounded scratch: fewer, longer lanes
+        k = max(a.min_k, (max_size + (1u << L) - 1) >> L);
+        if (k == 0) k = 1;
+    }
+    uint32_t list_base = 0;
+    for (uint32_t base = 0; base < ng; base += PLAN_WG) {
+        const uint32_t g = base + tid;
+        const uint32_t cnt = g < ng ? a.grp[g].n_atts : 0u;
+        uint32_t tc;
+        const uint32_t ls = block_scan_1024<uint32_t>(cnt, wt32, &tc);
+        if (g < ng) {
+            AttGroup& G = a.grp[g];
+            G.list_start = list_base + ls;
+            UnionGroup u;
+            u.list_start = list_base + ls;
+            u.n_atts = cnt;
+            u.n_bits = G.n_bits;
+            u.out_word = G.out_word;
+            a.ug[g] = u;
+            const bool ok = G.status_agg == ST_OK;
+            G1Group d;
+            d.member_start = G.member_base;
+            d.n_members = ok ? G.size : 0u;
+            d.bits_word = G.out_word;
+            d.slot_base = g << L;
+            d.n_tasks = ok ? (G.size + k - 1) / k : 0u;
+            d.k = k | (G.table == 1 ? 0x80000000u : 0u);
+            d.log2_block = L;
+            d.out_base = g;
+            a.g1[g] = d;
+        }
+        list_base += tc;
+    }
+
+    // ---- 5. rows per committee of each candidate table (unordered lists; consumers order by group id)
+    for (int t = 0; t < 2; ++t) {
+        if (!a.tables.t[t].valid) continue;
+        const uint32_t nc = a.tables.t[t].n_committees;
+        for (uint32_t c = tid; c <= nc; c += PLAN_WG) a.crow_cursor[t][c] = 0;
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += PLAN_WG) {
+        const AttGroup& G = a.grp[g];
+        if (G.status_agg == ST_OK) atomicAdd(&a.crow_cursor[G.table][G.pos], 1u);
+    }
+    __syncthreads();
+    for (int t = 0; t < 2; ++t) {
+        if (!a.tables.t[t].valid) continue;
+        const uint32_t nc = a.tables.t[t].n_committees;
+        uint32_t run = 0;
+        for (uint32_t base = 0; base <= nc; base += PLAN_WG) {
+            const uint32_t c = base + tid;
+            const uint32_t cnt = c < nc ? a.crow_cursor[t][c] : 0u;
+            uint32_t tc;
+            const uint32_t st0 = block_scan_1024<uint32_t>(cnt, wt32, &tc);
+            if (c <= nc) a.crow_start[t][c] = run + st0;
+            run += tc;
+        }
+        __syncthreads();
+        for (uint32_t c = tid; c < nc; c += PLAN_WG) a.crow_cursor[t][c] = a.crow_start[t][c];
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += PLAN_WG) {
+        const AttGroup& G = a.grp[g];
+        if (G.status_agg == ST_OK) a.crow_list[G.table][atomicAdd(&a.crow_cursor[G.table][G.pos], 1u)] = g;
+    }
+
+    // ---- 6. the plan, for the kernels that follow and (pinned mirror) for the host's completion
+    if (tid == 0) {
+        uint32_t err = s_err;
+        if (!err && byte_base > a.out_arena_cap) err = ERR_CAPACITY;  // "output bit arena too small"
+        AttPlan p;
+        p.n_groups = err ? 0u : ng;  // a failing aggregate forms no groups: the handlers behind it apply nothing
+        p.n_slots = p.n_groups << L;
+        p.k = k;
+        p.log2_block = L;
+        p.out_words = word_base;
+        p.out_bytes = byte_base;
+        p.error = err;
+        p.packed_same = s_not_aligned ? 0u : 1u;
+        p.n_rows_table[0] = s_rows_t[0];
+        p.n_rows_table[1] = s_rows_t[1];
+        p.n_rows_in = n;
+        p.reserved = 0;
+        p.total_members = total_members;
+        *a.plan = p;
+        *a.plan_host = p;
+    }
+}
+
+void launch_att_plan(hipStream_t s, const AttPlanArgs& a)
+{
+    hipLaunchKernelGGL(k_att_plan, dim3(1), dim3(PLAN_WG), 0, s, a);
+}
+
+// ------------------------------------------------------------------ members
+__global__ void __launch_bounds__(256)
+k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, const uint32_t* __restrict__ slot_of,
+              const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ gid_of_row, AttGroup* __restrict__ grp,
+              AttPlan* __restrict__ plan, uint32_t* __restrict__ ubytes, uint32_t* __restrict__ member_row,
+              uint32_t* __restrict__ host_group_of, uint4* __restrict__ host_out_rows)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = slot_of[i];
+    if (plan->n_groups) {
+        const uint32_t rep = rep_of[i];
+        const uint32_t g = gid_of_row[rep];
+        const uint4 q8 = rows[(size_t)9 * i + 8];
+        if (host_group_of) host_group_of[i] = g;
+        AttGroup& G = grp[g];
+        const uint32_t p = G.list_start + atomicAdd(&G.cursor, 1u);
+        ubytes[p] = q8.x;       // byte offset of the member's bits in the arena (copied whole, offset 0)
+        member_row[p] = i;
+        if (!(q8.z & FLAG_SIG_VALID)) atomicAnd(&G.sig_valid, 0u);
+        if (rep == i && host_out_rows) {  // the group's output row: its data, bits_offset into the packed output arena
+            uint4* o = host_out_rows + (size_t)9 * g;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = rows[(size_t)9 * i + k];
+            o[8] = make_uint4(G.out_byte, q8.y, q8.z, 0u);  // flags: the host folds in the verdicts at completion
+        }
+    }
+    tab[slot] = ATT_EMPTY;  // every row of a class clears the class's slot: the table is empty again for the next call
+    if (i == 0) plan->error = 0;  // consumed by k_att_plan (mirrored to the host): k_att_ingest of the next call starts clean
+}
+
+void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, const uint32_t* slot_of,
+                        const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
+                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_att_members, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
+                       slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row, host_group_of,
+                       static_cast<uint4*>(host_out_rows));
+}
+
+// ------------------------------------------------------------------ block lookups
+namespace {
+__device__ __forceinline__ uint32_t find_block_dev(const BlockTableDev& bt, const uint4& r0, const uint4& r1)
+{
+    uint32_t h = r0.x & bt.root_mask;  // roots are hash outputs: the leading word is uniform
+    for (;;) {
+        const uint32_t idx = bt.root_tab[h];
+        if (idx == NONE32) return NONE32;
+        const uint4* q = reinterpret_cast<const uint4*>(bt.roots + 32ull * idx);
+        if (same4(q[0], r0) && same4(q[1], r1)) return idx;
+        h = (h + 1) & bt.root_mask;
+    }
+}
+__device__ __forceinline__ bool root_equals(const uint8_t* root32, const uint4& r0, const uint4& r1)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(root32);
+    return w[0] == r0.x && w[1] == r0.y && w[2] == r0.z && w[3] == r0.w && w[4] == r1.x && w[5] == r1.y && w[6] == r1.z &&
+           w[7] == r1.w;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ validate_on_attestation (A.4) per group
+__global__ void __launch_bounds__(256)
+k_att_validate_fc(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
+                  uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* __restrict__ union_info,
+                  AttRow* __restrict__ out_rows, int32_t* __restrict__ status_dev, int32_t* __restrict__ status_host,
+                  uint32_t* __restrict__ count_host, uint32_t* __restrict__ err_host)
+{
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ng = plan->n_groups;
+    if (ng > cap) {  // the caller's status / count arrays hold fewer entries than groups were formed: nothing applies
+        if (g < ng) status_dev[g] = -1;
+        if (g == 0) *err_host = ERR_CAPACITY;
+        return;
+    }
+    if (g >= ng) return;
+    const AttGroup G = grp[g];
+    Row9 r;
+    load_row(r, rows, G.rep);
+    const unsigned long long slot = row_slot(r), tep = row_target_epoch(r), spe = fc.slots_per_epoch;
+    const uint32_t flags = r.q[8].z;
+    int32_t st = ST_OK;
+    uint32_t blk = NONE32;
+    // validate_target_epoch_against_current_time (skipped for attestations from blocks, pe:1423)
+    if (!(flags & FLAG_FROM_BLOCK) && tep != fc.cur_epoch && tep != fc.prev_epoch) st = ST_EPOCH_TIME;
+    else if (tep != slot / spe) st = ST_EPOCH_SLOT;
+    else {
+        const uint32_t tgt = find_block_dev(bt, r.q[6], r.q[7]);
+        if (tgt == NONE32) st = ST_UNKNOWN_TARGET;
+        else {
+            blk = find_block_dev(bt, r.q[1], r.q[2]);
+            if (blk == NONE32) st = ST_UNKNOWN_BLOCK;
+            else {
+                uint32_t p = bt.pos_of_idx[blk];
+                if (bt.slot_pos[p] > slot) st = ST_BLOCK_AFTER_SLOT;
+                else {
+                    // get_ancestor(store, beacon_block_root, compute_start_slot_at_epoch(target.epoch)) (A.2): the
+                    // block's slot is <= data.slot and the epoch is data.slot's, so the walk is at most
+                    // SLOTS_PER_EPOCH parent steps (slots strictly increase along parent links)
+                    const unsigned long long start = tep * spe;
+                    while (bt.slot_pos[p] > start && bt.parent_pos[p] != NONE32) p = bt.parent_pos[p];
+                    if (p != bt.pos_of_idx[tgt]) st = ST_TARGET_NOT_ANCESTOR;
+                    else if (fc.cur_slot < slot + 1) st = ST_SLOT_NOT_PAST;
+                }
+            }
+        }
+    }
+    if (st == ST_OK && G.status_agg) st = (int32_t)G.status_agg;  // committee resolution: table, index, bits length
+    // is_valid_indexed_attestation (A.7): the signature verdict, then what the OR-ed bits say (overlap, emptiness)
+    const uint32_t cnt = union_info[2 * g], overlap = union_info[2 * g + 1];
+    if (st == ST_OK) {
+        if (!G.sig_valid) st = ST_BAD_SIGNATURE;
+        else if (overlap) st = ST_BAD_SIGNATURE;
+        else if (cnt == 0) st = ST_EMPTY;
+    }
+    AttRow o;
+    o.member_base = G.member_base;
+    o.n_bits = G.size;
+    o.bits_word = G.out_word;
+    o.block_idx = blk;
+    o.epoch_p1 = (uint32_t)tep + 1;
+    o.order = g;
+    o.flag_mask = 0;
+    o.which = 0;
+    o.slot = (uint32_t)slot;
+    o.gate = g;
+    out_rows[g] = o;
+    status_dev[g] = st;
+    status_host[g] = st;
+    if (count_host) count_host[g] = st == ST_OK ? cnt : 0u;
+}
+
+void launch_att_validate_fc(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
+                            uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* union_info, AttRow* out_rows,
+                            int32_t* status_dev, int32_t* status_host, uint32_t* count_host, uint32_t* err_host)
+{
+    if (n_bound == 0) return;
+    hipLaunchKernelGGL(k_att_validate_fc, dim3((n_bound + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), grp,
+                       plan, cap, bt, fc, union_info, out_rows, status_dev, status_host, count_host, err_host);
+}
+
+// ------------------------------------------------------------------ process_attestation's asserts + flag indices per group
+__global__ void __launch_bounds__(256)
+k_att_validate_state(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
+                     uint32_t cap, BlockTableDev bt, const StateCtxDev* __restrict__ stp,
+                     const uint32_t* __restrict__ union_info, AttRow* __restrict__ out_rows,
+                     int32_t* __restrict__ status_dev, int32_t* __restrict__ status_host, uint32_t* __restrict__ err_host)
+{
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ng = plan->n_groups;
+    if (ng > cap) {
+        if (g < ng) status_dev[g] = -1;
+        if (g == 0) *err_host = ERR_CAPACITY;
+        return;
+    }
+    if (g >= ng) return;
+    const StateCtxDev& S = *stp;
+    const AttGroup G = grp[g];
+    Row9 r;
+    load_row(r, rows, G.rep);
+    const unsigned long long slot = row_slot(r), tep = row_target_epoch(r), spe = S.slots_per_epoch;
+    int32_t st = ST_OK;
+    uint32_t flag_mask = 0;
+    if (tep != S.prev_epoch && tep != S.cur_epoch) st = ST_EPOCH_TIME;                                   // pe:724
+    else if (tep != slot / spe) st = ST_EPOCH_SLOT;                                                       // pe:725
+    else if (!(slot + S.min_inclusion_delay <= S.slot && S.slot <= slot + spe)) st = ST_INCLUSION;        // pe:726
+    else if (G.status_agg) st = (int32_t)G.status_agg;                                                    // pe:727-730
+    else {
+        // get_attestation_participation_flag_indices (A.9)
+        const bool is_cur = tep == S.cur_epoch;
+        const unsigned long long j_epoch = is_cur ? S.cj_epoch : S.pj_epoch;
+        const uint8_t* j_root = is_cur ? S.cj_root : S.pj_root;
+        const uint4 s0 = make_uint4(r.q[3].z, r.q[3].w, r.q[4].x, r.q[4].y), s1 = make_uint4(r.q[4].z, r.q[4].w, r.q[5].x, r.q[5].y);
+        if (row_source_epoch(r) != j_epoch || !root_equals(j_root, s0, s1)) st = ST_SOURCE;  // assert is_matching_source
+        else {
+            const uint32_t tgt_blk = S.tgt_blk[is_cur ? 0 : 1];
+            const bool matching_target = tgt_blk != NONE32 && root_equals(bt.roots + 32ull * tgt_blk, r.q[6], r.q[7]);
+            const unsigned long long j = slot + spe - S.slot;  // pe:726 puts data.slot into [state.slot - spe, state.slot)
+            const uint32_t head_blk = j < 64 ? S.head_blk[j] : NONE32;
+            const bool matching_head = matching_target && head_blk != NONE32 &&
+                                       root_equals(bt.roots + 32ull * head_blk, r.q[1], r.q[2]);
+            const unsigned long long delay = S.slot - slot;
+            if (delay <= S.sqrt_spe) flag_mask |= 1u;                               // TIMELY_SOURCE
+            if (matching_target && delay <= spe) flag_mask |= 2u;                   // TIMELY_TARGET
+            if (matching_head && delay == S.min_inclusion_delay) flag_mask |= 4u;   // TIMELY_HEAD
+        }
+    }
+    const uint32_t cnt = union_info[2 * g], overlap = union_info[2 * g + 1];
+    if (st == ST_OK) {
+        if (!G.sig_valid) st = ST_BAD_SIGNATURE;   // pe:736
+        else if (overlap) st = ST_BAD_SIGNATURE;
+        else if (cnt == 0) st = ST_EMPTY;
+    }
+    AttRow o;
+    o.member_base = G.member_base;
+    o.n_bits = G.size;
+    o.bits_word = G.out_word;
+    o.block_idx = 0;
+    o.epoch_p1 = 0;
+    o.order = g;
+    o.flag_mask = flag_mask;
+    o.which = tep == S.cur_epoch ? 0u : 1u;  // pe:739-742
+    o.slot = 0;
+    o.gate = g;
+    out_rows[g] = o;
+    status_dev[g] = st;
+    status_host[g] = st;
+}
+
+void launch_att_validate_state(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
+                               uint32_t cap, BlockTableDev bt, const StateCtxDev* st, const uint32_t* union_info,
+                               AttRow* out_rows, int32_t* status_dev, int32_t* status_host, uint32_t* err_host)
+{
+    if (n_bound == 0) return;
+    hipLaunchKernelGGL(k_att_validate_state, dim3((n_bound + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows),
+                       grp, plan, cap, bt, st, union_info, out_rows, status_dev, status_host, err_host);
+}
+
+// ------------------------------------------------------------------ LMD update, validator-major, both tables
+// One lane per validator walks the rows of ITS committee.  The lists are unordered, so the spec's sequential rule
+// (pe:1435-1441: a later target epoch wins; among equal epochs the first in batch order, and only against a stored vote
+// of a strictly earlier epoch) is applied by comparing (epoch, order) explicitly.
+__global__ void __launch_bounds__(256)
+k_lmd_vm_tables(const AttRow* __restrict__ rows, TablesDev tables, const uint32_t* __restrict__ cs0,
+                const uint32_t* __restrict__ cs1, const uint32_t* __restrict__ cl0, const uint32_t* __restrict__ cl1,
+                const AttPlan* __restrict__ plan, const uint32_t* __restrict__ bit_arena,
+                const uint8_t* __restrict__ flags, unsigned long long n_val, unsigned long long* __restrict__ vote_key,
+                uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot, const uint32_t* __restrict__ gates)
+{
+    __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
+    const int t = blockIdx.y;
+    if (!tables.t[t].valid || plan->n_rows_table[t] == 0) return;
+    const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_val) return;
+    const uint32_t c = tables.t[t].inv_comm[v];
+    if (c == NONE32) return;
+    const uint32_t* crow_start = t ? cs1 : cs0;
+    const uint32_t* crow_list = t ? cl1 : cl0;
+    const uint32_t kb = crow_start[c], ke = crow_start[c + 1];
+    if (kb == ke) return;
+    if (flags[v] & VAL_EQUIVOCATING_BIT) return;  // pe:1438
+    const uint32_t i = tables.t[t].inv_pos[v];
+    const uint32_t stored_e = (uint32_t)(vote_key[v] >> 32);  // epoch + 1; 0 = no latest message
+    uint32_t best_e = stored_e, best_order = NONE32, new_block = NONE32, new_slot = 0;
+    for (uint32_t k = kb; k < ke; ++k) {
+        const AttRow r = rows[crow_list[k]];
+        if (i >= r.n_bits) continue;
+        if (gates[r.gate] != 0) continue;  // rejected by validation (or voided: overlapping members)
+        if (!((bit_arena[r.bits_word + (i >> 5)] >> (i & 31)) & 1u)) continue;
+        if (r.epoch_p1 > best_e || (r.epoch_p1 == best_e && new_block != NONE32 && r.order < best_order)) {
+            best_e = r.epoch_p1;
+            best_order = r.order;
+            new_block = r.block_idx;
+            new_slot = r.slot;
+        }
+    }
+    if (new_block != NONE32) {
+        vote_key[v] = ((unsigned long long)best_e << 32) | 0xFFFFFFFFull;
+        vote_block[v] = new_block;
+        if (vote_slot) vote_slot[v] = new_slot;
+    }
+}
+
+void launch_lmd_vm_tables(hipStream_t s, const AttRow* rows, TablesDev tables, uint32_t* const crow_start[2],
+                          uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
+                          const uint8_t* flags, uint64_t n_val, uint64_t* vote_key, uint32_t* vote_block,
+                          uint32_t* vote_slot, const uint32_t* gates)
+{
+    if (n_val == 0) return;
+    const unsigned ny = tables.t[1].valid ? 2u : 1u;
+    hipLaunchKernelGGL(k_lmd_vm_tables, dim3((unsigned)((n_val + 255) / 256), ny), dim3(256), 0, s, rows, tables,
+                       crow_start[0], crow_start[1], crow_list[0], crow_list[1], plan, bit_arena, flags,
+                       (unsigned long long)n_val, reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot,
+                       gates);
+}
+
+// ------------------------------------------------------------------ participation flags, one wave per committee
+__global__ void __launch_bounds__(256)
+k_participation_tables(const AttRow* __restrict__ rows, TablesDev tables, const uint32_t* __restrict__ cs0,
+                       const uint32_t* __restrict__ cs1, const uint32_t* __restrict__ cl0,
+                       const uint32_t* __restrict__ cl1, const AttPlan* __restrict__ plan,
+                       const uint32_t* __restrict__ bit_arena, const uint16_t* __restrict__ eff_increments,
+                       unsigned long long base_reward_per_increment, uint32_t* __restrict__ part_cur,
+                       uint32_t* __restrict__ part_prev, unsigned long long* __restrict__ numerators,
+                       const uint32_t* __restrict__ gates)
+{
+    const int t = blockIdx.y;
+    if (!tables.t[t].valid || plan->n_rows_table[t] == 0) return;
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= tables.t[t].n_committees) return;
+    const uint32_t* crow_start = t ? cs1 : cs0;
+    const uint32_t* crow_list = t ? cl1 : cl0;
+    const uint32_t kb = crow_start[c], ke = crow_start[c + 1];
+    if (kb == ke) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t* members = tables.t[t].members;
+    // the committee's rows in batch order (ascending group id): a selection loop, the lists hold one or a few rows
+    uint32_t last = NONE32;  // NONE32 + 1 == 0
+    for (uint32_t done = kb; done < ke; ++done) {
+        uint32_t g = NONE32;
+        for (uint32_t k = kb; k < ke; ++k) {
+            const uint32_t x = crow_list[k];
+            if ((last == NONE32 || x > last) && x < g) g = x;
+        }
+        last = g;
+        const AttRow r = rows[g];
+        unsigned long long num = 0;
+        if (gates[r.gate] == 0) {
+            uint32_t* part = r.which ? part_prev : part_cur;
+            for (uint32_t i = lane; i < r.n_bits; i += 64) {
+                const uint32_t word = bit_arena[r.bits_word + (i >> 5)];
+                if (!((word >> (i & 31)) & 1u)) continue;
+                const uint32_t v = members[r.member_base + i];
+                uint8_t* pb = reinterpret_cast<uint8_t*>(part) + v;
+                const uint32_t old = *pb;
+                const uint32_t fresh = r.flag_mask & ~old & 0x7u;
+                if (fresh) {
+                    *pb = (uint8_t)(old | r.flag_mask);
+                    // PARTICIPATION_FLAG_WEIGHTS = [14, 26, 14] (Appendix A.9)
+                    const uint32_t wsum = ((fresh & 1u) ? 14u : 0u) + ((fresh & 2u) ? 26u : 0u) + ((fresh & 4u) ? 14u : 0u);
+                    num += (unsigned long long)eff_increments[v] * base_reward_per_increment * wsum;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) num += __shfl_xor(num, off, 64);
+        if (lane == 0) numerators[g] = num;
+        // the next row of this committee may touch the same validators: this wave's byte stores must be visible to its
+        // own later loads (same wave, program order: they are)
+    }
+}
+
+void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev tables, uint32_t* const crow_start[2],
+                                 uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
+                                 const uint16_t* eff_increments, uint64_t base_reward_per_increment,
+                                 uint32_t* part_cur_words, uint32_t* part_prev_words, uint64_t* numerators,
+                                 const uint32_t* gates)
+{
+    uint32_t nc = tables.t[0].valid ? tables.t[0].n_committees : 0u;
+    if (tables.t[1].valid) nc = nc > tables.t[1].n_committees ? nc : tables.t[1].n_committees;
+    if (nc == 0) return;
+    const unsigned ny = tables.t[1].valid ? 2u : 1u;
+    hipLaunchKernelGGL(k_participation_tables, dim3((nc + 3) / 4, ny), dim3(256), 0, s, rows, tables, crow_start[0],
+                       crow_start[1], crow_list[0], crow_list[1], plan, bit_arena, eff_increments,
+                       (unsigned long long)base_reward_per_increment, part_cur_words, part_prev_words,
+                       reinterpret_cast<unsigned long long*>(numerators), gates);
+}
+
+}  // namespace posevo

@@ -90,6 +90,11 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
     int rc = need_init(h, /*flush=*/false);
     if (rc) return rc;
     if (n && (!atts || !bits_arena || !status)) return PE_ERR_INVALID_ARG;
+    if (atts == PE_ROWS_RESIDENT) {  // the groups of the last pe_aggregate over rows in device memory, validated there
+        if (bits_arena != PE_BITS_RESIDENT || out_aggpk96)
+            return fail(h, PE_ERR_INVALID_ARG, "PE_ROWS_RESIDENT goes with PE_BITS_RESIDENT; the aggregate pubkeys are pe_aggregate's");
+        return on_attestation_resident(h, n, status, out_count);
+    }
     if (out_aggpk96 && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     if (n == 0) return PE_OK;
     const bool resident = bits_arena == PE_BITS_RESIDENT;
@@ -421,6 +426,12 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
     if (want_pk && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     *out_n_groups = 0;
     if (n == 0) return PE_OK;
+    if (rows_on_device(atts)) {  // rows the host cannot read: grouped, resolved and validated on the device
+        if (sig_points96 || out_sig96 || dev_partials)
+            return fail(h, PE_ERR_INVALID_ARG, "rows in device memory: signature points and sharded partials take host rows");
+        return aggregate_resident(h, atts, n, bits_arena, arena_len, out_atts, out_n_groups, group_of, out_bits_arena,
+                                  out_arena_cap, out_aggpk96, out_count);
+    }
     HostLap lap(&h->trace);
     auto stp = std::make_shared<AggState>();
     AggState& A = *stp;
@@ -868,6 +879,10 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     int rc = need_init(h, /*flush=*/false);
     if (rc) return rc;
     if (!st || (n && (!atts || !bits_arena || !status || !out_numerators))) return PE_ERR_INVALID_ARG;
+    if (atts == PE_ROWS_RESIDENT) {
+        if (bits_arena != PE_BITS_RESIDENT) return fail(h, PE_ERR_INVALID_ARG, "PE_ROWS_RESIDENT goes with PE_BITS_RESIDENT");
+        return process_attestation_resident(h, st, n, status, out_numerators);
+    }
     if (n == 0) return PE_OK;
     const bool resident = bits_arena == PE_BITS_RESIDENT;
     if (resident && !h->res_valid) return fail(h, PE_ERR_STATE, "PE_BITS_RESIDENT: no pe_aggregate result is resident");

@@ -245,6 +245,8 @@ void pe_engine_destroy(pe_engine* h)
         a.d_res_info.release();
         a.d_partials.release();
         a.d_lane_partials.release();
+        a.d_rr_tab.release();
+        a.d_rr.release();
         a.d_stage.release();
         a.d_outblk.release();
         a.h_stage.release();
@@ -255,6 +257,7 @@ void pe_engine_destroy(pe_engine* h)
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
                       &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head,
+                      &h->d_broot_tab, &h->d_broots, &h->d_bslot_pos,
                       &h->d_partials, &h->d_lane_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
         b->release();
     for (auto& t : h->tables) { t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release(); }

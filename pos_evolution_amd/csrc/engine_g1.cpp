@@ -18,10 +18,12 @@ void g1_stream_guard(pe_engine* h, hipStream_t s)
 // Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
 // fin != s: the tree and finish kernels go to their own stream behind an event (a pipelined aggregate: they then overlap
 // the next aggregate's accumulation); partials / lane_partials: the scratch the kernels hand over through (per arena
-// when pipelined).
+// when pipelined).  plan_dev: the plan lives on the device (rows resident there, engine_resident.cpp): `plan` then holds
+// upper bounds that size grids and scratch; d_members1: member array of the groups of the second candidate table.
 int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
-                      hipStream_t s, hipStream_t fin, DevBuf* partials, DevBuf* lane_partials)
+                      hipStream_t s, hipStream_t fin, DevBuf* partials, DevBuf* lane_partials, const AttPlan* plan_dev,
+                      const uint32_t* d_members1)
 {
     if (plan.n_groups == 0) return PE_OK;
     if (!s) s = h->stream;
@@ -35,7 +37,7 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     {
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s);
         launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             lane_partials->as<uint32_t>(), partials->as<uint32_t>());
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
     }
     if (fin != s) {
         HIP_TRY(h, hipEventRecord(h->ev_acc, s));
@@ -44,11 +46,12 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     {
         ProfScope ps(h, PE_KERNEL_G1_TREE, fin);
         launch_g1_tree(fin, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
-                       /*one_per_cu=*/fin != s ? 1 : 0);  // on its own stream it meets the next step's k_tree: leave it room
+                       /*one_per_cu=*/fin != s ? 1 : 0,   // on its own stream it meets the next step's k_tree: leave it room
+                       plan_dev);
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_NORMALISE, fin);
-        launch_g1_finish(fin, partials->as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac);
+        launch_g1_finish(fin, partials->as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac, plan_dev);
     }
     HIP_TRY(h, hipGetLastError());
     return PE_OK;

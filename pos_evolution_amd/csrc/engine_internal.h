@@ -215,6 +215,8 @@ struct pe_engine {
     // ---- tree snapshot (pre-order) ----
     bool tree_dirty = true;
     DevBuf d_tsize, d_tparent, d_trank, d_tleaf, d_tpos, d_tidx, d_direct, d_weights, d_totals, d_head;
+    DevBuf d_broot_tab, d_broots, d_bslot_pos;  // device-side block lookups (root -> index hash table, roots, slot by position)
+    uint32_t broot_mask = 0;
     std::vector<uint32_t> h_pos_of_idx;
     PinBuf h_head;  // 64 B of host-coherent pinned memory the tree kernel writes the head index into
     uint32_t votes_grid = 0;  // workgroups of the last k_votes launch on the engine's own buffers
@@ -238,6 +240,9 @@ struct pe_engine {
         PinBuf h_stage, h_pin;            // their pinned host mirrors (h_pin is host-coherent: kernels write into it)
         DevBuf d_res_bits, d_res_info;    // resident hand-over: OR-ed bit words | {popcount, overlap} per group
         DevBuf d_partials, d_lane_partials;  // tree -> finish | accumulate -> tree hand-over of this arena's pipelined aggregate
+        // rows resident on the device (engine_resident.cpp): grouping table (self-cleaning) and the per-call scratch
+        DevBuf d_rr_tab, d_rr;
+        uint32_t rr_rows_cap = 0, rr_comm_cap = 0, rr_tab_size = 0;
         size_t stage_cursor = 0, out_cursor = 0;
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr;  // recorded by pe_pipeline_end_lagged
@@ -266,6 +271,16 @@ struct pe_engine {
     bool res_valid = false;
     int res_arena = 0;                    // which arena holds the resident bits
     uint64_t res_generation = 0;          // which pe_aggregate the resident data belongs to
+
+    // ---- the last pe_aggregate over rows in DEVICE memory (PE_ROWS_RESIDENT hand-over to the handlers) ----
+    struct ResidentRows {
+        bool valid = false;
+        int arena = 0;
+        uint32_t n_in = 0;              // input rows = upper bound of the groups formed
+        const void* rows = nullptr;     // the caller's device rows (unchanged until the pipeline completes)
+        TablesDev tables{};             // the candidate committee tables the groups were resolved against
+        uint64_t generation = 0;
+    } rr;
 
     // ---- accumulate-shape autotune (large pubkey aggregations) ----
     // 131072 task slots (two waves per SIMD, 6 tree levels at 512-member committees) or 65536 (one wave, 5 levels):
@@ -546,7 +561,8 @@ void g1_stream_guard(pe_engine* h, hipStream_t s);
 int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
                       hipStream_t s = nullptr, hipStream_t fin = nullptr, DevBuf* partials = nullptr,
-                      DevBuf* lane_partials = nullptr);
+                      DevBuf* lane_partials = nullptr, const AttPlan* plan_dev = nullptr,
+                      const uint32_t* d_members1 = nullptr);
 
 // ------------------------------------------------------------------ attestation resolution
 struct Resolved {
@@ -604,6 +620,15 @@ struct Rccl {
     bool ok = false;
 };
 Rccl& rccl();
+
+// rows resident in device memory (engine_resident.cpp)
+bool rows_on_device(const void* p);
+BlockTableDev block_table_dev(const pe_engine* h);
+int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, const uint8_t* bits_arena,
+                       uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                       uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count);
+int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_t* out_count);
+int process_attestation_resident(pe_engine* h, const pe_state_ctx* st, uint32_t cap, int32_t* status, uint64_t* out_numerators);
 
 // pe_aggregate and its partial / sharded forms (engine_attest.cpp)
 int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,

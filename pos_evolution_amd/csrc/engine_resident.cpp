@@ -1,0 +1,514 @@
+// engine_resident.cpp -- pe_aggregate / pe_on_attestation_batch / pe_process_attestation_batch over attestation rows
+// that lie in DEVICE memory (PE_ROWS_RESIDENT, include/posevo.h).
+//
+// With host rows (engine_attest.cpp) one host thread groups the rows by 128-byte memcmp, walks
+// validate_on_attestation (A.4) per row and lays out every descriptor array -- ~300 us per 1 M-validator epoch, more
+// than the GPU needs for the epoch's G1 sums, and the same on every rank of a sharded run.  Here the host reads nothing
+// of the rows: it sizes grids and scratch by upper bounds (n input rows >= groups), enqueues a fixed sequence of
+// kernels (att_kernels.hip) and copies results out of the pinned block when the call completes.  Reference functions
+// replaced: the grouping of the validator guide's aggregation (A.8; pe:474/659), validate_on_attestation called at
+// pe:970, the asserts pe:724-730, get_attestation_participation_flag_indices (A.9), update_latest_messages
+// pe:1435-1441, the flag loop pe:745-749.  Results are identical to the host path (tests/test_gpu_resident_rows.py).
+//
+// Committees are resolved against the tables of the store's CURRENT and PREVIOUS epoch (the only target epochs
+// validate_on_attestation admits for gossip attestations); both must be partition tables (a real shuffling is).
+#include "engine_internal.h"
+
+using namespace posevo;
+
+namespace posevo {
+
+namespace {
+
+struct RrLayout {  // typed views into PipeArena::d_rr
+    AttPlan* plan;
+    uint32_t *slot_of, *rep_of, *gid_of_row, *rep_row, *ubytes, *member_row;
+    AttGroup* grp;
+    UnionGroup* ug;
+    G1Group* g1;
+    AttRow *rows_fc, *rows_st;
+    int32_t *status_fc, *status_st;
+    uint32_t *crow_start[2], *crow_cursor[2], *crow_list[2];
+    size_t bytes;
+};
+
+RrLayout rr_layout(uint8_t* base, uint32_t cap_n, uint32_t cap_c)
+{
+    RrLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        uint8_t* p = base ? base + off : nullptr;
+        off = (off + bytes + 255) & ~size_t(255);
+        return p;
+    };
+    L.plan = reinterpret_cast<AttPlan*>(take(sizeof(AttPlan)));
+    L.slot_of = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.rep_of = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.gid_of_row = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.rep_row = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.ubytes = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.member_row = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.grp = reinterpret_cast<AttGroup*>(take(sizeof(AttGroup) * (size_t)cap_n));
+    L.ug = reinterpret_cast<UnionGroup*>(take(sizeof(UnionGroup) * (size_t)cap_n));
+    L.g1 = reinterpret_cast<G1Group*>(take(sizeof(G1Group) * (size_t)cap_n));
+    L.rows_fc = reinterpret_cast<AttRow*>(take(sizeof(AttRow) * (size_t)cap_n));
+    L.rows_st = reinterpret_cast<AttRow*>(take(sizeof(AttRow) * (size_t)cap_n));
+    L.status_fc = reinterpret_cast<int32_t*>(take(4ull * cap_n));
+    L.status_st = reinterpret_cast<int32_t*>(take(4ull * cap_n));
+    for (int t = 0; t < 2; ++t) {
+        L.crow_start[t] = reinterpret_cast<uint32_t*>(take(4ull * (cap_c + 1)));
+        L.crow_cursor[t] = reinterpret_cast<uint32_t*>(take(4ull * (cap_c + 1)));
+        L.crow_list[t] = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    }
+    L.bytes = off;
+    return L;
+}
+
+RrLayout rr_of(pe_engine::PipeArena& a) { return rr_layout(a.d_rr.as<uint8_t>(), a.rr_rows_cap, a.rr_comm_cap); }
+
+// The arena's scratch for n input rows and tables of up to n_comm committees.  Growing waits for everything enqueued.
+int rr_ensure(pe_engine* h, pe_engine::PipeArena& a, uint32_t n, uint32_t n_comm)
+{
+    if (n <= a.rr_rows_cap && n_comm <= a.rr_comm_cap && a.d_rr.p && a.d_rr_tab.p) return PE_OK;
+    PE_TRY(flush_pending(h));
+    HIP_TRY(h, hipDeviceSynchronize());
+    uint32_t cap_n = std::max<uint32_t>(a.rr_rows_cap, 1024), cap_c = std::max<uint32_t>(a.rr_comm_cap, 64);
+    while (cap_n < n) cap_n *= 2;
+    while (cap_c < n_comm) cap_c *= 2;
+    uint32_t tab = 2048;
+    while (tab < 2 * cap_n) tab <<= 1;
+    const RrLayout L = rr_layout(nullptr, cap_n, cap_c);
+    a.d_rr.release();
+    a.d_rr_tab.release();
+    HIP_TRY(h, a.d_rr.ensure(L.bytes));
+    HIP_TRY(h, a.d_rr_tab.ensure(4ull * tab));
+    // the grouping table is kept empty by its users (k_att_members clears what k_att_ingest filled); the plan's error
+    // word starts at zero
+    HIP_TRY(h, hipMemsetAsync(a.d_rr_tab.p, 0xFF, 4ull * tab, h->stream));
+    HIP_TRY(h, hipMemsetAsync(a.d_rr.p, 0, L.bytes, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    a.rr_rows_cap = cap_n;
+    a.rr_comm_cap = cap_c;
+    a.rr_tab_size = tab;
+    return PE_OK;
+}
+
+// The tables a row's committee may come from: the store's current and previous epoch.
+int candidate_tables(pe_engine* h, TablesDev* out, CommitteeTable* tabs[2])
+{
+    memset(out, 0, sizeof(*out));
+    out->slots_per_epoch = h->cfg.slots_per_epoch;
+    const uint64_t cur = epoch_at_slot(h, current_slot(h));
+    const uint64_t prev = cur > 0 ? cur - 1 : cur;
+    const uint64_t epochs[2] = {cur, prev};
+    for (int k = 0; k < 2; ++k) {
+        tabs[k] = nullptr;
+        out->t[k].epoch = epochs[k];
+        if (k == 1 && prev == cur) continue;
+        CommitteeTable* t = find_table(h, epochs[k]);
+        if (!t) continue;
+        if (!t->is_partition || t->n_val_at_load != h->n_val || !t->d_inv_comm.p)
+            return fail(h, PE_ERR_INVALID_ARG,
+                        "rows in device memory: the committee tables of the current / previous epoch must partition the "
+                        "registry they were loaded for (use host rows otherwise)");
+        tabs[k] = t;
+        out->t[k].members = t->d_members.as<uint32_t>();
+        out->t[k].offsets = t->d_offsets.as<uint32_t>();
+        out->t[k].inv_comm = t->d_inv_comm.as<uint32_t>();
+        out->t[k].inv_pos = t->d_inv_pos.as<uint32_t>();
+        out->t[k].n_committees = t->n_committees;
+        out->t[k].valid = 1;
+    }
+    return PE_OK;
+}
+
+uint32_t g1_target_slots(const pe_engine* h)
+{
+    static const uint32_t pinned = [] { const char* e = getenv("POSEVO_G1_TARGET_SLOTS"); return e ? (uint32_t)atol(e) : 0u; }();
+    static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return e && atoi(e) != 0; }();
+    if (pinned) return pinned;
+    if (h->streaming) return one_wave ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
+    return h->g1_target_slots ? h->g1_target_slots : G1_TARGET_LANES;
+}
+
+int plan_error_to_status(pe_engine* h, uint32_t err, const char* who)
+{
+    switch (err) {
+        case 0: return PE_OK;
+        case 10: return fail(h, PE_ERR_CAPACITY, std::string(who) + ": output capacity too small for the groups formed");
+        case 11: return fail(h, PE_ERR_NO_COMMITTEES, std::string(who) + ": no committee table for a group's target epoch");
+        default:
+            return fail(h, PE_ERR_INVALID_ARG, std::string(who) + ": a row was refused on the device (bits exceed the arena, "
+                        "target epoch beyond 32 bits, committee index out of range or len(aggregation_bits) != len(committee))");
+    }
+}
+
+}  // namespace
+
+bool rows_on_device(const void* p)
+{
+    if (!p || p == (const void*)PE_ROWS_RESIDENT) return false;
+    hipPointerAttribute_t pa;
+    if (hipPointerGetAttributes(&pa, p) == hipSuccess) return pa.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();  // plain host memory is "invalid value" to older runtimes: not an error here
+    return false;
+}
+
+BlockTableDev block_table_dev(const pe_engine* h)
+{
+    BlockTableDev bt;
+    bt.root_tab = h->d_broot_tab.as<uint32_t>();
+    bt.root_mask = h->broot_mask;
+    bt.roots = h->d_broots.as<uint8_t>();
+    bt.slot_pos = h->d_bslot_pos.as<unsigned long long>();
+    bt.parent_pos = h->d_tparent.as<uint32_t>();
+    bt.pos_of_idx = h->d_tpos.as<uint32_t>();
+    bt.n_blocks = (uint32_t)h->blocks.size();
+    return bt;
+}
+
+// ---------------------------------------------------------------- pe_aggregate, rows in device memory
+int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, const uint8_t* bits_arena,
+                       uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                       uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count)
+{
+    if (!h->initialised) return fail(h, PE_ERR_STATE, "rows in device memory: the store's clock picks the committee tables; call pe_store_init first");
+    if ((uintptr_t)d_rows & 15) return fail(h, PE_ERR_INVALID_ARG, "rows in device memory must be 16-byte aligned");
+    if (arena_len >= 0xFFFFFFF0ull) return fail(h, PE_ERR_CAPACITY, "bit arena exceeds 4 GiB");
+    const bool want_pk = out_aggpk96 != nullptr;
+    if (want_pk && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
+    HostLap lap(&h->trace);
+    TablesDev tables;
+    CommitteeTable* tabs[2];
+    PE_TRY(candidate_tables(h, &tables, tabs));
+    const uint32_t n_comm = std::max(tables.t[0].n_committees, tables.t[1].n_committees);
+    pe_engine::PipeArena& A = h->A();
+    PE_TRY(rr_ensure(h, A, n, n_comm));
+    const RrLayout L = rr_of(A);
+    // upper bounds: groups <= n; lane slots of the G1 plan <= slot_cap (k_att_plan lengthens the lanes instead)
+    const uint32_t target = g1_target_slots(h);
+    const uint32_t slot_cap = std::max<uint32_t>(2 * G1_TARGET_LANES, (n + G1_WG - 1) / G1_WG * G1_WG);
+    const size_t words_cap = (size_t)out_arena_cap / 4 + n + 16;
+    Stage st(h);
+    PE_TRY(st.reserve((size_t)arena_len + 256));
+    const size_t off_arena = st.alloc((size_t)arena_len + 16);
+    PE_TRY(ensure_quiesced(h, A.d_res_bits, words_cap * 4 + 64));
+    PE_TRY(ensure_quiesced(h, A.d_res_info, 8ull * n + 64));
+    OutBlock ob(h);
+    const size_t off_plan = ob.alloc(sizeof(AttPlan));
+    const size_t off_rows = ob.alloc(sizeof(pe_attestation) * (size_t)n);
+    const size_t off_gof = ob.alloc(4ull * n);
+    const size_t off_obits = ob.alloc(words_cap * 4);
+    const size_t off_oinfo = ob.alloc(8ull * n);
+    const size_t off_opk = want_pk ? ob.alloc(96ull * n) : 0;
+    PE_TRY(ob.ensure());
+    if (want_pk) {  // scratch of the G1 chain, sized by the bounds before anything is in flight
+        PE_TRY(ensure_quiesced(h, A.d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
+        PE_TRY(ensure_quiesced(h, A.d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
+        PE_TRY(ensure_quiesced(h, h->d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
+        PE_TRY(ensure_quiesced(h, h->d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
+    }
+    lap.mark("ragg.1_reserve");
+    *out_n_groups = 0;  // known when the call completes
+    AttPlan* plan_host = ob.host<AttPlan>(off_plan);
+    memset(plan_host, 0, sizeof(AttPlan));
+    plan_host->error = 0xFFFFFFFFu;  // "k_att_plan has not run": a completion that finds it reports a failed launch
+    // ---- device ----
+    hipStream_t ms = h->stream;
+    // an earlier aggregate of THIS pipeline still has to read the arena's resident words / descriptors from its G1 launch
+    // (deferred in a streaming pipeline): issue it, then order this call's kernels behind that chain
+    if (!h->deferred.empty()) PE_TRY(run_deferred(h));
+    if (A.side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
+    h->res_valid = false;
+    h->rr.valid = false;
+    const size_t deferred_before = h->deferred.size();
+    struct Unwind {
+        pe_engine* h; size_t keep; bool armed = true;
+        ~Unwind() { if (armed) { h->rr.valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
+    } unwind{h, deferred_before};
+    int arena_kind = 0;  // 0 pageable host, 1 pinned host, 2 device
+    if (arena_len) {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, bits_arena) == hipSuccess) {
+            if (pa.type == hipMemoryTypeDevice) arena_kind = 2;
+            else if (pa.type == hipMemoryTypeHost) arena_kind = 1;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    memset(st.host<uint8_t>(off_arena) + arena_len, 0, 16);
+    if (arena_kind == 0) {
+        memcpy(st.host<uint8_t>(off_arena), bits_arena, arena_len);
+        HIP_TRY(h, st.upload());
+    } else {
+        if (arena_len)
+            HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena), bits_arena, arena_len,
+                                      arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
+        HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena) + arena_len, st.host<uint8_t>(off_arena) + arena_len, 16,
+                                  hipMemcpyHostToDevice, ms));
+    }
+    lap.mark("ragg.2_bits");
+    launch_att_ingest(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), A.rr_tab_size - 1, L.slot_of, arena_len, L.plan);
+    AttPlanArgs pa;
+    pa.rows = d_rows;
+    pa.n = n;
+    pa.tab = A.d_rr_tab.as<uint32_t>();
+    pa.slot_of = L.slot_of;
+    pa.rep_of = L.rep_of;
+    pa.gid_of_row = L.gid_of_row;
+    pa.rep_row = L.rep_row;
+    pa.grp = L.grp;
+    pa.ug = L.ug;
+    pa.g1 = L.g1;
+    for (int t = 0; t < 2; ++t) {
+        pa.crow_start[t] = L.crow_start[t];
+        pa.crow_cursor[t] = L.crow_cursor[t];
+        pa.crow_list[t] = L.crow_list[t];
+    }
+    pa.plan = L.plan;
+    pa.plan_host = plan_host;
+    pa.out_arena_cap = out_arena_cap;
+    pa.target_slots = target;
+    pa.slot_cap = slot_cap;
+    static const uint32_t min_k = [] { const char* e = getenv("POSEVO_G1_MIN_K"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 4u; }();
+    pa.min_k = min_k;
+    pa.want_pk = want_pk ? 1u : 0u;
+    pa.tables = tables;
+    launch_att_plan(ms, pa);
+    launch_att_members(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
+                       L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows));
+    {
+        ProfScope ps(h, PE_KERNEL_BITS_UNION);
+        launch_bits_union(ms, L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), A.d_res_bits.as<uint32_t>(),
+                          A.d_res_info.as<uint32_t>(), ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan);
+    }
+    HIP_TRY(h, hipGetLastError());
+    lap.mark("ragg.3_group_union");
+    if (want_pk) {
+        static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
+        const bool on_side = h->pipelining && side_ok && h->side_stream && h->stream == h->own_stream;
+        h->last_agg_on_side = on_side;
+        pe_engine::PipeArena* arena = &A;
+        const uint32_t* d_points = h->d_points.as<uint32_t>();
+        const uint32_t* d_union = A.d_res_bits.as<uint32_t>();
+        uint8_t* out_pk = ob.host<uint8_t>(off_opk);
+        G1Plan bound;
+        bound.n_groups = n;
+        bound.n_slots = slot_cap;
+        bound.n_partials = n;
+        const G1Group* d_groups = L.g1;
+        const AttPlan* d_plan = L.plan;
+        auto launch_g1 = [h, arena, d_points, tables, d_union, d_groups, bound, out_pk, on_side, d_plan]() -> int {
+            hipStream_t gs = on_side ? h->side_stream : h->stream;
+            if (on_side) {  // behind everything enqueued on the engine's stream so far (see aggregate_impl)
+                HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+                HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
+                if (arena->side_used) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
+            } else {
+                g1_stream_guard(h, gs);
+            }
+            PE_TRY(launch_g1_planned(h, d_points, tables.t[0].members, d_union, d_groups, bound, out_pk, nullptr, gs,
+                                     on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr,
+                                     on_side ? &arena->d_lane_partials : nullptr, d_plan, tables.t[1].members));
+            if (on_side) {
+                HIP_TRY(h, hipEventRecord(h->ev_join, h->fin_stream));
+                h->side_busy = true;
+                h->side_ever = true;
+                arena->side_used = true;
+            }
+            return PE_OK;
+        };
+        if (on_side && h->streaming) h->deferred.push_back(launch_g1);
+        else PE_TRY(launch_g1());
+        lap.mark("ragg.4_g1");
+    }
+    for (int t = 0; t < 2; ++t)
+        if (tabs[t]) tabs[t]->stamp = ++h->table_stamp;
+    unwind.armed = false;
+    h->rr.valid = true;
+    h->rr.arena = h->cur;
+    h->rr.n_in = n;
+    h->rr.rows = d_rows;
+    h->rr.tables = tables;
+    ++h->rr.generation;
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off_plan, off_rows, off_gof, off_obits, off_oinfo, off_opk, n, out_atts, out_n_groups,
+                     group_of, out_bits_arena, out_aggpk96, out_count]() -> int {
+        const uint8_t* pin = h->arena[ai].h_pin.as<uint8_t>() + base;
+        const AttPlan P = *reinterpret_cast<const AttPlan*>(pin + off_plan);
+        if (P.error) return plan_error_to_status(h, P.error == 0xFFFFFFFFu ? 1u : P.error, "pe_aggregate (rows in device memory)");
+        const uint32_t ng = P.n_groups;
+        if (ng > n) return fail(h, PE_ERR_NO_DEVICE, "k_att_plan returned more groups than rows");
+        *out_n_groups = ng;
+        memcpy(out_atts, pin + off_rows, sizeof(pe_attestation) * (size_t)ng);
+        if (group_of) memcpy(group_of, pin + off_gof, 4ull * n);
+        const uint32_t* obits = reinterpret_cast<const uint32_t*>(pin + off_obits);
+        const uint32_t* oinfo = reinterpret_cast<const uint32_t*>(pin + off_oinfo);
+        if (P.packed_same) memcpy(out_bits_arena, obits, P.out_bytes);
+        uint32_t word = 0;
+        for (uint32_t g = 0; g < ng; ++g) {
+            pe_attestation& o = out_atts[g];
+            const uint32_t nb = o.n_bits;
+            if (!P.packed_same) memcpy(out_bits_arena + o.bits_offset, obits + word, (nb + 7) / 8);
+            word += (nb + 31) / 32;
+            if (out_count) out_count[g] = oinfo[2 * g];
+            if (oinfo[2 * g + 1])  // members overlap (A.8): never verifiable, say so
+                o.flags = (o.flags & ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID) | PE_ATT_FLAG_OVERLAPPING_BITS;
+        }
+        if (out_aggpk96) memcpy(out_aggpk96, pin + off_opk, 96ull * ng);
+        return PE_OK;
+    };
+    HostLap lap2(&h->trace);
+    const int rc = finish_call(h, st, ob, complete);
+    lap2.mark("ragg.5_wait_outputs");
+    return rc;
+}
+
+// ---------------------------------------------------------------- on_attestation x groups of the resident aggregate
+static int resident_precheck(pe_engine* h, const char* who)
+{
+    if (!h->rr.valid) return fail(h, PE_ERR_STATE, std::string(who) + ": PE_ROWS_RESIDENT without a pe_aggregate over rows in device memory on this handle");
+    TablesDev now;
+    CommitteeTable* tabs[2];
+    PE_TRY(candidate_tables(h, &now, tabs));
+    for (int t = 0; t < 2; ++t)
+        if (now.t[t].epoch != h->rr.tables.t[t].epoch || now.t[t].valid != h->rr.tables.t[t].valid ||
+            now.t[t].members != h->rr.tables.t[t].members)
+            return fail(h, PE_ERR_STATE, std::string(who) + ": the store's clock or its committee tables changed since the resident pe_aggregate: aggregate again");
+    return PE_OK;
+}
+
+int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_t* out_count)
+{
+    PE_TRY(resident_precheck(h, "pe_on_attestation_batch"));
+    if (cap == 0) return PE_OK;
+    HostLap lap(&h->trace);
+    PE_TRY(refresh_tree(h));
+    pe_engine::PipeArena& RA = h->arena[h->rr.arena];
+    const RrLayout L = rr_of(RA);
+    Stage st(h);
+    OutBlock ob(h);
+    const size_t off_status = ob.alloc(4ull * cap);
+    const size_t off_count = ob.alloc(4ull * cap);
+    const size_t off_err = ob.alloc(16);
+    PE_TRY(ob.ensure());
+    *ob.host<uint32_t>(off_err) = 0;
+    FcCtx fc;
+    fc.cur_slot = current_slot(h);
+    fc.cur_epoch = epoch_at_slot(h, fc.cur_slot);
+    fc.prev_epoch = fc.cur_epoch > 0 ? fc.cur_epoch - 1 : 0;
+    fc.slots_per_epoch = h->cfg.slots_per_epoch;
+    const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);  // one lane per possible group
+    // entries past the groups formed read "nothing applied"
+    memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
+    memset(ob.host<uint32_t>(off_count), 0, 4ull * cap);
+    launch_att_validate_fc(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), fc,
+                           RA.d_res_info.as<uint32_t>(), L.rows_fc, L.status_fc, ob.host<int32_t>(off_status),
+                           ob.host<uint32_t>(off_count), ob.host<uint32_t>(off_err));
+    {
+        ProfScope ps(h, PE_KERNEL_LMD);
+        launch_lmd_vm_tables(h->stream, L.rows_fc, h->rr.tables, L.crow_start, L.crow_list, L.plan,
+                             RA.d_res_bits.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
+                             h->d_vote_block.as<uint32_t>(),
+                             h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr,
+                             reinterpret_cast<const uint32_t*>(L.status_fc));
+    }
+    HIP_TRY(h, hipGetLastError());
+    lap.mark("ratt.1_launch");
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off_status, off_count, off_err, cap, status, out_count]() -> int {
+        const uint8_t* pin = h->arena[ai].h_pin.as<uint8_t>() + base;
+        const uint32_t err = *reinterpret_cast<const uint32_t*>(pin + off_err);
+        if (err) return plan_error_to_status(h, err, "pe_on_attestation_batch (PE_ROWS_RESIDENT)");
+        memcpy(status, pin + off_status, 4ull * cap);
+        if (out_count) memcpy(out_count, pin + off_count, 4ull * cap);
+        return PE_OK;
+    };
+    HostLap lap2(&h->trace);
+    const int rc = finish_call(h, st, ob, complete);
+    lap2.mark("ratt.2_wait_outputs");
+    return rc;
+}
+
+// ---------------------------------------------------------------- process_attestation x groups of the resident aggregate
+int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t cap, int32_t* status, uint64_t* out_numerators)
+{
+    PE_TRY(resident_precheck(h, "pe_process_attestation_batch"));
+    if (cap == 0) return PE_OK;
+    const uint64_t spe = h->cfg.slots_per_epoch;
+    if (spe > 64) return fail(h, PE_ERR_CAPACITY, "PE_ROWS_RESIDENT: SLOTS_PER_EPOCH above 64");
+    uint32_t tip;
+    if (!find_block(h, to_root(sc->chain_tip_root), &tip)) return fail(h, PE_ERR_UNKNOWN_ROOT, "chain tip unknown");
+    HostLap lap(&h->trace);
+    PE_TRY(refresh_tree(h));
+    pe_engine::PipeArena& RA = h->arena[h->rr.arena];
+    const RrLayout L = rr_of(RA);
+    Stage st(h);
+    PE_TRY(st.reserve(sizeof(StateCtxDev) + 256));
+    const size_t off_ctx = st.alloc(sizeof(StateCtxDev));
+    StateCtxDev& S = *st.host<StateCtxDev>(off_ctx);
+    memset(&S, 0, sizeof(S));
+    S.slot = sc->slot;
+    S.cur_epoch = sc->slot / spe;
+    S.prev_epoch = S.cur_epoch > 0 ? S.cur_epoch - 1 : 0;
+    S.slots_per_epoch = spe;
+    S.min_inclusion_delay = h->cfg.min_attestation_inclusion_delay;
+    S.sqrt_spe = isqrt64(spe);
+    S.cj_epoch = sc->current_justified_epoch;
+    S.pj_epoch = sc->previous_justified_epoch;
+    memcpy(S.cj_root, sc->current_justified_root, 32);
+    memcpy(S.pj_root, sc->previous_justified_root, 32);
+    S.base_reward_per_increment = sc->base_reward_per_increment;
+    // get_block_root_at_slot(state, s) for the slots pe:726 admits, and get_block_root(state, epoch) for the two target
+    // epochs: the state's chain is the ancestry of chain_tip_root; one walk down from the tip serves them all
+    {
+        uint32_t cur = tip;
+        for (uint64_t j = spe; j-- > 0;) {
+            if (S.slot + j < spe) { S.head_blk[j] = NONE32; continue; }  // before slot 0
+            cur = get_ancestor(h, cur, S.slot + j - spe);
+            S.head_blk[j] = cur;
+        }
+        S.tgt_blk[0] = get_ancestor(h, tip, S.cur_epoch * spe);
+        S.tgt_blk[1] = get_ancestor(h, tip, S.prev_epoch * spe);
+    }
+    OutBlock ob(h);
+    const size_t off_status = ob.alloc(4ull * cap);
+    const size_t off_num = ob.alloc(8ull * cap);
+    const size_t off_err = ob.alloc(16);
+    PE_TRY(ob.ensure());
+    *ob.host<uint32_t>(off_err) = 0;
+    memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
+    memset(ob.host<uint64_t>(off_num), 0, 8ull * cap);  // k_participation_tables writes the rows it runs
+    HIP_TRY(h, st.upload());
+    const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);
+    launch_att_validate_state(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), st.dev<StateCtxDev>(off_ctx),
+                              RA.d_res_info.as<uint32_t>(), L.rows_st, L.status_st, ob.host<int32_t>(off_status),
+                              ob.host<uint32_t>(off_err));
+    {
+        ProfScope ps(h, PE_KERNEL_PARTICIPATION);
+        launch_participation_tables(h->stream, L.rows_st, h->rr.tables, L.crow_start, L.crow_list, L.plan,
+                                    RA.d_res_bits.as<uint32_t>(), h->d_incr.as<uint16_t>(), sc->base_reward_per_increment,
+                                    h->d_part_cur.as<uint32_t>(), h->d_part_prev.as<uint32_t>(), ob.host<uint64_t>(off_num),
+                                    reinterpret_cast<const uint32_t*>(L.status_st));
+    }
+    HIP_TRY(h, hipGetLastError());
+    lap.mark("rproc.1_launch");
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off_status, off_num, off_err, cap, status, out_numerators]() -> int {
+        const uint8_t* pin = h->arena[ai].h_pin.as<uint8_t>() + base;
+        const uint32_t err = *reinterpret_cast<const uint32_t*>(pin + off_err);
+        if (err) return plan_error_to_status(h, err, "pe_process_attestation_batch (PE_ROWS_RESIDENT)");
+        memcpy(status, pin + off_status, 4ull * cap);
+        memcpy(out_numerators, pin + off_num, 8ull * cap);
+        return PE_OK;
+    };
+    HostLap lap2(&h->trace);
+    const int rc = finish_call(h, st, ob, complete);
+    lap2.mark("rproc.2_wait_outputs");
+    return rc;
+}
+
+}  // namespace posevo

@@ -86,7 +86,30 @@ int refresh_tree(pe_engine* h)
     }
     HIP_TRY(h, h->d_head.ensure(64));
     HIP_TRY(h, h->h_head.ensure(64));
+    // device-side block lookups for validation of rows resident on the device (att_kernels.hip): root -> insertion index
+    // (open addressing on the leading word of the root), the roots themselves, the slot of the block at each position
+    uint32_t tab_size = 64;
+    while (tab_size < 2 * n) tab_size <<= 1;
+    std::vector<uint32_t> root_tab(tab_size, NONE32);
+    std::vector<uint8_t> roots_flat(32ull * n);
+    std::vector<uint64_t> slot_pos(n);
+    for (uint32_t b = 0; b < n; ++b) {
+        memcpy(&roots_flat[32ull * b], h->blocks[b].root.data(), 32);
+        slot_pos[pos_of[b]] = h->blocks[b].slot;
+        uint32_t w;
+        memcpy(&w, h->blocks[b].root.data(), 4);
+        uint32_t slot = w & (tab_size - 1);
+        while (root_tab[slot] != NONE32) slot = (slot + 1) & (tab_size - 1);
+        root_tab[slot] = b;
+    }
+    HIP_TRY(h, h->d_broot_tab.ensure(4ull * tab_size));
+    HIP_TRY(h, h->d_broots.ensure(32ull * cap));
+    HIP_TRY(h, h->d_bslot_pos.ensure(8ull * cap));
+    h->broot_mask = tab_size - 1;
     hipStream_t s = h->stream;
+    HIP_TRY(h, hipMemcpyAsync(h->d_broot_tab.p, root_tab.data(), 4ull * tab_size, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_broots.p, roots_flat.data(), 32ull * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->d_bslot_pos.p, slot_pos.data(), 8ull * n, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_tsize.p, sz_pos.data(), n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_tparent.p, parent_pos.data(), n * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(h, hipMemcpyAsync(h->d_trank.p, rank_pos.data(), n * 4, hipMemcpyHostToDevice, s));
@@ -263,6 +286,7 @@ int pe_store_init(pe_engine* h, uint64_t genesis_time, uint64_t anchor_slot, con
     for (auto& t : h->tables) { t.n_committees = 0; t.offsets.clear(); t.is_partition = false; t.stamp = 0; }
     h->state_view_set = false;
     h->res_valid = false;
+    h->rr.valid = false;
     if (h->n_val) {
         const size_t n4 = (h->n_val + 3) & ~size_t(3);
         HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, n4, h->stream));

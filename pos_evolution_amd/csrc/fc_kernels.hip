@@ -748,9 +748,11 @@ void launch_state_view_from_registry(hipStream_t s, const uint8_t* flags, const 
 __global__ void __launch_bounds__(256)
 k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ att_bytes,
              const uint8_t* __restrict__ bit_arena, uint32_t* __restrict__ out_arena,
-             uint32_t* __restrict__ out_info, uint32_t* __restrict__ host_arena, uint32_t* __restrict__ host_info)
+             uint32_t* __restrict__ out_info, uint32_t* __restrict__ host_arena, uint32_t* __restrict__ host_info,
+             const AttPlan* __restrict__ plan_dev)
 {
     POSEVO_FC_PRIO();
+    if (plan_dev) n_groups = plan_dev->n_groups;  // groups formed on the device: the grid covers an upper bound
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n_groups) return;
     const int lane = threadIdx.x & 63;
@@ -789,11 +791,11 @@ k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uin
 
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_bytes,
                        const uint8_t* bit_arena, uint32_t* out_arena, uint32_t* out_info, uint32_t* host_arena,
-                       uint32_t* host_info)
+                       uint32_t* host_info, const AttPlan* plan_dev)
 {
     if (n_groups == 0) return;
     hipLaunchKernelGGL(k_bits_union, dim3((n_groups + 3) / 4), dim3(256), 0, s, groups, n_groups, att_bytes,
-                       bit_arena, out_arena, out_info, host_arena, host_info);
+                       bit_arena, out_arena, out_info, host_arena, host_info, plan_dev);
 }
 
 }  // namespace posevo

@@ -324,9 +324,15 @@ __device__ __forceinline__ void lane_store_x(uint32_t* __restrict__ buf, uint32_
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
 k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ members,
                 const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
-                uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials)
+                uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials,
+                const AttPlan* __restrict__ plan_dev, const uint32_t* __restrict__ members1)
 {
     const int tid = threadIdx.x;
+    if (plan_dev) {  // rows resident on the device: the plan was made there; the grid is sized by an upper bound
+        n_groups = plan_dev->n_groups;
+        n_slots = plan_dev->n_slots;
+        if (blockIdx.x * G1_WG >= n_slots) return;
+    }
     const uint32_t slot = blockIdx.x * G1_WG + tid;
     G1_STAMP(0);
     G1_WAVE_BEGIN();
@@ -337,8 +343,10 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
     G1Group d;
     g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
     if (slot < n_slots && t < d.n_tasks) {
-        const uint32_t first = t * d.k;
-        const uint32_t count = min(d.k, d.n_members - first);
+        const uint32_t gk = d.k & 0x7FFFFFFFu;  // bit 31: the group's committee lives in the second member array
+        if (d.k >> 31) members = members1;
+        const uint32_t first = t * gk;
+        const uint32_t count = min(gk, d.n_members - first);
         // gather + mixed adds; the next point's loads are issued before the current add
         fp qx, qy, nx, ny;
         bool have = false, nhave = false;
@@ -378,8 +386,13 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
 // 0.14 vs 0.086 ms, step 0.396-0.404 vs 0.381-0.389 ms (gpurun_out/r02r_*, summary in profiles/README.md).
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_TREE_WAVES_PER_EU, POSEVO_G1_TREE_WAVES_PER_EU)))
 k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups, uint32_t n_groups,
-          uint32_t n_slots, uint32_t* __restrict__ wg_partials)
+          uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev)
 {
+    if (plan_dev) {
+        n_groups = plan_dev->n_groups;
+        n_slots = plan_dev->n_slots;
+        if (blockIdx.x * G1_WG >= n_slots) return;
+    }
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 48*256 partial words + 2*256 block info
     uint32_t* lds_out = lds + G1X_WORDS * G1_WG;  // output slot of the block a partial belongs to
     uint32_t* lds_sz = lds_out + G1_WG;           // current block size (0 = empty / retired)
@@ -527,12 +540,13 @@ k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict_
 
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
-                          uint32_t* lane_partials, uint32_t* wg_partials48)
+                          uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
+                          const uint32_t* members1)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), 0, s, points_mont24, members, bit_arena,
-                       groups, n_groups, n_slots, lane_partials, wg_partials48);
+                       groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
 }
 
 // one_per_cu: ask for 77 KB of LDS instead of the 50 KB the kernel uses, so that a CU holds ONE of its workgroups and
@@ -540,7 +554,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const ui
 // is when the fork-choice kernels of step N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096 blocks) then
 // found no CU with room until this kernel had drained: +60 us on every get_head (profiles/r02_timeline_tree_collision.txt).
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
-                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu)
+                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
@@ -553,15 +567,16 @@ void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group*
         lds_bytes = padded;
     }
     hipLaunchKernelGGL(k_g1_tree, dim3(blocks), dim3(G1_WG), lds_bytes, s, lane_partials, groups, n_groups, n_slots,
-                       wg_partials48);
+                       wg_partials48, plan_dev);
 }
 
 // ---------------------------------------------------------------- finish
 __global__ void __launch_bounds__(64)
 k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ groups, uint32_t n_groups,
             uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* __restrict__ out_be96,
-            uint32_t* __restrict__ out_jac)
+            uint32_t* __restrict__ out_jac, const AttPlan* __restrict__ plan_dev)
 {
+    if (plan_dev) n_groups = plan_dev->n_groups;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     // 32 waves of one long dependent chain each (the inversion).  In a stream of pipelined steps they run beside the
@@ -605,11 +620,12 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
 }
 
 void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
-                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_xyzz48)
+                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_xyzz48,
+                      const AttPlan* plan_dev)
 {
     if (n_groups == 0) return;
     hipLaunchKernelGGL(k_g1_finish, dim3((n_groups + 63) / 64), dim3(64), 0, s, partials48, groups, n_groups,
-                       n_parts_fixed, part_stride, out_be96, out_xyzz48);
+                       n_parts_fixed, part_stride, out_be96, out_xyzz48, plan_dev);
 }
 
 }  // namespace posevo

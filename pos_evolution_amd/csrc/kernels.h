@@ -50,17 +50,22 @@ struct G1Group {
 void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uint64_t n);
 // Per-lane XYZZ accumulation of k gathered points: one partial per lane slot into lane_partials (limb-major per
 // workgroup: ceil(n_slots / 256) * 256 * 192 bytes); single-task groups are written straight to wg_partials48.
+// plan_dev (nullable): n_groups / n_slots are read from this device-resident AttPlan instead (the arguments are then
+// upper bounds that size the grid); members1: the member array of groups whose G1Group::k has bit 31 set.
+struct AttPlan;
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups,
-                          uint32_t n_slots, uint32_t* lane_partials, uint32_t* wg_partials48);
+                          uint32_t n_slots, uint32_t* lane_partials, uint32_t* wg_partials48,
+                          const AttPlan* plan_dev = nullptr, const uint32_t* members1 = nullptr);
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
 // (group, workgroup) into wg_partials48.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
-                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0);
+                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0, const AttPlan* plan_dev = nullptr);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
 // g when first == null), then either write the XYZZ sum (48 u32) or normalise to 96-byte affine.
 void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
-                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_xyzz48);
+                      uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* out_be96, uint32_t* out_xyzz48,
+                      const AttPlan* plan_dev = nullptr);
 
 // ---- fork choice ----
 struct TreeDev {               // block tree in DFS pre-order (device arrays of n entries)
@@ -133,7 +138,105 @@ struct UnionGroup {
 // memory, so that no device-to-host copy command has to follow the kernel.
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_bytes,
                        const uint8_t* bit_arena, uint32_t* out_arena, uint32_t* out_info,
-                       uint32_t* host_arena = nullptr, uint32_t* host_info = nullptr);
+                       uint32_t* host_arena = nullptr, uint32_t* host_info = nullptr, const AttPlan* plan_dev = nullptr);
+
+// ---- attestation rows resident in device memory (att_kernels.hip; host side: engine_resident.cpp) ----------------
+// pe_aggregate / pe_on_attestation_batch / pe_process_attestation_batch with the rows handed over in device (or
+// pinned) memory: grouping by AttestationData (what aggregate_impl does with memcmp on the host), committee
+// resolution, validate_on_attestation (A.4) and the asserts of pe:724-730 run on the device; the host enqueues a
+// fixed sequence of launches sized by upper bounds and reads nothing of the rows.
+constexpr uint32_t ATT_EMPTY = 0xFFFFFFFFu;
+struct TableDev {                 // one candidate committee table (the store's current / previous epoch)
+    uint64_t epoch;
+    const uint32_t* members;
+    const uint32_t* offsets;      // n_committees + 1
+    const uint32_t* inv_comm;     // validator -> committee id (partition tables)
+    const uint32_t* inv_pos;      // validator -> index in its committee
+    uint32_t n_committees;
+    uint32_t valid;
+};
+struct TablesDev {
+    TableDev t[2];
+    uint64_t slots_per_epoch;
+};
+struct AttPlan {                  // one per resident-rows aggregate: written by k_att_plan (device copy + pinned mirror)
+    uint32_t n_groups;
+    uint32_t n_slots;             // G1 plan: uniform blocks of 1 << log2_block lane slots, group g at slot g << log2_block
+    uint32_t k, log2_block;
+    uint32_t out_words, out_bytes;
+    uint32_t error;               // 0 or -pe_status of the aggregate (reported when the call completes)
+    uint32_t packed_same;         // every union but the last is a whole number of words: word layout == byte layout
+    uint32_t n_rows_table[2];     // groups resolved against each candidate table
+    uint32_t n_rows_in;
+    uint32_t reserved;
+    unsigned long long total_members;
+};
+struct AttGroup {                 // one per group, in order of first appearance
+    uint32_t rep;                 // first input row of the group
+    uint32_t n_atts, list_start, cursor;
+    uint32_t n_bits, out_word, out_byte;
+    uint32_t table;               // 0 / 1 = candidate table, NONE32 = none
+    uint32_t pos, size, member_base;
+    uint32_t sig_valid;           // AND of the members' PE_ATT_FLAG_SIGNATURE_VALID
+    uint32_t status_agg;          // 0, or the pe_att_status that keeps the group from having a committee
+    uint32_t pad[3];
+};
+struct BlockTableDev {            // the store's blocks for device-side validation (built by refresh_tree)
+    const uint32_t* root_tab;     // open addressing: slot -> insertion index (NONE32 = empty), keyed by the root's first 8 bytes
+    uint32_t root_mask;
+    const uint8_t* roots;         // 32 B per block, by insertion index
+    const unsigned long long* slot_pos;  // block slot by pre-order position
+    const uint32_t* parent_pos;   // parent's pre-order position
+    const uint32_t* pos_of_idx;
+    uint32_t n_blocks;
+};
+struct FcCtx {                    // store scalars validate_on_attestation reads (A.4)
+    unsigned long long cur_slot, cur_epoch, prev_epoch, slots_per_epoch;
+};
+struct StateCtxDev {              // the slice of BeaconState process_attestation reads (pe:722-754), resolved by the host
+    unsigned long long slot, cur_epoch, prev_epoch, slots_per_epoch, min_inclusion_delay, sqrt_spe;
+    unsigned long long cj_epoch, pj_epoch;
+    uint8_t cj_root[32], pj_root[32];
+    uint32_t tgt_blk[2];          // get_block_root(state, epoch): [0] current, [1] previous epoch (insertion index)
+    uint32_t head_blk[64];        // get_block_root_at_slot(state, slot - spe + j)
+    unsigned long long base_reward_per_increment;
+};
+void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t tab_mask,
+                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan);
+struct AttPlanArgs {
+    const void* rows; uint32_t n;
+    const uint32_t* tab; const uint32_t* slot_of;
+    uint32_t* rep_of; uint32_t* gid_of_row; uint32_t* rep_row;
+    AttGroup* grp; UnionGroup* ug; G1Group* g1;
+    uint32_t* crow_start[2]; uint32_t* crow_cursor[2]; uint32_t* crow_list[2];
+    AttPlan* plan; AttPlan* plan_host;
+    uint64_t out_arena_cap; uint32_t target_slots, slot_cap, min_k, want_pk;
+    TablesDev tables;
+};
+void launch_att_plan(hipStream_t s, const AttPlanArgs& a);
+void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, const uint32_t* slot_of,
+                        const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
+                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows);
+// n_bound: upper bound of the groups (sizes the grid); cap: entries of the caller's status / count arrays
+void launch_att_validate_fc(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
+                            uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* union_info, AttRow* out_rows,
+                            int32_t* status_dev, int32_t* status_host, uint32_t* count_host, uint32_t* err_host);
+void launch_att_validate_state(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
+                               uint32_t cap, BlockTableDev bt, const StateCtxDev* st, const uint32_t* union_info,
+                               AttRow* out_rows, int32_t* status_dev, int32_t* status_host, uint32_t* err_host);
+// validator-major LMD update over both candidate tables in one launch (blockIdx.y = table); the per-committee row
+// lists are unordered (built with atomics), the batch-order rule is applied by comparing AttRow::order.
+void launch_lmd_vm_tables(hipStream_t s, const AttRow* rows, TablesDev tables, uint32_t* const crow_start[2],
+                          uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
+                          const uint8_t* flags, uint64_t n_val, uint64_t* vote_key, uint32_t* vote_block,
+                          uint32_t* vote_slot, const uint32_t* gates);
+// process_attestation's flag loop, one wave per committee: the committee's rows run in batch order inside the wave
+// (committees of a partition table touch disjoint validators, so waves are independent).
+void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev tables, uint32_t* const crow_start[2],
+                                 uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
+                                 const uint16_t* eff_increments, uint64_t base_reward_per_increment,
+                                 uint32_t* part_cur_words, uint32_t* part_prev_words, uint64_t* numerators,
+                                 const uint32_t* gates);
 
 // The working-state view mirrors the registry (pe_store_init): sflags = active/slashed (+ active-in-previous-epoch),
 // increments = balance / effective_balance_increment.

@@ -37,6 +37,20 @@ class DeviceArena:
         self.ptr, self.size, self.keep = int(ptr), int(size), keep
 
 
+class DeviceRows:
+    """Attestation rows (``n`` x struct pe_attestation, 144 bytes each, 16-byte aligned) that lie in DEVICE memory:
+    ``Engine.aggregate(packed=(DeviceRows(...), arena))`` groups, resolves and validates them on the device
+    (include/posevo.h, PE_ROWS_RESIDENT) -- the host reads nothing of them.  Keep them unchanged (and ``keep`` alive)
+    until the call's outputs are complete."""
+    __slots__ = ("ptr", "n", "keep")
+
+    def __init__(self, ptr: int, n: int, keep=None):
+        self.ptr, self.n, self.keep = int(ptr), int(n), keep
+
+    def __len__(self):
+        return self.n
+
+
 def _ptr(a, ctype=None):
     """Address of a C-contiguous numpy buffer (None stays NULL).  c_char.from_buffer + addressof is the cheapest route
     ctypes offers; read-only or empty arrays take the slower ndarray.ctypes path."""
@@ -128,6 +142,17 @@ class _Resident:
 RESIDENT = _Resident()
 
 
+class _RowsResident:
+    """Sentinel for ``packed=(ROWS_RESIDENT, RESIDENT)``: every group of the last ``aggregate`` over DeviceRows, in
+    group order, validated on the device (PE_ROWS_RESIDENT)."""
+
+    def __repr__(self):
+        return "ROWS_RESIDENT"
+
+
+ROWS_RESIDENT = _RowsResident()
+
+
 class AggregateResult(dict):
     """Result of Engine.aggregate; ``res["bits"]`` decodes the OR-ed bitfields on demand."""
 
@@ -139,6 +164,35 @@ class AggregateResult(dict):
                 nb = (nbits + 7) // 8
                 out.append(np.unpackbits(arena[off:off + nb], bitorder="little")[:nbits].astype(bool))
             self["bits"] = out
+        return dict.__getitem__(self, key)
+
+
+class ResidentAggregateResult(dict):
+    """Result of Engine.aggregate over DeviceRows: nothing is host-derived, so every field -- the number of groups
+    included -- is valid once the call's outputs are complete (at return for a synchronous call, at the pipeline's
+    completion otherwise).  Fields are sliced to the groups formed when they are read."""
+
+    def __getitem__(self, key):
+        raw = dict.__getitem__(self, "_raw")
+        g = int(raw["n_groups"][0])
+        if key == "n_groups":
+            return g
+        if key == "group_of":
+            return raw["group_of"]
+        if key == "out_arena":
+            if g == 0:
+                return raw["out_arena"][:0]
+            last = raw["atts"][g - 1]
+            return raw["out_arena"][: int(last["bits_offset"]) + (int(last["n_bits"]) + 7) // 8]
+        if key == "bits":
+            arena, out = raw["out_arena"], []
+            for a in raw["atts"][:g]:
+                off, nbits = int(a["bits_offset"]), int(a["n_bits"])
+                out.append(np.unpackbits(arena[off:off + (nbits + 7) // 8], bitorder="little")[:nbits].astype(bool))
+            return out
+        if key in ("atts", "aggpk96", "count"):
+            v = raw[key]
+            return None if v is None else v[:g]
         return dict.__getitem__(self, key)
 
 
@@ -212,6 +266,24 @@ class Engine:
         self._ring = [dict() for _ in range(max(depth, 1))]
         self._ring_i = 0
         self._ring_ord = {}
+
+    def fill_ring(self):
+        """Allocate (and touch) in every ring slot the output sets seen so far in any slot: a caller that wants to keep
+        the outputs of a whole run -- ring depth = number of pipelines -- pays the allocations before its timed region."""
+        if self._ring is None:
+            return
+        seen = {}
+        for d in self._ring:
+            for k, (arrs, _) in d.items():
+                seen.setdefault(k, tuple(None if a is None else (a.shape, a.dtype) for a in arrs))
+        for d in self._ring:
+            for k, specs in seen.items():
+                if k not in d:
+                    arrs = tuple(None if sp is None else np.zeros(sp[0], dtype=sp[1]) for sp in specs)
+                    for a in arrs:
+                        if a is not None:
+                            a.fill(0)  # np.zeros maps pages lazily: touch them now
+                    d[k] = (arrs, tuple(_ptr(a) for a in arrs))
 
     def _outs(self, key, specs):
         """The output arrays of one call and their addresses: ``specs`` = ((shape, dtype) or None, ...).  With
@@ -369,9 +441,21 @@ class Engine:
         self._check(self._lib.pe_get_last_weights(self._h, _ptr(out, C.c_uint64), n))
         return out
 
-    def on_attestation_batch(self, rows=None, packed=None, want_aggregate_pubkeys=False):
-        """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n])."""
+    def on_attestation_batch(self, rows=None, packed=None, want_aggregate_pubkeys=False, cap: int = 0):
+        """-> (status int32[n], aggpk (n,96) u8 or None, count uint32[n]).
+        ``packed=(ROWS_RESIDENT, RESIDENT), cap=c``: every group of the last aggregate over DeviceRows; the arrays hold c
+        entries (c >= the groups formed; entries past them read 0)."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
+        if arr is ROWS_RESIDENT:
+            assert arena is RESIDENT and cap > 0 and not want_aggregate_pubkeys
+            (status, count), (p_status, p_count) = self._outs("ratt", ((cap, _I32), (cap, _U32)))
+            if self._pipe_keep is not None:
+                self._pipe_keep.append((status, count))
+            rc = self._lib.pe_on_attestation_batch(self._h, _abi.PE_ROWS_RESIDENT, cap, _abi.PE_BITS_RESIDENT, 0, p_status,
+                                                   None, p_count)
+            if rc:
+                self._check(rc)
+            return status, None, count
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
         (status, count, agg), (p_status, p_count, p_agg) = self._outs(
@@ -405,6 +489,20 @@ class Engine:
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
+        if arr.__class__ is DeviceRows:  # rows in device memory: grouped / resolved / validated there
+            assert sig_points96 is None and sig_points192 is None, "signature points take host rows"
+            (out_atts, group_of, out_arena, out_pk, count, ng), (p_atts, p_gof, p_arena, p_pk, p_count, p_ng) = self._outs(
+                "ragg", ((m, _ATT_DTYPE), (m, _U32), (max(arena.size, 1), _U8),
+                         ((m, 96), _U8) if want_aggregate_pubkeys else None, (m, _U32), (1, _U32)))
+            ng[0] = 0
+            if self._pipe_keep is not None:
+                self._pipe_keep.append((arr, arena, out_atts, group_of, out_arena, out_pk, count, ng))
+            rc = self._lib.pe_aggregate(self._h, arr.ptr, n, _ptr(arena, C.c_uint8), arena.size, None, p_atts, p_ng, p_gof,
+                                        p_arena, out_arena.size, None, p_pk, p_count)
+            if rc:
+                self._check(rc)
+            return ResidentAggregateResult(_raw=dict(n_groups=ng, atts=out_atts, group_of=group_of, out_arena=out_arena,
+                                                     aggpk96=out_pk, count=count), sig96=None, sig192=None)
         sig = None
         if sig_points96 is not None:
             sig = np.ascontiguousarray(sig_points96, dtype=np.uint8)
@@ -436,9 +534,20 @@ class Engine:
                                sig96=None if out_sig is None else out_sig[:g], sig192=sig192,
                                aggpk96=None if out_pk is None else out_pk[:g], count=count[:g])
 
-    def process_attestation_batch(self, state_ctx: pe_state_ctx, rows=None, packed=None):
-        """-> (status int32[n], proposer_reward_numerator uint64[n])."""
+    def process_attestation_batch(self, state_ctx: pe_state_ctx, rows=None, packed=None, cap: int = 0):
+        """-> (status int32[n], proposer_reward_numerator uint64[n]).  ``packed=(ROWS_RESIDENT, RESIDENT), cap=c`` as for
+        on_attestation_batch."""
         arr, arena = packed if packed is not None else pack_attestations(rows)
+        if arr is ROWS_RESIDENT:
+            assert arena is RESIDENT and cap > 0
+            (status, num), (p_status, p_num) = self._outs("rproc", ((cap, _I32), (cap, _U64)))
+            if self._pipe_keep is not None:
+                self._pipe_keep.append((status, num))
+            rc = self._lib.pe_process_attestation_batch(self._h, C.byref(state_ctx), _abi.PE_ROWS_RESIDENT, cap,
+                                                        _abi.PE_BITS_RESIDENT, 0, p_status, p_num)
+            if rc:
+                self._check(rc)
+            return status, num
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
         (status, num), (p_status, p_num) = self._outs("proc", ((m, _I32), (m, _U64)))

@@ -21,7 +21,7 @@ void stub_fail_next(int rc) { fail_next = rc; }
 uintptr_t stub_last_arena(void) { return last_arena; }
 static int ret(const char* n) { note(n); if (fail_next) { int r = fail_next; fail_next = 0; return r; } return 0; }
 typedef struct { uint8_t data[128]; uint32_t bits_offset, n_bits, flags, reserved0; } att;
-uint32_t pe_abi_version(void) { return 3; }
+uint32_t pe_abi_version(void) { return 4; }
 const char* pe_strerror(int s) { (void)s; return "stub"; }
 const char* pe_last_error(const void* h) { (void)h; return "stub detail"; }
 int pe_engine_create(const void* cfg, void** out) { (void)cfg; note("pe_engine_create"); *out = &dummy; return 0; }
