@@ -105,7 +105,7 @@ def _timed(name, fn, *a, **k):
     return r
 
 
-def run_step_single(e, w, st, pipelined=True, lagged=True):
+def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
     """One epoch through the per-function C ABI.  pipelined: the three batch calls enqueue and return, the aggregate's
     rows + OR-ed bits stay on the device for the two handlers (PE_BITS_RESIDENT), get_head polls its head word, and
     pe_pipeline_end waits ONCE for every output (include/posevo.h "pipelined calls").  Same results either way
@@ -121,7 +121,9 @@ def run_step_single(e, w, st, pipelined=True, lagged=True):
         with e.pipeline(lagged=lagged):
             agg = _timed("aggregate", e.aggregate, packed=(st["rows_in"], st["arena_in"]), want_aggregate_pubkeys=True)
             status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
-            head = _timed("get_head", e.get_head)
+            # the root arrives with the step's other outputs (two steps behind, like them): the loop never blocks on the
+            # device inside a step; --sync-head polls for it as pe_get_head does
+            head = _timed("get_head", e.get_head if sync_head else e.get_head_async)
             st2, num = _timed("process_attestation", e.process_attestation_batch, st["ctx"],
                               packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
         return dict(agg=agg, rows=None, status=status, count=count, pstatus=st2, numerators=num, head=head)
@@ -360,7 +362,7 @@ def whole_step_check(pea, w, st, chk, device):
     out["counts"] = bool(np.array_equal(agg["count"][inv], chk["count"]) and np.array_equal(r["count"][:C][inv], chk["count"]))
     out["aggregate_pubkeys"] = bool(np.array_equal(agg["aggpk96"][inv], chk["aggpk"]))
     out["latest_messages"] = bool(np.array_equal(e2.latest_messages()[1], chk["vote_block"]))
-    out["head"] = r["head"] == chk["head"]
+    out["head"] = bytes(r["head"]) == chk["head"]
     out["weights"] = bool(np.array_equal(e2.get_weights(), chk["weights"]))
     out["reward_numerators"] = bool(np.array_equal(r["numerators"][:C][inv], chk["numerators"]))
     out["participation"] = bool(np.array_equal(e2.participation_get(0), chk["part_cur"]) and
@@ -378,7 +380,7 @@ def step_digest(r):
     agg = r["agg"]
     g = int(agg["n_groups"])
     h = hashlib.sha256()
-    h.update(r["head"])
+    h.update(bytes(r["head"]))
     for a in (r["status"][:g], r["count"][:g], r["pstatus"][:g], r["numerators"][:g], agg["atts"][:g], agg["out_arena"],
               agg["aggpk96"][:g], agg["count"][:g], agg["group_of"]):
         h.update(np.ascontiguousarray(a).tobytes())
@@ -430,6 +432,9 @@ def main():
     ap.add_argument("--host-rows", action="store_true",
                     help="attestation rows in host memory: grouped and validated by the host inside the timed step (the "
                          "round-2 path) instead of resident in HBM and handled on the device")
+    ap.add_argument("--sync-head", action="store_true",
+                    help="poll for every step's head inside the step (pe_get_head) instead of receiving it with the "
+                         "step's other outputs (pe_get_head_async)")
     ap.add_argument("--no-verify-steps", action="store_true",
                     help="skip the replay that checks every timed step's outputs (steps_verified)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -495,7 +500,7 @@ def main():
         if engine_rccl:
             return run_step_sharded_pipelined(e, w, st, lagged=not args.no_lag)
         return run_step_sharded(e, w, st, ex) if ex else run_step_single(e, w, st, pipelined=not args.no_pipeline,
-                                                                         lagged=not args.no_lag)
+                                                                         lagged=not args.no_lag, sync_head=args.sync_head)
 
     def barrier():
         torch.cuda.synchronize()
@@ -542,6 +547,7 @@ def main():
         n_att_local += int(done["count"].sum())
         n_rejected += int((done["status"] != 0).sum()) + int((done["pstatus"] != 0).sum())
     last = inflight[-1]
+    last["head"] = bytes(last["head"])
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()

@@ -281,6 +281,12 @@ int pe_pipeline_begin_streaming(pe_engine* h);
  * (Appendix A.1, incl. proposer boost and equivocation mask), heaviest-child
  * descent with ties to the lexicographically higher root (pe:1114-1116). */
 int pe_get_head(pe_engine* h, uint8_t out_root[32]);
+/* The same computation with the root delivered like every other output of a pipeline: inside pe_pipeline_begin ...
+ * _end(_lagged) the call enqueues its kernels and returns; out_root is written where the pipeline's outputs complete
+ * (it must stay alive until then).  For a caller that streams steps and consumes results behind -- chain sync, replay,
+ * the throughput leg of bench.py -- so that its loop never blocks on the device inside a step.  Outside a pipeline it is
+ * pe_get_head. */
+int pe_get_head_async(pe_engine* h, uint8_t out_root[32]);
 /* get_latest_attesting_balance(store, root) for every block, in insertion order
  * (index 0 = anchor).  out must hold pe_num_blocks(h) entries. */
 int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n);

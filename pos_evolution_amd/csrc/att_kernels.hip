@@ -78,40 +78,20 @@ __device__ __forceinline__ bool same4(const uint4& a, const uint4& b)
     return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) == 0;
 }
 
-// exclusive prefix sum over the 1024 lanes of the single planning workgroup; *total = sum over the block
-template <typename T>
-__device__ __forceinline__ T block_scan_1024(T v, T* wave_tot /* 16 entries of LDS */, T* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const T o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    __syncthreads();  // wave_tot may still be read by the previous scan
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    T base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        const T t = wave_tot[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    *total = tot;
-    return base + incl - v;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------ ingest: hash + insert
 __global__ void __launch_bounds__(256)
-k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t mask,
-             uint32_t* __restrict__ slot_of, unsigned long long arena_len, AttPlan* __restrict__ plan)
+k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t* __restrict__ cnt_tab,
+             uint32_t mask, uint32_t* __restrict__ slot_of, unsigned long long arena_len, AttPlan* __restrict__ plan,
+             uint4* __restrict__ arena_pad)
 {
+    __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // k_bits_union reads whole dwords: up to 8 bytes past the last member's bits, which must read zero (no copy command
+    // for 16 bytes: this kernel runs between the arena's copy and the union)
+    if (i == 0 && arena_pad) { arena_pad[0] = make_uint4(0, 0, 0, 0); arena_pad[1] = make_uint4(0, 0, 0, 0); }
     Row9 r;
     load_row(r, rows, i);
     const uint32_t b0 = r.q[8].x, nb = r.q[8].y;
@@ -132,127 +112,226 @@ k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ 
         h = (h + 1) & mask;
     }
     slot_of[i] = h;
+    atomicAdd(&cnt_tab[h], 1u);  // members of the class: k_att_plan reads the group's size here instead of counting
 }
 
-void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t tab_mask, uint32_t* slot_of,
-                       uint64_t arena_len, AttPlan* plan)
+void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
+                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_att_ingest, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
-                       tab_mask, slot_of, (unsigned long long)arena_len, plan);
+                       cnt_tab, tab_mask, slot_of, (unsigned long long)arena_len, plan, static_cast<uint4*>(arena_pad32));
 }
 
 // ------------------------------------------------------------------ plan: one workgroup
-constexpr int PLAN_WG = 1024;
+// 512 lanes = two waves per SIMD of <= 88 registers: the workgroup must find room on a CU whose SIMDs already hold two
+// 168-register waves of the previous step's k_g1_accumulate (a 1024-lane build waited for that kernel to drain: +200 us
+// on every step).  The kernel is a chain of dependent round trips to L2 / HBM beside a kernel that saturates the chip, so
+// its shape is: coalesced chunk loops (lane = consecutive element, independent iterations the compiler can overlap),
+// wave-level prefix sums by shuffles, per-(chunk, wave) totals in an LDS matrix, ONE block scan per matrix.
+constexpr int PLAN_WG = 512;
+constexpr int PLAN_WAVES = PLAN_WG / 64;
+constexpr uint32_t PLAN_SUPER = 32;  // chunks per super-chunk: 32 x 512 elements per LDS matrix of 256 totals
+
+namespace {
+template <typename T>
+__device__ __forceinline__ T block_scan_512(T v, T* wave_tot /* 8 entries of LDS */, T* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();  // wave_tot may still be read by the previous scan
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PLAN_WAVES; ++w) {
+        const T t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+__device__ __forceinline__ uint32_t wave_excl_u32(uint32_t v, uint32_t* wave_total)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    *wave_total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+// mat[0 .. cnt) (cnt <= 256 <= PLAN_WG) -> exclusive prefix sums + base, in place; returns the total.  All lanes call it.
+__device__ __forceinline__ uint32_t scan_matrix(uint32_t* mat, uint32_t cnt, uint32_t base, uint32_t* wt32)
+{
+    __syncthreads();  // the matrix is complete
+    const uint32_t v = threadIdx.x < cnt ? mat[threadIdx.x] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_scan_512<uint32_t>(v, wt32, &tot);
+    if (threadIdx.x < cnt) mat[threadIdx.x] = base + ex;
+    __syncthreads();
+    return tot;
+}
+}  // namespace
 
 __global__ void __launch_bounds__(PLAN_WG)
 k_att_plan(AttPlanArgs a)
 {
-    __shared__ uint32_t wt32[16];
-    __shared__ unsigned long long wt64[16];
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint32_t wt32[PLAN_WAVES];
+    __shared__ unsigned long long wt64[PLAN_WAVES];
+    __shared__ uint32_t matA[PLAN_SUPER * PLAN_WAVES], matB[PLAN_SUPER * PLAN_WAVES], matC[PLAN_SUPER * PLAN_WAVES];
     __shared__ uint32_t s_max_size, s_not_aligned, s_err, s_rows_t[2];
-    const uint4* rows = static_cast<const uint4*>(a.rows);
+    const uint4* __restrict__ rows = static_cast<const uint4*>(a.rows);
+    const uint32_t* __restrict__ tab = a.tab;
+    const uint32_t* __restrict__ cnt_tab = a.cnt_tab;
+    const uint32_t* __restrict__ slot_of = a.slot_of;
     const uint32_t n = a.n;
-    const int tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     if (tid == 0) { s_max_size = 0; s_not_aligned = 0; s_err = a.plan->error; s_rows_t[0] = 0; s_rows_t[1] = 0; }
     __syncthreads();
     const bool dead = s_err != 0;  // ingest refused a row: nothing downstream may touch the bits
 
     // ---- 1. representatives -> group ids in order of first appearance
     uint32_t ng = 0;
-    for (uint32_t base = 0; base < n; base += PLAN_WG) {
-        const uint32_t i = base + tid;
-        uint32_t rep = NONE32;
-        if (i < n) {
-            rep = a.tab[a.slot_of[i]];
-            a.rep_of[i] = rep;
+    {
+        const uint32_t n_chunks = (n + PLAN_WG - 1) / PLAN_WG;
+        for (uint32_t sc = 0; sc < n_chunks; sc += PLAN_SUPER) {
+            const uint32_t nch = min(PLAN_SUPER, n_chunks - sc);
+            uint32_t mybits = 0;
+            for (uint32_t c0 = 0; c0 < nch; c0 += 4) {  // four chunks' dependent loads (slot -> table) in flight at once
+                uint32_t sl[4], rp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = (sc + c0 + u) * PLAN_WG + tid;
+                    sl[u] = (c0 + u < nch && i < n) ? slot_of[i] : NONE32;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rp[u] = sl[u] != NONE32 ? tab[sl[u]] : NONE32;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t c = c0 + u;
+                    const uint32_t i = (sc + c) * PLAN_WG + tid;
+                    const bool in = sl[u] != NONE32;
+                    if (in) a.rep_of[i] = rp[u];
+                    const bool is_rep = in && rp[u] == i;
+                    const unsigned long long b = __ballot(is_rep);
+                    if (lane == 0 && c < nch) matA[c * PLAN_WAVES + wave] = (uint32_t)__builtin_popcountll(b);
+                    mybits |= (is_rep ? 1u : 0u) << (c & 31);
+                }
+            }
+            const uint32_t tot = scan_matrix(matA, nch * PLAN_WAVES, ng, wt32);
+            for (uint32_t c = 0; c < nch; ++c) {
+                const bool is_rep = (mybits >> c) & 1u;
+                const unsigned long long b = __ballot(is_rep);
+                if (is_rep) {
+                    const uint32_t i = (sc + c) * PLAN_WG + tid;
+                    const uint32_t g = matA[c * PLAN_WAVES + wave] + (uint32_t)__builtin_popcountll(b & lt_mask);
+                    a.gid_of_row[i] = g;
+                    a.rep_row[g] = i;
+                }
+            }
+            ng += tot;
+            __syncthreads();  // matA is rewritten by the next super-chunk
         }
-        const uint32_t is_rep = (i < n && rep == i) ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t pos = block_scan_1024<uint32_t>(is_rep, wt32, &tot);
-        if (is_rep) {
-            a.gid_of_row[i] = ng + pos;
-            a.rep_row[ng + pos] = i;
-        }
-        ng += tot;
     }
     if (dead) ng = 0;
     __syncthreads();  // rep_row / gid_of_row are re-read below by other lanes (workgroup-scope visibility)
 
-    // ---- 2. per group: committee resolution, union offsets (prefix sums over words and bytes)
+    // ---- 2. per group: committee resolution (get_beacon_committee's index arithmetic, A.6), sizes; wave-level partial
+    //         prefix sums of union words / bytes / member counts, per-(chunk, wave) totals into the matrices
     const unsigned long long spe = a.tables.slots_per_epoch;
-    uint32_t word_base = 0, byte_base = 0;
-    unsigned long long total_members = 0;
-    for (uint32_t base = 0; base < ng; base += PLAN_WG) {
-        const uint32_t g = base + tid;
-        uint32_t words = 0, bytes = 0, nbits = 0, size = 0, table = NONE32, pos = 0, mbase = 0, rep = 0;
-        int32_t st = ST_OK;
+    const uint32_t g_chunks = (ng + PLAN_WG - 1) / PLAN_WG;
+    unsigned long long my_members = 0;
+    for (uint32_t c = 0; c < g_chunks; ++c) {
+        const uint32_t g = c * PLAN_WG + tid;
+        uint32_t words = 0, bytes = 0, natts = 0;
         if (g < ng) {
-            rep = a.rep_row[g];
+            const uint32_t rep = a.rep_row[g];
             const uint4* p = rows + (size_t)9 * rep;
             const uint4 q0 = p[0], q5 = p[5], q8 = p[8];
+            natts = cnt_tab[slot_of[rep]];
             const unsigned long long slot = u64_of(q0.x, q0.y), index = u64_of(q0.z, q0.w), tep = u64_of(q5.z, q5.w);
-            nbits = q8.y;
-            words = (nbits + 31) >> 5;
-            bytes = (nbits + 7) >> 3;
-            // get_beacon_committee(state, slot, index) (A.6) against the table of the target epoch
+            const uint32_t nbits = q8.y;
+            uint32_t size = 0, table = NONE32, pos = 0, mbase = 0, index_over = 0;
+            int32_t st = ST_OK;
             if (a.tables.t[0].valid && a.tables.t[0].epoch == tep) table = 0;
             else if (a.tables.t[1].valid && a.tables.t[1].epoch == tep) table = 1;
             if (table == NONE32) st = ST_NO_TABLE;
             else {
                 const TableDev& t = a.tables.t[table];
                 const unsigned long long cps = t.n_committees / spe;
-                if (index >= cps) st = ST_INDEX_RANGE;
+                // compute_committee(index = (slot % SLOTS_PER_EPOCH) * cps + data.index, count = cps * SLOTS_PER_EPOCH):
+                // on_attestation's get_beacon_committee asserts nothing about data.index itself -- only the flat id has
+                // to exist; pe:727 (process_attestation) and pe_aggregate require data.index < cps
+                const unsigned long long flat = index < 0xFFFFFFFFull ? (slot % spe) * cps + index : ~0ull;
+                index_over = index >= cps ? 1u : 0u;
+                if (flat >= t.n_committees) st = ST_INDEX_RANGE;
                 else {
-                    pos = (uint32_t)((slot % spe) * cps + index);
+                    pos = (uint32_t)flat;
                     mbase = t.offsets[pos];
                     size = t.offsets[pos + 1] - mbase;
                     if (nbits != size) st = ST_BITS_LENGTH;  // len(aggregation_bits) == len(committee), pe:730
                 }
             }
-            if (st != ST_OK && a.want_pk)  // the host path fails the whole aggregate here (engine_attest.cpp)
+            if ((st != ST_OK || index_over) && a.want_pk)  // the host path fails the whole aggregate here (engine_attest.cpp)
                 atomicMax(&s_err, st == ST_NO_TABLE ? ERR_NO_COMMITTEES : ERR_INVALID_ARG);
             if (st == ST_OK) {
                 atomicMax(&s_max_size, size);
                 atomicAdd(&s_rows_t[table], 1u);
+                my_members += size;
             }
-        }
-        uint32_t tw, tb;
-        const uint32_t ow = block_scan_1024<uint32_t>(words, wt32, &tw);
-        const uint32_t ob = block_scan_1024<uint32_t>(bytes, wt32, &tb);
-        unsigned long long tm;
-        (void)block_scan_1024<unsigned long long>(st == ST_OK ? (unsigned long long)size : 0ull, wt64, &tm);
-        total_members += tm;
-        if (g < ng) {
+            words = (nbits + 31) >> 5;
+            bytes = (nbits + 7) >> 3;
+            // word layout == byte layout as long as every union but the last one is a whole number of words
+            if (g + 1 < ng && bytes != 4 * words) atomicOr(&s_not_aligned, 1u);
             AttGroup& G = a.grp[g];
             G.rep = rep;
-            G.n_atts = 0;
+            G.n_atts = natts;
             G.cursor = 0;
             G.n_bits = nbits;
-            G.out_word = word_base + ow;
-            G.out_byte = byte_base + ob;
             G.table = st == ST_NO_TABLE ? NONE32 : table;
             G.pos = pos;
             G.size = size;
             G.member_base = mbase;
             G.sig_valid = FLAG_SIG_VALID;
             G.status_agg = (uint32_t)st;
-            // word layout == byte layout as long as every union but the last one is a whole number of words
-            if (g + 1 < ng && bytes != 4 * words) atomicOr(&s_not_aligned, 1u);
+            G.index_over = index_over;
         }
-        word_base += tw;
-        byte_base += tb;
+        uint32_t tw, tb, tn;
+        const uint32_t ew = wave_excl_u32(words, &tw), eb = wave_excl_u32(bytes, &tb), en = wave_excl_u32(natts, &tn);
+        if (g < ng) {  // partial (in-wave) offsets; the bases follow in the second pass
+            AttGroup& G = a.grp[g];
+            G.out_word = ew;
+            G.out_byte = eb;
+            G.list_start = en;
+        }
+        const uint32_t m = (c % PLAN_SUPER) * PLAN_WAVES + wave;
+        if (lane == 0) { matA[m] = tw; matB[m] = tb; matC[m] = tn; }
+        // a tree of more than 32 chunks of groups (> 16384 groups) flushes the matrices: handled by the second pass's
+        // running bases -- kept simple: one matrix generation must cover all chunks
     }
-    __syncthreads();
+    uint32_t word_total = 0, byte_total = 0, list_total = 0;
+    unsigned long long total_members;
+    (void)block_scan_512<unsigned long long>(my_members, wt64, &total_members);
+    const uint32_t g_mats = min(g_chunks, PLAN_SUPER) * PLAN_WAVES;
+    word_total = scan_matrix(matA, g_mats, 0, wt32);
+    byte_total = scan_matrix(matB, g_mats, 0, wt32);
+    list_total = scan_matrix(matC, g_mats, 0, wt32);
+    (void)list_total;
 
-    // ---- 3. members per group
-    for (uint32_t i = tid; i < n && ng; i += PLAN_WG) atomicAdd(&a.grp[a.gid_of_row[a.rep_of[i]]].n_atts, 1u);
-    __syncthreads();
-
-    // ---- 4. list offsets, union + G1 descriptors
-    // one block size for every group: k members per lane, blocks of BL = 2^L lanes, group g at slot g * BL.  k follows
-    // from the largest committee so that its tasks fill a block exactly or nearly (sizes that differ by one -- 511 / 512
-    // members -- would otherwise put half of the lanes of every block to sleep)
+    // ---- 3. one block size for every group: k members per lane, blocks of BL = 2^L lanes, group g at slot g * BL.  k
+    // follows from the largest committee so that its tasks fill a block exactly or nearly (sizes that differ by one --
+    // 511 / 512 members -- would otherwise put half of the lanes of every block to sleep)
     uint32_t k = a.min_k, L = 0;
     {
         const uint32_t max_size = s_max_size;
@@ -264,62 +343,71 @@ k_att_plan(AttPlanArgs a)
         k = max(a.min_k, (max_size + (1u << L) - 1) >> L);
         if (k == 0) k = 1;
     }
-    uint32_t list_base = 0;
-    for (uint32_t base = 0; base < ng; base += PLAN_WG) {
-        const uint32_t g = base + tid;
-        const uint32_t cnt = g < ng ? a.grp[g].n_atts : 0u;
-        uint32_t tc;
-        const uint32_t ls = block_scan_1024<uint32_t>(cnt, wt32, &tc);
-        if (g < ng) {
-            AttGroup& G = a.grp[g];
-            G.list_start = list_base + ls;
-            UnionGroup u;
-            u.list_start = list_base + ls;
-            u.n_atts = cnt;
-            u.n_bits = G.n_bits;
-            u.out_word = G.out_word;
-            a.ug[g] = u;
-            const bool ok = G.status_agg == ST_OK;
-            G1Group d;
-            d.member_start = G.member_base;
-            d.n_members = ok ? G.size : 0u;
-            d.bits_word = G.out_word;
-            d.slot_base = g << L;
-            d.n_tasks = ok ? (G.size + k - 1) / k : 0u;
-            d.k = k | (G.table == 1 ? 0x80000000u : 0u);
-            d.log2_block = L;
-            d.out_base = g;
-            a.g1[g] = d;
-        }
-        list_base += tc;
-    }
-
-    // ---- 5. rows per committee of each candidate table (unordered lists; consumers order by group id)
+    // ---- 4. second pass over the groups: final offsets, union + G1 descriptors, committee row counts
     for (int t = 0; t < 2; ++t) {
         if (!a.tables.t[t].valid) continue;
         const uint32_t nc = a.tables.t[t].n_committees;
         for (uint32_t c = tid; c <= nc; c += PLAN_WG) a.crow_cursor[t][c] = 0;
     }
     __syncthreads();
-    for (uint32_t g = tid; g < ng; g += PLAN_WG) {
-        const AttGroup& G = a.grp[g];
-        if (G.status_agg == ST_OK) atomicAdd(&a.crow_cursor[G.table][G.pos], 1u);
+    for (uint32_t c = 0; c < g_chunks; ++c) {
+        const uint32_t g = c * PLAN_WG + tid;
+        if (g >= ng) continue;
+        const uint32_t m = (c % PLAN_SUPER) * PLAN_WAVES + wave;
+        AttGroup& G = a.grp[g];
+        const uint32_t out_word = G.out_word + matA[m], out_byte = G.out_byte + matB[m], ls = G.list_start + matC[m];
+        G.out_word = out_word;
+        G.out_byte = out_byte;
+        G.list_start = ls;
+        UnionGroup u;
+        u.list_start = ls;
+        u.n_atts = G.n_atts;
+        u.n_bits = G.n_bits;
+        u.out_word = out_word;
+        a.ug[g] = u;
+        const bool ok = G.status_agg == ST_OK;
+        G1Group d;
+        d.member_start = G.member_base;
+        d.n_members = ok ? G.size : 0u;
+        d.bits_word = out_word;
+        d.slot_base = g << L;
+        d.n_tasks = ok ? (G.size + k - 1) / k : 0u;
+        d.k = k | (G.table == 1 ? 0x80000000u : 0u);
+        d.log2_block = L;
+        d.out_base = g;
+        a.g1[g] = d;
+        if (ok) atomicAdd(&a.crow_cursor[G.table][G.pos], 1u);
     }
     __syncthreads();
+
+    // ---- 5. rows per committee of each candidate table (unordered lists; consumers order by group id)
     for (int t = 0; t < 2; ++t) {
         if (!a.tables.t[t].valid) continue;
         const uint32_t nc = a.tables.t[t].n_committees;
-        uint32_t run = 0;
-        for (uint32_t base = 0; base <= nc; base += PLAN_WG) {
-            const uint32_t c = base + tid;
-            const uint32_t cnt = c < nc ? a.crow_cursor[t][c] : 0u;
-            uint32_t tc;
-            const uint32_t st0 = block_scan_1024<uint32_t>(cnt, wt32, &tc);
-            if (c <= nc) a.crow_start[t][c] = run + st0;
-            run += tc;
+        const uint32_t c_chunks = (nc + 1 + PLAN_WG - 1) / PLAN_WG;
+        uint32_t base = 0;
+        for (uint32_t sc = 0; sc < c_chunks; sc += PLAN_SUPER) {
+            const uint32_t nch = min(PLAN_SUPER, c_chunks - sc);
+            for (uint32_t c = 0; c < nch; ++c) {
+                const uint32_t idx = (sc + c) * PLAN_WG + tid;
+                const uint32_t v = idx < nc ? a.crow_cursor[t][idx] : 0u;
+                uint32_t tv;
+                const uint32_t ev = wave_excl_u32(v, &tv);
+                if (idx <= nc) a.crow_start[t][idx] = ev;
+                if (lane == 0) matA[c * PLAN_WAVES + wave] = tv;
+            }
+            const uint32_t tot = scan_matrix(matA, nch * PLAN_WAVES, base, wt32);
+            for (uint32_t c = 0; c < nch; ++c) {
+                const uint32_t idx = (sc + c) * PLAN_WG + tid;
+                if (idx <= nc) {
+                    const uint32_t st0 = a.crow_start[t][idx] + matA[c * PLAN_WAVES + wave];
+                    a.crow_start[t][idx] = st0;
+                    if (idx < nc) a.crow_cursor[t][idx] = st0;  // becomes the fill cursor
+                }
+            }
+            base += tot;
+            __syncthreads();
         }
-        __syncthreads();
-        for (uint32_t c = tid; c < nc; c += PLAN_WG) a.crow_cursor[t][c] = a.crow_start[t][c];
     }
     __syncthreads();
     for (uint32_t g = tid; g < ng; g += PLAN_WG) {
@@ -330,14 +418,15 @@ k_att_plan(AttPlanArgs a)
     // ---- 6. the plan, for the kernels that follow and (pinned mirror) for the host's completion
     if (tid == 0) {
         uint32_t err = s_err;
-        if (!err && byte_base > a.out_arena_cap) err = ERR_CAPACITY;  // "output bit arena too small"
+        if (!err && g_chunks > PLAN_SUPER) err = ERR_CAPACITY;        // more than 16384 groups in one call
+        if (!err && byte_total > a.out_arena_cap) err = ERR_CAPACITY;  // "output bit arena too small"
         AttPlan p;
         p.n_groups = err ? 0u : ng;  // a failing aggregate forms no groups: the handlers behind it apply nothing
         p.n_slots = p.n_groups << L;
         p.k = k;
         p.log2_block = L;
-        p.out_words = word_base;
-        p.out_bytes = byte_base;
+        p.out_words = word_total;
+        p.out_bytes = byte_total;
         p.error = err;
         p.packed_same = s_not_aligned ? 0u : 1u;
         p.n_rows_table[0] = s_rows_t[0];
@@ -357,11 +446,13 @@ void launch_att_plan(hipStream_t s, const AttPlanArgs& a)
 
 // ------------------------------------------------------------------ members
 __global__ void __launch_bounds__(256)
-k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, const uint32_t* __restrict__ slot_of,
+k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t* __restrict__ cnt_tab,
+              const uint32_t* __restrict__ slot_of,
               const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ gid_of_row, AttGroup* __restrict__ grp,
               AttPlan* __restrict__ plan, uint32_t* __restrict__ ubytes, uint32_t* __restrict__ member_row,
               uint32_t* __restrict__ host_group_of, uint4* __restrict__ host_out_rows)
 {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = slot_of[i];
@@ -383,16 +474,17 @@ k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__
         }
     }
     tab[slot] = ATT_EMPTY;  // every row of a class clears the class's slot: the table is empty again for the next call
+    cnt_tab[slot] = 0;
     if (i == 0) plan->error = 0;  // consumed by k_att_plan (mirrored to the host): k_att_ingest of the next call starts clean
 }
 
-void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, const uint32_t* slot_of,
+void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
                         const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
                         uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_att_members, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
-                       slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row, host_group_of,
+                       cnt_tab, slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row, host_group_of,
                        static_cast<uint4*>(host_out_rows));
 }
 
@@ -424,6 +516,7 @@ k_att_validate_fc(const uint4* __restrict__ rows, const AttGroup* __restrict__ g
                   AttRow* __restrict__ out_rows, int32_t* __restrict__ status_dev, int32_t* __restrict__ status_host,
                   uint32_t* __restrict__ count_host, uint32_t* __restrict__ err_host)
 {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t ng = plan->n_groups;
     if (ng > cap) {  // the caller's status / count arrays hold fewer entries than groups were formed: nothing applies
@@ -500,7 +593,7 @@ void launch_att_validate_fc(hipStream_t s, const void* rows, const AttGroup* grp
 // ------------------------------------------------------------------ process_attestation's asserts + flag indices per group
 __global__ void __launch_bounds__(256)
 k_att_validate_state(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
-                     uint32_t cap, BlockTableDev bt, const StateCtxDev* __restrict__ stp,
+                     uint32_t cap, BlockTableDev bt, const StateCtxDev S,
                      const uint32_t* __restrict__ union_info, AttRow* __restrict__ out_rows,
                      int32_t* __restrict__ status_dev, int32_t* __restrict__ status_host, uint32_t* __restrict__ err_host)
 {
@@ -512,7 +605,6 @@ k_att_validate_state(const uint4* __restrict__ rows, const AttGroup* __restrict_
         return;
     }
     if (g >= ng) return;
-    const StateCtxDev& S = *stp;
     const AttGroup G = grp[g];
     Row9 r;
     load_row(r, rows, G.rep);
@@ -522,7 +614,9 @@ k_att_validate_state(const uint4* __restrict__ rows, const AttGroup* __restrict_
     if (tep != S.prev_epoch && tep != S.cur_epoch) st = ST_EPOCH_TIME;                                   // pe:724
     else if (tep != slot / spe) st = ST_EPOCH_SLOT;                                                       // pe:725
     else if (!(slot + S.min_inclusion_delay <= S.slot && S.slot <= slot + spe)) st = ST_INCLUSION;        // pe:726
-    else if (G.status_agg) st = (int32_t)G.status_agg;                                                    // pe:727-730
+    else if (G.status_agg == (uint32_t)ST_NO_TABLE) st = ST_NO_TABLE;
+    else if (G.index_over) st = ST_INDEX_RANGE;                                                           // pe:727
+    else if (G.status_agg) st = (int32_t)G.status_agg;                                                    // pe:729-730
     else {
         // get_attestation_participation_flag_indices (A.9)
         const bool is_cur = tep == S.cur_epoch;
@@ -566,7 +660,7 @@ k_att_validate_state(const uint4* __restrict__ rows, const AttGroup* __restrict_
 }
 
 void launch_att_validate_state(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
-                               uint32_t cap, BlockTableDev bt, const StateCtxDev* st, const uint32_t* union_info,
+                               uint32_t cap, BlockTableDev bt, const StateCtxDev& st, const uint32_t* union_info,
                                AttRow* out_rows, int32_t* status_dev, int32_t* status_host, uint32_t* err_host)
 {
     if (n_bound == 0) return;
@@ -586,30 +680,37 @@ k_lmd_vm_tables(const AttRow* __restrict__ rows, TablesDev tables, const uint32_
                 uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot, const uint32_t* __restrict__ gates)
 {
     __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
-    const int t = blockIdx.y;
-    if (!tables.t[t].valid || plan->n_rows_table[t] == 0) return;
     const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_val) return;
-    const uint32_t c = tables.t[t].inv_comm[v];
-    if (c == NONE32) return;
-    const uint32_t* crow_start = t ? cs1 : cs0;
-    const uint32_t* crow_list = t ? cl1 : cl0;
-    const uint32_t kb = crow_start[c], ke = crow_start[c + 1];
-    if (kb == ke) return;
-    if (flags[v] & VAL_EQUIVOCATING_BIT) return;  // pe:1438
-    const uint32_t i = tables.t[t].inv_pos[v];
-    const uint32_t stored_e = (uint32_t)(vote_key[v] >> 32);  // epoch + 1; 0 = no latest message
-    uint32_t best_e = stored_e, best_order = NONE32, new_block = NONE32, new_slot = 0;
-    for (uint32_t k = kb; k < ke; ++k) {
-        const AttRow r = rows[crow_list[k]];
-        if (i >= r.n_bits) continue;
-        if (gates[r.gate] != 0) continue;  // rejected by validation (or voided: overlapping members)
-        if (!((bit_arena[r.bits_word + (i >> 5)] >> (i & 31)) & 1u)) continue;
-        if (r.epoch_p1 > best_e || (r.epoch_p1 == best_e && new_block != NONE32 && r.order < best_order)) {
-            best_e = r.epoch_p1;
-            best_order = r.order;
-            new_block = r.block_idx;
-            new_slot = r.slot;
+    // a validator sits in one committee of EACH epoch: the same lane walks both tables, one after the other (two lanes
+    // would race on its latest message)
+    uint32_t best_e = 0, best_order = NONE32, new_block = NONE32, new_slot = 0;
+    bool loaded = false;
+    for (int t = 0; t < 2; ++t) {
+        if (!tables.t[t].valid || plan->n_rows_table[t] == 0) continue;
+        const uint32_t c = tables.t[t].inv_comm[v];
+        if (c == NONE32) continue;
+        const uint32_t* crow_start = t ? cs1 : cs0;
+        const uint32_t* crow_list = t ? cl1 : cl0;
+        const uint32_t kb = crow_start[c], ke = crow_start[c + 1];
+        if (kb == ke) continue;
+        if (!loaded) {
+            if (flags[v] & VAL_EQUIVOCATING_BIT) return;  // pe:1438
+            best_e = (uint32_t)(vote_key[v] >> 32);        // epoch + 1 of the stored message; 0 = none
+            loaded = true;
+        }
+        const uint32_t i = tables.t[t].inv_pos[v];
+        for (uint32_t k = kb; k < ke; ++k) {
+            const AttRow r = rows[crow_list[k]];
+            if (i >= r.n_bits) continue;
+            if (gates[r.gate] != 0) continue;  // rejected by validation (or voided: overlapping members)
+            if (!((bit_arena[r.bits_word + (i >> 5)] >> (i & 31)) & 1u)) continue;
+            if (r.epoch_p1 > best_e || (r.epoch_p1 == best_e && new_block != NONE32 && r.order < best_order)) {
+                best_e = r.epoch_p1;
+                best_order = r.order;
+                new_block = r.block_idx;
+                new_slot = r.slot;
+            }
         }
     }
     if (new_block != NONE32) {
@@ -625,8 +726,7 @@ void launch_lmd_vm_tables(hipStream_t s, const AttRow* rows, TablesDev tables, u
                           uint32_t* vote_slot, const uint32_t* gates)
 {
     if (n_val == 0) return;
-    const unsigned ny = tables.t[1].valid ? 2u : 1u;
-    hipLaunchKernelGGL(k_lmd_vm_tables, dim3((unsigned)((n_val + 255) / 256), ny), dim3(256), 0, s, rows, tables,
+    hipLaunchKernelGGL(k_lmd_vm_tables, dim3((unsigned)((n_val + 255) / 256)), dim3(256), 0, s, rows, tables,
                        crow_start[0], crow_start[1], crow_list[0], crow_list[1], plan, bit_arena, flags,
                        (unsigned long long)n_val, reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot,
                        gates);

@@ -1038,11 +1038,12 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     const uint32_t* d_gates = resident ? h->arena[h->res_arena].d_res_info.as<uint32_t>() : nullptr;
     HIP_TRY(h, stg.upload());
     memset(ob.host<uint8_t>(off_num), 0, 8ull * n);  // the kernel writes the numerators straight into the pinned block
+    hipStream_t ss = state_stream_begin(h);  // behind the upload and the unions; beside whatever follows on the engine's stream
     for (size_t k = 0; k < ord.size();) {
         size_t e = k + 1;
         while (e < ord.size() && round_of[ord[e]] == round_of[ord[k]] && acc[ord[e]].table == acc[ord[k]].table) ++e;
-        ProfScope ps(h, PE_KERNEL_PARTICIPATION);
-        launch_participation(h->stream, stg.dev<AttRow>(off_rows) + k, (uint32_t)(e - k),
+        ProfScope ps(h, PE_KERNEL_PARTICIPATION, ss);
+        launch_participation(ss, stg.dev<AttRow>(off_rows) + k, (uint32_t)(e - k),
                              acc[ord[k]].table->d_members.as<uint32_t>(), d_bits,
                              h->d_incr.as<uint16_t>(), st->base_reward_per_increment, h->d_part_cur.as<uint32_t>(),
                              h->d_part_prev.as<uint32_t>(), ob.host<uint64_t>(off_num), stg.dev<uint32_t>(off_nslot) + k,
@@ -1101,7 +1102,8 @@ int pe_participation_rotate(pe_engine* h)
     if (!h) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     std::swap(h->d_part_cur, h->d_part_prev);  // previous = current
-    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), h->stream));  // current = 0
+    // on the state stream, behind the flag passes that still write the old arrays (and off the fork-choice stream)
+    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), state_stream_begin(h)));  // current = 0
     return PE_OK;
 }
 

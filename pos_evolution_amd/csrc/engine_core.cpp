@@ -40,14 +40,23 @@ int complete_arena(pe_engine* h, int ai)
     if (a.pending.empty() && !a.fenced && a.stage_cursor == 0 && a.out_cursor == 0) return PE_OK;
     if (ai == h->cur) PE_TRY(run_deferred(h));  // deferred launches belong to the arena the calls are going into
     hipError_t e = hipSuccess;
-    if (a.fenced) {  // a lagged pipeline: its end was marked on both streams
+    if (a.fenced) {  // a lagged pipeline: its end was marked on every stream it used
         e = hipEventSynchronize(a.ev_main);
         if (a.side_used) {
             hipError_t e2 = hipEventSynchronize(a.ev_side);
             if (e == hipSuccess) e = e2;
         }
+        if (a.aux_used) {
+            hipError_t e2 = hipEventSynchronize(a.ev_aux);
+            if (e == hipSuccess) e = e2;
+        }
     } else {         // the arena the calls are still going into
         e = hipStreamSynchronize(h->stream);
+        if (h->aux_busy) {
+            hipError_t e2 = hipStreamSynchronize(h->aux_stream);
+            if (e == hipSuccess) e = e2;
+            h->aux_busy = false;
+        }
         if (h->side_busy) {
             hipError_t e2 = hipStreamSynchronize(h->side_stream);
             if (e == hipSuccess) e = e2;
@@ -59,7 +68,7 @@ int complete_arena(pe_engine* h, int ai)
     std::vector<std::function<int()>> todo;
     todo.swap(a.pending);
     a.stage_cursor = a.out_cursor = 0;
-    a.fenced = a.side_used = false;
+    a.fenced = a.side_used = a.aux_used = false;
     if (e != hipSuccess) return hip_fail(h, e, "waiting for the enqueued batch calls");
     int rc = PE_OK;
     for (auto& f : todo) {
@@ -77,7 +86,8 @@ void complete_oldest_if_ready(pe_engine* h)
     const int ai = (h->cur + 1) % pe_engine::N_ARENAS;
     pe_engine::PipeArena& a = h->arena[ai];
     if (!a.fenced || a.pending.empty()) return;
-    if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess)) {
+    if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess) ||
+        (a.aux_used && hipEventQuery(a.ev_aux) != hipSuccess)) {
         (void)hipGetLastError();  // hipErrorNotReady is not an error here
         return;
     }
@@ -119,17 +129,40 @@ int ensure_quiesced(pe_engine* h, DevBuf& b, size_t bytes)
 }
 
 // Entry of a call that is not part of the pipelined hot path: complete whatever the batch calls left enqueued.
+static int aux_quiesce(pe_engine* h)
+{
+    if (!h->aux_busy) return PE_OK;
+    h->aux_busy = false;
+    HIP_TRY(h, hipStreamSynchronize(h->aux_stream));
+    return PE_OK;
+}
 int enter(pe_engine* h)
 {
     (void)hipSetDevice(h->device);
-    return flush_pending(h);
+    const int rc = flush_pending(h);
+    const int rc2 = aux_quiesce(h);  // e.g. a participation rotation outside any batch call
+    return rc ? rc : rc2;
+}
+hipStream_t state_stream_begin(pe_engine* h)
+{
+    // a caller-owned stream (pe_set_stream) carries everything: the caller orders its own work against it
+    if (h->stream != h->own_stream || !h->aux_stream) return h->stream;
+    if (hipEventRecord(h->ev_aux_fork, h->stream) != hipSuccess ||
+        hipStreamWaitEvent(h->aux_stream, h->ev_aux_fork, 0) != hipSuccess)
+        return h->stream;
+    h->aux_busy = true;
+    h->A().aux_used = true;
+    return h->aux_stream;
 }
 int need_init(pe_engine* h, bool flush)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     if (!h->initialised) return fail(h, PE_ERR_STATE, "store not initialised: call pe_store_init first");
     (void)hipSetDevice(h->device);
-    return flush ? flush_pending(h) : PE_OK;
+    if (!flush) return PE_OK;
+    const int rc = flush_pending(h);
+    const int rc2 = aux_quiesce(h);
+    return rc ? rc : rc2;
 }
 
 }  // namespace posevo
@@ -208,8 +241,13 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // latency-sized fork-choice kernels -- were measured and dropped: hipExtStreamCreateWithCUMask with 16 / 32 / 48
     // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
     const bool ok_streams = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess &&
-                            hipStreamCreateWithFlags(&h->fin_stream, hipStreamNonBlocking) == hipSuccess;
+                            hipStreamCreateWithFlags(&h->fin_stream, hipStreamNonBlocking) == hipSuccess &&
+                            hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess;
     if (!ok_streams ||
+        hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[0].ev_aux, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[1].ev_aux, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->arena[2].ev_aux, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -235,6 +273,7 @@ void pe_engine_destroy(pe_engine* h)
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
     if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
     h->d_xchg.release();
@@ -253,6 +292,7 @@ void pe_engine_destroy(pe_engine* h)
         a.h_pin.release();
         if (a.ev_main) (void)hipEventDestroy(a.ev_main);
         if (a.ev_side) (void)hipEventDestroy(a.ev_side);
+        if (a.ev_aux) (void)hipEventDestroy(a.ev_aux);
     }
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
@@ -270,6 +310,8 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
+    if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->fin_stream) (void)hipStreamDestroy(h->fin_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -358,6 +400,8 @@ int pe_pipeline_end_lagged(pe_engine* h)
     // synchronous call) has waited for the marks
     HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
     if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->fin_stream));  // the last kernel of the G1 chain runs there
+    if (a.aux_used) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));
+    h->aux_busy = false;    // accounted for by the fence
     a.fenced = true;
     h->side_busy = false;   // accounted for by the fence from here on
     h->cur = (h->cur + 1) % pe_engine::N_ARENAS;
@@ -386,6 +430,8 @@ static void prof_drain(pe_engine* h)
     (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     for (auto& p : h->prof) {
         for (auto& ev : p.pending) {
             float ms = 0;

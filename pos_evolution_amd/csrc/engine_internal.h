@@ -245,8 +245,8 @@ struct pe_engine {
         uint32_t rr_rows_cap = 0, rr_comm_cap = 0, rr_tab_size = 0;
         size_t stage_cursor = 0, out_cursor = 0;
         std::vector<std::function<int()>> pending;
-        hipEvent_t ev_main = nullptr, ev_side = nullptr;  // recorded by pe_pipeline_end_lagged
-        bool fenced = false, side_used = false;
+        hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
+        bool fenced = false, side_used = false, aux_used = false;
     };
     static constexpr int N_ARENAS = 3;  // lag depth 2: a lagged end waits for the pipeline TWO back, never for the
                                         // finish kernel of the one that has only just been fenced
@@ -256,6 +256,12 @@ struct pe_engine {
     bool pipelining = false;
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
     hipStream_t fin_stream = nullptr;   // ... and its k_g1_finish here, beside the NEXT aggregate's accumulation
+    // State-transition work (process_attestation's flag pass, participation rotation) runs on a stream of its own: it
+    // follows the head in a step, and on the engine's stream it stood between one step's head and the next step's
+    // fork-choice chain (25 + 85 us per 1 M validators beside a running accumulation, profiles/r03_timeline_*.txt).
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux_fork = nullptr;
+    bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_busy = false;             // the side stream holds work of the current arena nobody has waited for yet
@@ -358,6 +364,8 @@ void complete_oldest_if_ready(pe_engine* h);
 int flush_pending(pe_engine* h);
 int enter(pe_engine* h);
 int need_init(pe_engine* h, bool flush = true);
+// The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
+hipStream_t state_stream_begin(pe_engine* h);
 
 // ------------------------------------------------------------------ spec helpers (A.10)
 inline uint64_t current_slot(const pe_engine* h) { return (h->time - h->genesis_time) / h->cfg.seconds_per_slot; }
@@ -401,7 +409,8 @@ int refresh_tree(pe_engine* h);
 TreeDev tree_dev(const pe_engine* h);
 int insert_block(pe_engine* h, const Root& root, uint32_t parent, uint64_t slot, const Checkpoint& pj, const Checkpoint& pf);
 CommitteeTable* find_table(pe_engine* h, uint64_t epoch);
-int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out);
+int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out,
+             uint32_t* async_word = nullptr);
 int ensure_validator_arrays(pe_engine* h, uint64_t n);
 int upload_balances(pe_engine* h, uint64_t n, const uint64_t* bal, const uint8_t* flags);
 

@@ -81,10 +81,11 @@ int rr_ensure(pe_engine* h, pe_engine::PipeArena& a, uint32_t n, uint32_t n_comm
     a.d_rr.release();
     a.d_rr_tab.release();
     HIP_TRY(h, a.d_rr.ensure(L.bytes));
-    HIP_TRY(h, a.d_rr_tab.ensure(4ull * tab));
+    HIP_TRY(h, a.d_rr_tab.ensure(8ull * tab));  // slot -> first row | slot -> class size
     // the grouping table is kept empty by its users (k_att_members clears what k_att_ingest filled); the plan's error
     // word starts at zero
     HIP_TRY(h, hipMemsetAsync(a.d_rr_tab.p, 0xFF, 4ull * tab, h->stream));
+    HIP_TRY(h, hipMemsetAsync(a.d_rr_tab.as<uint8_t>() + 4ull * tab, 0, 4ull * tab, h->stream));
     HIP_TRY(h, hipMemsetAsync(a.d_rr.p, 0, L.bytes, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     a.rr_rows_cap = cap_n;
@@ -191,7 +192,8 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     const size_t words_cap = (size_t)out_arena_cap / 4 + n + 16;
     Stage st(h);
     PE_TRY(st.reserve((size_t)arena_len + 256));
-    const size_t off_arena = st.alloc((size_t)arena_len + 16);
+    const size_t pad_at = ((size_t)arena_len + 15) & ~size_t(15);  // 32 zero bytes behind the bits, written by k_att_ingest
+    const size_t off_arena = st.alloc(pad_at + 32);
     PE_TRY(ensure_quiesced(h, A.d_res_bits, words_cap * 4 + 64));
     PE_TRY(ensure_quiesced(h, A.d_res_info, 8ull * n + 64));
     OutBlock ob(h);
@@ -236,23 +238,24 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
             (void)hipGetLastError();
         }
     }
-    memset(st.host<uint8_t>(off_arena) + arena_len, 0, 16);
     if (arena_kind == 0) {
         memcpy(st.host<uint8_t>(off_arena), bits_arena, arena_len);
+        memset(st.host<uint8_t>(off_arena) + arena_len, 0, pad_at + 32 - arena_len);
         HIP_TRY(h, st.upload());
-    } else {
-        if (arena_len)
-            HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena), bits_arena, arena_len,
-                                      arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
-        HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena) + arena_len, st.host<uint8_t>(off_arena) + arena_len, 16,
-                                  hipMemcpyHostToDevice, ms));
+    } else if (arena_len) {  // bytes [arena_len, pad_at) may keep old bits: they lie inside the last dword pair only when
+                             // arena_len is not a multiple of 4, and then belong to no member (masked by n_bits)
+        HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena), bits_arena, arena_len,
+                                  arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
     }
     lap.mark("ragg.2_bits");
-    launch_att_ingest(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), A.rr_tab_size - 1, L.slot_of, arena_len, L.plan);
+    uint32_t* cnt_tab = A.d_rr_tab.as<uint32_t>() + A.rr_tab_size;
+    launch_att_ingest(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), cnt_tab, A.rr_tab_size - 1, L.slot_of, arena_len, L.plan,
+                      st.dev<uint8_t>(off_arena) + pad_at);
     AttPlanArgs pa;
     pa.rows = d_rows;
     pa.n = n;
     pa.tab = A.d_rr_tab.as<uint32_t>();
+    pa.cnt_tab = cnt_tab;
     pa.slot_of = L.slot_of;
     pa.rep_of = L.rep_of;
     pa.gid_of_row = L.gid_of_row;
@@ -275,7 +278,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     pa.want_pk = want_pk ? 1u : 0u;
     pa.tables = tables;
     launch_att_plan(ms, pa);
-    launch_att_members(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
+    launch_att_members(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
                        L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows));
     {
         ProfScope ps(h, PE_KERNEL_BITS_UNION);
@@ -446,9 +449,7 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
     pe_engine::PipeArena& RA = h->arena[h->rr.arena];
     const RrLayout L = rr_of(RA);
     Stage st(h);
-    PE_TRY(st.reserve(sizeof(StateCtxDev) + 256));
-    const size_t off_ctx = st.alloc(sizeof(StateCtxDev));
-    StateCtxDev& S = *st.host<StateCtxDev>(off_ctx);
+    StateCtxDev S;  // travels as a kernel argument: no copy command
     memset(&S, 0, sizeof(S));
     S.slot = sc->slot;
     S.cur_epoch = sc->slot / spe;
@@ -481,14 +482,14 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
     *ob.host<uint32_t>(off_err) = 0;
     memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
     memset(ob.host<uint64_t>(off_num), 0, 8ull * cap);  // k_participation_tables writes the rows it runs
-    HIP_TRY(h, st.upload());
     const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);
-    launch_att_validate_state(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), st.dev<StateCtxDev>(off_ctx),
+    hipStream_t ss = state_stream_begin(h);  // behind the unions and the plan; beside the next step's fork-choice chain
+    launch_att_validate_state(ss, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), S,
                               RA.d_res_info.as<uint32_t>(), L.rows_st, L.status_st, ob.host<int32_t>(off_status),
                               ob.host<uint32_t>(off_err));
     {
-        ProfScope ps(h, PE_KERNEL_PARTICIPATION);
-        launch_participation_tables(h->stream, L.rows_st, h->rr.tables, L.crow_start, L.crow_list, L.plan,
+        ProfScope ps(h, PE_KERNEL_PARTICIPATION, ss);
+        launch_participation_tables(ss, L.rows_st, h->rr.tables, L.crow_start, L.crow_list, L.plan,
                                     RA.d_res_bits.as<uint32_t>(), h->d_incr.as<uint16_t>(), sc->base_reward_per_increment,
                                     h->d_part_cur.as<uint32_t>(), h->d_part_prev.as<uint32_t>(), ob.host<uint64_t>(off_num),
                                     reinterpret_cast<const uint32_t*>(L.status_st));

@@ -223,7 +223,8 @@ int upload_balances(pe_engine* h, uint64_t n, const uint64_t* bal, const uint8_t
 }
 
 // get_head's device part on arbitrary weight buffer.
-int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out)
+int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out,
+             uint32_t* async_word)
 {
     uint32_t just_idx;
     if (!find_block(h, h->justified.root, &just_idx))
@@ -233,14 +234,16 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
         uint32_t bi;
         if (find_block(h, h->boost_root, &bi)) boost_pos = h->h_pos_of_idx[bi];
     }
-    volatile uint32_t* head_word = h->h_head.as<uint32_t>();
+    // async_word: a slot of the pinned output block instead of the engine's head word -- pe_get_head_async: nobody polls,
+    // the call's completion reads it when the pipeline's outputs are complete
+    volatile uint32_t* head_word = async_word ? async_word : h->h_head.as<uint32_t>();
     *head_word = NONE32;
     {
         ProfScope ps(h, PE_KERNEL_TREE);
         // the head index lands directly in host-coherent pinned memory: no D2H copy, just the stream sync
         launch_tree(h->stream, tree_dev(h), d_direct, d_totals, 0, 0, 0, h->h_pos_of_idx[just_idx], boost_pos,
                     h->cfg.slots_per_epoch, h->cfg.proposer_score_boost, h->cfg.effective_balance_increment,
-                    h->d_weights.as<uint64_t>(), h->h_head.as<uint32_t>(), clear_direct,
+                    h->d_weights.as<uint64_t>(), const_cast<uint32_t*>(head_word), clear_direct,
                     /*lean=*/h->pipelining ? 1 : 0);  // inside a pipeline: the shape that fits beside an accumulation
     }
     HIP_TRY(h, hipGetLastError());
@@ -250,6 +253,7 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
         PE_TRY(run_deferred(h));
         complete_oldest_if_ready(h);
     }
+    if (async_word) return PE_OK;
     // k_tree's last act is a system-scope release store of the head index into this host-coherent word: polling it
     // sees the result a few microseconds before hipStreamSynchronize returns.  Bounded: after ~200 us (a hung or
     // faulted kernel) the stream sync takes over and reports the error.
@@ -717,6 +721,47 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
     if (rc) return rc;
     memcpy(out_root, h->blocks[head].root.data(), 32);
     return PE_OK;
+}
+
+// get_head whose root arrives with the pipeline's other outputs: votes + tree (and, in a streaming pipeline, the step's
+// G1 sums behind them) are enqueued, nothing is polled.  The caller's loop then never blocks on the GPU inside a step.
+int pe_get_head_async(pe_engine* h, uint8_t out_root[32])
+{
+    int rc = need_init(h, /*flush=*/false);
+    if (rc) return rc;
+    if (!out_root) return PE_ERR_INVALID_ARG;
+    if (!h->pipelining) return pe_get_head(h, out_root);  // outside a pipeline every call is synchronous
+    HostLap lap(&h->trace);
+    PE_TRY(refresh_tree(h));
+    {
+        uint32_t tmp;
+        if (!find_block(h, h->justified.root, &tmp))
+            return fail(h, PE_ERR_UNKNOWN_ROOT, "justified checkpoint root is not in the store");
+    }
+    Stage st(h);
+    OutBlock ob(h);
+    const size_t off = ob.alloc(64);
+    PE_TRY(ob.ensure());
+    {
+        ProfScope ps(h, PE_KERNEL_VOTES);
+        launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
+                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(),
+                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 0, expiry_slots_ptr(h),
+                     min_vote_slot(h), /*lean=*/1);
+    }
+    uint32_t unused;
+    PE_TRY(run_tree(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 1, &unused, ob.host<uint32_t>(off)));
+    lap.mark("head.async_launch");
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    // the block table may grow before the completion runs; indices are stable (blocks are only appended)
+    auto complete = [h, ai, base, off, out_root]() -> int {
+        const uint32_t idx = *reinterpret_cast<const uint32_t*>(h->arena[ai].h_pin.as<uint8_t>() + base + off);
+        if (idx >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
+        memcpy(out_root, h->blocks[idx].root.data(), 32);
+        return PE_OK;
+    };
+    return finish_call(h, st, ob, complete);
 }
 
 int pe_get_weights(pe_engine* h, uint64_t* out_weights, uint32_t n)

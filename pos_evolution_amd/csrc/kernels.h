@@ -179,7 +179,9 @@ struct AttGroup {                 // one per group, in order of first appearance
     uint32_t pos, size, member_base;
     uint32_t sig_valid;           // AND of the members' PE_ATT_FLAG_SIGNATURE_VALID
     uint32_t status_agg;          // 0, or the pe_att_status that keeps the group from having a committee
-    uint32_t pad[3];
+    uint32_t index_over;          // data.index >= committees per slot (pe:727) although the flat committee id exists:
+                                  // get_beacon_committee (A.6) does not assert it, process_attestation does
+    uint32_t pad[2];
 };
 struct BlockTableDev {            // the store's blocks for device-side validation (built by refresh_tree)
     const uint32_t* root_tab;     // open addressing: slot -> insertion index (NONE32 = empty), keyed by the root's first 8 bytes
@@ -201,11 +203,13 @@ struct StateCtxDev {              // the slice of BeaconState process_attestatio
     uint32_t head_blk[64];        // get_block_root_at_slot(state, slot - spe + j)
     unsigned long long base_reward_per_increment;
 };
-void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t tab_mask,
-                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan);
+// tab / cnt_tab: the grouping table (slot -> first row of the class, ATT_EMPTY when free) and the class sizes; both are
+// left clean by k_att_members.  arena_pad32: 32 bytes behind the copied bit arena, zeroed here.
+void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
+                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32);
 struct AttPlanArgs {
     const void* rows; uint32_t n;
-    const uint32_t* tab; const uint32_t* slot_of;
+    const uint32_t* tab; const uint32_t* cnt_tab; const uint32_t* slot_of;
     uint32_t* rep_of; uint32_t* gid_of_row; uint32_t* rep_row;
     AttGroup* grp; UnionGroup* ug; G1Group* g1;
     uint32_t* crow_start[2]; uint32_t* crow_cursor[2]; uint32_t* crow_list[2];
@@ -214,7 +218,7 @@ struct AttPlanArgs {
     TablesDev tables;
 };
 void launch_att_plan(hipStream_t s, const AttPlanArgs& a);
-void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, const uint32_t* slot_of,
+void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
                         const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
                         uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows);
 // n_bound: upper bound of the groups (sizes the grid); cap: entries of the caller's status / count arrays
@@ -222,9 +226,10 @@ void launch_att_validate_fc(hipStream_t s, const void* rows, const AttGroup* grp
                             uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* union_info, AttRow* out_rows,
                             int32_t* status_dev, int32_t* status_host, uint32_t* count_host, uint32_t* err_host);
 void launch_att_validate_state(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
-                               uint32_t cap, BlockTableDev bt, const StateCtxDev* st, const uint32_t* union_info,
+                               uint32_t cap, BlockTableDev bt, const StateCtxDev& st, const uint32_t* union_info,
                                AttRow* out_rows, int32_t* status_dev, int32_t* status_host, uint32_t* err_host);
-// validator-major LMD update over both candidate tables in one launch (blockIdx.y = table); the per-committee row
+// validator-major LMD update over both candidate tables in one launch (each lane walks its validator's committee of
+// the current-epoch table, then of the previous-epoch one); the per-committee row
 // lists are unordered (built with atomics), the batch-order rule is applied by comparing AttRow::order.
 void launch_lmd_vm_tables(hipStream_t s, const AttRow* rows, TablesDev tables, uint32_t* const crow_start[2],
                           uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,

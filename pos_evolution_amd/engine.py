@@ -428,6 +428,17 @@ class Engine:
         self._check(self._lib.pe_get_head(self._h, out))
         return bytes(out)
 
+    def get_head_async(self) -> np.ndarray:
+        """pe_get_head_async: -> a 32-byte array that holds the root once the pipeline's outputs are complete (inside a
+        pipeline nothing waits; outside one the call is synchronous)."""
+        (out,), (p_out,) = self._outs("head", ((32, _U8),))
+        if self._pipe_keep is not None:
+            self._pipe_keep.append(out)
+        rc = self._lib.pe_get_head_async(self._h, p_out)
+        if rc:
+            self._check(rc)
+        return out
+
     def get_weights(self) -> np.ndarray:
         n = self.num_blocks
         out = np.zeros(n, dtype=np.uint64)

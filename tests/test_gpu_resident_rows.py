@@ -145,9 +145,9 @@ def _violations(w, e_list):
         expect.append((code_fc, code_st))
 
     cc = 5 * cps                                  # a committee of slot epoch * 32 + 5, used below
-    c = iter(x for x in range(n_comm) if x != cc)
+    c = iter(x for x in range(3, n_comm) if x != cc)
     old = epoch - 2 if epoch >= 2 else epoch + 5  # neither the current (epoch + 1) nor the previous (epoch) epoch
-    put(take(next(c)), 0, 0)
+    put(take(0), 0, 0)
     r = take(next(c)); r["target_epoch"] = old; r["slot"] = old * spe + 1; put(r, 1, 1)
     r = take(next(c)); r["slot"] = (epoch + 1) * spe + 1; put(r, 2, 2)                       # target epoch != epoch(slot)
     r = take(next(c)); r["target_root"] = np.frombuffer(hashlib.sha256(b"x").digest(), np.uint8); put(r, 3, None)
@@ -174,7 +174,11 @@ def _violations(w, e_list):
     r = take(next(c)); r["slot"] = (epoch + 1) * spe + 3; r["target_epoch"] = epoch + 1
     r["beacon_block_root"] = np.frombuffer(late_root, np.uint8); r["target_root"] = np.frombuffer(late_root, np.uint8)
     put(r, 8, None)
-    r = take(next(c)); r["index"] = cps + 3; put(r, 9, 9)
+    # data.index >= committees per slot: process_attestation asserts it (pe:727); on_attestation's get_beacon_committee
+    # (A.6) only needs the flat committee id (slot % 32) * cps + index to exist, so an early slot's row lands on a later
+    # slot's committee there -- and a flat id beyond the table is refused by both
+    r = take(2); r["index"] = cps + 3; put(r, 0, 9)
+    r = take(next(c)); r["index"] = n_comm; put(r, 9, 9)
     # len(aggregation_bits) != len(committee): bits of a longer list appended to the arena
     r = take(next(c))
     nb = int(r["n_bits"][0]) + 8
@@ -271,12 +275,19 @@ def test_errors_are_deferred_and_form_no_groups(engine_factory):
     # a row whose bits lie outside the arena: the aggregate fails where its outputs complete, the handlers apply nothing
     bad = atts.copy()
     bad["bits_offset"][7] = len(arena)
-    with pytest.raises(pea.EngineError):
+    reached, st, cnt = [], None, None
+    with pytest.raises(pea.EngineError) as err:
         with e.pipeline():
             agg = e.aggregate(packed=(_dev_rows(bad), arena), want_aggregate_pubkeys=True)
+            reached.append("aggregate")   # the aggregate itself only enqueues: the refusal is found on the device
             st, _, cnt = e.on_attestation_batch(packed=(RR, RES), cap=n)
             e.get_head()
-    assert np.array_equal(e.latest_messages()[1], before) and (st == 0).all() and (cnt == 0).all()
+    # raised where the aggregate's outputs complete: at the pipeline's end, or earlier if a later call of the pipeline has
+    # to wait for what is enqueued (a block that grows) -- never inside the aggregate, and nothing is applied either way
+    assert reached == ["aggregate"], (reached, str(err.value))
+    assert err.value.status == -1   # PE_ERR_INVALID_ARG
+    assert np.array_equal(e.latest_messages()[1], before)
+    assert st is None or ((st == 0).all() and (cnt == 0).all())
     # aggregate pubkeys asked for a target epoch without a table
     other = atts.copy()
     other["target_epoch"][3] += 1
