@@ -441,6 +441,9 @@ def main():
                     help="one wait per call instead of one per step (A/B of the pipelined C ABI)")
     ap.add_argument("--no-lag", action="store_true",
                     help="complete every step's outputs at the end of that step (pe_pipeline_end instead of _end_lagged)")
+    ap.add_argument("--lag", type=int, default=4,
+                    help="lag depth of the streaming pipelines (pe_pipeline_set_lag): a step's outputs are complete when "
+                         "the lag-th next step has been enqueued")
     args = ap.parse_args()
 
     import torch
@@ -512,7 +515,8 @@ def main():
     if (ex is None or engine_rccl) and not args.no_pipeline:
         # a streaming caller reuses its output buffers (results are consumed two steps behind); to verify every timed
         # step afterwards the ring is as deep as the run, allocated and touched before the clock starts
-        e.reuse_outputs(total + 2 if verify else 4)
+        e.set_pipeline_lag(args.lag)
+        e.reuse_outputs(total + 2 if verify else args.lag + 2)
     kept = []
     for s in range(args.warmup):
         kept.append(step(w["steps"][s]))
@@ -538,7 +542,7 @@ def main():
         if verify:
             kept.append(inflight[-1])
         stamps.append(time.perf_counter())
-        if len(inflight) > 2:  # complete by now (a lagged step completes when the second next one's block exits)
+        if len(inflight) > args.lag:  # complete by now (a lagged step completes when the lag-th next one's block exits)
             done = inflight.pop(0)
             n_att_local += int(done["count"].sum())
             n_rejected += int((done["status"] != 0).sum()) + int((done["pstatus"] != 0).sum())

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PE_ABI_VERSION 4
+#define PE_ABI_VERSION 5
 
 typedef struct pe_engine pe_engine;
 
@@ -232,11 +232,18 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
  * Results are the same as with synchronous calls.  pe_pipeline_end returns the first deferred error, if any. */
 int pe_pipeline_begin(pe_engine* h);
 int pe_pipeline_end(pe_engine* h);
-/* Lagged end, for a caller that streams step after step: returns once the pipeline TWO before this one is complete
- * (its buffers filled, its deferred error returned); this one completes at the second next pe_pipeline_end_lagged, at
- * pe_pipeline_end or at any other synchronous call.  The G1 sums of step N then run while the host prepares and
- * enqueues step N+1.  Buffers handed to the calls of a lagged pipeline must stay alive until that later completion. */
+/* Lagged end, for a caller that streams step after step: returns once the pipeline L before this one is complete
+ * (its buffers filled, its deferred error returned), L = the lag depth (default 2); this one completes at the L-th next
+ * pe_pipeline_end_lagged, at pe_pipeline_end or at any other synchronous call.  The G1 sums of step N then run while
+ * the host prepares and enqueues steps N+1 .. N+L-1.  Buffers handed to the calls of a lagged pipeline must stay alive
+ * until that later completion. */
 int pe_pipeline_end_lagged(pe_engine* h);
+/* Lag depth of the lagged pipelines, 1 .. 7 (L + 1 sets of staging / output blocks rotate; they allocate on first use).
+ * Depth 2 keeps a step's outputs two steps behind; depth 3 lets the host run far enough ahead that the device queue never
+ * drains while a step's latency-bound tail (tree, normalisation) is still in flight -- what bench.py's throughput leg
+ * uses.  Completes everything in flight first; not inside a pipeline (PE_ERR_STATE). */
+int pe_pipeline_set_lag(pe_engine* h, uint32_t depth);
+uint32_t pe_pipeline_get_lag(const pe_engine* h);
 /* pe_pipeline_begin for a pipeline that will end lagged: the G1 sums of its pe_aggregate are not launched by that call
  * but by pe_pipeline_end_lagged, BEHIND the step's fork-choice kernels.  k_g1_accumulate fills every CU for its whole
  * run, so launched first it would hold pe_get_head (and with it the host's preparation of the next step) back until it

@@ -744,9 +744,9 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
                                        on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr,
                                        on_side ? &arena->d_lane_partials : nullptr);
             if (rc) return rc;
-            if (arm >= 0) (void)hipEventRecord(h->g1_tune_ev[1], on_side ? h->fin_stream : gs);
+            if (arm >= 0) (void)hipEventRecord(h->g1_tune_ev[1], on_side ? h->g1_tail() : gs);
             if (on_side) {
-                HIP_TRY(h, hipEventRecord(h->ev_join, h->fin_stream));
+                HIP_TRY(h, hipEventRecord(h->ev_join, h->g1_tail()));
                 h->side_busy = true;
                 h->side_ever = true;
                 arena->side_used = true;

@@ -62,6 +62,10 @@ int complete_arena(pe_engine* h, int ai)
             if (e == hipSuccess) e = e2;
             e2 = hipStreamSynchronize(h->fin_stream);
             if (e == hipSuccess) e = e2;
+            if (h->norm_stream) {
+                e2 = hipStreamSynchronize(h->norm_stream);
+                if (e == hipSuccess) e = e2;
+            }
             h->side_busy = false;
         }
     }
@@ -83,7 +87,7 @@ int complete_arena(pe_engine* h, int ai)
 // next call that completes pipelines.
 void complete_oldest_if_ready(pe_engine* h)
 {
-    const int ai = (h->cur + 1) % pe_engine::N_ARENAS;
+    const int ai = (h->cur + 1) % h->n_arenas;
     pe_engine::PipeArena& a = h->arena[ai];
     if (!a.fenced || a.pending.empty()) return;
     if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess) ||
@@ -99,8 +103,8 @@ int flush_pending(pe_engine* h)
 {
     int rc = h->early_rc;
     h->early_rc = PE_OK;
-    for (int k = 1; k <= pe_engine::N_ARENAS; ++k) {  // oldest first, the current one last
-        const int r = complete_arena(h, (h->cur + k) % pe_engine::N_ARENAS);
+    for (int k = 1; k <= h->n_arenas; ++k) {  // oldest first, the current one last
+        const int r = complete_arena(h, (h->cur + k) % h->n_arenas);
         if (r && !rc) rc = r;
     }
     return rc;
@@ -243,22 +247,34 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     const bool ok_streams = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess &&
                             hipStreamCreateWithFlags(&h->fin_stream, hipStreamNonBlocking) == hipSuccess &&
                             hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    {
+        const char* e = getenv("POSEVO_G1_NORM_STREAM");  // 0: tree and finish share the finishing stream
+        if (hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming) != hipSuccess ||
+            (ok_streams && (!e || atoi(e) != 0) &&
+             hipStreamCreateWithFlags(&h->norm_stream, hipStreamNonBlocking) != hipSuccess)) {
+            pe_engine_destroy(h);
+            return PE_ERR_NO_DEVICE;
+        }
+    }
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[0].ev_aux, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[1].ev_aux, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[2].ev_aux, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[0].ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[0].ev_side, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[1].ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[1].ev_side, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[2].ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->arena[2].ev_side, hipEventDisableTiming) != hipSuccess) {
+        false) {
         pe_engine_destroy(h);
         return PE_ERR_NO_DEVICE;
+    }
+    for (auto& a : h->arena)
+        if (hipEventCreateWithFlags(&a.ev_main, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.ev_side, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess) {
+            pe_engine_destroy(h);
+            return PE_ERR_NO_DEVICE;
+        }
+    if (const char* e = getenv("POSEVO_PIPELINE_LAG")) {
+        const int lag = atoi(e);
+        if (lag >= 1 && lag < pe_engine::MAX_ARENAS) h->n_arenas = lag + 1;
     }
     h->tables.reserve(c.max_committee_tables ? c.max_committee_tables : 4u);
     *out = h;
@@ -273,6 +289,7 @@ void pe_engine_destroy(pe_engine* h)
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
     if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
@@ -311,6 +328,8 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
+    if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
+    if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->fin_stream) (void)hipStreamDestroy(h->fin_stream);
@@ -386,6 +405,17 @@ int pe_pipeline_begin_streaming(pe_engine* h)
     return rc;
 }
 
+int pe_pipeline_set_lag(pe_engine* h, uint32_t depth)
+{
+    if (!h || depth < 1 || depth >= (uint32_t)pe_engine::MAX_ARENAS) return PE_ERR_INVALID_ARG;
+    if (h->pipelining) return fail(h, PE_ERR_STATE, "pe_pipeline_set_lag inside a pipeline");
+    PE_TRY(enter(h));  // nothing is in flight afterwards: the rotation may change
+    h->n_arenas = (int)depth + 1;
+    h->cur = 0;
+    return PE_OK;
+}
+uint32_t pe_pipeline_get_lag(const pe_engine* h) { return h ? (uint32_t)h->n_arenas - 1 : 0; }
+
 int pe_pipeline_end_lagged(pe_engine* h)
 {
     if (!h) return PE_ERR_INVALID_ARG;
@@ -399,13 +429,13 @@ int pe_pipeline_end_lagged(pe_engine* h)
     // mark the end of this pipeline on both streams; its completions run when the NEXT lagged end (or any
     // synchronous call) has waited for the marks
     HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
-    if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->fin_stream));  // the last kernel of the G1 chain runs there
+    if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->g1_tail()));  // the last kernel of the G1 chain runs there
     if (a.aux_used) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));
     h->aux_busy = false;    // accounted for by the fence
     a.fenced = true;
     h->side_busy = false;   // accounted for by the fence from here on
-    h->cur = (h->cur + 1) % pe_engine::N_ARENAS;
-    int rc = complete_arena(h, h->cur);  // the oldest pipeline still in flight (two back): its arena is reused next
+    h->cur = (h->cur + 1) % h->n_arenas;
+    int rc = complete_arena(h, h->cur);  // the oldest pipeline still in flight (lag depth back): its arena is reused next
     if (!rc) rc = h->early_rc;           // ... unless pe_get_head found it ready and completed it already
     h->early_rc = PE_OK;
     lap.mark("pipe.end_lagged_wait_previous");
@@ -431,6 +461,7 @@ static void prof_drain(pe_engine* h)
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+    if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     for (auto& p : h->prof) {
         for (auto& ev : p.pending) {

@@ -91,6 +91,7 @@ int pe_dist_destroy(pe_engine* h)
     if (h->comm) {
         (void)hipStreamSynchronize(h->stream);
         if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
+        if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
         (void)rccl().CommDestroy(h->comm);
         if (h->comm_g1) (void)rccl().CommDestroy(h->comm_g1);
         h->comm = h->comm_g1 = nullptr;
@@ -179,7 +180,7 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
     const bool on_side = h->last_agg_on_side;
     auto exchange = [h, ng, pin_pk, on_side]() -> int {
         HostLap lap(&h->trace);
-        hipStream_t xs = on_side ? h->fin_stream : h->stream;  // where this aggregate's partials were produced
+        hipStream_t xs = on_side ? h->g1_tail() : h->stream;  // where this aggregate's partials were produced
         RCCL_TRY(h, rccl().AllGather(h->d_xpart.p, h->d_xgather.p, (size_t)ng * (PE_G1_PARTIAL_BYTES / 4), ncclUint32,
                                      h->comm_g1, xs));
         lap.mark("dist.all_gather_enqueue");

@@ -12,7 +12,7 @@ void g1_stream_guard(pe_engine* h, hipStream_t s)
 {
     // ev_join marks the end of the last G1 launch on the side stream (a lagged pipeline may still be running it);
     // waiting on a completed event costs nothing
-    if (h->side_ever && s != h->side_stream && s != h->fin_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+    if (h->side_ever && s != h->side_stream && s != h->fin_stream && s != h->norm_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
 }
 
 // Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
@@ -39,19 +39,32 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
         launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
                              lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
     }
-    if (fin != s) {
+    // POSEVO_G1_TREE_SERIAL=1: the tree stays on the accumulation's stream (the next accumulation starts behind it)
+    static const bool tree_serial = [] { const char* e = getenv("POSEVO_G1_TREE_SERIAL"); return e && atoi(e) != 0; }();
+    const bool chain = fin != s && fin == h->fin_stream;  // a side-stream chain
+    hipStream_t ts = chain && tree_serial ? s : fin;
+    if (ts != s) {
         HIP_TRY(h, hipEventRecord(h->ev_acc, s));
-        HIP_TRY(h, hipStreamWaitEvent(fin, h->ev_acc, 0));
+        HIP_TRY(h, hipStreamWaitEvent(ts, h->ev_acc, 0));
     }
     {
-        ProfScope ps(h, PE_KERNEL_G1_TREE, fin);
-        launch_g1_tree(fin, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
-                       /*one_per_cu=*/fin != s ? 1 : 0,   // on its own stream it meets the next step's k_tree: leave it room
+        ProfScope ps(h, PE_KERNEL_G1_TREE, ts);
+        launch_g1_tree(ts, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
+                       /*one_per_cu=*/ts != s ? 1 : 0,   // on its own stream it meets the next step's k_tree: leave it room
                        plan_dev);
     }
+    hipStream_t ns = fin;
+    if (chain && h->norm_stream) {  // the finish gets a stream of its own
+        ns = h->norm_stream;
+        HIP_TRY(h, hipEventRecord(h->ev_tree, ts));
+        HIP_TRY(h, hipStreamWaitEvent(ns, h->ev_tree, 0));
+    } else if (ts != fin) {
+        HIP_TRY(h, hipEventRecord(h->ev_tree, ts));
+        HIP_TRY(h, hipStreamWaitEvent(fin, h->ev_tree, 0));
+    }
     {
-        ProfScope ps(h, PE_KERNEL_G1_NORMALISE, fin);
-        launch_g1_finish(fin, partials->as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac, plan_dev);
+        ProfScope ps(h, PE_KERNEL_G1_NORMALISE, ns);
+        launch_g1_finish(ns, partials->as<uint32_t>(), d_groups, plan.n_groups, 0, 0, d_out96, dev_jac, plan_dev);
     }
     HIP_TRY(h, hipGetLastError());
     return PE_OK;

@@ -248,14 +248,22 @@ struct pe_engine {
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
         bool fenced = false, side_used = false, aux_used = false;
     };
-    static constexpr int N_ARENAS = 3;  // lag depth 2: a lagged end waits for the pipeline TWO back, never for the
-                                        // finish kernel of the one that has only just been fenced
-    PipeArena arena[N_ARENAS];
+    // lag depth L (pe_pipeline_set_lag, default 2) = L + 1 arenas in rotation: a lagged end waits for the pipeline L
+    // back, never for the finish kernel of the one that has only just been fenced.  Arenas allocate on first use.
+    static constexpr int MAX_ARENAS = 8;
+    int n_arenas = 3;
+    PipeArena arena[MAX_ARENAS];
     int cur = 0;
     PipeArena& A() { return arena[cur]; }
     bool pipelining = false;
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
-    hipStream_t fin_stream = nullptr;   // ... and its k_g1_finish here, beside the NEXT aggregate's accumulation
+    hipStream_t fin_stream = nullptr;   // ... its k_g1_tree here, beside the NEXT aggregate's accumulation
+    // ... and its k_g1_finish here: on the tree's stream the two latency-bound guests of a step ran one behind the other
+    // (tree 250-300 us beside an accumulation + finish 130 us), and that stream, not the accumulation, set the period
+    // of a streaming run once the host was off the critical path (profiles/r03_timeline_fin_stream.txt)
+    hipStream_t norm_stream = nullptr;
+    hipEvent_t ev_tree = nullptr;       // tree done -> finish may start
+    hipStream_t g1_tail() const { return norm_stream ? norm_stream : fin_stream; }  // where a side-stream G1 chain ends
     // State-transition work (process_attestation's flag pass, participation rotation) runs on a stream of its own: it
     // follows the head in a step, and on the engine's stream it stood between one step's head and the next step's
     // fork-choice chain (25 + 85 us per 1 M validators beside a running accumulation, profiles/r03_timeline_*.txt).

@@ -314,7 +314,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                                      on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr,
                                      on_side ? &arena->d_lane_partials : nullptr, d_plan, tables.t[1].members));
             if (on_side) {
-                HIP_TRY(h, hipEventRecord(h->ev_join, h->fin_stream));
+                HIP_TRY(h, hipEventRecord(h->ev_join, h->g1_tail()));
                 h->side_busy = true;
                 h->side_ever = true;
                 arena->side_used = true;

@@ -361,12 +361,13 @@ k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ m
             return true;
         };
         if (count > 0) have = fetch(0, qx, qy);
+        bool acc_affine = false;
         for (uint32_t j = 0; j < count; ++j) {
             nhave = false;
             if (j + 1 < count) nhave = fetch(j + 1, nx, ny);
             if (have) {
                 const bool q_inf = fp_is_zero(qx) && fp_is_zero(qy);  // (0,0) encodes infinity in the table
-                g1x_add_affine(acc, qx, qy, q_inf);
+                g1x_add_affine_run(acc, acc_affine, qx, qy, q_inf);
             }
             qx = nx; qy = ny; have = nhave;
         }
@@ -559,7 +560,8 @@ void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group*
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
-    if (one_per_cu) {
+    static const bool pad_ok = [] { const char* e = getenv("POSEVO_G1_TREE_PAD_LDS"); return !e || atoi(e) != 0; }();
+    if (one_per_cu && pad_ok) {
         constexpr size_t padded = 77 * 1024;
         if (first_use_on_this_device<77>())
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_tree), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -204,10 +204,10 @@ class _Pipeline:
     def __enter__(self):
         e = self.e
         # a lagged pipeline still in flight stays in flight
-        if self.lagged and e._ring is not None and len(e._ring) < 4:
-            # outputs of lagged pipeline k are written at the exit of k + 2: a set handed out again before k + 3 would
-            # never be stable to read
-            raise ValueError("reuse_outputs(depth) must be >= 4 with lagged pipelines (lag depth 2)")
+        if self.lagged and e._ring is not None and len(e._ring) < e._lag + 2:
+            # outputs of lagged pipeline k are written at the exit of k + lag: a set handed out again before k + lag + 1
+            # would never be stable to read
+            raise ValueError(f"reuse_outputs(depth) must be >= {e._lag + 2} with lagged pipelines of lag depth {e._lag}")
         e._check((e._lib.pe_pipeline_begin_streaming if self.lagged else e._lib.pe_pipeline_begin)(e._h))
         e._pipe_keep = []
         e._ring_ord = {}
@@ -217,8 +217,8 @@ class _Pipeline:
         e = self.e
         if self.lagged and exc_type is None:
             rc = e._lib.pe_pipeline_end_lagged(e._h)
-            # lag depth 2: the generation two back is complete now, keep this one and the previous one alive
-            e._lagged_keep = [e._pipe_keep] + (e._lagged_keep or [])[:1]
+            # lag depth L: the generation L back is complete now, keep this one and the L - 1 before it alive
+            e._lagged_keep = [e._pipe_keep] + (e._lagged_keep or [])[:e._lag - 1]
         else:
             rc = e._lib.pe_pipeline_end(e._h)
             e._lagged_keep = None
@@ -254,6 +254,14 @@ class Engine:
         self._ring = None
         self._ring_i = 0
         self._ring_ord = {}
+        self._lag = int(self._lib.pe_pipeline_get_lag(self._h)) or 2
+
+    def set_pipeline_lag(self, depth: int):
+        """Lag depth of ``pipeline(lagged=True)`` blocks (pe_pipeline_set_lag): a block's outputs are complete when the
+        depth-th next lagged block exits.  Completes everything in flight first."""
+        self._check(self._lib.pe_pipeline_set_lag(self._h, int(depth)))
+        self._lag = int(depth)
+        self._lagged_keep = None
 
     # -- plumbing ---------------------------------------------------------
     def reuse_outputs(self, depth: int = 4):
@@ -262,7 +270,7 @@ class Engine:
         ``np.empty`` allocations (whose first touch page-faults: 50+ us per step for the 1 MB of rows and bits an epoch
         returns).  An array stays valid for depth - 1 further pipelines / synchronous calls; copy what must live longer.
         Two calls of the same kind inside ONE pipeline get distinct sets (keyed by their ordinal in the pipeline).
-        depth >= 4 with lagged pipelines (lag depth 2: entering one with a shallower ring raises)."""
+        depth >= lag + 2 with lagged pipelines (4 at the default lag depth 2: entering one with a shallower ring raises)."""
         self._ring = [dict() for _ in range(max(depth, 1))]
         self._ring_i = 0
         self._ring_ord = {}
@@ -334,8 +342,9 @@ class Engine:
         """``with engine.pipeline(): ...`` -- the batch calls inside return once their device work is enqueued
         (pe_pipeline_begin); their output arrays are complete when the block exits (pe_pipeline_end): one wait per
         step instead of one per call.  get_head() inside the block is still synchronous.
-        lagged=True (pe_pipeline_end_lagged): the block's outputs are complete when the SECOND next lagged block exits
-        (or at drain() / any other synchronous call) -- step N's G1 sums run while step N+1 is being prepared."""
+        lagged=True (pe_pipeline_end_lagged): the block's outputs are complete when the L-th next lagged block exits
+        (L = lag depth, default 2; or at drain() / any other synchronous call) -- step N's G1 sums run while the steps
+        behind it are being prepared."""
         return _Pipeline(self, lagged)
 
     def drain(self):

@@ -24,7 +24,8 @@ def test_library_exports_every_symbol():
     lib = _abi.load()
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert lib.pe_abi_version() == 4
+    want = int(re.search(r"#define\s+PE_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "posevo.h")).read()).group(1))
+    assert lib.pe_abi_version() == want   # the library was built from this header
 
 
 def test_struct_layouts():
@@ -80,7 +81,7 @@ def test_header_is_plain_c_and_cxx(tmp_path):
                    'int main(void) {\n'
                    '    pe_config c; pe_engine* h = 0; int rc;\n'
                    '    pe_config_default(&c);\n'
-                   '    if (sizeof(pe_attestation) != 144 || pe_abi_version() != 4) return 2;\n'
+                   '    if (sizeof(pe_attestation) != 144 || pe_abi_version() != PE_ABI_VERSION) return 2;\n'
                    '    rc = pe_engine_create(&c, &h);            /* no GPU here: must report PE_ERR_NO_DEVICE */\n'
                    '    if (rc == PE_OK) { pe_engine_destroy(h); return 0; }\n'
                    '    return rc == PE_ERR_NO_DEVICE ? 0 : 3;\n'
