@@ -61,7 +61,8 @@ typedef enum pe_status {
     PE_ERR_NO_COMMITTEES = -11, /* no committee table loaded for the attestation's target epoch */
     PE_ERR_NOT_SLASHABLE = -12, /* on_attester_slashing: is_slashable_attestation_data false (pe:1453) */
     PE_ERR_INVALID_INDEXED = -13, /* is_valid_indexed_attestation false (pe:1455-1456) */
-    PE_ERR_STATE = -14          /* call sequence error (e.g. store not initialised) */
+    PE_ERR_STATE = -14,         /* call sequence error (e.g. store not initialised) */
+    PE_ERR_TIMEOUT = -15        /* multi-GPU: a collective did not complete within the engine's bounded wait */
 } pe_status;
 
 /* Per-attestation result codes written by the *_batch calls (0 = applied).  Each
@@ -491,6 +492,9 @@ int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
  * The id holds two ncclUniqueIds: the all-reduce and the all-gather have a communicator each, because inside a
  * pipeline the G1 chain of a step (partials -> all-gather -> finish) runs on the engine's finishing stream beside the
  * next step's fork-choice kernels and their all-reduce, and one communicator must not be driven from two streams.
+ * pe_aggregate_sharded takes its rows from host memory or -- like pe_aggregate -- from DEVICE memory (grouping and
+ * committee resolution on the device, handlers with PE_ROWS_RESIDENT; every rank passes the same rows in the same order,
+ * each with the bits of ITS members).
  * Both calls may be made inside pe_pipeline_begin(_streaming) ... _end(_lagged): nothing then waits except the poll
  * for the head; pe_aggregate_sharded's unions are handed on with PE_BITS_RESIDENT like pe_aggregate's, its outputs are
  * complete where the pipeline's are.  Every rank must make the same sequence of calls (collectives pair up by order).
@@ -499,6 +503,38 @@ int pe_aggregate_partial(pe_engine* h, const pe_attestation* atts, uint32_t n,
 #define PE_DIST_ID_BYTES 256
 int pe_dist_unique_id(uint8_t out_id[PE_DIST_ID_BYTES]);
 int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world);
+/* Flags for pe_dist_init_ex (pe_dist_init = flags 0, or PE_DIST_SINGLE_COMM when POSEVO_DIST_SINGLE_COMM=1 is set):
+ *   PE_DIST_SINGLE_COMM  both collectives on ONE communicator and ONE stream (the engine's): every rank then issues them
+ *                        in program order on one queue, so two collective kernels can never become resident in different
+ *                        orders on different ranks.  Costs overlap: a step's all-gather (behind its G1 partials) holds
+ *                        the next step's fork-choice kernels back.  The form to fall back to when the two-communicator
+ *                        form times out (PE_ERR_TIMEOUT). */
+#define PE_DIST_SINGLE_COMM 1u
+int pe_dist_init_ex(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world, uint32_t flags);
+/* The same exchange through the CALLER's collectives (MPI, a host-staged shim, a test double): two function pointers
+ * replace RCCL.  Both operate on DEVICE memory and are ordered on the given HIP stream: an implementation either enqueues
+ * on that stream or synchronises it, exchanges and returns -- work the engine enqueues on the stream afterwards must see
+ * the result.  Return 0 on success; anything else fails the engine call with PE_ERR_NO_DEVICE.  The engine-owned
+ * streaming sharded step runs unchanged on top (tests/test_gpu_dist_custom.py drives it with two ranks that share one
+ * GPU). */
+typedef struct pe_collectives {
+    void* user;
+    /* in-place sum over ranks of count uint64 at dev_buf */
+    int (*all_reduce_u64)(void* user, void* dev_buf, uint64_t count, void* hip_stream);
+    /* rank r's bytes_per_rank bytes at dev_send land at dev_recv + r * bytes_per_rank on every rank */
+    int (*all_gather)(void* user, const void* dev_send, void* dev_recv, uint64_t bytes_per_rank, void* hip_stream);
+} pe_collectives;
+int pe_dist_init_custom(pe_engine* h, int rank, int world, const pe_collectives* fn);
+/* Bounded waits (default 30 000 ms; 0 = wait for ever; POSEVO_DIST_TIMEOUT_MS presets it): once a handle has
+ * pe_dist_init'ed, the waits for enqueued work poll with this limit; past it the call aborts the communicators
+ * (ncclCommAbort), returns PE_ERR_TIMEOUT and the handle refuses further sharded calls until pe_dist_destroy +
+ * pe_dist_init(_ex).  A hung exchange thus surfaces as an error on every rank instead of a stuck job. */
+int pe_dist_set_timeout_ms(pe_engine* h, uint32_t ms);
+/* Upper bound of the groups one pe_aggregate_sharded over rows in DEVICE memory may form (default: its row count n).  The
+ * all-gather of such a call is sized before the device has formed the groups; a caller that knows its epoch has C
+ * committees sets C and ships C x 192 B per rank instead of n x 192 B.  More groups than the bound: PE_ERR_CAPACITY where
+ * the outputs complete. */
+int pe_dist_set_max_groups(pe_engine* h, uint32_t max_groups);
 int pe_dist_destroy(pe_engine* h);
 int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32]);
 int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n,

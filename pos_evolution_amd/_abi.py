@@ -16,6 +16,8 @@ PE_OK = 0
 PE_ERR_NO_DEVICE = -2
 PE_ERR_CAPACITY = -10
 PE_ERR_STATE = -14
+PE_ERR_TIMEOUT = -15
+PE_DIST_SINGLE_COMM = 1
 NONE32 = 0xFFFFFFFF
 
 PE_VAL_ACTIVE, PE_VAL_SLASHED, PE_VAL_EQUIVOCATING, PE_VAL_ACTIVE_PREV = 0x01, 0x02, 0x04, 0x08
@@ -77,6 +79,15 @@ _u8p = _u32p = _u64p = _i32p = _attp = C.c_void_p
 _H = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/posevo.h declares
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class pe_collectives(C.Structure):
+    """struct pe_collectives (include/posevo.h): the caller's collectives for pe_dist_init_custom."""
+    _fields_ = [("user", C.c_void_p), ("all_reduce_u64", ALL_REDUCE_FN), ("all_gather", ALL_GATHER_FN)]
+
+
 SIGNATURES = {
     "pe_abi_version": (C.c_uint32, []),
     "pe_config_default": (None, [_P(pe_config)]),
@@ -147,6 +158,10 @@ SIGNATURES = {
     "pe_dist_unique_id": (C.c_int, [_u8p]),
     "pe_dist_init": (C.c_int, [_H, _u8p, C.c_int, C.c_int]),
     "pe_dist_destroy": (C.c_int, [_H]),
+    "pe_dist_init_ex": (C.c_int, [_H, _u8p, C.c_int, C.c_int, C.c_uint32]),
+    "pe_dist_init_custom": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "pe_dist_set_timeout_ms": (C.c_int, [_H, C.c_uint32]),
+    "pe_dist_set_max_groups": (C.c_int, [_H, C.c_uint32]),
     "pe_get_head_sharded": (C.c_int, [_H, _u8p]),
     "pe_aggregate_sharded": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _attp, _u32p, _u32p, _u8p,
                                        C.c_uint64, _u8p, _u32p]),

@@ -41,29 +41,26 @@ int complete_arena(pe_engine* h, int ai)
     if (ai == h->cur) PE_TRY(run_deferred(h));  // deferred launches belong to the arena the calls are going into
     hipError_t e = hipSuccess;
     if (a.fenced) {  // a lagged pipeline: its end was marked on every stream it used
-        e = hipEventSynchronize(a.ev_main);
+        e = bounded_event_sync(h, a.ev_main);
         if (a.side_used) {
-            hipError_t e2 = hipEventSynchronize(a.ev_side);
+            hipError_t e2 = bounded_event_sync(h, a.ev_side);
             if (e == hipSuccess) e = e2;
         }
         if (a.aux_used) {
-            hipError_t e2 = hipEventSynchronize(a.ev_aux);
+            hipError_t e2 = bounded_event_sync(h, a.ev_aux);
             if (e == hipSuccess) e = e2;
         }
     } else {         // the arena the calls are still going into
-        e = hipStreamSynchronize(h->stream);
+        e = bounded_stream_sync(h, h->stream);
         if (h->aux_busy) {
-            hipError_t e2 = hipStreamSynchronize(h->aux_stream);
+            hipError_t e2 = bounded_stream_sync(h, h->aux_stream);
             if (e == hipSuccess) e = e2;
             h->aux_busy = false;
         }
         if (h->side_busy) {
-            hipError_t e2 = hipStreamSynchronize(h->side_stream);
-            if (e == hipSuccess) e = e2;
-            e2 = hipStreamSynchronize(h->fin_stream);
-            if (e == hipSuccess) e = e2;
-            if (h->norm_stream) {
-                e2 = hipStreamSynchronize(h->norm_stream);
+            for (hipStream_t s : {h->side_stream, h->fin_stream, h->norm_stream}) {
+                if (!s) continue;
+                hipError_t e2 = bounded_stream_sync(h, s);
                 if (e == hipSuccess) e = e2;
             }
             h->side_busy = false;
@@ -73,6 +70,9 @@ int complete_arena(pe_engine* h, int ai)
     todo.swap(a.pending);
     a.stage_cursor = a.out_cursor = 0;
     a.fenced = a.side_used = a.aux_used = false;
+    if (e == hipErrorNotReady)
+        return fail(h, PE_ERR_TIMEOUT, "a collective did not complete within " + std::to_string(h->dist_timeout_ms) +
+                    " ms: the communicators were aborted (pe_dist_destroy, then pe_dist_init_ex with PE_DIST_SINGLE_COMM)");
     if (e != hipSuccess) return hip_fail(h, e, "waiting for the enqueued batch calls");
     int rc = PE_OK;
     for (auto& f : todo) {
@@ -209,6 +209,7 @@ const char* pe_strerror(int status)
         case PE_ERR_NOT_SLASHABLE: return "attestation data not slashable";
         case PE_ERR_INVALID_INDEXED: return "invalid indexed attestation";
         case PE_ERR_STATE: return "call sequence error";
+        case PE_ERR_TIMEOUT: return "multi-GPU exchange timed out";
         default: return "unknown status";
     }
 }
@@ -329,6 +330,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
+    if (h->ev_xchg) (void)hipEventDestroy(h->ev_xchg);
     if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);

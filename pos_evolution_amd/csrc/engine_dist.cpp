@@ -19,6 +19,7 @@ Rccl& rccl()
         x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.lib, "ncclGetUniqueId"));
         x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.lib, "ncclCommInitRank"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.lib, "ncclCommDestroy"));
+        x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(dlsym(x.lib, "ncclCommAbort"));
         x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(x.lib, "ncclAllReduce"));
         x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.lib, "ncclAllGather"));
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.lib, "ncclGroupStart"));
@@ -40,6 +41,74 @@ int rccl_fail(pe_engine* h, ncclResult_t r, const char* what)
         if (_r != ncclSuccess) return rccl_fail((h), _r, #expr);   \
     } while (0)
 static_assert(2 * sizeof(ncclUniqueId) == PE_DIST_ID_BYTES, "PE_DIST_ID_BYTES must hold two ncclUniqueIds");
+
+// ---------------------------------------------------------------- the two exchange steps
+int dist_all_reduce_u64(pe_engine* h, void* dev_buf, size_t count, hipStream_t s)
+{
+    if (h->dist_wedged) return fail(h, PE_ERR_TIMEOUT, "an earlier exchange timed out on this handle: pe_dist_destroy, then initialise again");
+    if (h->coll_custom) {
+        if (h->coll.all_reduce_u64(h->coll.user, dev_buf, count, s) != 0)
+            return fail(h, PE_ERR_NO_DEVICE, "the caller's all_reduce_u64 failed");
+        return PE_OK;
+    }
+    RCCL_TRY(h, rccl().AllReduce(dev_buf, dev_buf, count, ncclUint64, ncclSum, h->comm, s));
+    return PE_OK;
+}
+int dist_all_gather(pe_engine* h, const void* send, void* recv, size_t bytes_per_rank, hipStream_t s)
+{
+    if (h->dist_wedged) return fail(h, PE_ERR_TIMEOUT, "an earlier exchange timed out on this handle: pe_dist_destroy, then initialise again");
+    if (h->coll_custom) {
+        if (h->coll.all_gather(h->coll.user, send, recv, bytes_per_rank, s) != 0)
+            return fail(h, PE_ERR_NO_DEVICE, "the caller's all_gather failed");
+        return PE_OK;
+    }
+    // its own communicator when it travels on the G1 chain's stream beside the engine stream's all-reduce
+    ncclComm_t c = (s == h->stream || h->dist_single_comm) ? h->comm : h->comm_g1;
+    RCCL_TRY(h, rccl().AllGather(send, recv, bytes_per_rank / 4, ncclUint32, c, s));
+    return PE_OK;
+}
+
+// ---------------------------------------------------------------- bounded waits
+// A rank whose peer never arrives would wait for ever inside hipEventSynchronize with a collective kernel spinning on
+// the device.  On a handle that exchanges with other ranks the waits poll instead and give up after dist_timeout_ms:
+// the communicators are aborted (their kernels leave the device), the handle is marked, and the caller gets an error it
+// can act on -- every rank of the job sees the same thing, because every rank waits for the same exchange.
+static void dist_abort(pe_engine* h)
+{
+    h->dist_wedged = true;
+    if (h->coll_custom || !rccl().ok || !rccl().CommAbort) return;
+    if (h->comm) (void)rccl().CommAbort(h->comm);
+    if (h->comm_g1 && h->comm_g1 != h->comm) (void)rccl().CommAbort(h->comm_g1);
+    h->comm = h->comm_g1 = nullptr;
+}
+template <typename Query>
+static hipError_t bounded_wait(pe_engine* h, Query query)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 0;; ++it) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        (void)hipGetLastError();
+        if ((it & 255) == 255) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > (double)h->dist_timeout_ms) {
+                dist_abort(h);
+                return hipErrorNotReady;
+            }
+            if (ms > 2.0) std::this_thread::yield();  // long waits (a drain) need not burn the core
+        }
+    }
+}
+hipError_t bounded_event_sync(pe_engine* h, hipEvent_t ev)
+{
+    if (!h->dist_ready() || h->dist_timeout_ms == 0 || h->dist_world < 2) return hipEventSynchronize(ev);
+    return bounded_wait(h, [ev] { return hipEventQuery(ev); });
+}
+hipError_t bounded_stream_sync(pe_engine* h, hipStream_t s)
+{
+    if (!h->dist_ready() || h->dist_timeout_ms == 0 || h->dist_world < 2) return hipStreamSynchronize(s);
+    return bounded_wait(h, [s] { return hipStreamQuery(s); });
+}
 }  // namespace posevo
 
 extern "C" {
@@ -59,46 +128,104 @@ int pe_dist_unique_id(uint8_t out_id[PE_DIST_ID_BYTES])
     return PE_OK;
 }
 
-int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world)
+int pe_dist_init_ex(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world, uint32_t flags)
 {
-    if (!h || !id || world < 1 || rank < 0 || rank >= world) return PE_ERR_INVALID_ARG;
+    if (!h || !id || world < 1 || rank < 0 || rank >= world || (flags & ~PE_DIST_SINGLE_COMM)) return PE_ERR_INVALID_ARG;
     PE_TRY(enter(h));
     if (!rccl().ok) return fail(h, PE_ERR_NO_DEVICE, "librccl could not be loaded (dlopen librccl.so.1)");
-    if (h->comm) return fail(h, PE_ERR_STATE, "pe_dist_init: this handle already has a communicator");
+    if (h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_dist_init: this handle already has a communicator");
     // Two communicators: the all-reduce of get_head travels on the engine's stream, the all-gather of the G1
     // partials on the finishing stream of the G1 chain (beside the next step's fork-choice kernels).  One communicator
-    // must not be driven from two streams at once; two of them may.
+    // must not be driven from two streams at once; two of them may.  PE_DIST_SINGLE_COMM: one communicator, and the
+    // all-gather comes back to the engine's stream (see pe_aggregate_sharded).
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     RCCL_TRY(h, rccl().CommInitRank(&h->comm, world, uid, rank));
-    memcpy(&uid, id + sizeof(uid), sizeof(uid));
-    ncclResult_t r2 = rccl().CommInitRank(&h->comm_g1, world, uid, rank);
-    if (r2 != ncclSuccess) {
-        (void)rccl().CommDestroy(h->comm);
-        h->comm = nullptr;
-        h->comm_g1 = nullptr;
-        return rccl_fail(h, r2, "ncclCommInitRank (aggregation communicator)");
+    h->dist_single_comm = (flags & PE_DIST_SINGLE_COMM) != 0;
+    if (h->dist_single_comm) {
+        h->comm_g1 = h->comm;
+    } else {
+        memcpy(&uid, id + sizeof(uid), sizeof(uid));
+        ncclResult_t r2 = rccl().CommInitRank(&h->comm_g1, world, uid, rank);
+        if (r2 != ncclSuccess) {
+            (void)rccl().CommDestroy(h->comm);
+            h->comm = nullptr;
+            h->comm_g1 = nullptr;
+            return rccl_fail(h, r2, "ncclCommInitRank (aggregation communicator)");
+        }
     }
+    if (!h->ev_xchg) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_xchg, hipEventDisableTiming));
     h->dist_rank = rank;
     h->dist_world = world;
+    h->dist_wedged = false;
+    if (const char* e = getenv("POSEVO_DIST_TIMEOUT_MS")) h->dist_timeout_ms = (uint32_t)atol(e);
+    return PE_OK;
+}
+int pe_dist_init(pe_engine* h, const uint8_t id[PE_DIST_ID_BYTES], int rank, int world)
+{
+    const char* e = getenv("POSEVO_DIST_SINGLE_COMM");
+    return pe_dist_init_ex(h, id, rank, world, e && atoi(e) != 0 ? PE_DIST_SINGLE_COMM : 0u);
+}
+
+int pe_dist_init_custom(pe_engine* h, int rank, int world, const pe_collectives* fn)
+{
+    if (!h || !fn || !fn->all_reduce_u64 || !fn->all_gather || world < 1 || rank < 0 || rank >= world) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_dist_init_custom: this handle already has a communicator");
+    h->coll = *fn;
+    h->coll_custom = true;
+    h->dist_single_comm = false;
+    h->dist_rank = rank;
+    h->dist_world = world;
+    h->dist_wedged = false;
+    if (const char* e = getenv("POSEVO_DIST_TIMEOUT_MS")) h->dist_timeout_ms = (uint32_t)atol(e);
+    return PE_OK;
+}
+
+int pe_dist_set_timeout_ms(pe_engine* h, uint32_t ms)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    h->dist_timeout_ms = ms;
+    return PE_OK;
+}
+int pe_dist_set_max_groups(pe_engine* h, uint32_t max_groups)
+{
+    if (!h) return PE_ERR_INVALID_ARG;
+    h->dist_max_groups = max_groups;
     return PE_OK;
 }
 
 int pe_dist_destroy(pe_engine* h)
 {
     if (!h) return PE_ERR_INVALID_ARG;
-    PE_TRY(enter(h));
+    const int rc = h->dist_wedged ? PE_OK : enter(h);  // after a timeout the enqueued work is lost with the communicators
+    if (h->dist_wedged) {
+        (void)hipDeviceSynchronize();  // aborted collectives have left the device
+        for (auto& a : h->arena) {
+            a.pending.clear();
+            a.stage_cursor = a.out_cursor = 0;
+            a.fenced = a.side_used = a.aux_used = false;
+        }
+        h->deferred.clear();
+        h->pipelining = h->streaming = false;
+        h->side_busy = h->aux_busy = false;
+        h->res_valid = false;
+        h->rr.valid = false;
+        h->early_rc = PE_OK;
+    }
     if (h->comm) {
         (void)hipStreamSynchronize(h->stream);
-        if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
-        if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
+        for (hipStream_t s : {h->fin_stream, h->norm_stream})
+            if (s) (void)hipStreamSynchronize(s);
         (void)rccl().CommDestroy(h->comm);
-        if (h->comm_g1) (void)rccl().CommDestroy(h->comm_g1);
-        h->comm = h->comm_g1 = nullptr;
+        if (h->comm_g1 && h->comm_g1 != h->comm) (void)rccl().CommDestroy(h->comm_g1);
     }
+    h->comm = h->comm_g1 = nullptr;
+    h->coll_custom = false;
+    h->dist_wedged = false;
     h->dist_world = 1;
     h->dist_rank = 0;
-    return PE_OK;
+    return rc;
 }
 
 // get_head over all shards: this shard's direct weights -> ONE all-reduce(sum, u64) of B + PE_EXCHANGE_EXTRA words on
@@ -109,7 +236,7 @@ int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
     int rc = need_init(h, /*flush=*/!(h && h->pipelining));
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
-    if (!h->comm) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
+    if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
     const uint32_t nb = (uint32_t)h->blocks.size();
     const size_t words = (size_t)nb + PE_EXCHANGE_EXTRA;
     if (words * 8 > h->d_xchg.cap) {  // the engine's own exchange buffer is self-cleaning, like pe_get_head's: zero it once
@@ -139,7 +266,7 @@ int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
     }
     HIP_TRY(h, hipGetLastError());
     lap.mark("dist.votes_launch");
-    RCCL_TRY(h, rccl().AllReduce(h->d_xchg.p, h->d_xchg.p, words, ncclUint64, ncclSum, h->comm, h->stream));
+    PE_TRY(dist_all_reduce_u64(h, h->d_xchg.p, words, h->stream));
     lap.mark("dist.all_reduce_enqueue");
     uint32_t head;
     rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + nb), /*clear_direct=*/1, &head);
@@ -160,43 +287,80 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
     if (!h || !out_n_groups || !out_aggpk96) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
     if (!h->pipelining) PE_TRY(flush_pending(h));
-    if (!h->comm) return fail(h, PE_ERR_STATE, "pe_aggregate_sharded: call pe_dist_init first");
+    if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_aggregate_sharded: call pe_dist_init first");
     if (n == 0) { *out_n_groups = 0; return PE_OK; }
+    const bool dev_rows = rows_on_device(atts);
+    // slots of the exchange: host rows -- the groups the host formed; rows in device memory -- the caller's bound (the
+    // collective is sized before the device has formed the groups)
+    const uint32_t slots_bound = dev_rows && h->dist_max_groups ? std::min(n, h->dist_max_groups) : n;
     PE_TRY(ensure_quiesced(h, h->d_xpart, (size_t)PE_G1_PARTIAL_BYTES * n));
     PE_TRY(ensure_quiesced(h, h->d_xgather, (size_t)PE_G1_PARTIAL_BYTES * n * (size_t)h->dist_world));
-    int rc = aggregate_impl(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of, out_bits_arena,
+    int rc;
+    if (dev_rows)
+        rc = aggregate_resident(h, atts, n, bits_arena, arena_len, out_atts, out_n_groups, group_of, out_bits_arena,
+                                out_arena_cap, nullptr, out_count, h->d_xpart.as<uint32_t>());
+    else
+        rc = aggregate_impl(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of, out_bits_arena,
                             out_arena_cap, nullptr, nullptr, out_count, h->d_xpart.p, n, /*partials_may_defer=*/true);
     if (rc) return rc;
-    const uint32_t ng = *out_n_groups;
-    if (ng == 0) return PE_OK;
+    const uint32_t slots = dev_rows ? slots_bound : *out_n_groups;
+    if (slots == 0) return PE_OK;
     Stage st(h);
     OutBlock ob(h);
-    const size_t off_pk = ob.alloc(96ull * ng);
+    const size_t off_pk = ob.alloc(96ull * slots);
     PE_TRY(ob.ensure());
     uint8_t* pin_pk = ob.host<uint8_t>(off_pk);
     // all-gather of the ranks' partials, then the finishing add + normalisation, written straight into the pinned
     // block.  In a streaming pipeline the partials' kernels were deferred behind the step's fork-choice kernels; the
     // exchange follows them (every rank runs the same calls, so the collectives are issued in the same order everywhere)
     const bool on_side = h->last_agg_on_side;
-    auto exchange = [h, ng, pin_pk, on_side]() -> int {
+    const AttPlan* plan_dev = nullptr;
+    if (dev_rows) {  // the finish reads the number of groups where k_att_plan left it
+        const AttPlan* p = nullptr;
+        PE_TRY(resident_plan_dev(h, &p));
+        plan_dev = p;
+    }
+    auto exchange = [h, slots, pin_pk, on_side, plan_dev]() -> int {
         HostLap lap(&h->trace);
-        hipStream_t xs = on_side ? h->g1_tail() : h->stream;  // where this aggregate's partials were produced
-        RCCL_TRY(h, rccl().AllGather(h->d_xpart.p, h->d_xgather.p, (size_t)ng * (PE_G1_PARTIAL_BYTES / 4), ncclUint32,
-                                     h->comm_g1, xs));
+        hipStream_t cs = on_side ? h->g1_tail() : h->stream;  // where this aggregate's partials were produced
+        hipStream_t xs = cs;
+        if (on_side && h->dist_single_comm) {  // one communicator: the all-gather travels on the engine's stream
+            HIP_TRY(h, hipEventRecord(h->ev_xchg, cs));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_xchg, 0));
+            xs = h->stream;
+        }
+        PE_TRY(dist_all_gather(h, h->d_xpart.p, h->d_xgather.p, (size_t)slots * PE_G1_PARTIAL_BYTES, xs));
         lap.mark("dist.all_gather_enqueue");
+        if (xs != cs) {  // ... and the finish goes back to the chain's stream
+            HIP_TRY(h, hipEventRecord(h->ev_xchg, xs));
+            HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_xchg, 0));
+        }
         {
-            ProfScope ps(h, PE_KERNEL_G1_NORMALISE, xs);
-            launch_g1_finish(xs, h->d_xgather.as<uint32_t>(), nullptr, ng, (uint32_t)h->dist_world, ng, pin_pk, nullptr);
+            ProfScope ps(h, PE_KERNEL_G1_NORMALISE, cs);
+            launch_g1_finish(cs, h->d_xgather.as<uint32_t>(), nullptr, slots, (uint32_t)h->dist_world, slots, pin_pk, nullptr,
+                             plan_dev);
         }
         HIP_TRY(h, hipGetLastError());
-        if (on_side) HIP_TRY(h, hipEventRecord(h->ev_join, xs));  // the end of this arena's G1 chain moved
+        if (on_side) {
+            HIP_TRY(h, hipEventRecord(h->ev_join, cs));  // the end of this arena's G1 chain moved
+            // ... and the arena's completion has to wait for it: a block that grew between the aggregate and this
+            // exchange completed the arena (and cleared these marks) with the finish not yet enqueued
+            h->side_busy = true;
+            h->side_ever = true;
+            h->A().side_used = true;
+        }
         return PE_OK;
     };
     if (!h->deferred.empty()) h->deferred.push_back(exchange);
     else PE_TRY(exchange());
     const size_t base = ob.base;
     const int ai = h->cur;
-    auto complete = [h, ai, base, off_pk, ng, out_aggpk96]() -> int {
+    auto complete = [h, ai, base, off_pk, slots, out_aggpk96, out_n_groups, dev_rows]() -> int {
+        // rows in device memory: the group count is an output, set by the aggregate's own completion (which ran just
+        // before this one); host rows: it was known at the call (and *out_n_groups need not outlive it)
+        const uint32_t ng = dev_rows ? *out_n_groups : slots;
+        if (ng > slots)
+            return fail(h, PE_ERR_CAPACITY, "pe_aggregate_sharded: the rows formed more groups than pe_dist_set_max_groups allows");
         memcpy(out_aggpk96, h->arena[ai].h_pin.as<uint8_t>() + base + off_pk, 96ull * ng);
         return PE_OK;
     };

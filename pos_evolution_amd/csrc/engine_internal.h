@@ -26,6 +26,7 @@
 #include <new>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -314,6 +315,14 @@ struct pe_engine {
     bool last_agg_on_side = false;                  // the last aggregate's G1 chain went to the side / finishing streams
     int dist_rank = 0, dist_world = 1;
     DevBuf d_xchg, d_xpart, d_xgather;  // weights exchange | this rank's G1 partials | all ranks' partials
+    pe_collectives coll{};              // pe_dist_init_custom: the caller's collectives instead of RCCL
+    bool coll_custom = false;
+    bool dist_single_comm = false;      // PE_DIST_SINGLE_COMM: both collectives on `comm`, on the engine's stream
+    bool dist_wedged = false;           // a bounded wait expired: the communicators were aborted
+    uint32_t dist_timeout_ms = 30000;   // bounded waits once the handle exchanges with other ranks (0 = unbounded)
+    uint32_t dist_max_groups = 0;       // pe_dist_set_max_groups (0 = the row count of the call)
+    hipEvent_t ev_xchg = nullptr;       // single-communicator mode: G1 chain <-> engine stream hand-over
+    bool dist_ready() const { return comm != nullptr || coll_custom; }
 
     // ---- profiling ----
     bool profiling = false;
@@ -629,6 +638,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -637,13 +647,25 @@ struct Rccl {
     bool ok = false;
 };
 Rccl& rccl();
+// the two exchange steps, through RCCL or the caller's function table (engine_dist.cpp).  g1_chain: the all-gather of a
+// G1 chain (its own communicator unless PE_DIST_SINGLE_COMM)
+int dist_all_reduce_u64(pe_engine* h, void* dev_buf, size_t count, hipStream_t s);
+int dist_all_gather(pe_engine* h, const void* send, void* recv, size_t bytes_per_rank, hipStream_t s);
+// waits that give up after dist_timeout_ms on a handle that exchanges with other ranks (engine_dist.cpp)
+hipError_t bounded_event_sync(pe_engine* h, hipEvent_t ev);
+hipError_t bounded_stream_sync(pe_engine* h, hipStream_t s);
 
 // rows resident in device memory (engine_resident.cpp)
 bool rows_on_device(const void* p);
 BlockTableDev block_table_dev(const pe_engine* h);
+// dev_partials: the groups' sums stay XYZZ partials of this shard's members in that device buffer (n slots) instead of
+// being normalised into out_aggpk96 (pe_aggregate_sharded)
 int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, const uint8_t* bits_arena,
                        uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
-                       uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count);
+                       uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count,
+                       uint32_t* dev_partials = nullptr);
+// the device-side plan (group count, error word) of the last aggregate over rows in device memory
+int resident_plan_dev(pe_engine* h, const AttPlan** out);
 int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_t* out_count);
 int process_attestation_resident(pe_engine* h, const pe_state_ctx* st, uint32_t cap, int32_t* status, uint64_t* out_numerators);
 

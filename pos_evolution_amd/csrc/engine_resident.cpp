@@ -171,12 +171,13 @@ BlockTableDev block_table_dev(const pe_engine* h)
 // ---------------------------------------------------------------- pe_aggregate, rows in device memory
 int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, const uint8_t* bits_arena,
                        uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
-                       uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count)
+                       uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count,
+                       uint32_t* dev_partials)
 {
     if (!h->initialised) return fail(h, PE_ERR_STATE, "rows in device memory: the store's clock picks the committee tables; call pe_store_init first");
     if ((uintptr_t)d_rows & 15) return fail(h, PE_ERR_INVALID_ARG, "rows in device memory must be 16-byte aligned");
     if (arena_len >= 0xFFFFFFF0ull) return fail(h, PE_ERR_CAPACITY, "bit arena exceeds 4 GiB");
-    const bool want_pk = out_aggpk96 != nullptr;
+    const bool want_pk = out_aggpk96 != nullptr || dev_partials != nullptr;
     if (want_pk && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     HostLap lap(&h->trace);
     TablesDev tables;
@@ -202,7 +203,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     const size_t off_gof = ob.alloc(4ull * n);
     const size_t off_obits = ob.alloc(words_cap * 4);
     const size_t off_oinfo = ob.alloc(8ull * n);
-    const size_t off_opk = want_pk ? ob.alloc(96ull * n) : 0;
+    const size_t off_opk = out_aggpk96 ? ob.alloc(96ull * n) : 0;
     PE_TRY(ob.ensure());
     if (want_pk) {  // scratch of the G1 chain, sized by the bounds before anything is in flight
         PE_TRY(ensure_quiesced(h, A.d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
@@ -294,14 +295,14 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
         pe_engine::PipeArena* arena = &A;
         const uint32_t* d_points = h->d_points.as<uint32_t>();
         const uint32_t* d_union = A.d_res_bits.as<uint32_t>();
-        uint8_t* out_pk = ob.host<uint8_t>(off_opk);
+        uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
         G1Plan bound;
         bound.n_groups = n;
         bound.n_slots = slot_cap;
         bound.n_partials = n;
         const G1Group* d_groups = L.g1;
         const AttPlan* d_plan = L.plan;
-        auto launch_g1 = [h, arena, d_points, tables, d_union, d_groups, bound, out_pk, on_side, d_plan]() -> int {
+        auto launch_g1 = [h, arena, d_points, tables, d_union, d_groups, bound, out_pk, on_side, d_plan, dev_partials]() -> int {
             hipStream_t gs = on_side ? h->side_stream : h->stream;
             if (on_side) {  // behind everything enqueued on the engine's stream so far (see aggregate_impl)
                 HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
@@ -310,7 +311,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
             } else {
                 g1_stream_guard(h, gs);
             }
-            PE_TRY(launch_g1_planned(h, d_points, tables.t[0].members, d_union, d_groups, bound, out_pk, nullptr, gs,
+            PE_TRY(launch_g1_planned(h, d_points, tables.t[0].members, d_union, d_groups, bound, out_pk, dev_partials, gs,
                                      on_side ? h->fin_stream : gs, on_side ? &arena->d_partials : nullptr,
                                      on_side ? &arena->d_lane_partials : nullptr, d_plan, tables.t[1].members));
             if (on_side) {
@@ -366,6 +367,13 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     const int rc = finish_call(h, st, ob, complete);
     lap2.mark("ragg.5_wait_outputs");
     return rc;
+}
+
+int resident_plan_dev(pe_engine* h, const AttPlan** out)
+{
+    if (!h->rr.valid) return fail(h, PE_ERR_STATE, "no aggregate over rows in device memory on this handle");
+    *out = rr_of(h->arena[h->rr.arena]).plan;
+    return PE_OK;
 }
 
 // ---------------------------------------------------------------- on_attestation x groups of the resident aggregate

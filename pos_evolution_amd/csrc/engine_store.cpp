@@ -268,7 +268,13 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
                 break;
         }
     }
-    if (!seen) HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!seen) {
+        const hipError_t e = bounded_stream_sync(h, h->stream);  // a sharded head waits behind an all-reduce
+        if (e == hipErrorNotReady)
+            return fail(h, PE_ERR_TIMEOUT, "get_head: the weights' all-reduce did not complete within the bounded wait; "
+                                           "the communicators were aborted");
+        HIP_TRY(h, e);
+    }
     *head_out = *head_word;
     if (*head_out >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
     return PE_OK;

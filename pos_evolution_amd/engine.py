@@ -7,6 +7,7 @@ with the pyspec) on a non-zero status.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -687,8 +688,43 @@ class Engine:
         buf = (C.c_uint8 * _abi.PE_DIST_ID_BYTES).from_buffer_copy(unique_id)
         self._check(self._lib.pe_dist_init(self._h, buf, rank, world))
 
+    def dist_init_ex(self, unique_id: bytes, rank: int, world: int, single_comm: bool = False):
+        assert len(unique_id) == _abi.PE_DIST_ID_BYTES
+        buf = (C.c_uint8 * _abi.PE_DIST_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.pe_dist_init_ex(self._h, buf, rank, world, _abi.PE_DIST_SINGLE_COMM if single_comm else 0))
+
+    def dist_init_custom(self, rank: int, world: int, all_reduce_u64, all_gather):
+        """pe_dist_init_custom: the two exchange steps through Python callables
+        ``all_reduce_u64(dev_ptr, count, hip_stream) -> int`` (in-place sum over ranks) and
+        ``all_gather(dev_send, dev_recv, bytes_per_rank, hip_stream) -> int``, both on device memory, ordered on the stream
+        (pos_evolution_amd.sharded.HostStagedCollectives is one such pair over any torch.distributed backend)."""
+        def _ar(_user, buf, count, stream):
+            try:
+                return int(all_reduce_u64(buf or 0, int(count), stream or 0) or 0)
+            except Exception as err:  # never unwind through the C frames
+                print(f"[posevo] all_reduce_u64 callback failed: {err!r}", file=sys.stderr)
+                return 1
+
+        def _ag(_user, send, recv, nbytes, stream):
+            try:
+                return int(all_gather(send or 0, recv or 0, int(nbytes), stream or 0) or 0)
+            except Exception as err:
+                print(f"[posevo] all_gather callback failed: {err!r}", file=sys.stderr)
+                return 1
+
+        fn = _abi.pe_collectives(None, _abi.ALL_REDUCE_FN(_ar), _abi.ALL_GATHER_FN(_ag))
+        self._coll_keep = fn  # the engine calls through these pointers until dist_destroy
+        self._check(self._lib.pe_dist_init_custom(self._h, rank, world, C.addressof(fn)))
+
+    def dist_set_timeout_ms(self, ms: int):
+        self._check(self._lib.pe_dist_set_timeout_ms(self._h, int(ms)))
+
+    def dist_set_max_groups(self, n: int):
+        self._check(self._lib.pe_dist_set_max_groups(self._h, int(n)))
+
     def dist_destroy(self):
         self._check(self._lib.pe_dist_destroy(self._h))
+        self._coll_keep = None
 
     def get_head_sharded(self) -> bytes:
         """get_head over all shards through the engine's own RCCL communicator (one all-reduce on its stream)."""
@@ -702,6 +738,18 @@ class Engine:
         arr, arena = packed if packed is not None else pack_attestations(rows)
         n = len(rows) if rows is not None else len(arr)
         m = max(n, 1)
+        if arr.__class__ is DeviceRows:  # rows in device memory: grouped / resolved there; the handlers take ROWS_RESIDENT
+            (out_atts, group_of, out_arena, out_pk, count, ng), (p_atts, p_gof, p_arena, p_pk, p_count, p_ng) = self._outs(
+                "raggsh", ((m, _ATT_DTYPE), (m, _U32), (max(arena.size, 1), _U8), ((m, 96), _U8), (m, _U32), (1, _U32)))
+            ng[0] = 0
+            if self._pipe_keep is not None:
+                self._pipe_keep.append((arr, arena, out_atts, group_of, out_arena, out_pk, count, ng))
+            rc = self._lib.pe_aggregate_sharded(self._h, arr.ptr, n, _ptr(arena, C.c_uint8), arena.size, p_atts, p_ng,
+                                                p_gof, p_arena, out_arena.size, p_pk, p_count)
+            if rc:
+                self._check(rc)
+            return ResidentAggregateResult(_raw=dict(n_groups=ng, atts=out_atts, group_of=group_of, out_arena=out_arena,
+                                                     aggpk96=out_pk, count=count), sig96=None, sig192=None)
         (out_atts, group_of, out_arena, out_pk, count), (p_atts, p_gof, p_arena, p_pk, p_count) = self._outs(
             "aggsh", ((m, _ATT_DTYPE), (m, _U32), (max(arena.size, 1), _U8), ((m, 96), _U8), (m, _U32)))
         n_groups = C.c_uint32(0)

@@ -109,3 +109,52 @@ class ShardedForkChoice:
             gathered.copy_(part)
         res["aggpk96"] = self.engine.g1_finish(gathered.data_ptr(), self.world, g)
         return res
+
+
+class HostStagedCollectives:
+    """The two exchange steps as host-staged collectives over ANY torch.distributed backend (gloo included): the pair of
+    callables ``Engine.dist_init_custom`` takes (pe_dist_init_custom, include/posevo.h).  Each call synchronises the
+    stream it is ordered on, copies the device buffer to the host, runs the collective there and copies the result back
+    -- slow, and exactly what is needed to run the engine-owned sharded step with several ranks that SHARE one GPU (RCCL
+    refuses two ranks on one device), or on a node whose GPUs have no peer links.  Not a performance path."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist, self.group, self.C = torch, dist, group, C
+        self.world = dist.get_world_size(group)
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.calls = {"all_reduce": 0, "all_gather": 0}
+
+    def _sync(self, stream):
+        if self.hip.hipStreamSynchronize(self.C.c_void_p(stream)) != 0:
+            raise RuntimeError("hipStreamSynchronize failed")
+
+    def _copy(self, dst, src, nbytes, kind):
+        if self.hip.hipMemcpy(self.C.c_void_p(dst), self.C.c_void_p(src), nbytes, kind) != 0:
+            raise RuntimeError("hipMemcpy failed")
+
+    def all_reduce_u64(self, buf, count, stream):
+        self._sync(stream)
+        host = self.torch.empty(count, dtype=self.torch.int64)  # two's-complement sums = u64 sums
+        self._copy(host.data_ptr(), buf, 8 * count, 2)          # hipMemcpyDeviceToHost
+        self.dist.all_reduce(host, group=self.group)
+        self._copy(buf, host.data_ptr(), 8 * count, 1)          # hipMemcpyHostToDevice
+        self.calls["all_reduce"] += 1
+        return 0
+
+    def all_gather(self, send, recv, nbytes, stream):
+        self._sync(stream)
+        mine = self.torch.empty(nbytes, dtype=self.torch.uint8)
+        self._copy(mine.data_ptr(), send, nbytes, 2)
+        parts = [self.torch.empty(nbytes, dtype=self.torch.uint8) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        allb = self.torch.cat(parts)
+        self._copy(recv, allb.data_ptr(), nbytes * self.world, 1)
+        self.calls["all_gather"] += 1
+        return 0

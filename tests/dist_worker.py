@@ -1,0 +1,141 @@
+"""Worker of tests/test_gpu_dist_custom.py: one rank of a job whose ranks SHARE one GPU.  The engine-owned sharded step
+(pe_aggregate_sharded over rows in device memory -> on_attestation -> pe_get_head_sharded -> process_attestation, inside
+streaming pipelines) runs over the caller's collectives (pe_dist_init_custom: gloo, staged through the host); every rank
+compares every step, bit for bit, with an UNSHARDED twin engine over the whole registry.
+
+    python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/dist_worker.py [host|device] [lagged|plain]
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rows_mode = sys.argv[1] if len(sys.argv) > 1 else "device"
+    pipe_mode = sys.argv[2] if len(sys.argv) > 2 else "lagged"
+    import torch
+    import torch.distributed as dist
+
+    import pos_evolution_amd as pea
+    import pos_evolution_amd.synth as synth
+    from pos_evolution_amd import RESIDENT, ROWS_RESIDENT, DeviceArena, DeviceRows
+    from pos_evolution_amd._abi import pe_state_ctx
+    from pos_evolution_amd.sharded import HostStagedCollectives
+    from tests import helpers as H
+    from tests.test_gpu_sharded import _local_attestations, _local_committees
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)  # every rank on the same device
+    dist.init_process_group(backend="gloo")
+
+    V, C, spe, steps = 30011, 64, 32, 5           # an odd registry: shards of unequal size, ragged local committees
+    bounds = [r * V // world + (7 if 0 < r < world else 0) for r in range(world + 1)]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    tree = synth.random_tree(200, 9, "bushy")
+    bal = synth.balances(V, 9, mixed=True)
+    flags = synth.validator_flags(V, 9, inactive_frac=0.01)
+    whole = pea.Engine(device=0, max_committee_tables=steps + 1)
+    shard = pea.Engine(device=0, max_committee_tables=steps + 1)
+    pts, _ = H.oracle_points(V)
+    H.load_tree(whole, tree)
+    H.load_tree(shard, tree)
+    whole.set_validators(bal, flags, pts)
+    shard.set_validators(bal[lo:hi], flags[lo:hi], pts[lo:hi])
+    boost = tree.roots[tree.roots.shape[0] - 1].tobytes()
+    whole.set_proposer_boost(boost)
+    shard.set_proposer_boost(boost)   # the boost needs the GLOBAL active balance: carried by the all-reduce
+
+    coll = HostStagedCollectives()
+    shard.dist_init_custom(rank, world, coll.all_reduce_u64, coll.all_gather)
+    shard.dist_set_max_groups(C)
+    ep0 = int(tree.slot.max()) // spe + 1
+    keep = []
+    for s in range(steps):
+        ep = ep0 + s
+        comm = synth.random_committees(V, C, 100 + s)
+        lc = _local_committees(comm, lo, hi)
+        whole.set_committees(ep, comm.offsets, comm.members)
+        shard.set_committees(ep, lc.offsets, lc.members)
+        atts, arena, bit_rows = synth.epoch_attestations(comm, tree, ep, spe, seed=s, density=0.9, parts=2,
+                                                         source=(0, tree.roots[0].tobytes()), vote_recent=32)
+        la, larena = _local_attestations(atts, bit_rows, comm, lo, hi)
+        ctx = pe_state_ctx()
+        ctx.slot = (ep + 1) * spe
+        ctx.chain_tip_root[:] = tree.roots[tree.roots.shape[0] - 1].tobytes()
+        ctx.current_justified_root[:] = tree.roots[0].tobytes()
+        ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+        ctx.base_reward_per_increment = 777
+        # the unsharded twin, synchronous host-row calls
+        for e in (whole, shard):
+            e.on_tick((ep + 1) * spe * 12)
+            e.participation_rotate()
+        ref = whole.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+        st, _, cnt = whole.on_attestation_batch(packed=(ref["atts"], ref["out_arena"]))
+        ref_head, ref_w = whole.get_head(), whole.get_weights()
+        pst, num = whole.process_attestation_batch(ctx, packed=(ref["atts"], ref["out_arena"]))
+        # the sharded step
+        if rows_mode == "device":
+            r = torch.from_numpy(la.view(np.uint8).reshape(-1)).cuda()
+            b = torch.from_numpy(larena).cuda()
+            packed = (DeviceRows(r.data_ptr(), len(la), keep=r), DeviceArena(b.data_ptr(), b.numel(), keep=b))
+            keep.append((r, b))
+        else:
+            packed = (la, larena)
+        if pipe_mode == "plain":
+            agg = shard.aggregate_sharded(packed=packed)
+            hrows = (ROWS_RESIDENT, RESIDENT) if rows_mode == "device" else (agg["atts"], agg["out_arena"])
+            kw = dict(cap=C) if rows_mode == "device" else {}
+            lst, _, lcnt = shard.on_attestation_batch(packed=hrows, **kw)
+            head = shard.get_head_sharded()
+            lpst, lnum = shard.process_attestation_batch(ctx, packed=hrows, **kw)
+        else:
+            with shard.pipeline(lagged=(pipe_mode == "lagged")):
+                agg = shard.aggregate_sharded(packed=packed)
+                hrows = (ROWS_RESIDENT, RESIDENT) if rows_mode == "device" else (agg["atts"], RESIDENT)
+                kw = dict(cap=C) if rows_mode == "device" else {}
+                lst, _, lcnt = shard.on_attestation_batch(packed=hrows, **kw)
+                head = shard.get_head_sharded()
+                lpst, lnum = shard.process_attestation_batch(ctx, packed=hrows, **kw)
+            shard.drain()   # compare step by step
+        g = ref["n_groups"]
+        assert agg["n_groups"] == g, (agg["n_groups"], g)
+        assert head == ref_head, f"step {s}: heads differ"
+        assert np.array_equal(shard.last_weights(), ref_w), f"step {s}: reduced weights differ from the unsharded ones"
+        got_pk = np.asarray(agg["aggpk96"])[:g]
+        bad = np.nonzero((got_pk != ref["aggpk96"]).any(axis=1))[0]
+        assert bad.size == 0, f"step {s}: aggregate pubkeys differ in {bad.size} of {g} groups, first {bad[:8]}"
+        assert (st == 0).all() and (np.asarray(lst)[:g] == 0).all() and (np.asarray(lpst)[:g] == 0).all()
+        # the local unions are the global ones restricted to this rank's members; local counts add up over ranks
+        cps = C // spe
+        for k in range(g):
+            a = ref["atts"][k]
+            c = int((a["slot"] % spe) * cps + a["index"])
+            m = comm.members[comm.offsets[c]:comm.offsets[c + 1]]
+            sel = (m >= lo) & (m < hi)
+            assert np.array_equal(np.asarray(agg["bits"][k]), np.asarray(ref["bits"][k])[sel]), f"step {s} group {k}: union"
+        tot = torch.from_numpy(np.asarray(lcnt)[:g].astype(np.int64))
+        dist.all_reduce(tot)
+        assert np.array_equal(tot.numpy(), cnt[:g].astype(np.int64)), f"step {s}: counts"
+        numt = torch.from_numpy(np.asarray(lnum)[:g].astype(np.int64))
+        dist.all_reduce(numt)
+        assert np.array_equal(numt.numpy(), num[:g].astype(np.int64)), f"step {s}: reward numerators"
+        # shard-local state = the slice of the global one
+        assert np.array_equal(shard.latest_messages()[1], whole.latest_messages()[1][lo:hi]), f"step {s}: latest messages"
+        assert np.array_equal(shard.participation_get(0), whole.participation_get(0)[lo:hi]), f"step {s}: participation"
+    assert coll.calls["all_reduce"] >= steps and coll.calls["all_gather"] == steps, coll.calls
+    shard.dist_destroy()
+    dist.barrier()
+    digest = hashlib.sha256(ref_head).hexdigest()[:12]
+    sys.stdout.write(f"DIST_WORKER_OK rank {rank} rows={rows_mode} pipe={pipe_mode} steps={steps} head={digest} "
+                     f"collectives={coll.calls}\n")
+    sys.stdout.flush()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
