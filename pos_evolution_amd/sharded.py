@@ -28,7 +28,11 @@ from . import _abi
 
 
 class ShardedForkChoice:
-    def __init__(self, engine, n_groups_max: int = 2048, group=None, device=None, use_engine_rccl: bool = False):
+    def __init__(self, engine, n_groups_max: int = 2048, group=None, device=None, use_engine_rccl: bool = False,
+                 single_comm: bool = False, collectives=None):
+        """use_engine_rccl: the exchange lives behind the C ABI (pe_get_head_sharded / pe_aggregate_sharded) -- over the
+        engine's own RCCL communicators (single_comm: PE_DIST_SINGLE_COMM), or, with ``collectives`` (an object with
+        all_reduce_u64 / all_gather, e.g. HostStagedCollectives), over the caller's (pe_dist_init_custom)."""
         import torch
         import torch.distributed as dist
 
@@ -47,10 +51,14 @@ class ShardedForkChoice:
         self._gathered = torch.zeros(self.world * n_groups_max * self._pw, dtype=torch.int32, device=device)
         self.n_groups_max = n_groups_max
         if use_engine_rccl:
+            if collectives is not None:
+                self.collectives = collectives
+                engine.dist_init_custom(self.rank, self.world, collectives.all_reduce_u64, collectives.all_gather)
+                return
             ids = [engine.dist_unique_id() if self.rank == 0 else None]
             if dist.is_initialized() and self.world > 1:
                 dist.broadcast_object_list(ids, src=0, group=group)
-            engine.dist_init(ids[0], self.rank, self.world)
+            engine.dist_init_ex(ids[0], self.rank, self.world, single_comm=single_comm)
             return
         if device.type == "cuda":
             # engine kernels and RCCL ordered on one (non-null) stream

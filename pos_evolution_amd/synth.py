@@ -256,6 +256,12 @@ def registry_points(engine, n: int, a: int = 0x1234567, b: int = 0x89ABCDE, lo: 
     return out
 
 
+def registry_closed_form_cs(count: int, index_sum: int, a: int = 0x1234567, b: int = 0x89ABCDE) -> bytes:
+    """registry_closed_form from the number of indices and their sum alone (what ranks of a sharded run exchange)."""
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    return _enc96(_ec_mul((int(count) * a + int(index_sum) * b) % r, _G))
+
+
 def registry_closed_form(indices, a: int = 0x1234567, b: int = 0x89ABCDE) -> bytes:
     """96-byte encoding of sum_{v in indices} (A + v*B) by one double-and-add (pure Python)."""
     r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001

@@ -211,6 +211,10 @@ def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     assert d["config"]["parallelism"] == f"validator-range shards x2 ({scaling} scaling)"
     per_gpu = 65536 // 2 if scaling == "strong" else 65536
     assert d["config"]["validators_per_gpu"] == per_gpu and d["config"]["validators_total"] == 2 * per_gpu
+    # the engine-owned streaming step over the caller's collectives, and the run's first step held against the oracle on
+    # every rank (shard-local state, head + weights over the gathered vote tables, all aggregate pubkeys)
+    assert "pe_dist_init_custom" in d["config"]["call_mode"]
+    assert d["checked_against_oracle"] is True and d["oracle_check"]["aggregate_pubkeys"] and d["oracle_check"]["weights"]
 
 
 @pytest.mark.parametrize("lagged", [False, True])
@@ -282,3 +286,4 @@ def test_bench_engine_rccl_path_one_rank():
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert "collectives issued by the engine" in d["config"]["call_mode"]
+    assert d["checked_against_oracle"] is True, d.get("oracle_check")

@@ -1,1 +1,1 @@
-K="dist_custom or sharded" bash tools/gpu.sh r03h tests
+K="sharded" bash tools/gpu.sh r03i tests
