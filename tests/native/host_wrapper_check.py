@@ -139,7 +139,7 @@ for kwargs in ({}, {"proposer_index": 0}):
 from pos_evolution_amd.sharded import ShardedForkChoice
 lib.stub_reset()
 sh = ShardedForkChoice(e, n_groups_max=4, use_engine_rccl=True)
-assert calls() == ["pe_dist_unique_id", "pe_dist_init"]
+assert calls() == ["pe_dist_unique_id", "pe_dist_init_ex"]
 assert len(sh.get_head()) == 32
 with e.pipeline(lagged=True):
     res = sh.aggregate(packed=(atts, bits))
