@@ -60,8 +60,19 @@ def build_workload(e, args, rank, n_steps_total):
         atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=seed, density=0.99, parts=args.parts,
                                                   source=(0, tree.roots[0].tobytes()), vote_recent=64,
                                                   vote_seed=4)  # committee c votes the same block on every shard
-        steps.append(dict(epoch=ep, comm=comm, atts=atts, arena=arena))
+        steps.append(dict(epoch=ep, comm=comm, atts=atts, arena=arena, ep_seed=ep_seed))
     w = dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe)
+    shuffle_from = 0 if args.with_shuffle else getattr(args, "shuffle_variant_from", n_steps_total)
+    if shuffle_from < n_steps_total:
+        # the NEXT epoch's committee table is shuffled inside each step (pe_compute_committees_async: same seed, same
+        # table, rewritten in place -- the epoch it feeds has not started); the last step shuffles one epoch more
+        for s, st in enumerate(steps):
+            if s < shuffle_from:
+                continue
+            # one epoch of lookahead (MIN_SEED_LOOKAHEAD): step s shuffles the table of step s + 2
+            nxt = (steps[s + 2] if s + 2 < len(steps) else
+                   dict(epoch=st["epoch"] + 2, ep_seed=hashlib.sha256(b"tail" + bytes([s & 255])).digest()))
+            st["next_shuffle"] = (nxt["epoch"], nxt["ep_seed"], V, C, 90)
     for st in steps:  # the working state's context of each step is an input like the attestations: built up front
         st["ctx"] = state_ctx(w, st["epoch"])
     if not args.host_arena:
@@ -118,6 +129,11 @@ def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
     if "rows_in" in st and pipelined:
         # rows + bits resident in HBM: the host enqueues a fixed sequence of launches and reads nothing of the rows
         cap = st["comm"].offsets.size - 1   # one AttestationData per committee in this workload: groups <= committees
+        if "next_shuffle" in st:
+            # --with-shuffle: the per-epoch swap-or-not shuffle (pe:495-534) on the clock.  The table it makes is the one
+            # the NEXT step resolves its current-epoch rows against, so it goes out first: on its own stream it runs
+            # beside this step's kernels
+            _timed("compute_committees", e.compute_committees_async, *st["next_shuffle"])
         with e.pipeline(lagged=lagged):
             agg = _timed("aggregate", e.aggregate, packed=(st["rows_in"], st["arena_in"]), want_aggregate_pubkeys=True)
             status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
@@ -520,6 +536,11 @@ def main():
                     help="one wait per call instead of one per step (A/B of the pipelined C ABI)")
     ap.add_argument("--no-lag", action="store_true",
                     help="complete every step's outputs at the end of that step (pe_pipeline_end instead of _end_lagged)")
+    ap.add_argument("--with-shuffle", action="store_true",
+                    help="run the NEXT epoch's committee shuffle (pe_compute_committees_async: 90-round swap-or-not over "
+                         "the registry + inverse committee map) inside every timed step, on the state-transition stream")
+    ap.add_argument("--no-shuffle-variant", action="store_true",
+                    help="skip the extra steps that report ms_per_step_with_shuffle")
     ap.add_argument("--no-oracle-check", action="store_true",
                     help="N > 1: skip the check of the run's first step against the oracle")
     ap.add_argument("--lag", type=int, default=4,
@@ -558,13 +579,18 @@ def main():
     assert args.validators_local % args.committees == 0, "validators per rank must be a multiple of the committee count"
     total = args.warmup + args.steps
     lag = 1 if args.no_lag else args.lag
+    # the reported variant with the per-epoch shuffle on the clock: extra steps behind the timed ones (one GPU, streaming)
+    n_var = 0 if (args.with_shuffle or args.no_shuffle_variant or world > 1 or args.no_pipeline or args.host_rows
+                  or args.host_arena) else min(args.steps, 60)
+    args.shuffle_variant_from = total
+    total_all = total + n_var
 
     def setup(single_comm):
         """Engine + workload + (N > 1) the exchange: RCCL owned by the engine (two communicators, or one after a timeout),
         the caller's collectives staged through the host when the backend is not RCCL (dry runs on a shared GPU), or
         torch.distributed between synchronous calls (--sharded-mode torch)."""
-        e = pea.Engine(device=local_rank, max_committee_tables=total + 1)
-        w = build_workload(e, args, rank, total)
+        e = pea.Engine(device=local_rank, max_committee_tables=total_all + 3)
+        w = build_workload(e, args, rank, total_all)
         ex, engine_rccl, how = None, False, None
         if dist is not None:
             from pos_evolution_amd.sharded import HostStagedCollectives, ShardedForkChoice
@@ -613,7 +639,7 @@ def main():
             # timed step afterwards the ring is as deep as the run, allocated and touched before the clock starts
             if not args.no_lag:
                 e.set_pipeline_lag(args.lag)
-            e.reuse_outputs(total + 2 if verify else lag + 2)
+            e.reuse_outputs(total_all + 2 if verify else lag + 2)
         kept, sharded_chk = [], None
         for s in range(args.warmup):
             kept.append(step(w["steps"][s]))
@@ -657,8 +683,22 @@ def main():
         prof = e.profile()
         e.profile_enable(False)
         assert n_rejected == 0, "synthetic attestations were rejected"
+        dt_var = None
+        if n_var:  # the same steps with the next epoch's shuffle enqueued inside each of them
+            gc.collect()
+            gc.disable()
+            barrier()
+            t1 = time.perf_counter()
+            more = [step(w["steps"][s]) for s in range(total, total_all)]
+            e.drain()
+            barrier()
+            dt_var = time.perf_counter() - t1
+            gc.enable()
+            assert all(int((m["status"] != 0).sum()) + int((m["pstatus"] != 0).sum()) == 0 for m in more)
+            if verify:
+                kept.extend(more)
         return dict(dt=dt, stamps=stamps, n_att_local=n_att_local, last=last, prof=prof, kept=kept, verify=verify,
-                    sharded_chk=sharded_chk)
+                    sharded_chk=sharded_chk, dt_var=dt_var)
 
     e, w, ex, engine_rccl, exchange_how = setup(single_comm=False)
     dist_fallback = None
@@ -779,8 +819,11 @@ def main():
                         "the device: PE_ROWS_RESIDENT); ")
                        + ("aggregation bits in pageable host memory, copied over PCIe inside the timed step"
                           if args.host_arena else "aggregation bits resident in HBM before the timed region")),
-            "per_epoch_setup_outside_the_step": "pe_compute_committees (GPU swap-or-not shuffle + inverse committee "
-                                                "map) runs once per epoch when the workload is built, not in the step",
+            "per_epoch_setup_outside_the_step": ("nothing: the next epoch's committee shuffle (pe_compute_committees_async) "
+                                                 "runs inside every step (--with-shuffle)" if args.with_shuffle else
+                                                 "pe_compute_committees (GPU swap-or-not shuffle + inverse committee map) "
+                                                 "runs once per epoch when the workload is built, not in the step; "
+                                                 "--with-shuffle puts it on the clock"),
         },
         "step_ms_p50": float(np.median(per_step)), "step_ms_min": float(per_step.min()),
         "step_ms_p90": float(np.percentile(per_step, 90)),
@@ -821,14 +864,24 @@ def main():
                                           "vs the C oracle, head + all weights vs cport.get_head over the gathered vote "
                                           "tables, every aggregate pubkey vs the registry's closed form; AND over ranks")
             assert out["checked_against_oracle"], f"sharded step differs from the oracle: {R['sharded_chk']}"
+    if R["dt_var"] is not None:
+        out["ms_per_step_with_shuffle"] = R["dt_var"] / n_var * 1e3
+        out["with_shuffle_detail"] = (f"{n_var} further steps, each also enqueuing the NEXT epoch's committee shuffle "
+                                      "(pe_compute_committees_async: k_shuffle_tables + k_shuffle_indices, 90 rounds over the "
+                                      "registry, + the inverse committee map) on the state-transition stream; ramp and drain "
+                                      "of the pipeline included")
     if verify:
         # every step's outputs (kept in the deep ring) against a synchronous host-row replay, after the clock stopped
-        same = replay_and_verify(pea, w, local_rank, kept, total)
+        same = replay_and_verify(pea, w, local_rank, kept, total_all)
         out["steps_verified"] = int(sum(same[args.warmup:]))
         out["steps_verified_detail"] = ("sha256 of each timed step's outputs (head, statuses, counts, numerators, aggregate "
                                         "rows, OR-ed bits, aggregate pubkeys, grouping) == the same step replayed with "
                                         "synchronous host-row calls on a fresh engine; warm-up steps replayed too: "
                                         f"{int(sum(same[:args.warmup]))}/{args.warmup} identical")
+        out["steps_verified"] = int(sum(same[args.warmup:total]))
+        if n_var:
+            out["steps_verified_with_shuffle"] = int(sum(same[total:]))
+            assert out["steps_verified_with_shuffle"] == n_var, "with-shuffle steps differ from their synchronous replay"
         assert out["steps_verified"] == args.steps, f"timed steps differ from their synchronous replay: {same}"
     if not args.no_cpu_baseline and world == 1:
         base, chk = cpu_baseline(w, w["steps"][0])

@@ -57,7 +57,10 @@ def write(path: str, w: dict):
     n_val, n_blocks = w["bal"].size, tree.roots.shape[0]
     n_comm = steps[0]["offsets"].size - 1
     with open(path, "wb") as f:
-        f.write(struct.pack("<8Q", MAGIC, n_val, n_comm, n_blocks, len(steps), w["spe"], 0, 0))
+        # steps that carry "sigs" ((n_atts, 96) uint8: one compressed BLSSignature per attestation) set header flag 1; the
+        # client then runs pe_aggregate_signed and hands back every aggregate's compressed signature
+        has_sigs = all("sigs" in st for st in steps)
+        f.write(struct.pack("<8Q", MAGIC, n_val, n_comm, n_blocks, len(steps), w["spe"], 0, 1 if has_sigs else 0))
         f.write(np.ascontiguousarray(tree.roots, dtype=np.uint8).tobytes())
         f.write(np.ascontiguousarray(tree.parent, dtype=np.uint32).tobytes())
         f.write(np.ascontiguousarray(tree.slot, dtype=np.uint64).tobytes())
@@ -71,6 +74,9 @@ def write(path: str, w: dict):
             f.write(np.ascontiguousarray(st["members"], dtype=np.uint32).tobytes())
             f.write(np.ascontiguousarray(st["atts"]).tobytes())
             f.write(np.ascontiguousarray(st["arena"], dtype=np.uint8).tobytes())
+            if has_sigs:
+                assert st["sigs"].shape == (len(st["atts"]), 96)
+                f.write(np.ascontiguousarray(st["sigs"], dtype=np.uint8).tobytes())
 
 
 if __name__ == "__main__":

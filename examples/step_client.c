@@ -47,14 +47,15 @@ typedef struct {
     uint32_t* members;      /* n_val */
     pe_attestation* atts;   /* n_atts */
     uint8_t* arena;         /* arena_len */
+    uint8_t* sigs;          /* n_atts x 96: the attestations' compressed BLSSignatures (files with header flag 1) */
 } wl_step;
 
 typedef struct {            /* the outputs of one step: a ring of these, consumed two steps behind when streaming */
     pe_attestation* out_atts;
     uint32_t n_groups;
     uint32_t *group_of, *count, *att_count;
-    uint8_t *out_bits, *aggpk;
-    int32_t *status, *pstatus;
+    uint8_t *out_bits, *aggpk, *out_sigs;   /* out_sigs: 96-byte compressed aggregate signature per group */
+    int32_t *status, *pstatus, *sig_status;
     uint64_t* numerators;
     uint8_t head[32];
     uint64_t arena_len;
@@ -82,6 +83,7 @@ static double now_ms(void)
 }
 
 /* fold one completed step into the hash: everything the four calls handed back */
+static int with_sigs;
 static uint64_t fold(uint64_t hsh, const step_out* o)
 {
     const uint32_t g = o->n_groups;
@@ -98,6 +100,7 @@ static uint64_t fold(uint64_t hsh, const step_out* o)
     hsh = fnv(hsh, o->pstatus, 4ull * g);
     hsh = fnv(hsh, o->numerators, 8ull * g);
     hsh = fnv(hsh, o->head, 32);
+    if (with_sigs) hsh = fnv(hsh, o->out_sigs, 96ull * g);   /* Attestation.signature of every aggregate (pe:717) */
     return hsh;
 }
 
@@ -112,6 +115,7 @@ int main(int argc, char** argv)
     if (!f) { perror(argv[1]); return 2; }
     wl_header hd;
     if (fread(&hd, sizeof hd, 1, f) != 1 || hd.magic != 0x30764F5645534F50ull) { fprintf(stderr, "bad workload file\n"); return 2; }
+    with_sigs = (hd.reserved & 1) != 0;   /* the file carries one compressed BLSSignature per attestation */
 
     pe_engine* h = NULL;
     pe_config cfg;
@@ -144,6 +148,7 @@ int main(int argc, char** argv)
         st->members = (uint32_t*)xread(f, 4 * hd.n_val);
         st->atts = (pe_attestation*)xread(f, sizeof(pe_attestation) * st->n_atts);
         st->arena = (uint8_t*)xread(f, st->arena_len);
+        st->sigs = with_sigs ? (uint8_t*)xread(f, 96 * st->n_atts) : NULL;
         CHECK(pe_set_committees(h, st->epoch, (uint32_t)hd.n_comm, st->offsets, st->members));
         if (st->n_atts > max_atts) max_atts = st->n_atts;
         if (st->arena_len > max_arena) max_arena = st->arena_len;
@@ -162,6 +167,8 @@ int main(int argc, char** argv)
         o->status = (int32_t*)calloc(max_atts, 4);
         o->pstatus = (int32_t*)calloc(max_atts, 4);
         o->numerators = (uint64_t*)calloc(max_atts, 8);
+        o->out_sigs = (uint8_t*)calloc(max_atts, 96);
+        o->sig_status = (int32_t*)calloc(max_atts, 4);
         o->arena_len = max_arena;
     }
     uint64_t hsh = 0xCBF29CE484222325ull, n_att = 0, n_att_warm = 0;
@@ -176,8 +183,13 @@ int main(int argc, char** argv)
         CHECK(pe_participation_rotate(h));
         if (streaming) CHECK(pe_pipeline_begin_streaming(h));
         else if (pipelined) CHECK(pe_pipeline_begin(h));
-        CHECK(pe_aggregate(h, st->atts, (uint32_t)st->n_atts, st->arena, st->arena_len, NULL, o->out_atts, &o->n_groups,
-                           o->group_of, o->out_bits, o->arena_len, NULL, o->aggpk, o->count));
+        if (with_sigs)  /* pe_aggregate + bls.Aggregate over the members' signatures: the aggregate a validator publishes */
+            CHECK(pe_aggregate_signed(h, st->atts, (uint32_t)st->n_atts, st->arena, st->arena_len, st->sigs,
+                                      PE_SIG_G2_COMPRESSED, o->out_atts, &o->n_groups, o->group_of, o->out_bits,
+                                      o->arena_len, o->out_sigs, o->sig_status, o->aggpk, o->count));
+        else
+            CHECK(pe_aggregate(h, st->atts, (uint32_t)st->n_atts, st->arena, st->arena_len, NULL, o->out_atts, &o->n_groups,
+                               o->group_of, o->out_bits, o->arena_len, NULL, o->aggpk, o->count));
         /* the rows are complete at return; bits / counts / pubkeys when the pipeline is (two ends later when streaming) */
         const uint8_t* bits = pipelined ? PE_BITS_RESIDENT : o->out_bits;
         CHECK(pe_on_attestation_batch(h, o->out_atts, o->n_groups, bits, o->arena_len, o->status, NULL, o->att_count));
@@ -209,10 +221,15 @@ int main(int argc, char** argv)
     const uint64_t timed = hd.n_steps - warmup;
     /* streaming: the steps consumed inside the timed window lag two behind; the rate below charges the whole window
        with the attestations of the timed steps (the two-step skew cancels: two warm-up steps complete inside it) */
+    char sig_hex[200] = "";
+    if (with_sigs && hd.n_steps) {  /* the compressed aggregate signature of the last step's first aggregate */
+        const step_out* d = &ring[(hd.n_steps - 1) % RING];
+        for (int i = 0; i < 96 && d->n_groups; ++i) sprintf(sig_hex + 2 * i, "%02x", d->out_sigs[i]);
+    }
     printf("{\"mode\": \"%s\", \"steps\": %llu, \"timed_steps\": %llu, \"ms_per_step\": %.4f, \"attestations\": %llu, "
-           "\"attestations_per_s\": %.1f, \"hash\": \"%016llx\"}\n",
+           "\"attestations_per_s\": %.1f, \"hash\": \"%016llx\", \"aggregate_signature\": \"%s\"}\n",
            mode, (unsigned long long)hd.n_steps, (unsigned long long)timed, dt / (double)timed, (unsigned long long)n_att,
-           (double)(n_att - n_att_warm) / (dt * 1e-3), (unsigned long long)hsh);
+           (double)(n_att - n_att_warm) / (dt * 1e-3), (unsigned long long)hsh, sig_hex);
     pe_engine_destroy(h);
     return 0;
 }

@@ -219,6 +219,15 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
                           uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
                           uint32_t* out_offsets, uint32_t* out_members);
 
+/* The same shuffle without a wait and without a read-back, for a caller that streams epochs: the kernels go to a
+ * stream of their own (beside the steps' G1 sums and fork-choice kernels; a shuffling is known one epoch ahead --
+ * MIN_SEED_LOOKAHEAD, get_seed pe:481-486 -- so it is enqueued an epoch before the calls that read it), the table is
+ * registered at once, and the first call that reads it makes the engine's stream wait for the shuffle.  A caller that streams with lag depth L keeps
+ * max_committee_tables >= L + 3: the least recently used table is rewritten in place, and if work in flight may still
+ * read it the call first completes everything in flight. */
+int pe_compute_committees_async(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
+                                uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count);
+
 /* ---- pipelined calls: one wait per step --------------------------------- */
 /* Between pe_pipeline_begin and pe_pipeline_end the batch calls (pe_aggregate, pe_on_attestation_batch,
  * pe_process_attestation_batch) validate on the host, enqueue their device work and RETURN WITHOUT WAITING:
@@ -446,6 +455,43 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
                          uint64_t* finalized_epoch, uint8_t finalized_root[32],
                          uint64_t* best_justified_epoch, uint8_t best_justified_root[32],
                          uint8_t proposer_boost_root[32]);
+
+/* ---- pe_aggregate with its signature leg (bls.Aggregate, pe:659, pe:714-717) -------------------------------------- */
+/* Everything pe_aggregate does, plus Attestation.signature of every aggregate it forms: the sum in G2 of the member
+ * attestations' BLSSignatures, returned in the 96-byte compressed wire form (pe:37, pe:717) -- what a validator client
+ * publishes as "a well-packed aggregate attestation" (pe:659).
+ *   signatures        n signatures, one per input row, in host or device memory:
+ *                     PE_SIG_G2_COMPRESSED    96 bytes each (x.c1 | x.c0 big-endian, flag bits in the leading byte): decoded
+ *                                             on the device (square root in Fp2, sign and canonicity checks, curve membership);
+ *                     PE_SIG_G2_UNCOMPRESSED  192 bytes each (x.c1 | x.c0 | y.c1 | y.c0): converted, trusted to lie on the curve;
+ *   | PE_SIG_CHECK_SUBGROUP  additionally r * P = infinity for every decoded point (a curve point outside G2 is not a
+ *                     BLSSignature; is_valid_indexed_attestation, pe:736 / pe:976, presumes members of G2);
+ *   out_signatures96  96 bytes per group formed, group order as out_atts (capacity: n entries);
+ *   sig_status        n entries, one per input row: PE_SIG_OK, PE_SIG_MALFORMED (encoding), PE_SIG_NOT_ON_CURVE,
+ *                     PE_SIG_NOT_IN_SUBGROUP.
+ * A member whose signature does not decode is left out of its group's sum and the group's row loses
+ * PE_ATT_FLAG_SIGNATURE_VALID (the handlers then reject it with PE_ATT_BAD_SIGNATURE): an aggregate over an invalid
+ * signature can never verify.  Members with overlapping bits: the row carries PE_ATT_FLAG_OVERLAPPING_BITS as with
+ * pe_aggregate, and its signature is the plain sum (which counts a validator twice -- such an aggregate does not verify
+ * either, Appendix A.8).  Rows in host or device memory, synchronous or inside a pipeline, exactly as pe_aggregate; the
+ * signature sums run on the engine's state-transition stream beside the aggregate pubkeys and the fork-choice kernels. */
+#define PE_SIG_G2_COMPRESSED   1u
+#define PE_SIG_G2_UNCOMPRESSED 2u
+#define PE_SIG_CHECK_SUBGROUP  0x100u
+#define PE_SIG_OK 0
+#define PE_SIG_MALFORMED 1
+#define PE_SIG_NOT_ON_CURVE 2
+#define PE_SIG_NOT_IN_SUBGROUP 3
+int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n,
+                        const uint8_t* bits_arena, uint64_t arena_len,
+                        const uint8_t* signatures, uint32_t sig_format_flags,
+                        pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
+                        uint8_t* out_bits_arena, uint64_t out_arena_cap,
+                        uint8_t* out_signatures96, int32_t* sig_status,
+                        uint8_t* out_aggpk96, uint32_t* out_count);
+/* The subgroup check on its own: n points in the 192-byte uncompressed form (host memory); status[i] = PE_SIG_OK or
+ * PE_SIG_NOT_IN_SUBGROUP (infinity passes). */
+int pe_g2_subgroup_check(pe_engine* h, const uint8_t* points192, uint64_t n, int32_t* status);
 
 /* ---- multi-GPU exchange (validator-range shards) ----------- */
 /* Each rank owns a contiguous validator range and the whole (small) block table.

@@ -18,6 +18,7 @@ PE_ERR_CAPACITY = -10
 PE_ERR_STATE = -14
 PE_ERR_TIMEOUT = -15
 PE_DIST_SINGLE_COMM = 1
+PE_SIG_G2_COMPRESSED, PE_SIG_G2_UNCOMPRESSED, PE_SIG_CHECK_SUBGROUP = 1, 2, 0x100
 NONE32 = 0xFFFFFFFF
 
 PE_VAL_ACTIVE, PE_VAL_SLASHED, PE_VAL_EQUIVOCATING, PE_VAL_ACTIVE_PREV = 0x01, 0x02, 0x04, 0x08
@@ -109,8 +110,12 @@ SIGNATURES = {
                                           C.c_uint64]),
     "pe_set_committees": (C.c_int, [_H, C.c_uint64, C.c_uint32, _u32p, _u32p]),
     "pe_compute_committees": (C.c_int, [_H, C.c_uint64, _u8p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p]),
+    "pe_compute_committees_async": (C.c_int, [_H, C.c_uint64, _u8p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pe_get_head": (C.c_int, [_H, _u8p]),
     "pe_get_head_async": (C.c_int, [_H, _u8p]),
+    "pe_aggregate_signed": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _u8p, C.c_uint32, _attp, _u32p, _u32p, _u8p,
+                                      C.c_uint64, _u8p, _i32p, _u8p, _u32p]),
+    "pe_g2_subgroup_check": (C.c_int, [_H, _u8p, C.c_uint64, _i32p]),
     "pe_pipeline_set_lag": (C.c_int, [_H, C.c_uint32]),
     "pe_pipeline_get_lag": (C.c_uint32, [_H]),
     "pe_get_weights": (C.c_int, [_H, _u64p, C.c_uint32]),

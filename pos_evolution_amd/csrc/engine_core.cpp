@@ -292,6 +292,8 @@ void pe_engine_destroy(pe_engine* h)
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (h->prep_stream) { (void)hipStreamSynchronize(h->prep_stream); (void)hipStreamDestroy(h->prep_stream); }
+    h->d_shuffle_scratch.release();
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
     if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
     h->d_xchg.release();
@@ -304,6 +306,9 @@ void pe_engine_destroy(pe_engine* h)
         a.d_lane_partials.release();
         a.d_rr_tab.release();
         a.d_rr.release();
+        a.d_sig_in.release();
+        a.d_sig_pts.release();
+        a.d_sig_status.release();
         a.d_stage.release();
         a.d_outblk.release();
         a.h_stage.release();
@@ -318,7 +323,11 @@ void pe_engine_destroy(pe_engine* h)
                       &h->d_broot_tab, &h->d_broots, &h->d_bslot_pos,
                       &h->d_partials, &h->d_lane_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
         b->release();
-    for (auto& t : h->tables) { t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release(); }
+    for (auto& t : h->tables) {
+        t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release();
+        t.d_stage.release(); t.h_stage.release();
+        if (t.ev_ready) (void)hipEventDestroy(t.ev_ready);
+    }
     h->h_head.release();
     for (auto& p : h->prof)
         for (auto& ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -385,6 +394,7 @@ int pe_pipeline_begin(pe_engine* h)
         if (part) HIP_TRY(h, a.d_partials.ensure(part));
         if (lane) HIP_TRY(h, a.d_lane_partials.ensure(lane));
     }
+    h->A().table_stamp_at_begin = h->table_stamp;
     h->pipelining = true;
     return PE_OK;
 }

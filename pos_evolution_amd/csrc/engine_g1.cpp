@@ -363,4 +363,132 @@ int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points, const u
     return PE_OK;
 }
 
+// ---------------------------------------------------------------- pe_aggregate with its signature leg
+int pe_g2_subgroup_check(pe_engine* h, const uint8_t* points192, uint64_t n, int32_t* status)
+{
+    if (!h || (n && (!points192 || !status))) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (n == 0) return PE_OK;
+    if (n >= 0xFFFFFFFFull / 48) return fail(h, PE_ERR_CAPACITY, "too many points");
+    HIP_TRY(h, h->d_tmp_be.ensure(192ull * n + 4ull * n));
+    HIP_TRY(h, h->d_tmp_points.ensure(192ull * n));
+    int32_t* d_st = reinterpret_cast<int32_t*>(h->d_tmp_be.as<uint8_t>() + 192ull * n);
+    HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points192, 192ull * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(d_st, 0, 4ull * n, h->stream));
+    launch_g2_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
+    launch_g2_subgroup_check(h->stream, h->d_tmp_points.as<uint32_t>(), n, d_st);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(status, d_st, 4ull * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return PE_OK;
+}
+
+int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena, uint64_t arena_len,
+                        const uint8_t* signatures, uint32_t sig_format_flags, pe_attestation* out_atts,
+                        uint32_t* out_n_groups, uint32_t* group_of, uint8_t* out_bits_arena, uint64_t out_arena_cap,
+                        uint8_t* out_signatures96, int32_t* sig_status, uint8_t* out_aggpk96, uint32_t* out_count)
+{
+    if (!h || !out_n_groups || !out_atts || (n && (!atts || !signatures || !out_signatures96 || !sig_status)))
+        return PE_ERR_INVALID_ARG;
+    const uint32_t fmt = sig_format_flags & 0xFFu;
+    if ((fmt != PE_SIG_G2_COMPRESSED && fmt != PE_SIG_G2_UNCOMPRESSED) || (sig_format_flags & ~(0xFFu | PE_SIG_CHECK_SUBGROUP)))
+        return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate_signed: unknown signature format / flags");
+    (void)hipSetDevice(h->device);
+    if (n == 0) return pe_aggregate(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of,
+                                    out_bits_arena, out_arena_cap, nullptr, out_aggpk96, out_count);
+    const bool dev_rows = rows_on_device(atts);
+    const size_t sig_bytes = fmt == PE_SIG_G2_COMPRESSED ? 96 : 192;
+    {   // the arena's signature scratch, sized while nothing of this call is in flight
+        if (!h->pipelining) PE_TRY(flush_pending(h));
+        pe_engine::PipeArena& A = h->A();
+        PE_TRY(ensure_quiesced(h, A.d_sig_in, sig_bytes * n));
+        PE_TRY(ensure_quiesced(h, A.d_sig_pts, 192ull * n));
+        PE_TRY(ensure_quiesced(h, A.d_sig_status, 4ull * n));
+    }
+    // host rows: the grouping comes back in group_of (host-derived, complete at return) -- keep one if the caller has none
+    auto gof_p = std::make_shared<std::vector<uint32_t>>();
+    if (!dev_rows && !group_of) {
+        gof_p->resize(n);
+        group_of = gof_p->data();
+    }
+    const int rc = pe_aggregate(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of, out_bits_arena,
+                                out_arena_cap, nullptr, out_aggpk96, out_count);
+    if (rc) return rc;
+    pe_engine::PipeArena& A = h->A();
+    const UnionGroup* d_ug = nullptr;
+    const uint32_t* d_member_row = nullptr;
+    const AttPlan* plan_dev = nullptr;
+    uint32_t ng_bound = n;
+    Stage st(h);
+    if (dev_rows) {
+        PE_TRY(resident_lists(h, &d_ug, &d_member_row));
+        PE_TRY(resident_plan_dev(h, &plan_dev));
+    } else {
+        const uint32_t ng = *out_n_groups;
+        ng_bound = ng;
+        PE_TRY(st.reserve(sizeof(UnionGroup) * (size_t)ng + 4ull * n + 1024));
+        const size_t off_ug = st.alloc(sizeof(UnionGroup) * (size_t)std::max<uint32_t>(ng, 1));
+        const size_t off_ord = st.alloc(4ull * n);
+        UnionGroup* ug = st.host<UnionGroup>(off_ug);
+        uint32_t* order = st.host<uint32_t>(off_ord);
+        for (uint32_t g = 0; g < ng; ++g) ug[g] = UnionGroup{0, 0, 0, 0};
+        for (uint32_t i = 0; i < n; ++i) {
+            if (group_of[i] >= ng) return fail(h, PE_ERR_NO_DEVICE, "pe_aggregate returned a group index out of range");
+            ug[group_of[i]].n_atts += 1;
+        }
+        uint32_t run = 0;
+        for (uint32_t g = 0; g < ng; ++g) { ug[g].list_start = run; run += ug[g].n_atts; ug[g].n_atts = 0; }
+        for (uint32_t i = 0; i < n; ++i) { UnionGroup& u = ug[group_of[i]]; order[u.list_start + u.n_atts++] = i; }
+        HIP_TRY(h, st.upload());
+        d_ug = st.dev<UnionGroup>(off_ug);
+        d_member_row = st.dev<uint32_t>(off_ord);
+    }
+    OutBlock ob(h);
+    const size_t off_sig = ob.alloc(96ull * std::max<uint32_t>(ng_bound, 1));
+    const size_t off_bad = ob.alloc(4ull * std::max<uint32_t>(ng_bound, 1));
+    const size_t off_st = ob.alloc(4ull * n);
+    PE_TRY(ob.ensure());
+    memset(ob.host<uint32_t>(off_bad), 0, 4ull * std::max<uint32_t>(ng_bound, 1));
+    hipStream_t ss = state_stream_begin(h);  // behind the grouping; beside the aggregate pubkeys and the fork-choice kernels
+    bool sig_on_device = false;
+    {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, signatures) == hipSuccess) sig_on_device = pa.type == hipMemoryTypeDevice;
+        else (void)hipGetLastError();
+    }
+    HIP_TRY(h, hipMemcpyAsync(A.d_sig_in.p, signatures, sig_bytes * n,
+                              sig_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ss));
+    int32_t* d_status = A.d_sig_status.as<int32_t>();
+    uint32_t* d_pts = A.d_sig_pts.as<uint32_t>();
+    if (fmt == PE_SIG_G2_COMPRESSED) {
+        launch_g2_decompress(ss, A.d_sig_in.as<uint8_t>(), n, d_pts, nullptr, d_status);
+    } else {
+        HIP_TRY(h, hipMemsetAsync(d_status, 0, 4ull * n, ss));
+        launch_g2_convert(ss, A.d_sig_in.as<uint8_t>(), d_pts, n);
+    }
+    if (sig_format_flags & PE_SIG_CHECK_SUBGROUP) launch_g2_subgroup_check(ss, d_pts, n, d_status);
+    {
+        ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
+        launch_g2_aggregate_rows(ss, d_pts, d_status, d_ug, d_member_row, ng_bound, plan_dev, ob.host<uint8_t>(off_sig),
+                                 ob.host<uint32_t>(off_bad));
+    }
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(ob.host<int32_t>(off_st), d_status, 4ull * n, hipMemcpyDeviceToHost, ss));
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off_sig, off_bad, off_st, n, ng_bound, dev_rows, out_n_groups, out_atts, out_signatures96,
+                     sig_status, gof_p]() -> int {
+        const uint8_t* pin = h->arena[ai].h_pin.as<uint8_t>() + base;
+        const uint32_t ng = dev_rows ? *out_n_groups : ng_bound;  // device rows: set by the aggregate's completion just before
+        if (ng > ng_bound) return fail(h, PE_ERR_NO_DEVICE, "pe_aggregate_signed: more groups than rows");
+        memcpy(out_signatures96, pin + off_sig, 96ull * ng);
+        memcpy(sig_status, pin + off_st, 4ull * n);
+        const uint32_t* bad = reinterpret_cast<const uint32_t*>(pin + off_bad);
+        for (uint32_t g = 0; g < ng; ++g)
+            if (bad[g]) out_atts[g].flags &= ~(uint32_t)PE_ATT_FLAG_SIGNATURE_VALID;  // an undecodable member: never verifiable
+        return PE_OK;
+    };
+    return finish_call(h, st, ob, complete);
+}
+
 }  // extern "C"

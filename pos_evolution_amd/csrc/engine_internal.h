@@ -132,6 +132,10 @@ struct CommitteeTable {
     bool is_partition = false;      // every validator in at most one committee (true for a real shuffling)
     uint64_t n_val_at_load = 0;     // registry size the inverse map was built for
     uint64_t stamp = 0;
+    PinBuf h_stage;                 // pe_compute_committees_async: the call's seed | offsets | active indices ...
+    DevBuf d_stage;                 // ... and their device copy
+    hipEvent_t ev_ready = nullptr;  // pe_compute_committees_async: recorded behind the shuffle on the stream it ran on
+    bool ready_pending = false;     // ... and not yet waited for by the engine's stream
 };
 
 // Diagnostic only (POSEVO_HOST_TRACE=1): wall time of host phases, printed at pe_engine_destroy.
@@ -243,8 +247,10 @@ struct pe_engine {
         DevBuf d_partials, d_lane_partials;  // tree -> finish | accumulate -> tree hand-over of this arena's pipelined aggregate
         // rows resident on the device (engine_resident.cpp): grouping table (self-cleaning) and the per-call scratch
         DevBuf d_rr_tab, d_rr;
+        DevBuf d_sig_in, d_sig_pts, d_sig_status;  // pe_aggregate_signed: wire bytes | Montgomery points | decode status
         uint32_t rr_rows_cap = 0, rr_comm_cap = 0, rr_tab_size = 0;
         size_t stage_cursor = 0, out_cursor = 0;
+        uint64_t table_stamp_at_begin = 0;  // h->table_stamp when the pipeline that fills this arena began
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
         bool fenced = false, side_used = false, aux_used = false;
@@ -269,6 +275,8 @@ struct pe_engine {
     // follows the head in a step, and on the engine's stream it stood between one step's head and the next step's
     // fork-choice chain (25 + 85 us per 1 M validators beside a running accumulation, profiles/r03_timeline_*.txt).
     hipStream_t aux_stream = nullptr;
+    hipStream_t prep_stream = nullptr;  // pe_compute_committees_async: next epochs' shuffles, beside everything else
+    DevBuf d_shuffle_scratch;           // ... and their hash tables (the synchronous call uses d_tmp_be)
     hipEvent_t ev_aux_fork = nullptr;
     bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
@@ -666,6 +674,8 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                        uint32_t* dev_partials = nullptr);
 // the device-side plan (group count, error word) of the last aggregate over rows in device memory
 int resident_plan_dev(pe_engine* h, const AttPlan** out);
+// ... and its grouping lists: group g's member rows are member_row[ug[g].list_start .. + ug[g].n_atts)
+int resident_lists(pe_engine* h, const UnionGroup** ug, const uint32_t** member_row);
 int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_t* out_count);
 int process_attestation_resident(pe_engine* h, const pe_state_ctx* st, uint32_t cap, int32_t* status, uint64_t* out_numerators);
 

@@ -376,6 +376,15 @@ int resident_plan_dev(pe_engine* h, const AttPlan** out)
     return PE_OK;
 }
 
+int resident_lists(pe_engine* h, const UnionGroup** ug, const uint32_t** member_row)
+{
+    if (!h->rr.valid) return fail(h, PE_ERR_STATE, "no aggregate over rows in device memory on this handle");
+    const RrLayout L = rr_of(h->arena[h->rr.arena]);
+    *ug = L.ug;
+    *member_row = L.member_row;
+    return PE_OK;
+}
+
 // ---------------------------------------------------------------- on_attestation x groups of the resident aggregate
 static int resident_precheck(pe_engine* h, const char* who)
 {

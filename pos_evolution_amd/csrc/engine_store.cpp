@@ -153,13 +153,20 @@ int insert_block(pe_engine* h, const Root& root, uint32_t parent, uint64_t slot,
 CommitteeTable* find_table(pe_engine* h, uint64_t epoch)
 {
     // the rows of a batch nearly always share one target epoch: try the table of the previous hit first
+    CommitteeTable* hit = nullptr;
     if (h->last_table < h->tables.size()) {
         CommitteeTable& t = h->tables[h->last_table];
-        if (t.epoch == epoch && t.n_committees) return &t;
+        if (t.epoch == epoch && t.n_committees) hit = &t;
     }
-    for (size_t i = 0; i < h->tables.size(); ++i)
-        if (h->tables[i].epoch == epoch && h->tables[i].n_committees) { h->last_table = i; return &h->tables[i]; }
-    return nullptr;
+    for (size_t i = 0; !hit && i < h->tables.size(); ++i)
+        if (h->tables[i].epoch == epoch && h->tables[i].n_committees) { h->last_table = i; hit = &h->tables[i]; }
+    if (hit && hit->ready_pending) {
+        // shuffled by pe_compute_committees_async on the state-transition stream: whoever is about to read the table
+        // enqueues on (or forks from) the engine's stream, which waits for the shuffle once
+        (void)hipStreamWaitEvent(h->stream, hit->ev_ready, 0);
+        hit->ready_pending = false;
+    }
+    return hit;
 }
 
 // Re-pack one attestation's bits into 32-bit words (zero padded, masked to n_use bits); returns popcount.
@@ -603,12 +610,15 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const
     return PE_OK;
 }
 
-int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
-                          uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
-                          uint32_t* out_offsets, uint32_t* out_members)
+// asynchronous = true: pe_compute_committees_async -- nothing is waited for and nothing read back; the kernels go to the
+// state-transition stream, and the engine's stream waits for them before the next batch call reads the table
+static int compute_committees_impl(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
+                                   uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
+                                   uint32_t* out_offsets, uint32_t* out_members, bool asynchronous)
 {
     if (!h || !seed) return PE_ERR_INVALID_ARG;
-    PE_TRY(enter(h));
+    if (asynchronous) (void)hipSetDevice(h->device);
+    else PE_TRY(enter(h));
     HostLap lap(&h->trace);
     if (n_committees == 0 || n_committees % h->cfg.slots_per_epoch != 0)
         return fail(h, PE_ERR_INVALID_ARG, "n_committees must be a positive multiple of SLOTS_PER_EPOCH");
@@ -645,9 +655,84 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
         } else {
             t = &*std::min_element(h->tables.begin(), h->tables.end(),
                                    [](const CommitteeTable& a, const CommitteeTable& b) { return a.stamp < b.stamp; });
+            if (asynchronous) {
+                // the least recently used table is rewritten in place: work still in flight must not be reading it.  A
+                // pipeline notes the stamp counter at its begin; a table stamped after the oldest pipeline in flight
+                // began may be one of its tables -- then everything in flight completes first (a caller that streams
+                // with lag depth L keeps at least L + 3 tables and never gets here)
+                uint64_t oldest = h->table_stamp + 1;
+                for (int k = 0; k < h->n_arenas; ++k) {
+                    const pe_engine::PipeArena& a = h->arena[k];
+                    if (a.fenced || !a.pending.empty()) oldest = std::min(oldest, a.table_stamp_at_begin);
+                }
+                if (t->stamp >= oldest) PE_TRY(flush_pending(h));
+            }
         }
     }
+    // an earlier asynchronous shuffle into this slot (its staging pair and the table's arrays are about to be rewritten):
+    // let it finish; a completed or never recorded event returns at once
+    if (t->ev_ready) HIP_TRY(h, hipEventSynchronize(t->ev_ready));
+    t->ready_pending = false;
     const uint32_t nb = (n_active + 255) / 256;
+    if (asynchronous) {
+        // Nothing of this call touches the pipelines' arenas or the engine's stream: the table carries its own small
+        // staging pair (seed | offsets | active indices), the shuffle has its own stream and scratch, and the table's
+        // event is what a later reader waits for (find_table).
+        if (!h->prep_stream) {
+            // the runtime maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order,
+            // and streams that share a queue run in order: POSEVO_PREP_SLOT skips that many slots first
+            static const int skip = [] { const char* e = getenv("POSEVO_PREP_SLOT"); return e ? atoi(e) : 0; }();
+            for (int k = 0; k < skip; ++k) { hipStream_t dummy; (void)hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking); }
+            static const int prio = [] { const char* e = getenv("POSEVO_PREP_PRIO"); return e ? atoi(e) : 0; }();
+            if (prio) {  // -1: the lowest priority the device offers, 1: the highest (each has hardware queues of its own)
+                int least = 0, greatest = 0;
+                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+                HIP_TRY(h, hipStreamCreateWithPriority(&h->prep_stream, hipStreamNonBlocking, prio < 0 ? least : greatest));
+            } else {
+                HIP_TRY(h, hipStreamCreateWithFlags(&h->prep_stream, hipStreamNonBlocking));
+            }
+        }
+        const size_t o_seed = 0, o_offs = 64, o_idx = (64 + 4ull * (n_committees + 1) + 63) & ~size_t(63);
+        const size_t bytes = o_idx + (identity ? 0 : 4ull * n_active) + 64;
+        HIP_TRY(h, t->h_stage.ensure(bytes));
+        HIP_TRY(h, t->d_stage.ensure(bytes));
+        uint8_t* hs = t->h_stage.as<uint8_t>();
+        uint32_t* sw = reinterpret_cast<uint32_t*>(hs + o_seed);
+        for (int i = 0; i < 8; ++i)
+            sw[i] = ((uint32_t)seed[4 * i] << 24) | ((uint32_t)seed[4 * i + 1] << 16) | ((uint32_t)seed[4 * i + 2] << 8) | seed[4 * i + 3];
+        memcpy(hs + o_offs, offsets.data(), 4ull * (n_committees + 1));
+        if (!identity && n_active) memcpy(hs + o_idx, active_indices, 4ull * n_active);
+        HIP_TRY(h, t->d_members.ensure(std::max<size_t>(64, 4ull * n_active)));
+        HIP_TRY(h, t->d_offsets.ensure(4ull * (n_committees + 1)));
+        HIP_TRY(h, h->d_shuffle_scratch.ensure(std::max<size_t>(64, 32ull * nb * shuffle_round_count + 4ull * shuffle_round_count + 64)));
+        if (h->n_val) {
+            HIP_TRY(h, t->d_inv_comm.ensure(4ull * h->n_val));
+            HIP_TRY(h, t->d_inv_pos.ensure(4ull * h->n_val));
+        }
+        hipStream_t ps = h->prep_stream;
+        uint8_t* ds = t->d_stage.as<uint8_t>();
+        HIP_TRY(h, hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, ps));
+        uint32_t* d_source = h->d_shuffle_scratch.as<uint32_t>();
+        uint32_t* d_pivots = d_source + 8ull * nb * shuffle_round_count;
+        launch_shuffle(ps, reinterpret_cast<uint32_t*>(ds + o_seed), n_active, shuffle_round_count, d_source, d_pivots,
+                       identity ? nullptr : reinterpret_cast<uint32_t*>(ds + o_idx), t->d_members.as<uint32_t>());
+        HIP_TRY(h, hipMemcpyAsync(t->d_offsets.p, ds + o_offs, 4ull * (n_committees + 1), hipMemcpyDeviceToDevice, ps));
+        if (h->n_val)
+            launch_invert_committees(ps, t->d_members.as<uint32_t>(), t->d_offsets.as<uint32_t>(), n_committees,
+                                     t->d_inv_comm.as<uint32_t>(), t->d_inv_pos.as<uint32_t>(), h->n_val);
+        HIP_TRY(h, hipGetLastError());
+        if (!t->ev_ready) HIP_TRY(h, hipEventCreateWithFlags(&t->ev_ready, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(t->ev_ready, ps));
+        t->ready_pending = true;  // find_table makes the engine's stream wait before the table is read
+        t->epoch = epoch;
+        t->n_committees = n_committees;
+        t->offsets.swap(offsets);
+        t->is_partition = true;
+        t->n_val_at_load = h->n_val;
+        t->stamp = ++h->table_stamp;
+        lap.mark("comm.async_launch");
+        return PE_OK;
+    }
     Stage st(h);
     PE_TRY(st.reserve(64 + (identity ? 0 : 4ull * n_active) + 4ull * (n_committees + 1) + 1024));
     const size_t off_seed = st.alloc(32);
@@ -662,16 +747,17 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
     HIP_TRY(h, t->d_offsets.ensure(4ull * (n_committees + 1)));
     HIP_TRY(h, h->d_tmp_be.ensure(std::max<size_t>(64, 32ull * nb * shuffle_round_count + 4ull * shuffle_round_count + 64)));
     HIP_TRY(h, st.upload());
+    hipStream_t cs = h->stream;
     uint32_t* d_source = h->d_tmp_be.as<uint32_t>();
     uint32_t* d_pivots = d_source + 8ull * nb * shuffle_round_count;
-    launch_shuffle(h->stream, st.dev<uint32_t>(off_seed), n_active, shuffle_round_count, d_source, d_pivots,
+    launch_shuffle(cs, st.dev<uint32_t>(off_seed), n_active, shuffle_round_count, d_source, d_pivots,
                    identity ? nullptr : st.dev<uint32_t>(off_idx), t->d_members.as<uint32_t>());
     HIP_TRY(h, hipMemcpyAsync(t->d_offsets.p, st.dev<uint32_t>(off_offs), 4ull * (n_committees + 1),
-                              hipMemcpyDeviceToDevice, h->stream));
+                              hipMemcpyDeviceToDevice, cs));
     if (h->n_val) {
         HIP_TRY(h, t->d_inv_comm.ensure(4ull * h->n_val));
         HIP_TRY(h, t->d_inv_pos.ensure(4ull * h->n_val));
-        launch_invert_committees(h->stream, t->d_members.as<uint32_t>(), t->d_offsets.as<uint32_t>(), n_committees,
+        launch_invert_committees(cs, t->d_members.as<uint32_t>(), t->d_offsets.as<uint32_t>(), n_committees,
                                  t->d_inv_comm.as<uint32_t>(), t->d_inv_pos.as<uint32_t>(), h->n_val);
     }
     HIP_TRY(h, hipGetLastError());
@@ -697,6 +783,20 @@ int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], 
     t->stamp = ++h->table_stamp;
     lap.mark("comm.4_outputs");
     return PE_OK;
+}
+
+int pe_compute_committees(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
+                          uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
+                          uint32_t* out_offsets, uint32_t* out_members)
+{
+    return compute_committees_impl(h, epoch, seed, active_indices, n_active, n_committees, shuffle_round_count, out_offsets,
+                                   out_members, false);
+}
+int pe_compute_committees_async(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
+                                uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count)
+{
+    return compute_committees_impl(h, epoch, seed, active_indices, n_active, n_committees, shuffle_round_count, nullptr,
+                                   nullptr, true);
 }
 
 // ---------------------------------------------------------------- get_head

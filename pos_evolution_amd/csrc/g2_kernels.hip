@@ -405,4 +405,109 @@ void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* 
                        out_be192);
 }
 
+// ---------------------------------------------------------------- subgroup check
+// r * P == infinity for every decoded point (is_valid_indexed_attestation, pe:736 / pe:976, presumes signatures in G2:
+// a point of the curve outside the r-torsion is not a BLSSignature).  Lane pair per point, left-to-right double-and-add
+// over the 255 bits of r (uniform control flow: r is a constant), mixed adds of the affine input.  ~6.4 k Montgomery
+// products per lane: an explicit validation step (PE_SIG_CHECK_SUBGROUP), not part of the default hot path.
+// status[i]: 0 stays 0 when the point is in G2 (or is infinity), becomes 3 otherwise; non-zero entries are left alone.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_g2_subgroup_check(const uint32_t* __restrict__ pts, uint64_t n, int32_t* __restrict__ status)
+{
+    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = lane >> 1;
+    const bool role = lane & 1;
+    if (i >= n) return;
+    if (status[i] != 0) return;  // both lanes of the pair read the same word
+    fp px, py;
+    const uint32_t* p = pts + 48ull * i + (role ? 12 : 0);
+    ld12(px, p);
+    ld12(py, p + 24);
+    if (pair_and(fp_is_zero(px) && fp_is_zero(py))) return;  // infinity: in every subgroup
+    // r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, most significant word first
+    const uint32_t R[8] = {0x73EDA753u, 0x299D7D48u, 0x3339D808u, 0x09A1D805u, 0x53BDA402u, 0xFFFE5BFEu, 0xFFFFFFFFu, 0x00000001u};
+    g2x acc;
+    g2x_set_inf(acc);
+    g2x_add_affine(acc, px, py, false, role);  // the leading one of r (bit 254)
+    for (int w = 0; w < 8; ++w) {
+        for (int b = (w == 0 ? 29 : 31); b >= 0; --b) {  // word 0 holds bits 254 .. 224: bit 254 = its bit 30
+            acc = g2x_double(acc, role);
+            if ((R[w] >> b) & 1u) g2x_add_affine(acc, px, py, false, role);
+        }
+    }
+    if (!g2x_is_inf(acc) && !role) status[i] = 3;
+}
+
+void launch_g2_subgroup_check(hipStream_t s, const uint32_t* points_mont48, uint64_t n, int32_t* status)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_g2_subgroup_check, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, points_mont48, n, status);
+}
+
+// ---------------------------------------------------------------- the signature leg of pe_aggregate
+// bls.Aggregate (pe:659, pe:714-717) per aggregate: group g's signature = the sum of its members' signature points,
+// members listed by input row (member_row[list_start .. + n_atts), the lists the bitfield union runs over).  One lane
+// pair per group: an epoch's partial aggregates are a handful per committee, so the run is a few dependent mixed adds
+// and one normalisation deep -- latency-sized, on the state-transition stream beside everything else.  Output: the
+// 96-byte COMPRESSED BLSSignature (x.c1 | x.c0, flag bits: 0x80 compressed, 0x40 infinity, 0x20 y is the larger root)
+// and bad[g] = number of members whose signature did not decode (status != 0; they are left out of the sum -- the caller
+// clears PE_ATT_FLAG_SIGNATURE_VALID on the row).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_g2_aggregate_rows(const uint32_t* __restrict__ pts, const int32_t* __restrict__ status,
+                    const UnionGroup* __restrict__ ug, const uint32_t* __restrict__ member_row, uint32_t n_groups,
+                    const AttPlan* __restrict__ plan_dev, uint8_t* __restrict__ out96, uint32_t* __restrict__ out_bad)
+{
+    if (plan_dev) n_groups = plan_dev->n_groups;
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = lane >> 1;
+    const bool role = lane & 1;
+    if (g >= n_groups) return;
+    const UnionGroup u = ug[g];
+    g2x acc;
+    g2x_set_inf(acc);
+    uint32_t bad = 0;
+    for (uint32_t j = 0; j < u.n_atts; ++j) {
+        const uint32_t row = member_row[u.list_start + j];
+        if (status[row] != 0) { ++bad; continue; }
+        fp qx, qy;
+        const uint32_t* p = pts + 48ull * row + (role ? 12 : 0);
+        ld12(qx, p);
+        ld12(qy, p + 24);
+        const bool q_inf = pair_and(fp_is_zero(qx) && fp_is_zero(qy));
+        g2x_add_affine(acc, qx, qy, q_inf, role);
+    }
+    if (!role) out_bad[g] = bad;
+    uint8_t* o = out96 + 96ull * g;
+    uint8_t* ox = o + (role ? 0 : 48);  // wire order: x.c1 | x.c0 -- role 1 (c1) writes the leading 48 bytes
+    if (g2x_is_inf(acc)) {
+        uint32_t* wx = reinterpret_cast<uint32_t*>(ox);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) wx[j] = 0;
+        if (role) o[0] = 0xC0;
+        return;
+    }
+    fp x, y;
+    g2x_to_affine_plain(x, y, acc, role);  // plain residues: this lane's component of x and of y
+    // y > -y on (c1, c0): c1 decides unless it is zero
+    const bool mine_larger = limbs_gt(y, FP_HALF);
+    const bool mine_zero = fp_is_zero(y);
+    const bool other_larger = __shfl_xor((int)mine_larger, 1, 64) != 0;
+    const bool other_zero = __shfl_xor((int)mine_zero, 1, 64) != 0;
+    const bool c1_zero = role ? mine_zero : other_zero;
+    const bool c1_larger = role ? mine_larger : other_larger;
+    const bool c0_larger = role ? other_larger : mine_larger;
+    const bool sign = c1_zero ? c0_larger : c1_larger;
+    fp_store_be48(ox, x);
+    if (role) o[0] |= (uint8_t)(0x80 | (sign ? 0x20 : 0));
+}
+
+void launch_g2_aggregate_rows(hipStream_t s, const uint32_t* points_mont48, const int32_t* status, const UnionGroup* ug,
+                              const uint32_t* member_row, uint32_t n_groups, const AttPlan* plan_dev, uint8_t* out96,
+                              uint32_t* out_bad)
+{
+    if (n_groups == 0) return;
+    hipLaunchKernelGGL(k_g2_aggregate_rows, dim3((2 * n_groups + 63) / 64), dim3(64), 0, s, points_mont48, status, ug,
+                       member_row, n_groups, plan_dev, out96, out_bad);
+}
+
 }  // namespace posevo

@@ -263,6 +263,15 @@ void launch_g2_decompress(hipStream_t s, const uint8_t* in96, uint64_t n, uint32
                           int32_t* status);
 void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* groups, uint32_t n_groups,
                       uint8_t* out_be192);
+// r * P == infinity per decoded point: status 0 -> 3 where it fails (non-zero entries are left alone)
+void launch_g2_subgroup_check(hipStream_t s, const uint32_t* points_mont48, uint64_t n, int32_t* status);
+// the signature leg of pe_aggregate: per group the sum of its members' signature points (rows member_row[list_start ..
+// + n_atts) of `ug`), compressed to the 96-byte BLSSignature wire form; out_bad[g] = members that did not decode
+struct UnionGroup;
+struct AttPlan;
+void launch_g2_aggregate_rows(hipStream_t s, const uint32_t* points_mont48, const int32_t* status, const UnionGroup* ug,
+                              const uint32_t* member_row, uint32_t n_groups, const AttPlan* plan_dev, uint8_t* out96,
+                              uint32_t* out_bad);
 
 // get_indexed_attestation: sorted attesting indices per row, written at out_offsets[row] (committees <= 8192 members)
 void launch_indexed_attestations(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,

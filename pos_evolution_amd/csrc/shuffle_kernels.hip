@@ -116,6 +116,122 @@ k_shuffle_indices(const uint32_t* __restrict__ source, const uint32_t* __restric
     members[i] = indices ? indices[index] : index;
 }
 
+// The same walk with each round's table in LDS.  The global-memory form above is bound by L2 line requests: every lane
+// of a wave reads 4 bytes of a different 128-byte line (after a few rounds the 64 indices of a wave are spread over the
+// whole list), 94 M requests per 1 M validators x 90 rounds = 0.3 ms.  But a round touches only HALF of its table:
+//   index <= pivot: flip = pivot - index          -> position = max(index, flip) in [ceil(pivot / 2), pivot]
+//   index >  pivot: flip = pivot + n - index      -> position                     in [ceil((pivot + n) / 2), n - 1]
+// two contiguous ranges of n / 2 positions together = n / 16 bytes of hashes (64 KB per 1 M validators).  One workgroup
+// of 1024 lanes x PER indices copies those two ranges into LDS with coalesced 16-byte loads (4x fewer line requests
+// than the gather, all of them full lines that the workgroups of an XCD share in its L2), looks its indices up there,
+// and goes on to the next round: 2 barriers per round.  Same arithmetic, same result.
+constexpr int SHUF_WG = 1024;
+constexpr size_t SHUF_LDS_CAP = 96 * 1024;
+constexpr int SHUF_NQ = (int)(SHUF_LDS_CAP / 16 / SHUF_WG);  // 16-byte pieces of a round's table per lane: 6
+
+// the two block ranges a round reads, in 256-position blocks
+struct ShufRanges { uint32_t a0, len_a, b0, len_b; };
+__device__ __forceinline__ ShufRanges shuffle_ranges(uint32_t pivot, uint32_t n)
+{
+    ShufRanges g;
+    g.a0 = ((pivot + 1) >> 1) >> 8;                                  // [ceil(pivot / 2), pivot]
+    g.len_a = (pivot >> 8) - g.a0 + 1;
+    const uint32_t lo_b = (uint32_t)(((uint64_t)pivot + n + 1) >> 1);  // [ceil((pivot + n) / 2), n - 1]
+    g.b0 = min(lo_b, n - 1) >> 8;
+    g.len_b = ((n - 1) >> 8) - g.b0 + 1;
+    return g;
+}
+
+// 16-byte pieces of a round's two ranges in registers: SHUF_NQ = 6 named values per lane (an indexed array, even with
+// constant indices after unrolling, was kept in scratch memory by the compiler: 208 B per lane and a 3x slower kernel)
+struct ShufPieces { uint4 v0, v1, v2, v3, v4, v5; };
+static_assert(SHUF_NQ == 6, "ShufPieces holds six pieces");
+
+__device__ __forceinline__ uint4 shuffle_piece(const uint4* __restrict__ src, const ShufRanges& g, uint32_t qa,
+                                               uint32_t total, int j)
+{
+    const uint32_t q = min(threadIdx.x + j * SHUF_WG, total - 1);  // clamped: an unconditional load of a valid piece
+    return src[q < qa ? 2 * (uint64_t)g.a0 + q : 2 * (uint64_t)g.b0 + (q - qa)];
+}
+__device__ __forceinline__ ShufPieces shuffle_prefetch(const uint32_t* __restrict__ source,
+                                                       const uint32_t* __restrict__ pivots, uint32_t r, uint32_t n,
+                                                       uint32_t n_blocks256)
+{
+    const ShufRanges g = shuffle_ranges(pivots[r], n);
+    const uint4* src = reinterpret_cast<const uint4*>(source + (uint64_t)r * n_blocks256 * 8);
+    const uint32_t qa = 2 * g.len_a, total = qa + 2 * g.len_b;  // 2 x uint4 per 32-byte block
+    ShufPieces p;
+    p.v0 = shuffle_piece(src, g, qa, total, 0);
+    p.v1 = shuffle_piece(src, g, qa, total, 1);
+    p.v2 = shuffle_piece(src, g, qa, total, 2);
+    p.v3 = shuffle_piece(src, g, qa, total, 3);
+    p.v4 = shuffle_piece(src, g, qa, total, 4);
+    p.v5 = shuffle_piece(src, g, qa, total, 5);
+    return p;
+}
+
+template <int PER>
+__device__ __forceinline__ void shuffle_round(const ShufPieces p, uint32_t (&index)[PER], uint32_t* tab,
+                                              uint32_t pivot, uint32_t n)
+{
+    const ShufRanges g = shuffle_ranges(pivot, n);
+    const uint32_t total = 2 * (g.len_a + g.len_b);
+    uint4* dst = reinterpret_cast<uint4*>(tab);
+    const uint32_t t = threadIdx.x;
+    if (t < total) dst[t] = p.v0;
+    if (t + SHUF_WG < total) dst[t + SHUF_WG] = p.v1;
+    if (t + 2 * SHUF_WG < total) dst[t + 2 * SHUF_WG] = p.v2;
+    if (t + 3 * SHUF_WG < total) dst[t + 3 * SHUF_WG] = p.v3;
+    if (t + 4 * SHUF_WG < total) dst[t + 4 * SHUF_WG] = p.v4;
+    if (t + 5 * SHUF_WG < total) dst[t + 5 * SHUF_WG] = p.v5;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t idx = index[k];
+        uint32_t flip = pivot + n - idx;
+        if (flip >= n) flip -= n;
+        const uint32_t position = min(max(idx, flip), n - 1);  // idx >= n (padding lanes) stays harmless
+        const uint32_t blk = position >> 8;
+        const uint32_t lb = position <= pivot ? blk - g.a0 : g.len_a + (blk - g.b0);
+        const uint32_t byte_idx = (position & 255u) >> 3;
+        const uint32_t word = tab[lb * 8 + (byte_idx >> 2)];
+        const uint32_t byte = (word >> (8 * (3 - (byte_idx & 3)))) & 0xffu;
+        index[k] = (idx < n && ((byte >> (position & 7u)) & 1u)) ? flip : idx;
+    }
+}
+
+template <int PER>
+__global__ void __launch_bounds__(SHUF_WG)
+k_shuffle_indices_lds(const uint32_t* __restrict__ source, const uint32_t* __restrict__ pivots, uint32_t n,
+                      uint32_t n_blocks256, uint32_t rounds, const uint32_t* __restrict__ indices,
+                      uint32_t* __restrict__ members)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];  // [blocks of range A | blocks of range B] x 8 words
+    const uint32_t base = blockIdx.x * (SHUF_WG * PER) + threadIdx.x;
+    uint32_t index[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) index[k] = base + k * SHUF_WG;  // lane-contiguous per k: coalesced final store
+    // The tables of the next TWO rounds travel from L2 into registers while this round's lookups run from LDS: a round
+    // costs an LDS write, two barriers and PER lookups instead of an exposed L2 round trip.
+    ShufPieces p0 = shuffle_prefetch(source, pivots, 0, n, n_blocks256);
+    ShufPieces p1 = shuffle_prefetch(source, pivots, rounds > 1 ? 1 : 0, n, n_blocks256);
+    for (uint32_t r = 0; r < rounds; r += 2) {
+        shuffle_round<PER>(p0, index, tab, pivots[r], n);
+        p0 = shuffle_prefetch(source, pivots, min(r + 2, rounds - 1), n, n_blocks256);
+        __syncthreads();  // the table is overwritten by the next round
+        if (r + 1 < rounds) {
+            shuffle_round<PER>(p1, index, tab, pivots[r + 1], n);
+            p1 = shuffle_prefetch(source, pivots, min(r + 3, rounds - 1), n, n_blocks256);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const uint32_t i = base + k * SHUF_WG;
+        if (i < n) members[i] = indices ? indices[index[k]] : index[k];
+    }
+}
+
 int launch_shuffle(hipStream_t s, const uint32_t* d_seed_be, uint32_t n, uint32_t rounds, uint32_t* d_source,
                    uint32_t* d_pivots, const uint32_t* d_indices, uint32_t* d_members)
 {
@@ -125,6 +241,20 @@ int launch_shuffle(hipStream_t s, const uint32_t* d_seed_be, uint32_t n, uint32_
     if (hashes)
         hipLaunchKernelGGL(k_shuffle_tables, dim3((unsigned)((hashes + 255) / 256)), dim3(256), 0, s, d_seed_be, n, nb,
                            rounds, d_source, d_pivots);
+    // the LDS form needs n / 16 bytes (+ the ragged ends) of LDS: up to ~1.5 M indices inside 96 KB; larger lists and
+    // POSEVO_SHUFFLE_LDS=0 take the gather
+    static const bool lds_ok = [] { const char* e = getenv("POSEVO_SHUFFLE_LDS"); return !e || atoi(e) != 0; }();
+    const size_t lds_bytes = 32ull * ((size_t)nb / 2 + 4);
+    constexpr size_t LDS_CAP = SHUF_LDS_CAP;
+    if (lds_ok && lds_bytes <= LDS_CAP && n >= 4096 && rounds > 0) {
+        constexpr int PER = 4;
+        if (first_use_on_this_device<4242>())
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_shuffle_indices_lds<PER>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP);
+        hipLaunchKernelGGL(k_shuffle_indices_lds<PER>, dim3((n + SHUF_WG * PER - 1) / (SHUF_WG * PER)), dim3(SHUF_WG), lds_bytes,
+                           s, d_source, d_pivots, n, nb, rounds, d_indices, d_members);
+        return 0;
+    }
     hipLaunchKernelGGL(k_shuffle_indices, dim3((n + 255) / 256), dim3(256), 0, s, d_source, d_pivots, n, nb, rounds,
                        d_indices, d_members);
     return 0;

@@ -191,9 +191,11 @@ class ResidentAggregateResult(dict):
                 off, nbits = int(a["bits_offset"]), int(a["n_bits"])
                 out.append(np.unpackbits(arena[off:off + (nbits + 7) // 8], bitorder="little")[:nbits].astype(bool))
             return out
-        if key in ("atts", "aggpk96", "count"):
-            v = raw[key]
+        if key in ("atts", "aggpk96", "count", "sig96c"):
+            v = raw.get(key)
             return None if v is None else v[:g]
+        if key == "sig_status":
+            return raw.get(key)
         return dict.__getitem__(self, key)
 
 
@@ -432,6 +434,15 @@ class Engine:
                                                     _ptr(mem, C.c_uint32)))
         return (off, mem[:n_act]) if want_result else None
 
+    def compute_committees_async(self, epoch: int, seed: bytes, n_active: int, n_committees: int,
+                                 shuffle_round_count: int = 90):
+        """pe_compute_committees_async over validators 0 .. n_active - 1: enqueued on the state-transition stream, nothing
+        waited for or read back; the table is usable by the calls that follow."""
+        rc = self._lib.pe_compute_committees_async(self._h, epoch, _root(seed), None, int(n_active), n_committees,
+                                                   shuffle_round_count)
+        if rc:
+            self._check(rc)
+
     # -- hot path ---------------------------------------------------------
     def get_head(self) -> bytes:
         out = (C.c_uint8 * 32)()
@@ -554,6 +565,44 @@ class Engine:
         return AggregateResult(n_groups=g, atts=out_atts[:g], group_of=group_of[:n], out_arena=out_arena,
                                sig96=None if out_sig is None else out_sig[:g], sig192=sig192,
                                aggpk96=None if out_pk is None else out_pk[:g], count=count[:g])
+
+    def aggregate_signed(self, signatures, rows=None, packed=None, compressed: bool = True, check_subgroup: bool = False,
+                         want_aggregate_pubkeys: bool = False):
+        """pe_aggregate_signed: pe_aggregate plus bls.Aggregate over the members' BLSSignatures (pe:659, pe:714-717).
+        signatures: (n, 96) compressed or (n, 192) uncompressed uint8 (or a DeviceArena holding them).  -> the aggregate
+        result with ``sig96c`` ((groups, 96) uint8: the compressed aggregate signature of every group) and ``sig_status``
+        (int32[n]: PE_SIG_* per input row).  Host rows or DeviceRows, synchronous or inside a pipeline, as aggregate()."""
+        arr, arena = packed if packed is not None else pack_attestations(rows)
+        n = len(rows) if rows is not None else len(arr)
+        m = max(n, 1)
+        fmt = (_abi.PE_SIG_G2_COMPRESSED if compressed else _abi.PE_SIG_G2_UNCOMPRESSED) | (
+            _abi.PE_SIG_CHECK_SUBGROUP if check_subgroup else 0)
+        sig = signatures if signatures.__class__ is DeviceArena else np.ascontiguousarray(signatures, dtype=np.uint8)
+        assert sig.size == (96 if compressed else 192) * n, "one signature per input row"
+        dev = arr.__class__ is DeviceRows
+        (out_atts, group_of, out_arena, out_pk, count, ng, osig, sst), (p_atts, p_gof, p_arena, p_pk, p_count, p_ng, p_osig,
+                                                                       p_sst) = self._outs(
+            "saggd" if dev else "sagg", ((m, _ATT_DTYPE), (m, _U32), (max(arena.size, 1), _U8),
+                                         ((m, 96), _U8) if want_aggregate_pubkeys else None, (m, _U32), (1, _U32),
+                                         ((m, 96), _U8), (m, _I32)))
+        ng[0] = 0
+        if self._pipe_keep is not None:
+            self._pipe_keep.append((arr, arena, sig, out_atts, group_of, out_arena, out_pk, count, ng, osig, sst))
+        rc = self._lib.pe_aggregate_signed(self._h, arr.ptr if dev else _att_ptr(arr), n, _ptr(arena, C.c_uint8), arena.size,
+                                           _ptr(sig, C.c_uint8), fmt, p_atts, p_ng, p_gof, p_arena, out_arena.size, p_osig,
+                                           p_sst, p_pk, p_count)
+        if rc:
+            self._check(rc)
+        return ResidentAggregateResult(_raw=dict(n_groups=ng, atts=out_atts, group_of=group_of, out_arena=out_arena,
+                                                 aggpk96=out_pk, count=count, sig96c=osig, sig_status=sst[:n]),
+                                       sig96=None, sig192=None)
+
+    def g2_subgroup_check(self, points192) -> np.ndarray:
+        """pe_g2_subgroup_check: int32[n], 0 = in G2 (r * P = infinity), 3 = not."""
+        pts = np.ascontiguousarray(points192, dtype=np.uint8).reshape(-1, 192)
+        st = np.zeros(max(len(pts), 1), dtype=np.int32)
+        self._check(self._lib.pe_g2_subgroup_check(self._h, _ptr(pts, C.c_uint8), len(pts), _ptr(st, C.c_int32)))
+        return st[:len(pts)]
 
     def process_attestation_batch(self, state_ctx: pe_state_ctx, rows=None, packed=None, cap: int = 0):
         """-> (status int32[n], proposer_reward_numerator uint64[n]).  ``packed=(ROWS_RESIDENT, RESIDENT), cap=c`` as for

@@ -139,3 +139,109 @@ def test_g2_decompress_vs_oracle(engine_factory):
     # wire-to-wire: compressed signatures in, compressed aggregate out
     agg = e.g2_compress(e.g2_sum(e.g2_decompress(comp[:64])[0], [0, 64]))[0].tobytes()
     assert agg == g2.compress(g2.sum_points(pts[:64]))
+
+
+# ---------------------------------------------------------------- the signature leg of pe_aggregate (pe_aggregate_signed)
+R_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def _off_subgroup_point():
+    """A point of E'(Fp2) outside G2: decode small x values until one lies on the curve (no cofactor clearing)."""
+    x0 = 1
+    while True:
+        b = bytearray((0).to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        b[0] |= 0x80
+        try:
+            p = g2.decompress(bytes(b))
+        except ValueError:
+            x0 += 1
+            continue
+        if g2.mul(R_ORDER, p) is not None:
+            return p
+        x0 += 1
+
+
+def _off_curve_x():
+    x0 = 1
+    while True:
+        b = bytearray((0).to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        b[0] |= 0x80
+        try:
+            g2.decompress(bytes(b))
+        except ValueError:
+            return bytes(b)
+        x0 += 1
+
+
+@pytest.mark.parametrize("rows_mode", ["host", "device"])
+@pytest.mark.parametrize("compressed", [True, False])
+def test_aggregate_signed_vs_oracle(engine_factory, rows_mode, compressed):
+    """bls.Aggregate as a leg of pe_aggregate through the C ABI: per group the sum of its members' BLSSignatures in the
+    compressed wire form, against oracle/g2.py's closed form; undecodable / off-curve / off-subgroup members are
+    reported per row, left out of the sum, and cost the group its PE_ATT_FLAG_SIGNATURE_VALID."""
+    import pos_evolution_amd as pea
+    from pos_evolution_amd import _abi
+    from tests.test_gpu_pipeline import _world
+    from tests.test_gpu_resident_rows import _dev_arena, _dev_rows
+
+    w = _world(engine_factory, 6000, 64, seed=3, density=0.8, parts=3)
+    e, atts, arena = w["e"], w["atts"], w["arena"]
+    n = len(atts)
+    a, b = 0xABCDEF12345, 0x1357
+    pts = g2.synthetic_points(n, a, b)          # signature of row i = (a + i * b) * G2
+    off_sub = _off_subgroup_point()
+    bad = {5: "malformed", 9: "off_curve", 11: "off_subgroup", 40: "infinity"} if compressed else {11: "off_subgroup", 40: "infinity"}
+    wire = []
+    for i, p in enumerate(pts):
+        kind = bad.get(i)
+        if kind == "off_subgroup":
+            p = off_sub
+        elif kind == "infinity":
+            p = None
+        enc = bytearray(g2.compress(p) if compressed else g2.to_bytes192(p))
+        if kind == "malformed":
+            enc[0] &= 0x7F                       # the compression bit cleared
+        elif kind == "off_curve":
+            enc = bytearray(_off_curve_x())
+        wire.append(bytes(enc))
+    sigs = np.frombuffer(b"".join(wire), dtype=np.uint8).reshape(n, -1)
+    packed = (_dev_rows(atts), _dev_arena(arena)) if rows_mode == "device" else (atts, arena)
+    ref = e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+    res = e.aggregate_signed(sigs, packed=packed, compressed=compressed, check_subgroup=True, want_aggregate_pubkeys=True)
+    g = res["n_groups"]
+    assert g == ref["n_groups"] and np.array_equal(res["group_of"][:n], ref["group_of"])
+    assert np.array_equal(res["aggpk96"], ref["aggpk96"]) and np.array_equal(res["count"], ref["count"])
+    want_st = np.zeros(n, dtype=np.int32)
+    for i, kind in bad.items():
+        want_st[i] = {"malformed": 1, "off_curve": 2, "off_subgroup": 3, "infinity": 0}[kind]
+    assert np.array_equal(res["sig_status"], want_st)
+    gof = np.asarray(ref["group_of"])
+    for k in range(g):
+        members = np.nonzero(gof == k)[0]
+        good = [int(i) for i in members if want_st[i] == 0 and bad.get(int(i)) != "infinity"]
+        exp = g2.mul((a * len(good) + b * sum(good)) % R_ORDER, g2.G2) if good else None
+        assert res["sig96c"][k].tobytes() == g2.compress(exp), f"group {k}"
+        valid = bool(res["atts"][k]["flags"] & _abi.PE_ATT_FLAG_SIGNATURE_VALID)
+        was_valid = bool(ref["atts"][k]["flags"] & _abi.PE_ATT_FLAG_SIGNATURE_VALID)
+        assert valid == (was_valid and all(want_st[i] == 0 for i in members)), f"group {k}: signature-valid flag"
+    # the same inside a pipeline: outputs complete at its end
+    with e.pipeline():
+        res2 = e.aggregate_signed(sigs, packed=packed, compressed=compressed, check_subgroup=True)
+    assert np.array_equal(res2["sig96c"], res["sig96c"]) and np.array_equal(res2["sig_status"], want_st)
+    # without the subgroup check the off-subgroup member is summed like any curve point
+    res3 = e.aggregate_signed(sigs, packed=packed, compressed=compressed, check_subgroup=False)
+    k = int(gof[11])
+    members = np.nonzero(gof == k)[0]
+    good = [int(i) for i in members if want_st[i] in (0, 3) and bad.get(int(i)) not in ("infinity", "off_subgroup")]
+    exp = g2.add(g2.mul((a * len(good) + b * sum(good)) % R_ORDER, g2.G2), off_sub)
+    assert res3["sig_status"][11] == 0 and res3["sig96c"][k].tobytes() == g2.compress(exp)
+
+
+def test_g2_subgroup_check(engine_factory):
+    e = engine_factory()
+    good = g2.synthetic_points(9, 77, 5)
+    off = _off_subgroup_point()
+    pts = _rows(good[:4] + [off, None] + good[4:] + [g2.double(off)])
+    st = e.g2_subgroup_check(pts)
+    want = [0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 3]
+    assert st.tolist() == want
