@@ -163,7 +163,11 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
     const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
     uint64_t blocks = (n_quads + VOTES_WG - 1) / VOTES_WG;
     // Grid-stride over few, fat workgroups: every workgroup zeroes, scans and flushes a whole n_blocks histogram, so
-    // at 1 M validators 64 workgroups (16 K validators each) beat 256 (k_votes 16 us vs 23 us, get_head p50 46 vs 53 us);
+    // at 1 M validators 64 workgroups (16 K validators each) beat 256 (k_votes 16 us vs 23 us, get_head p50 46 vs 53 us).
+    // Round 3 re-measured the alternatives against the 33.7 us p50 of this shape: eight flush rows (workgroup w adds into
+    // row w % 8, k_tree sums the rows) with 256 workgroups 40.8 us; four quads in flight per lane 30.0 vs 30.2 us (nothing);
+    // k_tree launched BESIDE k_votes on a second stream and released by a device-side ticket 70 us -- the cross-stream
+    // event that keeps the next call ordered costs more than the launch gap it removes (profiles/README.md);
     // the count grows with the registry up to one workgroup per CU.  POSEVO_VOTES_WGS overrides it for tuning.
     static const long forced = [] {
         const char* e = getenv("POSEVO_VOTES_WGS");
@@ -233,6 +237,44 @@ __device__ __forceinline__ void block_exclusive_scan(const T (&item)[TREE_PER_TH
         run += item[k];
     }
     if (tid == TREE_WG - 1 && (uint32_t)(TREE_WG * TREE_PER_THREAD) <= n) out[SK(n)] = run;
+    __syncthreads();
+}
+
+// Two exclusive prefix sums (u64 weights, u32 leaf counts) through ONE pair of barriers.
+template <int TREE_WG, int TREE_PER_THREAD>
+__device__ __forceinline__ void block_exclusive_scan2(const unsigned long long (&a)[TREE_PER_THREAD], unsigned long long* out_a,
+                                                      unsigned long long* wave_a, const uint32_t (&b)[TREE_PER_THREAD],
+                                                      uint32_t* out_b, uint32_t* wave_b, uint32_t n)
+{
+    auto SK = [](uint32_t i) { return SKT<TREE_PER_THREAD>(i); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long la = 0;
+    uint32_t lb = 0;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) { la += a[k]; lb += b[k]; }
+    unsigned long long ia = la;
+    uint32_t ib = lb;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long oa = __shfl_up(ia, off, 64);
+        const uint32_t ob = __shfl_up(ib, off, 64);
+        if (lane >= off) { ia += oa; ib += ob; }
+    }
+    if (lane == 63) { wave_a[wave] = ia; wave_b[wave] = ib; }
+    __syncthreads();
+    unsigned long long base_a = 0;
+    uint32_t base_b = 0;
+    for (int w = 0; w < wave; ++w) { base_a += wave_a[w]; base_b += wave_b[w]; }
+    unsigned long long ra = base_a + ia - la;
+    uint32_t rb = base_b + ib - lb;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        if (i <= n) { out_a[SK(i)] = ra; out_b[SK(i)] = rb; }
+        ra += a[k];
+        rb += b[k];
+    }
+    if (tid == TREE_WG - 1 && (uint32_t)(TREE_WG * TREE_PER_THREAD) <= n) { out_a[SK(n)] = ra; out_b[SK(n)] = rb; }
     __syncthreads();
 }
 
@@ -323,8 +365,7 @@ k_tree(TreeDev tree, uint32_t lds_entries, unsigned long long* __restrict__ dire
             if ((uint32_t)(tid * TREE_PER_THREAD + k) == boost_pos) w_item[k] += boost;
     }
 
-    block_exclusive_scan<unsigned long long, TREE_WG, TREE_PER_THREAD>(w_item, S, wave_tot64, n);
-    block_exclusive_scan<uint32_t, TREE_WG, TREE_PER_THREAD>(l_item, L, wave_tot32, n);
+    block_exclusive_scan2<TREE_WG, TREE_PER_THREAD>(w_item, S, wave_tot64, l_item, L, wave_tot32, n);
 
     unsigned long long W[TREE_PER_THREAD];
     uint32_t viable = 0;
@@ -345,7 +386,7 @@ k_tree(TreeDev tree, uint32_t lds_entries, unsigned long long* __restrict__ dire
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k) {
         const uint32_t i = tid * TREE_PER_THREAD + k;
-        if (i < n) { bestW[SK(i)] = 0; bestRank[SK(i)] = 0; jump[SK(i)] = i; }
+        if (i < n) { bestW[SK(i)] = 0; bestRank[SK(i)] = 0; }
     }
     __syncthreads();
     uint32_t par[TREE_PER_THREAD];
@@ -368,32 +409,53 @@ k_tree(TreeDev tree, uint32_t lds_entries, unsigned long long* __restrict__ dire
     for (int k = 0; k < TREE_PER_THREAD; ++k)
         if (par[k] != NONE32 && W[k] == bestW[SK(par[k])]) atomicMax(&bestRank[SK(par[k])], rk_g[k]);
     __syncthreads();
+    // The descent of pe:1107-1116 without walking: the head is the deepest node of the chain justified root -> best child
+    // -> best child ...  A node lies on that chain iff no ancestor-or-self below the justified root fails to be its
+    // parent's best child.  In pre-order a subtree is the interval [pos, pos + size), so with g(u) = 1 for every node
+    // strictly inside the justified subtree that is NOT the best child of its parent (0 elsewhere), the number of such
+    // ancestors-or-self of position p is the prefix sum of  D[pos(u)] += g(u), D[pos(u) + size(u)] -= g(u)  at p --
+    // one more block scan instead of up to log2(n) rounds of pointer jumping with two barriers each.  Chain nodes have
+    // count 0, their pre-order positions grow downwards: the head is the largest such position inside the subtree.
+    const uint32_t j_end = justified_pos + tree.size[justified_pos];
+    uint32_t* D = jump;            // n + 1 signed counters
+    uint32_t g_item[TREE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        const bool best = par[k] != NONE32 && W[k] == bestW[SK(par[k])] && rk_g[k] == bestRank[SK(par[k])];
+        g_item[k] = (i < n && i > justified_pos && i < j_end && !best) ? 1u : 0u;
+        if (i <= n) D[SK(i)] = g_item[k];   // entry n: only ever decremented
+    }
+    if (tid == TREE_WG - 1 && (uint32_t)(TREE_WG * TREE_PER_THREAD) <= n) D[SK(n)] = 0;
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < TREE_PER_THREAD; ++k)
-        if (par[k] != NONE32 && W[k] == bestW[SK(par[k])] && rk_g[k] == bestRank[SK(par[k])])
-            jump[SK(par[k])] = tid * TREE_PER_THREAD + k;
+        if (g_item[k]) atomicSub(&D[SK(tid * TREE_PER_THREAD + k + sz[k])], 1u);
     __syncthreads();
-    // descent by pointer jumping: after r rounds jump[i] is 2^r best-child steps below i (or the leaf);
-    // stop as soon as the justified root's pointer has reached a fixed point (a leaf of the viable tree)
-    for (uint32_t span = 1; span < n; span <<= 1) {
-        const uint32_t cur = jump[SK(justified_pos)];  // same address for all lanes: broadcast, uniform
-        if (jump[SK(cur)] == cur) break;
-        uint32_t nj[TREE_PER_THREAD];
+    uint32_t d_item[TREE_PER_THREAD];
 #pragma unroll
-        for (int k = 0; k < TREE_PER_THREAD; ++k) {
-            const uint32_t i = tid * TREE_PER_THREAD + k;
-            nj[k] = i < n ? jump[SK(jump[SK(i)])] : 0u;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < TREE_PER_THREAD; ++k) {
-            const uint32_t i = tid * TREE_PER_THREAD + k;
-            if (i < n) jump[SK(i)] = nj[k];
-        }
-        __syncthreads();
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        d_item[k] = i < n ? D[SK(i)] : 0u;
     }
+    uint32_t* C = L;  // bestRank's region: every lane has read it above (the scan's first barrier orders the reuse)
+    block_exclusive_scan<uint32_t, TREE_WG, TREE_PER_THREAD>(d_item, C, wave_tot32, n);
+    uint32_t best_pos = justified_pos;
+#pragma unroll
+    for (int k = 0; k < TREE_PER_THREAD; ++k) {
+        const uint32_t i = tid * TREE_PER_THREAD + k;
+        if (i > justified_pos && i < j_end && i < n && C[SK(i)] + d_item[k] == 0u && ((viable >> k) & 1u)) best_pos = max(best_pos, i);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best_pos = max(best_pos, (uint32_t)__shfl_xor((int)best_pos, off, 64));
+    uint32_t* head_pos = wave_tot32;  // reused: the scan is through with it
+    __syncthreads();
+    if (tid == 0) head_pos[0] = justified_pos;
+    __syncthreads();
+    if ((tid & 63) == 0) atomicMax(&head_pos[0], best_pos);
+    __syncthreads();
     if (tid == 0)  // host-coherent pinned word polled by the host: system-scope release
-        __hip_atomic_store(head_idx, tree.idx_of_pos[jump[SK(justified_pos)]], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(head_idx, tree.idx_of_pos[head_pos[0]], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int WG, int PER, bool LEAN = false>

@@ -1,10 +1,10 @@
-export STEPS=100
-for q in -1 1; do
-POSEVO_PREP_PRIO=$q BENCH_ARGS="--no-verify-steps" bash tools/gpu.sh r03n label:prio$q quick > /dev/null
+K="forkchoice or head or engine or pipeline or edge or shapes or full_size or golden" bash tools/gpu.sh r03q tests
+export STEPS=10
+for q in 2 4; do
+POSEVO_VOTES_QUADS=$q BENCH_ARGS="--no-verify-steps --no-shuffle-variant --head-calls 400" bash tools/gpu.sh r03q label:q$q quick > /dev/null
 python - <<PY
 import json
-d=json.loads(open("gpurun_out/r03n/bench_quick_prio$q.json").read().strip().splitlines()[-1])
-print("prep prio $q", {k:round(d.get(k),4) for k in ("ms_per_step","ms_per_step_with_shuffle")})
+d=json.loads(open("gpurun_out/r03q/bench_quick_q$q.json").read().strip().splitlines()[-1])
+print("quads $q", "p50", round(d["get_head_p50_us"],1), "p99", round(d["get_head_p99_us"],1), "ms/step", round(d["ms_per_step"],3))
 PY
 done
-POSEVO_PREP_PRIO=-1 STEPS=60 BENCH_ARGS="--with-shuffle --no-verify-steps" bash tools/gpu.sh r03n label:wsp timeline | head -45
