@@ -39,14 +39,17 @@ def build_workload(e, args, rank, n_steps_total):
     import pos_evolution_amd.synth as synth
 
     V, B, C, spe = args.validators_local, args.blocks, args.committees, 32
-    seed = 4 + rank  # config 4 of BASELINE.json, per-rank registry
+    by_committee = getattr(args, "by_committee", False)
+    # validator-range shards: a registry of its own per rank; committee shards: the SAME registry, tables and epoch of
+    # attestations on every rank, of which the rank is handed the rows of its own committees
+    seed = 4 if by_committee else 4 + rank  # config 4 of BASELINE.json
     tree = synth.random_tree(B, 4, "bushy")  # the tree is global: same on every rank
     e.store_init(0, 0, tree.roots[0].tobytes())
     for i in range(1, B):
         e.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
     bal = synth.balances(V, seed, mixed=args.mixed_balances)
     flags = synth.validator_flags(V, seed, inactive_frac=0.005)
-    pts = synth.registry_points(e, V, lo=rank * V)
+    pts = synth.registry_points(e, V, lo=0 if by_committee else rank * V)
     e.set_validators(bal, flags, pts)
     epoch0 = int(tree.slot.max()) // spe + 1
     steps = []
@@ -60,8 +63,21 @@ def build_workload(e, args, rank, n_steps_total):
         atts, arena, _ = synth.epoch_attestations(comm, tree, ep, spe, seed=seed, density=0.99, parts=args.parts,
                                                   source=(0, tree.roots[0].tobytes()), vote_recent=64,
                                                   vote_seed=4)  # committee c votes the same block on every shard
-        steps.append(dict(epoch=ep, comm=comm, atts=atts, arena=arena, ep_seed=ep_seed))
-    w = dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe)
+        st = dict(epoch=ep, comm=comm, atts=atts, arena=arena, ep_seed=ep_seed)
+        if by_committee:  # committees [rank * C / N, (rank + 1) * C / N) are this rank's (its attestation subnets)
+            world = getattr(args, "world", 1)
+            cps = C // spe
+            pos = ((atts["slot"] % spe) * cps + atts["index"]).astype(np.int64)
+            own = pos * world // C == rank
+            st["own"] = own
+            own_atts = atts[own].copy()
+            n_words = (own_atts["n_bits"].astype(np.int64) + 7) // 8
+            offs = np.concatenate([[0], np.cumsum(n_words)[:-1]]).astype(np.uint32)
+            st["own_arena"] = np.concatenate([arena[o:o + k] for o, k in zip(own_atts["bits_offset"], n_words)])
+            own_atts["bits_offset"] = offs
+            st["own_atts"] = own_atts
+        steps.append(st)
+    w = dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe, world=getattr(args, "world", 1))
     shuffle_from = 0 if args.with_shuffle else getattr(args, "shuffle_variant_from", n_steps_total)
     if shuffle_from < n_steps_total:
         # the NEXT epoch's committee table is shuffled inside each step (pe_compute_committees_async: same seed, same
@@ -82,11 +98,12 @@ def build_workload(e, args, rank, n_steps_total):
         import torch
         from pos_evolution_amd import DeviceArena, DeviceRows
         for st in steps:
-            t = torch.from_numpy(st["arena"]).cuda()
+            t = torch.from_numpy(st["own_arena"] if by_committee else st["arena"]).cuda()
             st["arena_in"] = DeviceArena(t.data_ptr(), t.numel(), keep=t)
             if not args.host_rows:
-                r = torch.from_numpy(st["atts"].view(np.uint8).reshape(-1)).cuda()
-                st["rows_in"] = DeviceRows(r.data_ptr(), len(st["atts"]), keep=r)
+                rows = st["own_atts"] if by_committee else st["atts"]
+                r = torch.from_numpy(rows.view(np.uint8).reshape(-1)).cuda()
+                st["rows_in"] = DeviceRows(r.data_ptr(), len(rows), keep=r)
         torch.cuda.synchronize()
     return w
 
@@ -189,6 +206,37 @@ def run_step_sharded_pipelined(e, w, st, lagged=True):
         head = e.get_head_sharded()                                   # all-reduce of (B + 512) x 8 B inside
         st2, num = e.process_attestation_batch(st["ctx"], packed=(rows, RESIDENT))
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
+
+
+class _Lazy:
+    """An array that exists when it is first used (outputs of a lagged pipeline are sliced by a count that is itself an output)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def sum(self):
+        return np.asarray(self.fn()).sum()
+
+
+def run_step_committee(e, w, st, lagged=True):
+    """The committee-sharded step (SURVEY.md 8e Option B): pe_aggregate over this rank's committees (unions + aggregate
+    pubkeys, no G1 collective) -> pe_aggregate_exchange (one all-gather of the aggregates) -> the handlers over the whole
+    epoch on this rank's full copy of the store -> the plain get_head."""
+    from pos_evolution_amd import RESIDENT, ROWS_RESIDENT
+
+    ep = st["epoch"]
+    e.on_tick((ep + 1) * w["spe"] * 12)
+    e.participation_rotate()
+    cap = len(st["comm"].offsets) - 1 + 8 * w.get("world", 1)
+    with e.pipeline(lagged=lagged):
+        agg = e.aggregate(packed=(st["rows_in"], st["arena_in"]), want_aggregate_pubkeys=True)
+        gx = e.aggregate_exchange(cap_groups=cap)
+        status, _, count = e.on_attestation_batch(packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
+        head = e.get_head_async()
+        st2, num = e.process_attestation_batch(st["ctx"], packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
+    # "count" is read when the step has completed: this rank's own aggregates (the ranks' sums add up to the epoch)
+    return dict(agg=agg, gx=gx, rows=None, status=status, count=_Lazy(lambda: agg["count"]), count_all=count, pstatus=st2,
+                numerators=num, head=head)
 
 
 def run_step_sharded(e, w, st, sh):
@@ -466,6 +514,45 @@ def sharded_step_check(e, w, st, r, rank, world, dist, args):
     return {k: bool(all(o.get(k, False) for o in allr)) for k in sorted(keys)}
 
 
+def committee_step_check(e, w, st, r, rank, world, dist, args):
+    """The first step of a committee-sharded run against the oracle: every rank holds the whole store, so every rank checks
+    the WHOLE epoch's outcome on its own copy -- LMD table, head, all weights, both participation arrays, the gathered
+    unions / counts / reward numerators -- plus the aggregate pubkeys and unions of the committees it served itself."""
+    inp = cpu_step_inputs(w, st)
+    V = w["bal"].size
+    chk = cpu_step(w, st, inp, True, np.zeros(V, dtype=np.uint64), np.full(V, 0xFFFFFFFF, dtype=np.uint32))
+    spe, comm = w["spe"], st["comm"]
+    C = comm.offsets.size - 1
+    cps = C // spe
+    off = inp["out_off"]
+    union_of = lambda c: np.unpackbits(chk["union"][off[c]:off[c + 1]], bitorder="little")[:inp["sizes"][c]].astype(bool)
+    out = {}
+    agg, gx = r["agg"], r["gx"]
+    pos_own = ((agg["atts"]["slot"] % spe) * cps + agg["atts"]["index"]).astype(np.int64)
+    out["own_committees"] = bool(np.array_equal(np.sort(pos_own), np.nonzero(np.arange(C) * world // C == rank)[0]))
+    out["own_union_bits"] = all(np.array_equal(agg["bits"][k], union_of(c)) for k, c in enumerate(pos_own))
+    out["own_counts"] = bool(np.array_equal(agg["count"], chk["count"][pos_own]))
+    out["own_aggregate_pubkeys"] = bool(np.array_equal(agg["aggpk96"], chk["aggpk"][pos_own]))
+    g = int(gx["n_groups"])
+    pos_all = ((gx["atts"]["slot"] % spe) * cps + gx["atts"]["index"]).astype(np.int64)
+    out["gathered_every_committee_once"] = bool(g == C and np.array_equal(np.sort(pos_all), np.arange(C)))
+    if out["gathered_every_committee_once"]:
+        out["gathered_union_bits"] = all(np.array_equal(gx["bits"][k], union_of(c)) for k, c in enumerate(pos_all))
+        out["gathered_counts"] = bool(np.array_equal(gx["count"], chk["count"][pos_all]) and
+                                      np.array_equal(np.asarray(r["count_all"])[:g], chk["count"][pos_all]))
+        out["reward_numerators"] = bool(np.array_equal(np.asarray(r["numerators"])[:g], chk["numerators"][pos_all]))
+    out["statuses_ok"] = bool((np.asarray(r["status"])[:g] == 0).all() and (np.asarray(r["pstatus"])[:g] == 0).all())
+    out["latest_messages"] = bool(np.array_equal(e.latest_messages()[1], chk["vote_block"]))
+    out["head"] = bytes(r["head"]) == chk["head"]
+    out["weights"] = bool(np.array_equal(e.last_weights(), chk["weights"]))
+    out["participation"] = bool(np.array_equal(e.participation_get(0), chk["part_cur"]) and
+                                np.array_equal(e.participation_get(1), chk["part_prev"]))
+    allr = [None] * world
+    dist.all_gather_object(allr, out)
+    keys = set().union(*[set(o) for o in allr])
+    return {k: bool(all(o.get(k, False) for o in allr)) for k in sorted(keys)}
+
+
 def step_digest(r):
     """sha256 over everything one step hands back: head, statuses, counts, reward numerators, the aggregate rows, the
     OR-ed bits, the aggregate pubkeys, the grouping."""
@@ -519,9 +606,12 @@ def main():
     ap.add_argument("--mixed-balances", action="store_true")
     ap.add_argument("--head-calls", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharded-mode", choices=["engine", "torch"], default="engine",
-                    help="N > 1: collectives issued by the engine on its own stream inside pipelined calls (engine), "
-                         "or by torch.distributed between synchronous calls (torch)")
+    ap.add_argument("--sharded-mode", choices=["engine", "torch", "committee"], default="engine",
+                    help="N > 1: validator-range shards with the collectives issued by the engine inside streaming pipelines "
+                         "(engine) or by torch.distributed between synchronous calls (torch); committee = committee shards "
+                         "(SURVEY 8e Option B): the whole registry on every rank, a rank aggregates its own committees, one "
+                         "all-gather of the aggregates, no G1 collective and no weight all-reduce (strong scaling of one "
+                         "registry)")
     ap.add_argument("--host-arena", action="store_true",
                     help="hand the aggregation bits over from pageable host memory (PCIe-inclusive) instead of HBM")
     ap.add_argument("--host-rows", action="store_true",
@@ -575,7 +665,12 @@ def main():
     import pos_evolution_amd as pea
 
     # validators this rank owns: the whole registry on one GPU; V/N (strong) or V (weak) of it on N
-    args.validators_local = args.validators // world if (world > 1 and args.scaling == "strong") else args.validators
+    args.by_committee = args.sharded_mode == "committee" and (world > 1 or bool(os.environ.get("POSEVO_FORCE_DIST")))
+    args.world = world
+    if args.by_committee:
+        args.scaling = "strong"   # one registry, replicated; the epoch's committees are what is divided
+    args.validators_local = (args.validators if args.by_committee else
+                             args.validators // world if (world > 1 and args.scaling == "strong") else args.validators)
     assert args.validators_local % args.committees == 0, "validators per rank must be a multiple of the committee count"
     total = args.warmup + args.steps
     lag = 1 if args.no_lag else args.lag
@@ -594,7 +689,7 @@ def main():
         ex, engine_rccl, how = None, False, None
         if dist is not None:
             from pos_evolution_amd.sharded import HostStagedCollectives, ShardedForkChoice
-            if args.sharded_mode == "engine" and not args.no_pipeline:
+            if args.sharded_mode in ("engine", "committee") and not args.no_pipeline:
                 ok_t = torch.tensor([1], device="cuda" if backend == "nccl" else "cpu")
                 try:
                     if backend == "nccl":  # the engine's own communicators; torch.distributed only carries the 256-byte id
@@ -606,7 +701,7 @@ def main():
                                                collectives=HostStagedCollectives())
                         how = f"pe_dist_init_custom: {backend} staged through the host (dry run, not a scaling measurement)"
                     engine_rccl = True
-                    e.dist_set_max_groups(args.committees)
+                    e.dist_set_max_groups((args.committees + world - 1) // world + 8 if args.by_committee else args.committees)
                 except Exception as err:  # e.g. no librccl to dlopen: the torch-carried exchange does the same job
                     print(f"[bench] engine-owned exchange unavailable ({err}); using torch.distributed", file=sys.stderr)
                     ok_t[0] = 0
@@ -628,6 +723,8 @@ def main():
 
     def run(e, w, ex, engine_rccl):
         def step(st):
+            if engine_rccl and args.by_committee:
+                return run_step_committee(e, w, st, lagged=not args.no_lag)
             if engine_rccl:
                 return run_step_sharded_pipelined(e, w, st, lagged=not args.no_lag)
             return run_step_sharded(e, w, st, ex) if ex else run_step_single(e, w, st, pipelined=not args.no_pipeline,
@@ -648,7 +745,8 @@ def main():
                 e.fill_ring()
                 if dist is not None and not args.no_oracle_check:
                     # N > 1: the first step of the run (a fresh store on every rank) against the oracle, before the clock
-                    sharded_chk = sharded_step_check(e, w, w["steps"][0], kept[0], rank, world, dist, args)
+                    sharded_chk = (committee_step_check if args.by_committee else sharded_step_check)(
+                        e, w, w["steps"][0], kept[0], rank, world, dist, args)
         e.drain()
         e.profile_enable(True)
         e.profile_reset()
@@ -723,10 +821,10 @@ def main():
     # get_head latency: full recomputation from the vote table, after the timed region
     lat = []
     for _ in range(20):
-        e.get_head() if ex is None else ex.get_head()
+        e.get_head() if (ex is None or args.by_committee) else ex.get_head()
     for _ in range(args.head_calls):
         t = time.perf_counter()
-        e.get_head() if ex is None else ex.get_head()
+        e.get_head() if (ex is None or args.by_committee) else ex.get_head()
         lat.append((time.perf_counter() - t) * 1e6)
     lat = np.sort(np.array(lat))
 
@@ -777,7 +875,7 @@ def main():
     votes_bytes = 13.0 * VL + 32.0 * args.blocks
     kernel_ms = {k: (v["total_ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()}
     per_step = np.diff(np.array(stamps)) * 1e3
-    V_total = VL * world
+    V_total = VL if args.by_committee else VL * world   # committee shards: one registry, on every rank
     shape = ("BASELINE configs[3] shape on every GPU" if (world > 1 and (VL, C, args.blocks) == (1 << 20, 2048, 4096))
              else "BASELINE configs[3] shape" if (V_total, C, args.blocks) == (1 << 20, 2048, 4096)
              else "BASELINE configs[4] shape" if (V_total, args.blocks) == (1 << 22, 8192)
@@ -811,7 +909,9 @@ def main():
                         f"99% participation, {args.blocks}-block tree, one epoch per step: pe_aggregate (union + "
                         f"aggregate pubkeys) -> pe_on_attestation_batch -> pe_get_head -> pe_process_attestation_batch",
             "validators_total": V_total, "validators_per_gpu": VL, "blocks": args.blocks, "committees": C,
-            "parallelism": f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU",
+            "parallelism": (f"committee shards x{world}: registry and store replicated, each rank aggregates C / {world} "
+                            f"committees ({scaling} scaling)" if args.by_committee else
+                            f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU"),
             "call_mode": mode,
             "inputs": (("attestation rows in host memory (grouped and validated by the host inside the timed step); "
                         if (args.host_rows or args.host_arena or (world > 1 and not engine_rccl)) else
@@ -852,8 +952,11 @@ def main():
         "kernel_avg_ms": kernel_ms,
     }
     if dist is not None:
-        out["config"]["exchange"] = ("per step: one all-reduce(sum) of (blocks + 512) u64 = "
-                                     f"{(args.blocks + 512) * 8} B, one all-gather of {C} x 192 B XYZZ partials per rank; "
+        out["config"]["exchange"] = (("per step: ONE all-gather of the ranks' aggregate attestations (144 B data + flags, count, "
+                                      f"256 B of OR-ed bits per aggregate; {(C + world - 1) // world + 8} slots per rank); no G1 "
+                                      "collective, no weight all-reduce; " if args.by_committee else
+                                      "per step: one all-reduce(sum) of (blocks + 512) u64 = "
+                                      f"{(args.blocks + 512) * 8} B, one all-gather of {C} x 192 B XYZZ partials per rank; ")
                                      + exchange_how)
         if dist_fallback:
             out["dist_fallback"] = dist_fallback

@@ -588,6 +588,26 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n,
                          pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
                          uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count);
 
+/* ---- committee-sharded steps (Option B; pe:474 "parallelising the aggregation of attestations") ---- */
+/* The other way to split an epoch over N GPUs: by COMMITTEE instead of by validator range.  Every rank holds the whole
+ * registry and the whole store; rank g is handed only the rows of the committees it serves (its attestation subnets) and
+ * runs pe_aggregate over them as on one GPU -- its unions and its aggregate pubkeys are complete, there is no G1
+ * collective, and a rank's grouping / union / G1 work is 1/N of the epoch's.  pe_aggregate_exchange then makes the
+ * epoch whole again: the aggregates of the LAST pe_aggregate over rows in device memory (AttestationData + OR-ed bits +
+ * attester count + verdict flags: the aggregate attestation a validator client publishes, pe:659, pe:714-717) are packed
+ * into fixed slots, all-gathered over the handle's communicator (pe_dist_init / pe_dist_init_custom), and ingested as ONE
+ * batch that becomes the handle's resident aggregate: the handlers that follow
+ *     pe_on_attestation_batch(h, PE_ROWS_RESIDENT, cap, PE_BITS_RESIDENT, 0, status, NULL, out_count)
+ *     pe_process_attestation_batch(h, state, PE_ROWS_RESIDENT, cap, PE_BITS_RESIDENT, 0, status, out_numerators)
+ * apply the whole epoch's votes and flags to this rank's copy of the store, and pe_get_head (the plain one: no weight
+ * exchange) returns the same head on every rank.  Outputs: the gathered aggregates, rank after rank (out_atts rows with
+ * bits_offset into out_bits_arena, out_count), cap_groups entries each -- cap_groups >= world x the bound of
+ * pe_dist_set_max_groups (or x the local row count when no bound is set).  Every rank calls it once per step; inside a
+ * pipeline nothing waits (with RCCL) and the local aggregate's G1 sums keep running beside the exchange.  A union may be
+ * at most max_validators_per_committee bits (pe_config). */
+int pe_aggregate_exchange(pe_engine* h, pe_attestation* out_atts, uint32_t* out_n_groups, uint8_t* out_bits_arena,
+                          uint64_t out_arena_cap, uint32_t* out_count, uint32_t cap_groups);
+
 /* ---- profiling hooks (bench.py roofline leg) ----------------------------- */
 /* When enabled, the engine brackets each launch of its kernels with HIP events on
  * the launch stream and accumulates per-kernel launch counts and durations. */

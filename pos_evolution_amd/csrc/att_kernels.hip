@@ -23,6 +23,7 @@
 //   k_participation_tables the flag loop of pe:745-749, one wave per committee, rows of a committee in batch order.
 //
 // Integer / byte work, latency- and HBM-bound: no MFMA.
+#include <algorithm>
 #include <cstdlib>
 #include "kernels.h"
 
@@ -31,7 +32,7 @@ namespace posevo {
 namespace {
 
 constexpr uint32_t VAL_EQUIVOCATING_BIT = 0x04u;
-constexpr uint32_t FLAG_SIG_VALID = 0x1u, FLAG_FROM_BLOCK = 0x2u;
+constexpr uint32_t FLAG_SIG_VALID = 0x1u, FLAG_FROM_BLOCK = 0x2u, FLAG_OVERLAPPING = 0x4u;  // PE_ATT_FLAG_* of include/posevo.h
 // pe_att_status values (include/posevo.h)
 constexpr int32_t ST_OK = 0, ST_EPOCH_TIME = 1, ST_EPOCH_SLOT = 2, ST_UNKNOWN_TARGET = 3, ST_UNKNOWN_BLOCK = 4,
                   ST_BLOCK_AFTER_SLOT = 5, ST_TARGET_NOT_ANCESTOR = 6, ST_SLOT_NOT_PAST = 7, ST_NO_TABLE = 8,
@@ -84,10 +85,12 @@ __device__ __forceinline__ bool same4(const uint4& a, const uint4& b)
 __global__ void __launch_bounds__(256)
 k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t* __restrict__ cnt_tab,
              uint32_t mask, uint32_t* __restrict__ slot_of, unsigned long long arena_len, AttPlan* __restrict__ plan,
-             uint4* __restrict__ arena_pad)
+             uint4* __restrict__ arena_pad, const uint32_t* __restrict__ n_dev)
 {
     __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
+    if (n_dev) n = min(n, *n_dev);  // the row count is itself a device result (pe_aggregate_exchange): n is its bound
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && arena_pad && n == 0) { arena_pad[0] = make_uint4(0, 0, 0, 0); arena_pad[1] = make_uint4(0, 0, 0, 0); }
     if (i >= n) return;
     // k_bits_union reads whole dwords: up to 8 bytes past the last member's bits, which must read zero (no copy command
     // for 16 bytes: this kernel runs between the arena's copy and the union)
@@ -116,11 +119,11 @@ k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ 
 }
 
 void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
-                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32)
+                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32, const uint32_t* n_dev)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_att_ingest, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
-                       cnt_tab, tab_mask, slot_of, (unsigned long long)arena_len, plan, static_cast<uint4*>(arena_pad32));
+                       cnt_tab, tab_mask, slot_of, (unsigned long long)arena_len, plan, static_cast<uint4*>(arena_pad32), n_dev);
 }
 
 // ------------------------------------------------------------------ plan: one workgroup
@@ -194,7 +197,7 @@ k_att_plan(AttPlanArgs a)
     const uint32_t* __restrict__ tab = a.tab;
     const uint32_t* __restrict__ cnt_tab = a.cnt_tab;
     const uint32_t* __restrict__ slot_of = a.slot_of;
-    const uint32_t n = a.n;
+    const uint32_t n = a.n_dev ? min(a.n, *a.n_dev) : a.n;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     if (tid == 0) { s_max_size = 0; s_not_aligned = 0; s_err = a.plan->error; s_rows_t[0] = 0; s_rows_t[1] = 0; }
@@ -450,10 +453,12 @@ k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__
               const uint32_t* __restrict__ slot_of,
               const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ gid_of_row, AttGroup* __restrict__ grp,
               AttPlan* __restrict__ plan, uint32_t* __restrict__ ubytes, uint32_t* __restrict__ member_row,
-              uint32_t* __restrict__ host_group_of, uint4* __restrict__ host_out_rows)
+              uint32_t* __restrict__ host_group_of, uint4* __restrict__ host_out_rows, const uint32_t* __restrict__ n_dev)
 {
     __builtin_amdgcn_s_setprio(3);
+    if (n_dev) n = min(n, *n_dev);
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && n == 0) plan->error = 0;
     if (i >= n) return;
     const uint32_t slot = slot_of[i];
     if (plan->n_groups) {
@@ -480,12 +485,104 @@ k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__
 
 void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
                         const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
-                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows)
+                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows,
+                        const uint32_t* n_dev)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_att_members, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
                        cnt_tab, slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row, host_group_of,
-                       static_cast<uint4*>(host_out_rows));
+                       static_cast<uint4*>(host_out_rows), n_dev);
+}
+
+// ------------------------------------------------------------------ committee-sharded exchange (pe_aggregate_exchange)
+// Every rank aggregates the rows of ITS committees; what the other ranks need of the result -- the aggregate attestation
+// itself: AttestationData + OR-ed bits (pe:714-717), its attester count and its verdict flags -- is packed into fixed
+// slots, all-gathered, and unpacked into one dense batch that the receiving rank ingests like any batch of rows.
+//   send buffer: [0] groups packed, [1] error, [2..3] reserved | slot g: 36 words row, count, reserved, `wps` words of bits
+__global__ void __launch_bounds__(256)
+k_att_pack(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
+           const uint32_t* __restrict__ res_bits, const uint32_t* __restrict__ res_info, uint32_t slots, uint32_t wps,
+           uint32_t* __restrict__ send)
+{
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ng_all = plan->n_groups;
+    const uint32_t ng = min(ng_all, slots);
+    if (g == 0) {
+        send[0] = ng;
+        send[1] = ng_all > slots ? ERR_CAPACITY : plan->error;
+        send[2] = send[3] = 0;
+    }
+    if (g >= ng) return;
+    const AttGroup G = grp[g];
+    const uint32_t slot_words = 38 + wps;
+    uint32_t* o = send + 4 + (size_t)g * slot_words;
+    const uint4* r = rows + (size_t)9 * G.rep;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint4 q = r[k];
+        o[4 * k] = q.x; o[4 * k + 1] = q.y; o[4 * k + 2] = q.z; o[4 * k + 3] = q.w;
+    }
+    const uint32_t count = res_info[2 * g], overlap = res_info[2 * g + 1];
+    uint32_t flags = r[8].z & ~FLAG_SIG_VALID;
+    if (G.sig_valid && !overlap) flags |= FLAG_SIG_VALID;   // the AND of the members' verdicts; overlapping members never verify (A.8)
+    if (overlap) flags |= FLAG_OVERLAPPING;
+    o[32] = 0;          // bits_offset: set by the receiver
+    o[33] = G.n_bits;
+    o[34] = flags;
+    o[35] = 0;
+    o[36] = count;
+    o[37] = 0;
+    const uint32_t nw = (G.n_bits + 31) >> 5;
+    if (nw > wps) { atomicMax(&send[1], ERR_CAPACITY); return; }
+    for (uint32_t j = 0; j < wps; ++j) o[38 + j] = j < nw ? res_bits[G.out_word + j] : 0u;
+}
+
+void launch_att_pack(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, const uint32_t* res_bits,
+                     const uint32_t* res_info, uint32_t slots, uint32_t wps, uint32_t* send)
+{
+    hipLaunchKernelGGL(k_att_pack, dim3((std::max(slots, 1u) + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), grp,
+                       plan, res_bits, res_info, slots, wps, send);
+}
+
+// recv: `world` send buffers back to back.  Rank r's groups land behind those of ranks < r: out_rows[base_r + j] with
+// bits_offset = (base_r + j) * 4 * wps into out_bits; *n_dev = the total; *err = the first non-zero error word.
+__global__ void __launch_bounds__(256)
+k_att_unpack(const uint32_t* __restrict__ recv, uint32_t world, uint32_t slots, uint32_t wps, uint32_t* __restrict__ out_rows,
+             uint32_t* __restrict__ out_bits, uint32_t* __restrict__ n_dev, uint32_t* __restrict__ err_host)
+{
+    const uint32_t slot_words = 38 + wps;
+    const size_t rank_words = 4 + (size_t)slots * slot_words;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = t / slots, j = t % slots;
+    if (t == 0) {
+        uint32_t total = 0, err = 0;
+        for (uint32_t q = 0; q < world; ++q) {
+            total += recv[q * rank_words];
+            if (!err) err = recv[q * rank_words + 1];
+        }
+        *n_dev = err ? 0u : total;   // a rank whose aggregate failed: nothing is applied anywhere
+        if (err_host) *err_host = err;
+    }
+    if (r >= world) return;
+    uint32_t base = 0;
+    for (uint32_t q = 0; q < r; ++q) base += recv[q * rank_words];
+    if (j >= recv[r * rank_words]) return;
+    const uint32_t* in = recv + r * rank_words + 4 + (size_t)j * slot_words;
+    const uint32_t dst = base + j;
+    uint32_t* o = out_rows + (size_t)36 * dst;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) o[k] = in[k];
+    o[32] = dst * 4 * wps;
+    uint32_t* b = out_bits + (size_t)dst * wps;
+    for (uint32_t k = 0; k < wps; ++k) b[k] = in[38 + k];
+}
+
+void launch_att_unpack(hipStream_t s, const uint32_t* recv, uint32_t world, uint32_t slots, uint32_t wps, void* out_rows,
+                       uint32_t* out_bits, uint32_t* n_dev, uint32_t* err_host)
+{
+    const uint32_t n = std::max(world * slots, 1u);
+    hipLaunchKernelGGL(k_att_unpack, dim3((n + 255) / 256), dim3(256), 0, s, recv, world, slots, wps,
+                       static_cast<uint32_t*>(out_rows), out_bits, n_dev, err_host);
 }
 
 // ------------------------------------------------------------------ block lookups

@@ -306,6 +306,8 @@ void pe_engine_destroy(pe_engine* h)
         a.d_lane_partials.release();
         a.d_rr_tab.release();
         a.d_rr.release();
+        for (DevBuf* b : {&a.x_rr_tab, &a.x_rr, &a.x_res_bits, &a.x_res_info, &a.d_xsend, &a.d_xrecv, &a.d_xrows, &a.d_xbits, &a.d_xn})
+            b->release();
         a.d_sig_in.release();
         a.d_sig_pts.release();
         a.d_sig_status.release();

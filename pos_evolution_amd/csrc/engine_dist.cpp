@@ -367,4 +367,72 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
     return finish_call(h, st, ob, complete);
 }
 
+// ---------------------------------------------------------------- committee-sharded steps (Option B)
+// "Parallelising the aggregation of attestations" (pe:474) along its natural axis: the committees.  Rank g is handed only
+// the rows of the committees it serves (its subnets) and sums THEIR aggregate pubkeys over a replicated registry -- no G1
+// collective, a rank's grouping / union / G1 work is 1/N of the epoch's.  What the other ranks need of the result is the
+// aggregate attestation itself (pe:714-717: data + OR-ed bits, the object a validator client publishes, pe:659); one
+// all-gather carries every rank's aggregates to every rank, which ingests them as ONE dense batch: the handlers behind
+// (PE_ROWS_RESIDENT) then apply the whole epoch's votes and flags to the rank's full copy of the store, and get_head is
+// the plain pe_get_head -- no weight exchange, every rank reaches the same head from the same latest messages.
+//   pe_aggregate(local device rows, ... out_aggpk96 ...)   -- this rank's committees: unions + aggregate pubkeys
+//   pe_aggregate_exchange(...)                              -- pack -> all-gather -> the gathered aggregates become the
+//                                                              resident aggregate the handlers run over
+// The G1 chain of the local aggregate keeps running beside the exchange (the gathered batch has scratch of its own).
+int pe_aggregate_exchange(pe_engine* h, pe_attestation* out_atts, uint32_t* out_n_groups, uint8_t* out_bits_arena,
+                          uint64_t out_arena_cap, uint32_t* out_count, uint32_t cap_groups)
+{
+    if (!h || !out_atts || !out_n_groups || !out_bits_arena) return PE_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    if (!h->pipelining) PE_TRY(flush_pending(h));
+    if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_aggregate_exchange: call pe_dist_init first");
+    if (!h->rr.valid || h->rr.set != 0 || h->rr.arena != h->cur)
+        return fail(h, PE_ERR_STATE, "pe_aggregate_exchange follows a pe_aggregate over rows in device memory (same pipeline)");
+    ResidentParts P;
+    PE_TRY(resident_parts(h, &P));
+    const uint32_t world = (uint32_t)h->dist_world;
+    const uint32_t slots = std::max<uint32_t>(1, h->dist_max_groups ? std::min(P.n_in, h->dist_max_groups) : P.n_in);
+    const uint32_t wps = (h->cfg.max_validators_per_committee + 31) / 32;  // words of one union
+    const uint32_t n_bound = world * slots;
+    if (cap_groups < n_bound)
+        return fail(h, PE_ERR_CAPACITY, "pe_aggregate_exchange: the output arrays hold fewer than world x max_groups entries");
+    const size_t rank_words = 4 + (size_t)slots * (38 + wps);
+    pe_engine::PipeArena& A = h->A();
+    PE_TRY(ensure_quiesced(h, A.d_xsend, rank_words * 4));
+    PE_TRY(ensure_quiesced(h, A.d_xrecv, rank_words * 4 * world));
+    PE_TRY(ensure_quiesced(h, A.d_xrows, (size_t)144 * n_bound + 64));
+    PE_TRY(ensure_quiesced(h, A.d_xbits, (size_t)4 * wps * n_bound + 64));
+    PE_TRY(ensure_quiesced(h, A.d_xn, 64));
+    Stage st(h);
+    OutBlock ob(h);
+    const size_t off_err = ob.alloc(16);
+    PE_TRY(ob.ensure());
+    *ob.host<uint32_t>(off_err) = 0;
+    hipStream_t ms = h->stream;
+    launch_att_pack(ms, P.rows, P.grp, P.plan, P.res_bits, P.res_info, slots, wps, A.d_xsend.as<uint32_t>());
+    HIP_TRY(h, hipGetLastError());
+    {
+        HostLap lap(&h->trace);
+        PE_TRY(dist_all_gather(h, A.d_xsend.p, A.d_xrecv.p, rank_words * 4, ms));  // on the engine's stream: `comm`
+        lap.mark("dist.exchange_all_gather_enqueue");
+    }
+    launch_att_unpack(ms, A.d_xrecv.as<uint32_t>(), world, slots, wps, A.d_xrows.p, A.d_xbits.as<uint32_t>(),
+                      A.d_xn.as<uint32_t>(), ob.host<uint32_t>(off_err));
+    HIP_TRY(h, hipGetLastError());
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off_err]() -> int {
+        const uint32_t err = *reinterpret_cast<const uint32_t*>(h->arena[ai].h_pin.as<uint8_t>() + base + off_err);
+        if (err == 10) return fail(h, PE_ERR_CAPACITY, "pe_aggregate_exchange: a rank formed more groups than pe_dist_set_max_groups "
+                                                        "allows, or a union longer than max_validators_per_committee bits");
+        if (err) return fail(h, PE_ERR_INVALID_ARG, "pe_aggregate_exchange: the aggregate of a rank failed; nothing was applied");
+        return PE_OK;
+    };
+    PE_TRY(finish_call(h, st, ob, complete));
+    // the gathered aggregates as this rank's resident aggregate (scratch set 1; the row count is a device result)
+    return aggregate_resident(h, static_cast<const pe_attestation*>(A.d_xrows.p), n_bound, A.d_xbits.as<uint8_t>(),
+                              (uint64_t)4 * wps * n_bound, out_atts, out_n_groups, nullptr, out_bits_arena, out_arena_cap,
+                              nullptr, out_count, nullptr, /*set=*/1, A.d_xn.as<uint32_t>());
+}
+
 }  // extern "C"

@@ -249,6 +249,11 @@ struct pe_engine {
         DevBuf d_rr_tab, d_rr;
         DevBuf d_sig_in, d_sig_pts, d_sig_status;  // pe_aggregate_signed: wire bytes | Montgomery points | decode status
         uint32_t rr_rows_cap = 0, rr_comm_cap = 0, rr_tab_size = 0;
+        // a second set of the same for the EXCHANGED aggregate of a committee-sharded step (pe_aggregate_exchange): the
+        // local aggregate's descriptors and unions are still being read by its G1 chain when the gathered one is ingested
+        DevBuf x_rr_tab, x_rr, x_res_bits, x_res_info;
+        uint32_t x_rows_cap = 0, x_comm_cap = 0, x_tab_size = 0;
+        DevBuf d_xsend, d_xrecv, d_xrows, d_xbits, d_xn;  // packed local groups | all ranks' | unpacked rows | bits | count
         size_t stage_cursor = 0, out_cursor = 0;
         uint64_t table_stamp_at_begin = 0;  // h->table_stamp when the pipeline that fills this arena began
         std::vector<std::function<int()>> pending;
@@ -303,6 +308,7 @@ struct pe_engine {
         const void* rows = nullptr;     // the caller's device rows (unchanged until the pipeline completes)
         TablesDev tables{};             // the candidate committee tables the groups were resolved against
         uint64_t generation = 0;
+        int set = 0;                    // 0: the arena's own scratch, 1: the exchanged aggregate's (x_*)
     } rr;
 
     // ---- accumulate-shape autotune (large pubkey aggregations) ----
@@ -671,7 +677,10 @@ BlockTableDev block_table_dev(const pe_engine* h);
 int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, const uint8_t* bits_arena,
                        uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
                        uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count,
-                       uint32_t* dev_partials = nullptr);
+                       uint32_t* dev_partials = nullptr, int set = 0, const uint32_t* n_dev = nullptr);
+// the pieces pe_aggregate_exchange packs: the resident aggregate's groups, unions and the caller's rows
+struct ResidentParts { const void* rows; const AttGroup* grp; const AttPlan* plan; const uint32_t* res_bits; const uint32_t* res_info; uint32_t n_in; };
+int resident_parts(pe_engine* h, ResidentParts* out);
 // the device-side plan (group count, error word) of the last aggregate over rows in device memory
 int resident_plan_dev(pe_engine* h, const AttPlan** out);
 // ... and its grouping lists: group g's member rows are member_row[ug[g].list_start .. + ug[g].n_atts)

@@ -64,11 +64,28 @@ RrLayout rr_layout(uint8_t* base, uint32_t cap_n, uint32_t cap_c)
     return L;
 }
 
-RrLayout rr_of(pe_engine::PipeArena& a) { return rr_layout(a.d_rr.as<uint8_t>(), a.rr_rows_cap, a.rr_comm_cap); }
+// One of the arena's two scratch sets (0: its own, 1: the exchanged aggregate's), by reference
+struct RrSet {
+    DevBuf &tab, &rr, &bits, &info;
+    uint32_t &rows_cap, &comm_cap, &tab_size;
+};
+RrSet rr_set(pe_engine::PipeArena& a, int set)
+{
+    if (set == 0) return RrSet{a.d_rr_tab, a.d_rr, a.d_res_bits, a.d_res_info, a.rr_rows_cap, a.rr_comm_cap, a.rr_tab_size};
+    return RrSet{a.x_rr_tab, a.x_rr, a.x_res_bits, a.x_res_info, a.x_rows_cap, a.x_comm_cap, a.x_tab_size};
+}
+RrLayout rr_of(pe_engine::PipeArena& a, int set = 0)
+{
+    const RrSet s = rr_set(a, set);
+    return rr_layout(s.rr.as<uint8_t>(), s.rows_cap, s.comm_cap);
+}
 
 // The arena's scratch for n input rows and tables of up to n_comm committees.  Growing waits for everything enqueued.
-int rr_ensure(pe_engine* h, pe_engine::PipeArena& a, uint32_t n, uint32_t n_comm)
+int rr_ensure(pe_engine* h, pe_engine::PipeArena& arena, int set, uint32_t n, uint32_t n_comm)
 {
+    struct View { DevBuf &d_rr_tab, &d_rr; uint32_t &rr_rows_cap, &rr_comm_cap, &rr_tab_size; };
+    const RrSet rs = rr_set(arena, set);
+    View a{rs.tab, rs.rr, rs.rows_cap, rs.comm_cap, rs.tab_size};
     if (n <= a.rr_rows_cap && n_comm <= a.rr_comm_cap && a.d_rr.p && a.d_rr_tab.p) return PE_OK;
     PE_TRY(flush_pending(h));
     HIP_TRY(h, hipDeviceSynchronize());
@@ -172,7 +189,7 @@ BlockTableDev block_table_dev(const pe_engine* h)
 int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, const uint8_t* bits_arena,
                        uint64_t arena_len, pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,
                        uint8_t* out_bits_arena, uint64_t out_arena_cap, uint8_t* out_aggpk96, uint32_t* out_count,
-                       uint32_t* dev_partials)
+                       uint32_t* dev_partials, int set, const uint32_t* n_dev)
 {
     if (!h->initialised) return fail(h, PE_ERR_STATE, "rows in device memory: the store's clock picks the committee tables; call pe_store_init first");
     if ((uintptr_t)d_rows & 15) return fail(h, PE_ERR_INVALID_ARG, "rows in device memory must be 16-byte aligned");
@@ -185,8 +202,9 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     PE_TRY(candidate_tables(h, &tables, tabs));
     const uint32_t n_comm = std::max(tables.t[0].n_committees, tables.t[1].n_committees);
     pe_engine::PipeArena& A = h->A();
-    PE_TRY(rr_ensure(h, A, n, n_comm));
-    const RrLayout L = rr_of(A);
+    PE_TRY(rr_ensure(h, A, set, n, n_comm));
+    const RrLayout L = rr_of(A, set);
+    const RrSet RS = rr_set(A, set);
     // upper bounds: groups <= n; lane slots of the G1 plan <= slot_cap (k_att_plan lengthens the lanes instead)
     const uint32_t target = g1_target_slots(h);
     const uint32_t slot_cap = std::max<uint32_t>(2 * G1_TARGET_LANES, (n + G1_WG - 1) / G1_WG * G1_WG);
@@ -195,8 +213,8 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     PE_TRY(st.reserve((size_t)arena_len + 256));
     const size_t pad_at = ((size_t)arena_len + 15) & ~size_t(15);  // 32 zero bytes behind the bits, written by k_att_ingest
     const size_t off_arena = st.alloc(pad_at + 32);
-    PE_TRY(ensure_quiesced(h, A.d_res_bits, words_cap * 4 + 64));
-    PE_TRY(ensure_quiesced(h, A.d_res_info, 8ull * n + 64));
+    PE_TRY(ensure_quiesced(h, RS.bits, words_cap * 4 + 64));
+    PE_TRY(ensure_quiesced(h, RS.info, 8ull * n + 64));
     OutBlock ob(h);
     const size_t off_plan = ob.alloc(sizeof(AttPlan));
     const size_t off_rows = ob.alloc(sizeof(pe_attestation) * (size_t)n);
@@ -220,8 +238,11 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     hipStream_t ms = h->stream;
     // an earlier aggregate of THIS pipeline still has to read the arena's resident words / descriptors from its G1 launch
     // (deferred in a streaming pipeline): issue it, then order this call's kernels behind that chain
-    if (!h->deferred.empty()) PE_TRY(run_deferred(h));
-    if (A.side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
+    // The exchanged aggregate of a committee-sharded step has a scratch set of its own (set 1) precisely so as NOT to wait.
+    if (set == 0) {
+        if (!h->deferred.empty()) PE_TRY(run_deferred(h));
+        if (A.side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
+    }
     h->res_valid = false;
     h->rr.valid = false;
     const size_t deferred_before = h->deferred.size();
@@ -249,13 +270,14 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                                   arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
     }
     lap.mark("ragg.2_bits");
-    uint32_t* cnt_tab = A.d_rr_tab.as<uint32_t>() + A.rr_tab_size;
-    launch_att_ingest(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), cnt_tab, A.rr_tab_size - 1, L.slot_of, arena_len, L.plan,
-                      st.dev<uint8_t>(off_arena) + pad_at);
+    uint32_t* cnt_tab = RS.tab.as<uint32_t>() + RS.tab_size;
+    launch_att_ingest(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, RS.tab_size - 1, L.slot_of, arena_len, L.plan,
+                      st.dev<uint8_t>(off_arena) + pad_at, n_dev);
     AttPlanArgs pa;
     pa.rows = d_rows;
     pa.n = n;
-    pa.tab = A.d_rr_tab.as<uint32_t>();
+    pa.n_dev = n_dev;
+    pa.tab = RS.tab.as<uint32_t>();
     pa.cnt_tab = cnt_tab;
     pa.slot_of = L.slot_of;
     pa.rep_of = L.rep_of;
@@ -279,12 +301,12 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     pa.want_pk = want_pk ? 1u : 0u;
     pa.tables = tables;
     launch_att_plan(ms, pa);
-    launch_att_members(ms, d_rows, n, A.d_rr_tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
-                       L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows));
+    launch_att_members(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
+                       L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev);
     {
         ProfScope ps(h, PE_KERNEL_BITS_UNION);
-        launch_bits_union(ms, L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), A.d_res_bits.as<uint32_t>(),
-                          A.d_res_info.as<uint32_t>(), ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan);
+        launch_bits_union(ms, L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), RS.bits.as<uint32_t>(),
+                          RS.info.as<uint32_t>(), ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan);
     }
     HIP_TRY(h, hipGetLastError());
     lap.mark("ragg.3_group_union");
@@ -294,7 +316,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
         h->last_agg_on_side = on_side;
         pe_engine::PipeArena* arena = &A;
         const uint32_t* d_points = h->d_points.as<uint32_t>();
-        const uint32_t* d_union = A.d_res_bits.as<uint32_t>();
+        const uint32_t* d_union = RS.bits.as<uint32_t>();
         uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
         G1Plan bound;
         bound.n_groups = n;
@@ -331,6 +353,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     unwind.armed = false;
     h->rr.valid = true;
     h->rr.arena = h->cur;
+    h->rr.set = set;
     h->rr.n_in = n;
     h->rr.rows = d_rows;
     h->rr.tables = tables;
@@ -372,14 +395,29 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
 int resident_plan_dev(pe_engine* h, const AttPlan** out)
 {
     if (!h->rr.valid) return fail(h, PE_ERR_STATE, "no aggregate over rows in device memory on this handle");
-    *out = rr_of(h->arena[h->rr.arena]).plan;
+    *out = rr_of(h->arena[h->rr.arena], h->rr.set).plan;
+    return PE_OK;
+}
+
+int resident_parts(pe_engine* h, ResidentParts* out)
+{
+    if (!h->rr.valid) return fail(h, PE_ERR_STATE, "no aggregate over rows in device memory on this handle");
+    pe_engine::PipeArena& RA = h->arena[h->rr.arena];
+    const RrLayout L = rr_of(RA, h->rr.set);
+    const RrSet RS = rr_set(RA, h->rr.set);
+    out->rows = h->rr.rows;
+    out->grp = L.grp;
+    out->plan = L.plan;
+    out->res_bits = RS.bits.as<uint32_t>();
+    out->res_info = RS.info.as<uint32_t>();
+    out->n_in = h->rr.n_in;
     return PE_OK;
 }
 
 int resident_lists(pe_engine* h, const UnionGroup** ug, const uint32_t** member_row)
 {
     if (!h->rr.valid) return fail(h, PE_ERR_STATE, "no aggregate over rows in device memory on this handle");
-    const RrLayout L = rr_of(h->arena[h->rr.arena]);
+    const RrLayout L = rr_of(h->arena[h->rr.arena], h->rr.set);
     *ug = L.ug;
     *member_row = L.member_row;
     return PE_OK;
@@ -406,7 +444,8 @@ int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_
     HostLap lap(&h->trace);
     PE_TRY(refresh_tree(h));
     pe_engine::PipeArena& RA = h->arena[h->rr.arena];
-    const RrLayout L = rr_of(RA);
+    const RrLayout L = rr_of(RA, h->rr.set);
+    const RrSet RS = rr_set(RA, h->rr.set);
     Stage st(h);
     OutBlock ob(h);
     const size_t off_status = ob.alloc(4ull * cap);
@@ -424,12 +463,12 @@ int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_
     memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
     memset(ob.host<uint32_t>(off_count), 0, 4ull * cap);
     launch_att_validate_fc(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), fc,
-                           RA.d_res_info.as<uint32_t>(), L.rows_fc, L.status_fc, ob.host<int32_t>(off_status),
+                           RS.info.as<uint32_t>(), L.rows_fc, L.status_fc, ob.host<int32_t>(off_status),
                            ob.host<uint32_t>(off_count), ob.host<uint32_t>(off_err));
     {
         ProfScope ps(h, PE_KERNEL_LMD);
         launch_lmd_vm_tables(h->stream, L.rows_fc, h->rr.tables, L.crow_start, L.crow_list, L.plan,
-                             RA.d_res_bits.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
+                             RS.bits.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
                              h->d_vote_block.as<uint32_t>(),
                              h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr,
                              reinterpret_cast<const uint32_t*>(L.status_fc));
@@ -464,7 +503,8 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
     HostLap lap(&h->trace);
     PE_TRY(refresh_tree(h));
     pe_engine::PipeArena& RA = h->arena[h->rr.arena];
-    const RrLayout L = rr_of(RA);
+    const RrLayout L = rr_of(RA, h->rr.set);
+    const RrSet RS = rr_set(RA, h->rr.set);
     Stage st(h);
     StateCtxDev S;  // travels as a kernel argument: no copy command
     memset(&S, 0, sizeof(S));
@@ -502,12 +542,12 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
     const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);
     hipStream_t ss = state_stream_begin(h);  // behind the unions and the plan; beside the next step's fork-choice chain
     launch_att_validate_state(ss, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), S,
-                              RA.d_res_info.as<uint32_t>(), L.rows_st, L.status_st, ob.host<int32_t>(off_status),
+                              RS.info.as<uint32_t>(), L.rows_st, L.status_st, ob.host<int32_t>(off_status),
                               ob.host<uint32_t>(off_err));
     {
         ProfScope ps(h, PE_KERNEL_PARTICIPATION, ss);
         launch_participation_tables(ss, L.rows_st, h->rr.tables, L.crow_start, L.crow_list, L.plan,
-                                    RA.d_res_bits.as<uint32_t>(), h->d_incr.as<uint16_t>(), sc->base_reward_per_increment,
+                                    RS.bits.as<uint32_t>(), h->d_incr.as<uint16_t>(), sc->base_reward_per_increment,
                                     h->d_part_cur.as<uint32_t>(), h->d_part_prev.as<uint32_t>(), ob.host<uint64_t>(off_num),
                                     reinterpret_cast<const uint32_t*>(L.status_st));
     }

@@ -206,9 +206,10 @@ struct StateCtxDev {              // the slice of BeaconState process_attestatio
 // tab / cnt_tab: the grouping table (slot -> first row of the class, ATT_EMPTY when free) and the class sizes; both are
 // left clean by k_att_members.  arena_pad32: 32 bytes behind the copied bit arena, zeroed here.
 void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
-                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32);
+                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32,
+                       const uint32_t* n_dev = nullptr);  // n_dev: the row count lives on the device, n bounds it
 struct AttPlanArgs {
-    const void* rows; uint32_t n;
+    const void* rows; uint32_t n; const uint32_t* n_dev;
     const uint32_t* tab; const uint32_t* cnt_tab; const uint32_t* slot_of;
     uint32_t* rep_of; uint32_t* gid_of_row; uint32_t* rep_row;
     AttGroup* grp; UnionGroup* ug; G1Group* g1;
@@ -220,7 +221,15 @@ struct AttPlanArgs {
 void launch_att_plan(hipStream_t s, const AttPlanArgs& a);
 void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
                         const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
-                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows);
+                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows,
+                        const uint32_t* n_dev = nullptr);
+// committee-sharded exchange (pe_aggregate_exchange): the groups of the resident aggregate packed into fixed slots
+// ([4 words header | slots x (36 words row, count, reserved, wps words of OR-ed bits)]), and `world` such buffers unpacked
+// into one dense batch of rows (36 words each) + bits (wps words per row); *n_dev = rows unpacked
+void launch_att_pack(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, const uint32_t* res_bits,
+                     const uint32_t* res_info, uint32_t slots, uint32_t wps, uint32_t* send);
+void launch_att_unpack(hipStream_t s, const uint32_t* recv, uint32_t world, uint32_t slots, uint32_t wps, void* out_rows,
+                       uint32_t* out_bits, uint32_t* n_dev, uint32_t* err_host);
 // n_bound: upper bound of the groups (sizes the grid); cap: entries of the caller's status / count arrays
 void launch_att_validate_fc(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
                             uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* union_info, AttRow* out_rows,

@@ -771,6 +771,22 @@ class Engine:
     def dist_set_max_groups(self, n: int):
         self._check(self._lib.pe_dist_set_max_groups(self._h, int(n)))
 
+    def aggregate_exchange(self, cap_groups: int, max_bits: int = 2048):
+        """pe_aggregate_exchange (committee-sharded steps): the aggregates of the last aggregate() over DeviceRows are
+        all-gathered and become the resident aggregate for the handlers.  -> the gathered aggregates (atts, out_arena,
+        count; fields valid when the call's outputs are complete).  cap_groups >= world x the local bound."""
+        m = max(int(cap_groups), 1)
+        (out_atts, out_arena, count, ng), (p_atts, p_arena, p_count, p_ng) = self._outs(
+            "xagg", ((m, _ATT_DTYPE), (m * ((max_bits + 31) // 32) * 4, _U8), (m, _U32), (1, _U32)))
+        ng[0] = 0
+        if self._pipe_keep is not None:
+            self._pipe_keep.append((out_atts, out_arena, count, ng))
+        rc = self._lib.pe_aggregate_exchange(self._h, p_atts, p_ng, p_arena, out_arena.size, p_count, m)
+        if rc:
+            self._check(rc)
+        return ResidentAggregateResult(_raw=dict(n_groups=ng, atts=out_atts, group_of=None, out_arena=out_arena, aggpk96=None,
+                                                 count=count), sig96=None, sig192=None)
+
     def dist_destroy(self):
         self._check(self._lib.pe_dist_destroy(self._h))
         self._coll_keep = None

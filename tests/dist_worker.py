@@ -51,6 +51,9 @@ def main():
     shard.set_proposer_boost(boost)   # the boost needs the GLOBAL active balance: carried by the all-reduce
 
     coll = HostStagedCollectives()
+    if rows_mode == "committee":
+        return committee_sharded(shard, whole, coll, rank, world, pipe_mode, dict(V=V, C=C, spe=spe, steps=steps, tree=tree,
+                                                                                bal=bal, flags=flags, pts=pts))
     shard.dist_init_custom(rank, world, coll.all_reduce_u64, coll.all_gather)
     shard.dist_set_max_groups(C)
     ep0 = int(tree.slot.max()) // spe + 1
@@ -132,6 +135,105 @@ def main():
     dist.barrier()
     digest = hashlib.sha256(ref_head).hexdigest()[:12]
     sys.stdout.write(f"DIST_WORKER_OK rank {rank} rows={rows_mode} pipe={pipe_mode} steps={steps} head={digest} "
+                     f"collectives={coll.calls}\n")
+    sys.stdout.flush()
+    dist.destroy_process_group()
+
+
+def committee_sharded(shard, whole, coll, rank, world, pipe_mode, W):
+    """Committee-sharded steps (pe_aggregate + pe_aggregate_exchange): every rank holds the whole registry and store, is
+    handed the rows of the committees c with c % world == rank, and must end every step with the unsharded twin's store."""
+    import torch
+    import torch.distributed as dist
+
+    import pos_evolution_amd.synth as synth
+    from pos_evolution_amd import RESIDENT, ROWS_RESIDENT, DeviceArena, DeviceRows
+    from pos_evolution_amd._abi import pe_state_ctx
+
+    V, C, spe, steps, tree = W["V"], W["C"], W["spe"], W["steps"], W["tree"]
+    shard.set_validators(W["bal"], W["flags"], W["pts"])   # the whole registry on every rank
+    shard.dist_init_custom(rank, world, coll.all_reduce_u64, coll.all_gather)
+    bound = C // world + 3                                 # uneven ownership: one rank serves a few committees more
+    shard.dist_set_max_groups(bound)
+    cps = C // spe
+    ep0 = int(tree.slot.max()) // spe + 1
+    keep = []
+    for s in range(steps):
+        ep = ep0 + s
+        comm = synth.random_committees(V, C, 100 + s)
+        for e in (whole, shard):
+            e.set_committees(ep, comm.offsets, comm.members)
+        atts, arena, bit_rows = synth.epoch_attestations(comm, tree, ep, spe, seed=s, density=0.9, parts=2,
+                                                         source=(0, tree.roots[0].tobytes()), vote_recent=32)
+        pos = ((atts["slot"] % spe) * cps + atts["index"]).astype(np.int64)
+        own = (pos % world == rank) if s % 2 == 0 else (pos * world // C == rank)   # interleaved / contiguous ownership
+        if rank == 0 and s == 1:
+            own |= pos == C - 1          # ... and rank 0 serves one committee more than its share
+        if rank == 1 and s == 1:
+            own &= pos != C - 1
+        la = atts[own].copy()
+        larena, offs, nb = synth.pack_bit_rows([b for b, o in zip(bit_rows, own) if o])
+        la["bits_offset"], la["n_bits"] = offs, nb
+        ctx = pe_state_ctx()
+        ctx.slot = (ep + 1) * spe
+        ctx.chain_tip_root[:] = tree.roots[tree.roots.shape[0] - 1].tobytes()
+        ctx.current_justified_root[:] = tree.roots[0].tobytes()
+        ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+        ctx.base_reward_per_increment = 777
+        for e in (whole, shard):
+            e.on_tick((ep + 1) * spe * 12)
+            e.participation_rotate()
+        ref = whole.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+        st, _, cnt = whole.on_attestation_batch(packed=(ref["atts"], ref["out_arena"]))
+        ref_head, ref_w = whole.get_head(), whole.get_weights()
+        pst, num = whole.process_attestation_batch(ctx, packed=(ref["atts"], ref["out_arena"]))
+        r = torch.from_numpy(la.view(np.uint8).reshape(-1)).cuda()
+        b = torch.from_numpy(larena).cuda()
+        keep.append((r, b))
+        cap = world * bound
+
+        def body():
+            agg = shard.aggregate(packed=(DeviceRows(r.data_ptr(), len(la), keep=r), DeviceArena(b.data_ptr(), b.numel(), keep=b)),
+                                  want_aggregate_pubkeys=True)
+            gx = shard.aggregate_exchange(cap_groups=cap)
+            lst, _, lcnt = shard.on_attestation_batch(packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
+            head = shard.get_head()
+            lpst, lnum = shard.process_attestation_batch(ctx, packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
+            return agg, gx, lst, lcnt, head, lpst, lnum
+
+        if pipe_mode == "plain":
+            agg, gx, lst, lcnt, head, lpst, lnum = body()
+        else:
+            with shard.pipeline(lagged=(pipe_mode == "lagged")):
+                agg, gx, lst, lcnt, head, lpst, lnum = body()
+            shard.drain()
+        g = ref["n_groups"]
+        key = lambda a: (int(a["slot"]), int(a["index"]), a["beacon_block_root"].tobytes())
+        ref_by = {key(a): k for k, a in enumerate(ref["atts"])}
+        # this rank's committees: complete unions and aggregate pubkeys, no collective behind them
+        assert agg["n_groups"] == len({key(a) for a in la}), (agg["n_groups"], len(la))
+        for k in range(agg["n_groups"]):
+            j = ref_by[key(agg["atts"][k])]
+            assert np.array_equal(agg["bits"][k], ref["bits"][j]) and agg["count"][k] == ref["count"][j], f"step {s} local group {k}"
+            assert np.array_equal(agg["aggpk96"][k], ref["aggpk96"][j]), f"step {s}: aggregate pubkey of local group {k}"
+        # the gathered epoch: every aggregate exactly once, rank after rank
+        assert gx["n_groups"] == g, (gx["n_groups"], g)
+        seen = set()
+        for k in range(g):
+            j = ref_by[key(gx["atts"][k])]
+            seen.add(j)
+            assert np.array_equal(gx["bits"][k], ref["bits"][j]) and gx["count"][k] == ref["count"][j], f"step {s} gathered group {k}"
+            assert lst[k] == 0 and lpst[k] == 0 and lcnt[k] == cnt[j] and lnum[k] == num[j], f"step {s} handlers, group {k}"
+        assert len(seen) == g and (np.asarray(lst)[g:] == 0).all()
+        # ... and the store of every rank is the unsharded one
+        assert head == ref_head, f"step {s}: heads differ"
+        assert np.array_equal(shard.last_weights(), ref_w), f"step {s}: weights"
+        assert np.array_equal(shard.latest_messages()[1], whole.latest_messages()[1]), f"step {s}: latest messages"
+        assert np.array_equal(shard.participation_get(0), whole.participation_get(0)), f"step {s}: participation"
+    assert coll.calls["all_gather"] == steps and coll.calls["all_reduce"] == 0, coll.calls
+    shard.dist_destroy()
+    dist.barrier()
+    sys.stdout.write(f"DIST_WORKER_OK rank {rank} rows=committee pipe={pipe_mode} steps={steps} head={ref_head.hex()[:12]} "
                      f"collectives={coll.calls}\n")
     sys.stdout.flush()
     dist.destroy_process_group()

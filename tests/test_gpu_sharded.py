@@ -217,6 +217,28 @@ def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     assert d["checked_against_oracle"] is True and d["oracle_check"]["aggregate_pubkeys"] and d["oracle_check"]["weights"]
 
 
+def test_bench_two_ranks_committee_sharded_dry_run_on_one_gpu():
+    """bench.py --sharded-mode committee with two processes sharing this GPU: committee shards (SURVEY.md 8e Option B), the
+    run's first step checked against the oracle on every rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEVO_DIST_BACKEND="gloo", POSEVO_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--validators", "65536", "--blocks", "512", "--committees", "256", "--head-calls", "5", "--no-cpu-baseline",
+           "--sharded-mode", "committee"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["parallelism"].startswith("committee shards x2")
+    assert d["config"]["validators_per_gpu"] == 65536 and "no G1 collective" in d["config"]["exchange"]
+    assert d["checked_against_oracle"] is True, d.get("oracle_check")
+    assert d["oracle_check"]["own_aggregate_pubkeys"] and d["oracle_check"]["head"] and d["oracle_check"]["latest_messages"]
+
+
 @pytest.mark.parametrize("lagged", [False, True])
 def test_engine_owned_rccl_pipelined_step_world_size_one(engine_factory, lagged):
     """The sharded step as bench.py runs it for N > 1: pe_aggregate_sharded, the handlers on the resident unions and
