@@ -76,6 +76,15 @@ def build_workload(e, args, rank, n_steps_total):
             st["own_arena"] = np.concatenate([arena[o:o + k] for o, k in zip(own_atts["bits_offset"], n_words)])
             own_atts["bits_offset"] = offs
             st["own_atts"] = own_atts
+            if getattr(args, "emulate_ranks", 0) > 1:   # every emulated rank's rows: recorded once, replayed in the timed run
+                st["rank_rows"] = []
+                for q in range(world):
+                    sel = pos * world // C == q
+                    a_q = atts[sel].copy()
+                    k_q = (a_q["n_bits"].astype(np.int64) + 7) // 8
+                    ar_q = np.concatenate([arena[o:o + k] for o, k in zip(a_q["bits_offset"], k_q)])
+                    a_q["bits_offset"] = np.concatenate([[0], np.cumsum(k_q)[:-1]]).astype(np.uint32)
+                    st["rank_rows"].append((a_q, ar_q))
         steps.append(st)
     w = dict(tree=tree, bal=bal, flags=flags, pts=pts, steps=steps, spe=spe, world=getattr(args, "world", 1))
     shuffle_from = 0 if args.with_shuffle else getattr(args, "shuffle_variant_from", n_steps_total)
@@ -206,6 +215,82 @@ def run_step_sharded_pipelined(e, w, st, lagged=True):
         head = e.get_head_sharded()                                   # all-reduce of (B + 512) x 8 B inside
         st2, num = e.process_attestation_batch(st["ctx"], packed=(rows, RESIDENT))
     return dict(agg=agg, rows=rows, status=status, count=count, pstatus=st2, numerators=num, head=head)
+
+
+class _SoloDist:
+    """torch.distributed's all_gather_object for a job of one process (the emulated-ranks run checks its one real rank)."""
+
+    @staticmethod
+    def all_gather_object(out, obj):
+        for i in range(len(out)):
+            out[i] = obj
+
+
+class ReplayCollectives:
+    """pe_dist_init_custom callbacks for `bench.py --emulate-ranks N`: ONE process and one GPU carry the per-rank load of an
+    N-rank committee-sharded job.  record(): a second engine runs pe_aggregate + pe_aggregate_exchange over every emulated
+    rank's rows of every step and the packed aggregates each rank would send are kept in HBM.  In the timed run the
+    all-gather is a device-to-device copy of that step's recording (+ the live buffer of rank 0): the exchange costs what a
+    copy costs, everything else -- this rank's aggregation, the ingestion of all ranks' aggregates, the handlers over the
+    whole epoch, the head -- is the real work of one rank."""
+
+    def __init__(self, world):
+        import ctypes as C
+
+        self.C, self.world = C, world
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        self.saved = {}       # step -> torch uint8 tensor of world x bytes_per_rank
+        self.mode, self.step, self.rank = "record", 0, 0
+
+    def all_reduce_u64(self, buf, count, stream):
+        return 1   # a committee-sharded step has no all-reduce
+
+    def all_gather(self, send, recv, nbytes, stream):
+        import torch
+
+        if self.mode == "record":
+            t = self.saved.get(self.step)
+            if t is None:
+                t = self.saved[self.step] = torch.zeros(self.world * nbytes, dtype=torch.uint8, device="cuda")
+            rc = self.hip.hipMemcpyAsync(t.data_ptr() + self.rank * nbytes, send, nbytes, 3, stream)
+            rc |= self.hip.hipMemsetAsync(recv, 0, nbytes * self.world, stream)   # nothing is ingested while recording
+            return rc
+        t = self.saved[self.step]
+        assert t.numel() == self.world * nbytes
+        rc = self.hip.hipMemcpyAsync(recv, t.data_ptr(), nbytes * self.world, 3, stream)
+        rc |= self.hip.hipMemcpyAsync(recv, send, nbytes, 3, stream)            # rank 0's slot: what it packed just now
+        return rc
+
+    def record(self, pea, args, w, device, cap):
+        import torch
+        from pos_evolution_amd import DeviceArena, DeviceRows
+
+        tree = w["tree"]
+        e2 = pea.Engine(device=device, max_committee_tables=len(w["steps"]) + 2)
+        e2.store_init(0, 0, tree.roots[0].tobytes())
+        for i in range(1, tree.roots.shape[0]):
+            e2.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+        e2.set_validators(w["bal"], w["flags"], w["pts"])
+        e2.dist_init_custom(0, self.world, self.all_reduce_u64, self.all_gather)
+        e2.dist_set_max_groups((args.committees + self.world - 1) // self.world + 8)
+        self.mode = "record"
+        for s, st in enumerate(w["steps"]):
+            e2.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
+            e2.on_tick((st["epoch"] + 1) * w["spe"] * 12)
+            self.step = s
+            for q, (a_q, ar_q) in enumerate(st["rank_rows"]):
+                self.rank = q
+                r = torch.from_numpy(a_q.view(np.uint8).reshape(-1)).cuda()
+                b = torch.from_numpy(ar_q).cuda()
+                e2.aggregate(packed=(DeviceRows(r.data_ptr(), len(a_q), keep=r), DeviceArena(b.data_ptr(), b.numel(), keep=b)))
+                e2.aggregate_exchange(cap_groups=cap)
+            del st["rank_rows"]
+        e2.dist_destroy()
+        e2.close()
+        torch.cuda.synchronize()
+        self.mode, self.rank = "replay", 0
 
 
 class _Lazy:
@@ -629,6 +714,10 @@ def main():
     ap.add_argument("--with-shuffle", action="store_true",
                     help="run the NEXT epoch's committee shuffle (pe_compute_committees_async: 90-round swap-or-not over "
                          "the registry + inverse committee map) inside every timed step, on the state-transition stream")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="ONE process / one GPU carrying the per-rank load of an N-rank committee-sharded job: the other "
+                         "ranks' aggregates are replayed from a recording, the all-gather is a device-to-device copy "
+                         "(ReplayCollectives).  A measurement of the per-rank step, not of a collective")
     ap.add_argument("--no-shuffle-variant", action="store_true",
                     help="skip the extra steps that report ms_per_step_with_shuffle")
     ap.add_argument("--no-oracle-check", action="store_true",
@@ -665,8 +754,11 @@ def main():
     import pos_evolution_amd as pea
 
     # validators this rank owns: the whole registry on one GPU; V/N (strong) or V (weak) of it on N
-    args.by_committee = args.sharded_mode == "committee" and (world > 1 or bool(os.environ.get("POSEVO_FORCE_DIST")))
-    args.world = world
+    emulate = args.emulate_ranks if args.emulate_ranks > 1 else 0
+    assert not (emulate and world > 1), "--emulate-ranks is a one-process run"
+    args.by_committee = bool(emulate) or (args.sharded_mode == "committee" and
+                                          (world > 1 or bool(os.environ.get("POSEVO_FORCE_DIST"))))
+    args.world = emulate or world
     if args.by_committee:
         args.scaling = "strong"   # one registry, replicated; the epoch's committees are what is divided
     args.validators_local = (args.validators if args.by_committee else
@@ -676,7 +768,9 @@ def main():
     lag = 1 if args.no_lag else args.lag
     # the reported variant with the per-epoch shuffle on the clock: extra steps behind the timed ones (one GPU, streaming)
     n_var = 0 if (args.with_shuffle or args.no_shuffle_variant or world > 1 or args.no_pipeline or args.host_rows
-                  or args.host_arena) else min(args.steps, 60)
+                  or args.host_arena or emulate) else min(args.steps, 60)
+    if emulate:
+        args.no_cpu_baseline = True   # the CPU legs belong to the one-GPU line
     args.shuffle_variant_from = total
     total_all = total + n_var
 
@@ -687,6 +781,17 @@ def main():
         e = pea.Engine(device=local_rank, max_committee_tables=total_all + 3)
         w = build_workload(e, args, rank, total_all)
         ex, engine_rccl, how = None, False, None
+        if emulate:
+            coll = ReplayCollectives(emulate)
+            cap = args.committees + 8 * emulate
+            coll.record(pea, args, w, local_rank, cap)
+            e.dist_init_custom(0, emulate, coll.all_reduce_u64, coll.all_gather)
+            e.dist_set_max_groups((args.committees + emulate - 1) // emulate + 8)
+            w["replay"] = coll
+            engine_rccl = True
+            ex = True
+            how = (f"EMULATED: one process carries rank 0 of {emulate}; the other ranks' aggregates are replayed from a "
+                   "recording and the all-gather is a device-to-device copy (bench.py ReplayCollectives)")
         if dist is not None:
             from pos_evolution_amd.sharded import HostStagedCollectives, ShardedForkChoice
             if args.sharded_mode in ("engine", "committee") and not args.no_pipeline:
@@ -722,7 +827,12 @@ def main():
         torch.cuda.synchronize()
 
     def run(e, w, ex, engine_rccl):
+        step_no = [0]
+
         def step(st):
+            if emulate:
+                w["replay"].step = step_no[0]   # steps run in workload order: warm-up, timed, nothing else
+                step_no[0] += 1
             if engine_rccl and args.by_committee:
                 return run_step_committee(e, w, st, lagged=not args.no_lag)
             if engine_rccl:
@@ -743,6 +853,8 @@ def main():
             if s == 0:
                 e.drain()
                 e.fill_ring()
+                if emulate and not args.no_oracle_check:
+                    sharded_chk = committee_step_check(e, w, w["steps"][0], kept[0], 0, emulate, _SoloDist, args)
                 if dist is not None and not args.no_oracle_check:
                     # N > 1: the first step of the run (a fresh store on every rank) against the oracle, before the clock
                     sharded_chk = (committee_step_check if args.by_committee else sharded_step_check)(
@@ -951,7 +1063,16 @@ def main():
         },
         "kernel_avg_ms": kernel_ms,
     }
-    if dist is not None:
+    if emulate:
+        g0 = kept[0]["gx"]
+        att_epoch = int(np.asarray(g0["count"]).sum())
+        out["emulated_ranks"] = emulate
+        out["emulated_job_attestations_per_s"] = att_epoch / (dt / args.steps)
+        out["emulated_detail"] = (f"rank 0 of an {emulate}-rank committee-sharded job on ONE GPU: `value` counts the attestations "
+                                  f"of rank 0's own {C // emulate} committees; emulated_job_attestations_per_s = the epoch's "
+                                  f"{att_epoch} attestations per rank-step time, i.e. the job's rate if every rank ran this step "
+                                  "concurrently and the all-gather cost what a device-to-device copy costs")
+    if dist is not None or emulate:
         out["config"]["exchange"] = (("per step: ONE all-gather of the ranks' aggregate attestations (144 B data + flags, count, "
                                       f"256 B of OR-ed bits per aggregate; {(C + world - 1) // world + 8} slots per rank); no G1 "
                                       "collective, no weight all-reduce; " if args.by_committee else
