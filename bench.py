@@ -979,7 +979,11 @@ def main():
     # VALU view of the same kernel: Montgomery products per launch against the measured chip ceiling
     # (tools/fpbench: 57 G products/s at the kernel's 2 waves/SIMD): 10 per mixed add (the 14-product tree adds run in
     # k_g1_tree since the kernel was split)
-    products = 10.0 * att_per_launch
+    # 10 per mixed add, 6 for the first add of a lane's run (affine + affine, round 3): k members per lane as the engine
+    # plans them (k = max(4, ceil(members / 131072)))
+    k_run = max(4, -(-VL // 131072))
+    lane_runs = C * -(-(VL // C) // k_run)
+    products = 10.0 * att_per_launch - 4.0 * lane_runs
     valu_peak = 57.0e9
     valu_ach = products / (acc_ms * 1e-3) if acc_ms else 0.0
     votes = prof["votes"]
@@ -1054,6 +1058,19 @@ def main():
             "kernel": "k_g1_accumulate", "bound": "integer VALU (v_mad_u64_u32 Montgomery products)",
             "achieved": valu_ach / 1e9, "peak": valu_peak / 1e9, "unit": "G Fp-products/s", "frac": valu_ach / valu_peak,
             "products_per_launch": products,
+            "peak_source": "tools/fpbench: this repository's own fp_mul in a dependent loop at 2 waves/SIMD -- a ceiling of the "
+                           "multiplier as written, not of the chip",
+            # the chip's own numbers (tools/ubench_valu, profiles/r01_ubench_valu_fpmul.log, 2 waves/SIMD): a product is 288
+            # multiply-accumulates; v_mad_u64_u32 issues every 2.496 ns per SIMD, the mad + v_addc_co pair every 3.600 ns
+            "instruction_ceilings": {
+                "mad_only_G_products_per_s": 1024 * 64 / (288 * 2.496),
+                "mad_plus_addc_G_products_per_s": 1024 * 64 / (288 * 3.600),
+                "frac_of_mad_only": valu_ach / 1e9 / (1024 * 64 / (288 * 2.496)),
+                "frac_of_mad_plus_addc": valu_ach / 1e9 / (1024 * 64 / (288 * 3.600)),
+                "note": "v_mad_u64_u32 has a carry-out but no carry-in: each of the 288 MACs of a 12 x 12-limb Montgomery "
+                        "product pays a v_addc_co_u32 for the third accumulator word; the mad-only figure is what a "
+                        "carry-free multiplier could reach, the mad + addc figure is the bound of this algorithm",
+            },
         },
         "roofline_votes": {
             "kernel": "k_votes", "bound": "hbm", "achieved": votes_bytes / (votes_ms * 1e-3) / 1e9 if votes_ms else 0.0,
