@@ -171,7 +171,8 @@ int main(int argc, char** argv)
         o->sig_status = (int32_t*)calloc(max_atts, 4);
         o->arena_len = max_arena;
     }
-    uint64_t hsh = 0xCBF29CE484222325ull, n_att = 0, n_att_warm = 0;
+    uint64_t hsh = 0xCBF29CE484222325ull, n_att = 0, n_att_warm = 0, consumed = 0;
+    const uint64_t first_gen = pe_pipeline_generation(h);   /* pipelines begun before the steps (none, normally) */
     /* the first steps grow the engine's pinned staging blocks (milliseconds each): untimed, like bench.py's warm-up */
     const uint64_t warmup = warmup_arg + 2 < hd.n_steps ? warmup_arg : 0;
     double t0 = now_ms();
@@ -198,21 +199,26 @@ int main(int argc, char** argv)
                                            o->numerators));
         if (streaming) CHECK(pe_pipeline_end_lagged(h));
         else if (pipelined) CHECK(pe_pipeline_end(h));
-        /* consume a completed step: this one, or -- streaming -- the one two steps back */
+        /* consume completed steps: this one, or -- streaming -- whatever pe_pipeline_completed says is complete (step s is
+           pipeline s + 1; with lag depth 2 that is the step two back, but the client need not know the depth) */
         if (!streaming) {
             if (hashing) hsh = fold(hsh, o);
             for (uint32_t k = 0; k < o->n_groups; ++k) n_att += o->count[k];
-        } else if (s >= 2) {
-            const step_out* d = &ring[(s - 2) % RING];
-            if (hashing) hsh = fold(hsh, d);
-            for (uint32_t k = 0; k < d->n_groups; ++k) n_att += d->count[k];
+        } else {
+            while (consumed < pe_pipeline_completed(h) - first_gen) {
+                const step_out* d = &ring[consumed % RING];
+                if (hashing) hsh = fold(hsh, d);
+                for (uint32_t k = 0; k < d->n_groups; ++k) n_att += d->count[k];
+                ++consumed;
+            }
+            if (s + 1 - consumed >= RING) { fprintf(stderr, "output ring too shallow for the lag depth\n"); return 3; }
         }
     }
-    if (streaming) {  /* drain: the last two steps complete here */
+    if (streaming) {  /* drain: the steps still in flight complete here */
         CHECK(pe_pipeline_begin(h));
         CHECK(pe_pipeline_end(h));
-        for (uint64_t s = hd.n_steps >= 2 ? hd.n_steps - 2 : 0; s < hd.n_steps; ++s) {
-            const step_out* d = &ring[s % RING];
+        for (; consumed < hd.n_steps; ++consumed) {
+            const step_out* d = &ring[consumed % RING];
             if (hashing) hsh = fold(hsh, d);
             for (uint32_t k = 0; k < d->n_groups; ++k) n_att += d->count[k];
         }

@@ -254,6 +254,13 @@ int pe_pipeline_end_lagged(pe_engine* h);
  * uses.  Completes everything in flight first; not inside a pipeline (PE_ERR_STATE). */
 int pe_pipeline_set_lag(pe_engine* h, uint32_t depth);
 uint32_t pe_pipeline_get_lag(const pe_engine* h);
+/* Which buffers may be touched: pipelines are numbered from 1 in the order of their pe_pipeline_begin(_streaming);
+ * pe_pipeline_generation = the number of the one begun last, pe_pipeline_completed = the highest number whose outputs
+ * are complete (they complete in order: after a pe_pipeline_end_lagged that is generation - lag or later, after
+ * pe_pipeline_end or any synchronous call it is generation).  A caller that rotates its output buffers reads set g
+ * when pe_pipeline_completed(h) >= g and hands it out again after that -- no need to count lagged ends itself. */
+uint64_t pe_pipeline_generation(const pe_engine* h);
+uint64_t pe_pipeline_completed(const pe_engine* h);
 /* pe_pipeline_begin for a pipeline that will end lagged: the G1 sums of its pe_aggregate are not launched by that call
  * but by pe_pipeline_end_lagged, BEHIND the step's fork-choice kernels.  k_g1_accumulate fills every CU for its whole
  * run, so launched first it would hold pe_get_head (and with it the host's preparation of the next step) back until it

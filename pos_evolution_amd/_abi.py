@@ -118,6 +118,8 @@ SIGNATURES = {
     "pe_g2_subgroup_check": (C.c_int, [_H, _u8p, C.c_uint64, _i32p]),
     "pe_pipeline_set_lag": (C.c_int, [_H, C.c_uint32]),
     "pe_pipeline_get_lag": (C.c_uint32, [_H]),
+    "pe_pipeline_generation": (C.c_uint64, [_H]),
+    "pe_pipeline_completed": (C.c_uint64, [_H]),
     "pe_get_weights": (C.c_int, [_H, _u64p, C.c_uint32]),
     "pe_on_attestation_batch": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _i32p, _u8p, _u32p]),
     "pe_get_indexed_attestations": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _i32p, _u32p, _u32p,

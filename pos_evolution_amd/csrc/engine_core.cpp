@@ -68,6 +68,9 @@ int complete_arena(pe_engine* h, int ai)
     }
     std::vector<std::function<int()>> todo;
     todo.swap(a.pending);
+    // arenas complete oldest first; the CURRENT arena completed in the middle of its own pipeline (a block that had to grow)
+    // is not a completed pipeline: the calls still to come put their outputs behind
+    if (a.generation > h->pipes_completed && !(h->pipelining && ai == h->cur)) h->pipes_completed = a.generation;
     a.stage_cursor = a.out_cursor = 0;
     a.fenced = a.side_used = a.aux_used = false;
     if (e == hipErrorNotReady)
@@ -397,6 +400,7 @@ int pe_pipeline_begin(pe_engine* h)
         if (lane) HIP_TRY(h, a.d_lane_partials.ensure(lane));
     }
     h->A().table_stamp_at_begin = h->table_stamp;
+    h->A().generation = ++h->pipes_begun;
     h->pipelining = true;
     return PE_OK;
 }
@@ -429,6 +433,8 @@ int pe_pipeline_set_lag(pe_engine* h, uint32_t depth)
     return PE_OK;
 }
 uint32_t pe_pipeline_get_lag(const pe_engine* h) { return h ? (uint32_t)h->n_arenas - 1 : 0; }
+uint64_t pe_pipeline_generation(const pe_engine* h) { return h ? h->pipes_begun : 0; }
+uint64_t pe_pipeline_completed(const pe_engine* h) { return h ? h->pipes_completed : 0; }
 
 int pe_pipeline_end_lagged(pe_engine* h)
 {

@@ -256,6 +256,7 @@ struct pe_engine {
         DevBuf d_xsend, d_xrecv, d_xrows, d_xbits, d_xn;  // packed local groups | all ranks' | unpacked rows | bits | count
         size_t stage_cursor = 0, out_cursor = 0;
         uint64_t table_stamp_at_begin = 0;  // h->table_stamp when the pipeline that fills this arena began
+        uint64_t generation = 0;            // ordinal of the pipeline that fills this arena (pe_pipeline_generation)
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
         bool fenced = false, side_used = false, aux_used = false;
@@ -268,6 +269,7 @@ struct pe_engine {
     int cur = 0;
     PipeArena& A() { return arena[cur]; }
     bool pipelining = false;
+    uint64_t pipes_begun = 0, pipes_completed = 0;  // pe_pipeline_generation / pe_pipeline_completed
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
     hipStream_t fin_stream = nullptr;   // ... its k_g1_tree here, beside the NEXT aggregate's accumulation
     // ... and its k_g1_finish here: on the tree's stream the two latency-bound guests of a step ran one behind the other

@@ -147,4 +147,51 @@ with e.pipeline(lagged=True):
     sh.get_head()
 assert calls() == ["pe_get_head_sharded", "pe_pipeline_begin_streaming", "pe_aggregate_sharded", "pe_on_attestation_batch",
                    "pe_get_head_sharded", "pe_pipeline_end_lagged"]
+# ---- round 3: lag depth, rows in device memory, the signature leg, the committee-sharded exchange, custom collectives ----
+lib.stub_reset()
+e.drain()
+e.reuse_outputs(4)
+e.set_pipeline_lag(4)                    # pe_pipeline_set_lag; the ring must then hold lag + 2 sets
+assert "pe_pipeline_set_lag" in calls()
+try:
+    step(True)
+    raise SystemExit("a ring of 4 is too shallow for lag depth 4")
+except ValueError:
+    pass
+e.reuse_outputs(6)
+ring = [step(True) for _ in range(13)]
+addr = [x[1].ctypes.data for x in ring]
+assert len(set(addr[:6])) == 6 and addr[6:12] == addr[:6]
+assert len(e._lagged_keep) == 4          # this block's buffers + the three before it stay alive
+e.drain()
+e.set_pipeline_lag(2)
+e.reuse_outputs(4)
+lib.stub_reset()
+rows = pea.DeviceRows(atts.ctypes.data, 8)   # rows "in device memory" travel as their address (the stub reads them: host memory here)
+with e.pipeline(lagged=True):
+    ragg = e.aggregate(packed=(rows, pea.DeviceArena(0xDEAD0000, 64)), want_aggregate_pubkeys=True)
+    st_r, _, cnt_r = e.on_attestation_batch(packed=(pea.ROWS_RESIDENT, pea.RESIDENT), cap=8)
+    hd = e.get_head_async()
+    pst_r, num_r = e.process_attestation_batch(ctx, packed=(pea.ROWS_RESIDENT, pea.RESIDENT), cap=8)
+    e.compute_committees_async(7, b"\x05" * 32, 64, 32)
+assert calls() == ["pe_pipeline_begin_streaming", "pe_aggregate", "pe_on_attestation_batch", "pe_get_head_async",
+                   "pe_process_attestation_batch", "pe_compute_committees_async", "pe_pipeline_end_lagged"]
+assert st_r.shape == (8,) and num_r.shape == (8,) and hd.shape == (32,) and ragg["n_groups"] == 2   # the stub's n / 4
+sigs = np.zeros((8, 96), dtype=np.uint8)
+sres = e.aggregate_signed(sigs, packed=(atts, bits), compressed=True, check_subgroup=True)
+assert "pe_aggregate_signed" in calls() and sres["sig96c"].shape[1] == 96 and sres["sig_status"].shape == (8,)
+try:
+    e.aggregate_signed(sigs[:3], packed=(atts, bits))
+    raise SystemExit("one signature per input row")
+except AssertionError:
+    pass
+lib.stub_reset()
+seen_cb = []
+e.dist_init_custom(0, 2, lambda buf, count, stream: seen_cb.append("ar") or 0, lambda s_, r_, nb, st_: seen_cb.append("ag") or 0)
+e.dist_set_max_groups(5)
+gx = e.aggregate_exchange(cap_groups=10)
+assert calls() == ["pe_dist_init_custom", "pe_dist_set_max_groups", "pe_aggregate_exchange"]
+assert gx["n_groups"] == 0 and e._coll_keep is not None        # the callback table outlives the call
+e.dist_destroy()
+assert e._coll_keep is None
 print("host wrapper ok")
