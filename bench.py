@@ -205,7 +205,7 @@ def run_step_sharded_pipelined(e, w, st, lagged=True):
         with e.pipeline(lagged=lagged):
             agg = e.aggregate_sharded(packed=(st["rows_in"], st["arena_in"]))         # all-gather of C x 192 B partials inside
             status, _, count = e.on_attestation_batch(packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
-            head = e.get_head_sharded()                                               # all-reduce of (B + 512) x 8 B inside
+            head = e.get_head_sharded_async()                                         # all-reduce of (B + 512) x 8 B inside
             st2, num = e.process_attestation_batch(st["ctx"], packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
         return dict(agg=agg, rows=None, status=status, count=count, pstatus=st2, numerators=num, head=head)
     with e.pipeline(lagged=lagged):
@@ -738,6 +738,13 @@ def main():
     #   POSEVO_DIST_BACKEND=gloo POSEVO_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
     # It validates the sharded code path end to end; its numbers are not a scaling measurement.
     backend = os.environ.get("POSEVO_DIST_BACKEND", "nccl")
+    # `backend` = what carries the ENGINE's exchange (nccl: RCCL owned by the engine; anything else: host-staged dry run).
+    # torch.distributed itself only carries ids, barriers and the oracle check's gathers, so it runs over gloo: torch's own
+    # NCCL process group brings high-priority streams into the process, and with those hardware queues beside the engine's
+    # the next step's fork-choice chain is scheduled BEHIND the running accumulation -- 0.59 instead of 0.37 ms/step with
+    # one rank over RCCL (gpurun_out/r03C).  --sharded-mode torch needs torch's NCCL for the exchange itself.
+    torch_backend = os.environ.get("POSEVO_TORCH_BACKEND",
+                                   backend if (args.sharded_mode == "torch" or backend != "nccl") else "gloo")
     if os.environ.get("POSEVO_SHARE_GPU"):
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -745,10 +752,10 @@ def main():
     if world > 1 or os.environ.get("POSEVO_FORCE_DIST"):
         import torch.distributed as dist
 
-        if backend == "nccl":
+        if torch_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=torch_backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node N"
 
     import pos_evolution_amd as pea
@@ -795,7 +802,7 @@ def main():
         if dist is not None:
             from pos_evolution_amd.sharded import HostStagedCollectives, ShardedForkChoice
             if args.sharded_mode in ("engine", "committee") and not args.no_pipeline:
-                ok_t = torch.tensor([1], device="cuda" if backend == "nccl" else "cpu")
+                ok_t = torch.tensor([1], device="cuda" if torch_backend == "nccl" else "cpu")
                 try:
                     if backend == "nccl":  # the engine's own communicators; torch.distributed only carries the 256-byte id
                         ex = ShardedForkChoice(e, n_groups_max=args.committees, use_engine_rccl=True, single_comm=single_comm)
@@ -941,7 +948,7 @@ def main():
     lat = np.sort(np.array(lat))
 
     if dist is not None:
-        t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda" if torch_backend == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -1089,6 +1096,8 @@ def main():
                                   f"of rank 0's own {C // emulate} committees; emulated_job_attestations_per_s = the epoch's "
                                   f"{att_epoch} attestations per rank-step time, i.e. the job's rate if every rank ran this step "
                                   "concurrently and the all-gather cost what a device-to-device copy costs")
+    if dist is not None:
+        out["config"]["torch_distributed_backend"] = torch_backend + " (ids, barriers and the oracle check only)"
     if dist is not None or emulate:
         out["config"]["exchange"] = (("per step: ONE all-gather of the ranks' aggregate attestations (144 B data + flags, count, "
                                       f"256 B of OR-ed bits per aggregate; {(C + world - 1) // world + 8} slots per rank); no G1 "

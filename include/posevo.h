@@ -590,6 +590,9 @@ int pe_dist_set_timeout_ms(pe_engine* h, uint32_t ms);
 int pe_dist_set_max_groups(pe_engine* h, uint32_t max_groups);
 int pe_dist_destroy(pe_engine* h);
 int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32]);
+/* pe_get_head_async's counterpart: inside a pipeline nothing waits, out_root is written where the pipeline's outputs
+ * complete (a streaming caller's loop then never waits for the all-reduce inside a step). */
+int pe_get_head_sharded_async(pe_engine* h, uint8_t out_root[32]);
 int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n,
                          const uint8_t* bits_arena, uint64_t arena_len,
                          pe_attestation* out_atts, uint32_t* out_n_groups, uint32_t* group_of,

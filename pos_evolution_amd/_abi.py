@@ -171,6 +171,7 @@ SIGNATURES = {
     "pe_dist_set_max_groups": (C.c_int, [_H, C.c_uint32]),
     "pe_aggregate_exchange": (C.c_int, [_H, _attp, _u32p, _u8p, C.c_uint64, _u32p, C.c_uint32]),
     "pe_get_head_sharded": (C.c_int, [_H, _u8p]),
+    "pe_get_head_sharded_async": (C.c_int, [_H, _u8p]),
     "pe_aggregate_sharded": (C.c_int, [_H, _attp, C.c_uint32, _u8p, C.c_uint64, _attp, _u32p, _u32p, _u8p,
                                        C.c_uint64, _u8p, _u32p]),
     "pe_pipeline_begin": (C.c_int, [_H]),

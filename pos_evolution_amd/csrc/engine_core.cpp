@@ -239,7 +239,21 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     if (!h) return PE_ERR_OOM;
     h->cfg = c;
     h->device = dev;
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    // Stream priorities: all normal.  The runtime maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    // default) per priority level, and how the engine's five streams fare depends on what else the process runs there:
+    // with torch's NCCL process group (high-priority streams) in the process the next step's fork-choice chain is scheduled
+    // behind the running accumulation (0.59 vs 0.37 ms/step, one rank over RCCL) -- bench.py keeps torch on gloo for that
+    // reason.  Priorities inside the engine (POSEVO_STREAM_PRIOS="m,s,f,n,a", -1 low / 0 normal / 1 high, for experiments)
+    // cut both ways: engine stream high + accumulation low repairs that case (0.37-0.44) and ruins the plain one
+    // (0.82-0.85 vs 0.34: the accumulation's waves get preempted); a fixed first-use order of the streams changes nothing.
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    int pr[5] = {0, 0, 0, 0, 0};  // main, side (accumulate), fin (tree), norm (finish), aux (state transition)
+    if (const char* e = getenv("POSEVO_STREAM_PRIOS")) (void)sscanf(e, "%d,%d,%d,%d,%d", &pr[0], &pr[1], &pr[2], &pr[3], &pr[4]);
+    auto mk = [&](hipStream_t* s, int p) {
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p > 0 ? prio_greatest : p < 0 ? prio_least : (prio_least + prio_greatest) / 2);
+    };
+    if (mk(&h->own_stream, pr[0]) != hipSuccess) {
         delete h;
         return PE_ERR_NO_DEVICE;
     }
@@ -248,14 +262,13 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // k_g1_finish of step N-1/N, each on its own stream.  (CU-masked streams -- a private CU partition for the
     // latency-sized fork-choice kernels -- were measured and dropped: hipExtStreamCreateWithCUMask with 16 / 32 / 48
     // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
-    const bool ok_streams = hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) == hipSuccess &&
-                            hipStreamCreateWithFlags(&h->fin_stream, hipStreamNonBlocking) == hipSuccess &&
-                            hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    const bool ok_streams = mk(&h->side_stream, pr[1]) == hipSuccess && mk(&h->fin_stream, pr[2]) == hipSuccess &&
+                            mk(&h->aux_stream, pr[4]) == hipSuccess;
     {
         const char* e = getenv("POSEVO_G1_NORM_STREAM");  // 0: tree and finish share the finishing stream
         if (hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming) != hipSuccess ||
             (ok_streams && (!e || atoi(e) != 0) &&
-             hipStreamCreateWithFlags(&h->norm_stream, hipStreamNonBlocking) != hipSuccess)) {
+             mk(&h->norm_stream, pr[3]) != hipSuccess)) {
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }

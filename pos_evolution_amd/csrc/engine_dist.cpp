@@ -230,13 +230,14 @@ int pe_dist_destroy(pe_engine* h)
 
 // get_head over all shards: this shard's direct weights -> ONE all-reduce(sum, u64) of B + PE_EXCHANGE_EXTRA words on
 // the engine's stream -> subtree sums + descent on every rank (same root everywhere; integer sums are order-free).
-int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
+static int get_head_sharded_impl(pe_engine* h, uint8_t out_root[32], bool async)
 {
     // inside a pipeline the call is ordered behind the enqueued batch calls on the stream, like pe_get_head
     int rc = need_init(h, /*flush=*/!(h && h->pipelining));
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
     if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
+    if (!h->pipelining) async = false;  // outside a pipeline every call is synchronous
     const uint32_t nb = (uint32_t)h->blocks.size();
     const size_t words = (size_t)nb + PE_EXCHANGE_EXTRA;
     if (words * 8 > h->d_xchg.cap) {  // the engine's own exchange buffer is self-cleaning, like pe_get_head's: zero it once
@@ -254,6 +255,18 @@ int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
     HostLap lap(&h->trace);
     rc = refresh_tree(h);
     if (rc) return rc;
+    {
+        uint32_t tmp;  // fail before anything is launched: k_votes adds into a buffer only k_tree clears
+        if (!find_block(h, h->justified.root, &tmp))
+            return fail(h, PE_ERR_UNKNOWN_ROOT, "justified checkpoint root is not in the store");
+    }
+    Stage st(h);
+    OutBlock ob(h);
+    size_t off = 0;
+    if (async) {
+        off = ob.alloc(64);
+        PE_TRY(ob.ensure());
+    }
     uint64_t* buf = h->d_xchg.as<uint64_t>();
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
@@ -268,12 +281,30 @@ int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32])
     lap.mark("dist.votes_launch");
     PE_TRY(dist_all_reduce_u64(h, h->d_xchg.p, words, h->stream));
     lap.mark("dist.all_reduce_enqueue");
-    uint32_t head;
-    rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + nb), /*clear_direct=*/1, &head);
-    if (rc == PE_OK) memcpy(out_root, h->blocks[head].root.data(), 32);
+    uint32_t head = 0;
+    rc = run_tree(h, buf, reinterpret_cast<const VoteTotals*>(buf + nb), /*clear_direct=*/1, &head,
+                  async ? ob.host<uint32_t>(off) : nullptr);
     lap.mark("dist.tree_wait");
-    return rc;
+    if (rc) return rc;
+    if (!async) {
+        memcpy(out_root, h->blocks[head].root.data(), 32);
+        return PE_OK;
+    }
+    const size_t base = ob.base;
+    const int ai = h->cur;
+    auto complete = [h, ai, base, off, out_root]() -> int {
+        const uint32_t idx = *reinterpret_cast<const uint32_t*>(h->arena[ai].h_pin.as<uint8_t>() + base + off);
+        if (idx >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
+        memcpy(out_root, h->blocks[idx].root.data(), 32);
+        return PE_OK;
+    };
+    return finish_call(h, st, ob, complete);
 }
+
+int pe_get_head_sharded(pe_engine* h, uint8_t out_root[32]) { return get_head_sharded_impl(h, out_root, false); }
+// the root delivered like every other output of the pipeline (pe_get_head_async's counterpart): a streaming caller's
+// loop then never waits for the all-reduce inside a step
+int pe_get_head_sharded_async(pe_engine* h, uint8_t out_root[32]) { return get_head_sharded_impl(h, out_root, true); }
 
 // pe_aggregate over all shards: rank-local bitfield unions, global aggregate pubkeys.  Every rank passes attestations
 // that form the SAME groups in the SAME order (group g of every rank = that rank's members of committee g); the

@@ -797,6 +797,16 @@ class Engine:
         self._check(self._lib.pe_get_head_sharded(self._h, out))
         return bytes(out)
 
+    def get_head_sharded_async(self) -> np.ndarray:
+        """pe_get_head_sharded_async: -> a 32-byte array that holds the root once the pipeline's outputs are complete."""
+        (out,), (p_out,) = self._outs("headsh", ((32, _U8),))
+        if self._pipe_keep is not None:
+            self._pipe_keep.append(out)
+        rc = self._lib.pe_get_head_sharded_async(self._h, p_out)
+        if rc:
+            self._check(rc)
+        return out
+
     def aggregate_sharded(self, rows=None, packed=None):
         """pe_aggregate over all shards (one all-gather of the XYZZ partials inside): rank-local unions, global
         aggregate pubkeys.  Inside a pipeline() block nothing waits; the unions can be handed on as RESIDENT."""

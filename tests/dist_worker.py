@@ -102,9 +102,11 @@ def main():
                 hrows = (ROWS_RESIDENT, RESIDENT) if rows_mode == "device" else (agg["atts"], RESIDENT)
                 kw = dict(cap=C) if rows_mode == "device" else {}
                 lst, _, lcnt = shard.on_attestation_batch(packed=hrows, **kw)
-                head = shard.get_head_sharded()
+                # lagged: the root arrives with the pipeline's outputs (pe_get_head_sharded_async), as bench.py's N > 1 step has it
+                head = shard.get_head_sharded_async() if pipe_mode == "lagged" else shard.get_head_sharded()
                 lpst, lnum = shard.process_attestation_batch(ctx, packed=hrows, **kw)
             shard.drain()   # compare step by step
+            head = bytes(head)
         g = ref["n_groups"]
         assert agg["n_groups"] == g, (agg["n_groups"], g)
         assert head == ref_head, f"step {s}: heads differ"
