@@ -610,8 +610,8 @@ int pe_set_committees(pe_engine* h, uint64_t epoch, uint32_t n_committees, const
     return PE_OK;
 }
 
-// asynchronous = true: pe_compute_committees_async -- nothing is waited for and nothing read back; the kernels go to the
-// state-transition stream, and the engine's stream waits for them before the next batch call reads the table
+// asynchronous = true: pe_compute_committees_async -- nothing is waited for and nothing read back; the kernels go to a
+// stream of their own, and the engine's stream waits for them the first time the table is read (find_table)
 static int compute_committees_impl(pe_engine* h, uint64_t epoch, const uint8_t seed[32], const uint32_t* active_indices,
                                    uint32_t n_active, uint32_t n_committees, uint32_t shuffle_round_count,
                                    uint32_t* out_offsets, uint32_t* out_members, bool asynchronous)
@@ -655,19 +655,20 @@ static int compute_committees_impl(pe_engine* h, uint64_t epoch, const uint8_t s
         } else {
             t = &*std::min_element(h->tables.begin(), h->tables.end(),
                                    [](const CommitteeTable& a, const CommitteeTable& b) { return a.stamp < b.stamp; });
-            if (asynchronous) {
-                // the least recently used table is rewritten in place: work still in flight must not be reading it.  A
-                // pipeline notes the stamp counter at its begin; a table stamped after the oldest pipeline in flight
-                // began may be one of its tables -- then everything in flight completes first (a caller that streams
-                // with lag depth L keeps at least L + 3 tables and never gets here)
-                uint64_t oldest = h->table_stamp + 1;
-                for (int k = 0; k < h->n_arenas; ++k) {
-                    const pe_engine::PipeArena& a = h->arena[k];
-                    if (a.fenced || !a.pending.empty()) oldest = std::min(oldest, a.table_stamp_at_begin);
-                }
-                if (t->stamp >= oldest) PE_TRY(flush_pending(h));
-            }
         }
+    }
+    if (asynchronous && t->n_committees) {
+        // The table (the epoch's own, shuffled again, or the least recently used one) is rewritten in place: work still
+        // in flight must not be reading it.  A pipeline notes the stamp counter at its begin and every use re-stamps a
+        // table, so a table stamped after the oldest pipeline in flight began may be one of its tables -- then everything
+        // in flight completes first (a caller that streams with lag depth L keeps at least L + 3 tables and shuffles an
+        // epoch before its first use: it never waits here)
+        uint64_t oldest = h->table_stamp + 1;
+        for (int k = 0; k < h->n_arenas; ++k) {
+            const pe_engine::PipeArena& a = h->arena[k];
+            if (a.fenced || !a.pending.empty()) oldest = std::min(oldest, a.table_stamp_at_begin);
+        }
+        if (t->stamp >= oldest) PE_TRY(flush_pending(h));
     }
     // an earlier asynchronous shuffle into this slot (its staging pair and the table's arrays are about to be rewritten):
     // let it finish; a completed or never recorded event returns at once
@@ -679,10 +680,6 @@ static int compute_committees_impl(pe_engine* h, uint64_t epoch, const uint8_t s
         // staging pair (seed | offsets | active indices), the shuffle has its own stream and scratch, and the table's
         // event is what a later reader waits for (find_table).
         if (!h->prep_stream) {
-            // the runtime maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation order,
-            // and streams that share a queue run in order: POSEVO_PREP_SLOT skips that many slots first
-            static const int skip = [] { const char* e = getenv("POSEVO_PREP_SLOT"); return e ? atoi(e) : 0; }();
-            for (int k = 0; k < skip; ++k) { hipStream_t dummy; (void)hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking); }
             static const int prio = [] { const char* e = getenv("POSEVO_PREP_PRIO"); return e ? atoi(e) : 0; }();
             if (prio) {  // -1: the lowest priority the device offers, 1: the highest (each has hardware queues of its own)
                 int least = 0, greatest = 0;
