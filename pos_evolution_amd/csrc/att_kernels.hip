@@ -99,7 +99,7 @@ k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ 
     load_row(r, rows, i);
     const uint32_t b0 = r.q[8].x, nb = r.q[8].y;
     // "attestation bits exceed the arena" / "target epoch must fit 32 bits" of the host path: the whole call fails
-    if ((unsigned long long)b0 + (nb + 7) / 8 > arena_len || row_target_epoch(r) >= 0xFFFFFFFEull) atomicMax(&plan->error, ERR_INVALID_ARG);
+    if (nb > 0x7FFFFFFFu || (unsigned long long)b0 + ((unsigned long long)nb + 7) / 8 > arena_len || row_target_epoch(r) >= 0xFFFFFFFEull) atomicMax(&plan->error, ERR_INVALID_ARG);
     uint32_t h = att_hash(r) & mask;
     for (;;) {
         const uint32_t prev = atomicCAS(&tab[h], ATT_EMPTY, i);

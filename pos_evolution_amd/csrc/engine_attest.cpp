@@ -113,9 +113,9 @@ int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n
                 return fail(h, PE_ERR_INVALID_ARG, "PE_BITS_RESIDENT: row is not a row of the last pe_aggregate");
             continue;
         }
-        if ((uint64_t)a.bits_offset + (a.n_bits + 7) / 8 > arena_len)
+        if (a.n_bits > 0x7FFFFFFFu || (uint64_t)a.bits_offset + ((uint64_t)a.n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
-        word_bound += (a.n_bits + 31) / 32 + 1;
+        word_bound += ((uint64_t)a.n_bits + 31) / 32 + 1;
     }
     lap.mark("att.1a_sizes_resident");
     Stage st(h);
@@ -320,9 +320,9 @@ int pe_get_indexed_attestations(pe_engine* h, const pe_attestation* atts, uint32
     if (bits_on_device(bits_arena)) return fail(h, PE_ERR_INVALID_ARG, "bits in device memory: only pe_aggregate reads them there");
     uint64_t word_bound = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
+        if (atts[i].n_bits > 0x7FFFFFFFu || (uint64_t)atts[i].bits_offset + ((uint64_t)atts[i].n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
-        word_bound += (atts[i].n_bits + 31) / 32 + 1;
+        word_bound += ((uint64_t)atts[i].n_bits + 31) / 32 + 1;
     }
     Stage st(h);
     PE_TRY(st.reserve(word_bound * 4 + (sizeof(AttRow) + 4) * (size_t)(n + 1) + 4096));
@@ -456,8 +456,8 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
     gof.resize(n);
     uint64_t lo = ~0ull, hi = 0;                    // byte span of the arena this call reads
     for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t b0 = atts[i].bits_offset, b1 = b0 + (atts[i].n_bits + 7) / 8;
-        if (b1 > arena_len) return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
+        const uint64_t b0 = atts[i].bits_offset, b1 = b0 + ((uint64_t)atts[i].n_bits + 7) / 8;
+        if (b1 > arena_len || atts[i].n_bits > 0x7FFFFFFFu) return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
         if (atts[i].n_bits) { lo = std::min(lo, b0); hi = std::max(hi, b1); }
         uint32_t slot = (uint32_t)hash_att(atts[i]) & (tab_size - 1);
         uint32_t g;
@@ -908,9 +908,9 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                 return fail(h, PE_ERR_INVALID_ARG, "PE_BITS_RESIDENT: row is not a row of the last pe_aggregate");
             continue;
         }
-        if ((uint64_t)atts[i].bits_offset + (atts[i].n_bits + 7) / 8 > arena_len)
+        if (atts[i].n_bits > 0x7FFFFFFFu || (uint64_t)atts[i].bits_offset + ((uint64_t)atts[i].n_bits + 7) / 8 > arena_len)
             return fail(h, PE_ERR_INVALID_ARG, "attestation bits exceed the arena");
-        word_bound += (atts[i].n_bits + 31) / 32 + 1;
+        word_bound += ((uint64_t)atts[i].n_bits + 31) / 32 + 1;
     }
     // get_block_root* walks from the chain tip: one per distinct slot asked, not one per row
     uint64_t anc_slot[64];

@@ -288,6 +288,16 @@ def test_errors_are_deferred_and_form_no_groups(engine_factory):
     assert err.value.status == -1   # PE_ERR_INVALID_ARG
     assert np.array_equal(e.latest_messages()[1], before)
     assert st is None or ((st == 0).all() and (cnt == 0).all())
+    # a length that wraps 32-bit byte arithmetic ((n_bits + 7) / 8 == 0) is refused like any other row outside the arena,
+    # rows in host memory or in HBM
+    for n_bits in (0xFFFFFFFF, 0xFFFFFFF9, 0x80000000):
+        wrap = atts.copy()
+        wrap["n_bits"][5] = n_bits
+        for rows in (wrap, _dev_rows(wrap)):
+            with pytest.raises(pea.EngineError) as err:
+                e.aggregate(packed=(rows, arena), want_aggregate_pubkeys=True)
+            assert err.value.status == -1
+    assert np.array_equal(e.latest_messages()[1], before)
     # aggregate pubkeys asked for a target epoch without a table
     other = atts.copy()
     other["target_epoch"][3] += 1
