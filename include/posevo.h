@@ -581,7 +581,9 @@ int pe_dist_init_custom(pe_engine* h, int rank, int world, const pe_collectives*
 /* Bounded waits (default 30 000 ms; 0 = wait for ever; POSEVO_DIST_TIMEOUT_MS presets it): once a handle has
  * pe_dist_init'ed, the waits for enqueued work poll with this limit; past it the call aborts the communicators
  * (ncclCommAbort), returns PE_ERR_TIMEOUT and the handle refuses further sharded calls until pe_dist_destroy +
- * pe_dist_init(_ex).  A hung exchange thus surfaces as an error on every rank instead of a stuck job. */
+ * pe_dist_init(_ex).  A hung exchange thus surfaces as an error on every rank instead of a stuck job.  The outputs of
+ * the calls and pipelines in flight at that moment are lost (pe_pipeline_completed stays where it was); the store
+ * keeps what the device had applied -- votes and flags are idempotent, the caller replays the lost steps. */
 int pe_dist_set_timeout_ms(pe_engine* h, uint32_t ms);
 /* Upper bound of the groups one pe_aggregate_sharded over rows in DEVICE memory may form (default: its row count n).  The
  * all-gather of such a call is sized before the device has formed the groups; a caller that knows its epoch has C

@@ -212,6 +212,7 @@ int pe_dist_destroy(pe_engine* h)
         h->res_valid = false;
         h->rr.valid = false;
         h->early_rc = PE_OK;
+        h->xchg_blocks = 0;  // what an aborted exchange left in the self-cleaning buffer is unknown: zeroed at the next use
     }
     if (h->comm) {
         (void)hipStreamSynchronize(h->stream);
@@ -237,6 +238,8 @@ static int get_head_sharded_impl(pe_engine* h, uint8_t out_root[32], bool async)
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
     if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
+    if (h->dist_wedged)  // before anything is launched: k_votes / the unions would otherwise run with no exchange to follow
+        return fail(h, PE_ERR_TIMEOUT, "an earlier exchange timed out on this handle: pe_dist_destroy, then initialise again");
     if (!h->pipelining) async = false;  // outside a pipeline every call is synchronous
     const uint32_t nb = (uint32_t)h->blocks.size();
     const size_t words = (size_t)nb + PE_EXCHANGE_EXTRA;
@@ -319,6 +322,8 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
     (void)hipSetDevice(h->device);
     if (!h->pipelining) PE_TRY(flush_pending(h));
     if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_aggregate_sharded: call pe_dist_init first");
+    if (h->dist_wedged)  // before anything is launched: k_votes / the unions would otherwise run with no exchange to follow
+        return fail(h, PE_ERR_TIMEOUT, "an earlier exchange timed out on this handle: pe_dist_destroy, then initialise again");
     if (n == 0) { *out_n_groups = 0; return PE_OK; }
     const bool dev_rows = rows_on_device(atts);
     // slots of the exchange: host rows -- the groups the host formed; rows in device memory -- the caller's bound (the
@@ -417,6 +422,8 @@ int pe_aggregate_exchange(pe_engine* h, pe_attestation* out_atts, uint32_t* out_
     (void)hipSetDevice(h->device);
     if (!h->pipelining) PE_TRY(flush_pending(h));
     if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_aggregate_exchange: call pe_dist_init first");
+    if (h->dist_wedged)  // before anything is launched: k_votes / the unions would otherwise run with no exchange to follow
+        return fail(h, PE_ERR_TIMEOUT, "an earlier exchange timed out on this handle: pe_dist_destroy, then initialise again");
     if (!h->rr.valid || h->rr.set != 0 || h->rr.arena != h->cur)
         return fail(h, PE_ERR_STATE, "pe_aggregate_exchange follows a pe_aggregate over rows in device memory (same pipeline)");
     ResidentParts P;

@@ -159,3 +159,101 @@ def test_aggregate_exchange_needs_its_preconditions(engine_factory):
         e.aggregate_exchange(cap_groups=len(atts))
     assert err.value.status == pea._abi.PE_ERR_NO_DEVICE and calls
     e.dist_destroy()
+
+
+class _SilentPeer:
+    """The two exchange steps of rank 0 of 2 whose peer holds no validators (it adds zeros to the weights and points at
+    infinity to the partials), carried out on the stream they are ordered on.  `stall_s` > 0: the exchange additionally
+    blocks its stream for that long -- a peer that has not arrived yet (a host function on the stream: nothing spins on
+    the device, and the wait ends by itself)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        self.HOSTFN = C.CFUNCTYPE(None, C.c_void_p)
+        self.hip.hipLaunchHostFunc.argtypes = [C.c_void_p, self.HOSTFN, C.c_void_p]
+        self.stall_s = 0.0
+        self.stalled = 0
+        self._sleep = self.HOSTFN(self._sleep_cb)   # kept alive: the runtime calls it from its own thread
+
+    def _sleep_cb(self, _):
+        import time
+        time.sleep(self.stall_s)
+
+    def _stall(self, stream):
+        if self.stall_s > 0:
+            self.stalled += 1
+            assert self.hip.hipLaunchHostFunc(self.C.c_void_p(stream), self._sleep, None) == 0
+
+    def all_reduce_u64(self, buf, count, stream):
+        self._stall(stream)
+        return 0
+
+    def all_gather(self, send, recv, nbytes, stream):
+        self._stall(stream)
+        s = self.C.c_void_p(stream)
+        assert self.hip.hipMemcpyAsync(self.C.c_void_p(recv), self.C.c_void_p(send), nbytes, 3, s) == 0   # device to device
+        assert self.hip.hipMemsetAsync(self.C.c_void_p(recv + nbytes), 0, nbytes, s) == 0
+        return 0
+
+
+def test_exchange_timeout_is_reported_and_the_handle_recovers(engine_factory):
+    """a rank whose peer never arrives must not wait for ever.  On a handle that exchanges with other
+    ranks every wait is bounded (pe_dist_set_timeout_ms): the call reports PE_ERR_TIMEOUT, the handle refuses further
+    exchanges until pe_dist_destroy, and after initialising again it computes what it computed before -- in a synchronous
+    call and in the middle of a streaming pipeline (the place bench.py's fallback catches it)."""
+    import time
+    from tests.test_gpu_pipeline import _world
+
+    w = _world(engine_factory, 6000, 32, seed=12, parts=2)
+    e, atts, arena, ctx = w["e"], w["atts"], w["arena"], w["ctx"]
+    TIMEOUT = pea._abi.PE_ERR_TIMEOUT
+    peer = _SilentPeer()
+    e.dist_init_custom(0, 2, peer.all_reduce_u64, peer.all_gather)
+    ref = e.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+    got = e.aggregate_sharded(packed=(atts, arena))
+    assert np.array_equal(got["aggpk96"], ref["aggpk96"])            # the silent peer changes nothing
+    st, _, _ = e.on_attestation_batch(packed=(ref["atts"], ref["out_arena"]))
+    assert (st == 0).all()
+    head = e.get_head()
+    assert e.get_head_sharded() == head
+
+    # ---- a synchronous call
+    e.dist_set_timeout_ms(100)
+    peer.stall_s = 0.6
+    t0 = time.perf_counter()
+    with pytest.raises(pea.EngineError) as err:
+        e.get_head_sharded()
+    waited = time.perf_counter() - t0
+    assert err.value.status == TIMEOUT and 0.09 < waited < 0.5 and peer.stalled == 1, (err.value.status, waited)
+    with pytest.raises(pea.EngineError) as err:                     # marked: nothing is exchanged on this handle any more
+        e.get_head_sharded()
+    assert err.value.status == TIMEOUT and peer.stalled == 1
+    peer.stall_s = 0.0
+    e.dist_destroy()                                                # waits for what the stalled stream still holds
+    assert e.get_head() == head                                     # the store is what it was
+    e.dist_init_custom(0, 2, peer.all_reduce_u64, peer.all_gather)
+    assert e.get_head_sharded() == head
+    got = e.aggregate_sharded(packed=(atts, arena))
+    assert np.array_equal(got["aggpk96"], ref["aggpk96"])
+
+    # ---- inside streaming pipelines: the timeout surfaces where the pipeline waits; destroy + close do not hang
+    e.dist_set_timeout_ms(100)
+    e.reuse_outputs(4)
+    peer.stall_s = 0.6
+    t0 = time.perf_counter()
+    with pytest.raises(pea.EngineError) as err:
+        for _ in range(4):
+            with e.pipeline(lagged=True):
+                agg = e.aggregate_sharded(packed=(atts, arena))
+                e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+                e.get_head_sharded_async()
+        e.drain()
+    assert err.value.status == TIMEOUT and time.perf_counter() - t0 < 3.0
+    peer.stall_s = 0.0
+    e.dist_destroy()
+    assert e.get_head() == head                                     # votes re-applied by the pipelines are the same votes
+    e.close()
