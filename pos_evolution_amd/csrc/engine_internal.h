@@ -536,6 +536,15 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
     size_t end() const { return base + used; }
 };
 
+// POSEVO_G1_DEFER=0: a streaming pipeline's G1 sums go out with the aggregate (behind its union) instead of behind the
+// step's k_tree -- the accumulations then queue back to back on their stream and the step's fork-choice kernels always
+// run as guests of one (A/B knob; the default keeps the deferral).
+inline bool g1_defer_enabled()
+{
+    static const bool on = [] { const char* e = getenv("POSEVO_G1_DEFER"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 // Register a batch call's completion.  Outside a pipeline: wait now and run it (the call is synchronous, as
 // include/posevo.h promises).  Inside one: advance the cursors and return; pe_pipeline_end waits once.
 int finish_call(pe_engine* h, const Stage& st, const OutBlock& ob, std::function<int()> complete, bool force_sync = false);

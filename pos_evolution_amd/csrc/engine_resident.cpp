@@ -344,7 +344,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
             }
             return PE_OK;
         };
-        if (on_side && h->streaming) h->deferred.push_back(launch_g1);
+        if (on_side && h->streaming && g1_defer_enabled()) h->deferred.push_back(launch_g1);
         else PE_TRY(launch_g1());
         lap.mark("ragg.4_g1");
     }
