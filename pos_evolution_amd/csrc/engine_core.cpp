@@ -289,6 +289,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
+    if (const char* e = getenv("POSEVO_ROWS_STREAM")) h->rows_stream_on = atoi(e);  // read per engine: bench.py opts in
     if (const char* e = getenv("POSEVO_PIPELINE_LAG")) {
         const int lag = atoi(e);
         if (lag >= 1 && lag < pe_engine::MAX_ARENAS) h->n_arenas = lag + 1;
@@ -309,6 +310,9 @@ void pe_engine_destroy(pe_engine* h)
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->prep_stream) { (void)hipStreamSynchronize(h->prep_stream); (void)hipStreamDestroy(h->prep_stream); }
+    if (h->rows_stream && h->rows_stream != h->aux_stream) { (void)hipStreamSynchronize(h->rows_stream); (void)hipStreamDestroy(h->rows_stream); }
+    h->rows_stream = nullptr;
+    if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
     h->d_shuffle_scratch.release();
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
     if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
@@ -496,6 +500,7 @@ static void prof_drain(pe_engine* h)
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (h->rows_stream) (void)hipStreamSynchronize(h->rows_stream);
     for (auto& p : h->prof) {
         for (auto& ev : p.pending) {
             float ms = 0;

@@ -338,6 +338,12 @@ struct pe_engine {
     uint32_t dist_timeout_ms = 30000;   // bounded waits once the handle exchanges with other ranks (0 = unbounded)
     uint32_t dist_max_groups = 0;       // pe_dist_set_max_groups (0 = the row count of the call)
     hipEvent_t ev_xchg = nullptr;       // single-communicator mode: G1 chain <-> engine stream hand-over
+    // POSEVO_ROWS_STREAM=1: the row chain of a streaming step's first device-row aggregate (copy, ingest, plan, members,
+    // union) on a stream of its own -- it depends on nothing the previous step's fork-choice kernels produce, so it runs
+    // beside them instead of behind them; the engine's stream takes over behind the union (engine_resident.cpp)
+    hipStream_t rows_stream = nullptr;
+    hipEvent_t ev_rows = nullptr;
+    int rows_stream_on = 0;  // 1: a stream of its own; 2: the state-transition stream carries the row chain
     bool dist_ready() const { return comm != nullptr || coll_custom; }
 
     // ---- profiling ----

@@ -235,7 +235,38 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     memset(plan_host, 0, sizeof(AttPlan));
     plan_host->error = 0xFFFFFFFFu;  // "k_att_plan has not run": a completion that finds it reports a failed launch
     // ---- device ----
-    hipStream_t ms = h->stream;
+    int arena_kind = 0;  // 0 pageable host, 1 pinned host, 2 device
+    if (arena_len) {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, bits_arena) == hipSuccess) {
+            if (pa.type == hipMemoryTypeDevice) arena_kind = 2;
+            else if (pa.type == hipMemoryTypeHost) arena_kind = 1;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    // The row chain reads the caller's rows and bits and this arena's scratch, nothing the store's kernels write: in a
+    // streaming step it may run on its own stream beside the PREVIOUS step's fork-choice kernels (the engine's stream
+    // holds them in order) -- for the first call into an arena only: a later aggregate of the same pipeline rewrites
+    // scratch whose readers are ordered on the engine's stream.
+    bool use_rows = h->rows_stream_on && h->streaming && set == 0 && !n_dev && arena_kind != 0 && !A.side_used &&
+                    A.pending.empty() && A.stage_cursor == 0 && A.out_cursor == 0 && h->stream == h->own_stream &&
+                    h->deferred.empty();
+    if (use_rows && !h->rows_stream) {
+        if (h->rows_stream_on == 2 && h->aux_stream) h->rows_stream = h->aux_stream;
+        if ((!h->rows_stream && hipStreamCreateWithFlags(&h->rows_stream, hipStreamNonBlocking) != hipSuccess) ||
+            hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->rows_stream && h->rows_stream != h->aux_stream) (void)hipStreamDestroy(h->rows_stream);
+            h->rows_stream = nullptr;
+            h->rows_stream_on = 0;
+            use_rows = false;
+        }
+    }
+    hipStream_t ms = use_rows ? h->rows_stream : h->stream;
+    if (use_rows)  // tables shuffled asynchronously: find_table made the ENGINE's stream wait for them
+        for (int t = 0; t < 2; ++t)
+            if (tabs[t] && tabs[t]->ev_ready) HIP_TRY(h, hipStreamWaitEvent(ms, tabs[t]->ev_ready, 0));
     // an earlier aggregate of THIS pipeline still has to read the arena's resident words / descriptors from its G1 launch
     // (deferred in a streaming pipeline): issue it, then order this call's kernels behind that chain
     // The exchanged aggregate of a committee-sharded step has a scratch set of its own (set 1) precisely so as NOT to wait.
@@ -247,19 +278,15 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     h->rr.valid = false;
     const size_t deferred_before = h->deferred.size();
     struct Unwind {
-        pe_engine* h; size_t keep; bool armed = true;
-        ~Unwind() { if (armed) { h->rr.valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
-    } unwind{h, deferred_before};
-    int arena_kind = 0;  // 0 pageable host, 1 pinned host, 2 device
-    if (arena_len) {
-        hipPointerAttribute_t pa;
-        if (hipPointerGetAttributes(&pa, bits_arena) == hipSuccess) {
-            if (pa.type == hipMemoryTypeDevice) arena_kind = 2;
-            else if (pa.type == hipMemoryTypeHost) arena_kind = 1;
-        } else {
-            (void)hipGetLastError();
+        pe_engine* h; size_t keep; bool rows; bool armed = true;
+        void join() const  // whatever reached the rows stream is ordered before the engine stream's next command
+        {
+            if (!rows) return;
+            (void)hipEventRecord(h->ev_rows, h->rows_stream);
+            (void)hipStreamWaitEvent(h->stream, h->ev_rows, 0);
         }
-    }
+        ~Unwind() { if (armed) { join(); h->rr.valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
+    } unwind{h, deferred_before, use_rows};
     if (arena_kind == 0) {
         memcpy(st.host<uint8_t>(off_arena), bits_arena, arena_len);
         memset(st.host<uint8_t>(off_arena) + arena_len, 0, pad_at + 32 - arena_len);
@@ -304,11 +331,12 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     launch_att_members(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
                        L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev);
     {
-        ProfScope ps(h, PE_KERNEL_BITS_UNION);
+        ProfScope ps(h, PE_KERNEL_BITS_UNION, ms);
         launch_bits_union(ms, L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), RS.bits.as<uint32_t>(),
                           RS.info.as<uint32_t>(), ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan);
     }
     HIP_TRY(h, hipGetLastError());
+    unwind.join();  // from here on the engine's stream carries the step: handlers, the head, the G1 launch's fork
     lap.mark("ragg.3_group_union");
     if (want_pk) {
         static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
