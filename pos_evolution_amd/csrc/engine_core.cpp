@@ -289,7 +289,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
-    if (const char* e = getenv("POSEVO_ROWS_STREAM")) h->rows_stream_on = atoi(e);  // read per engine: bench.py opts in
+    if (const char* e = getenv("POSEVO_ROWS_STREAM")) h->rows_stream_on = atoi(e);  // read per engine (A/B knob, off by default)
     if (const char* e = getenv("POSEVO_PIPELINE_LAG")) {
         const int lag = atoi(e);
         if (lag >= 1 && lag < pe_engine::MAX_ARENAS) h->n_arenas = lag + 1;
