@@ -271,6 +271,7 @@ static int get_head_sharded_impl(pe_engine* h, uint8_t out_root[32], bool async)
         PE_TRY(ob.ensure());
     }
     uint64_t* buf = h->d_xchg.as<uint64_t>();
+    PE_TRY(run_deferred_at(h, 3));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         // no memsets (k_tree zeroes the weights it read; the totals are plain per-workgroup stores), and inside a

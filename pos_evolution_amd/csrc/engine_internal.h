@@ -542,13 +542,19 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
     size_t end() const { return base + used; }
 };
 
-// POSEVO_G1_DEFER=0: a streaming pipeline's G1 sums go out with the aggregate (behind its union) instead of behind the
-// step's k_tree -- the accumulations then queue back to back on their stream and the step's fork-choice kernels always
-// run as guests of one (A/B knob; the default keeps the deferral).
-inline bool g1_defer_enabled()
+// POSEVO_G1_DEFER: where a streaming pipeline's G1 sums go out.  1 (default): behind the step's k_tree.  0: with the
+// aggregate, behind its union -- the accumulations queue back to back and every fork-choice kernel of the step runs as
+// the guest of one (measured: 0.312 vs 0.285 ms/step).  2: behind k_votes, in front of k_tree (the one-workgroup tree
+// then runs beside the start of the accumulation).  3: in front of k_votes.  (A/B knob.)
+inline int g1_defer_point()
 {
-    static const bool on = [] { const char* e = getenv("POSEVO_G1_DEFER"); return !e || atoi(e) != 0; }();
-    return on;
+    static const int p = [] { const char* e = getenv("POSEVO_G1_DEFER"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 3 ? v : 1; }();
+    return p;
+}
+inline bool g1_defer_enabled() { return g1_defer_point() != 0; }
+inline int run_deferred_at(pe_engine* h, int point)  // the launch sites in front of k_votes (3) and k_tree (2)
+{
+    return (h->streaming && g1_defer_point() == point) ? run_deferred(h) : PE_OK;
 }
 
 // Register a batch call's completion.  Outside a pipeline: wait now and run it (the call is synchronous, as

@@ -245,6 +245,7 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
     // the call's completion reads it when the pipeline's outputs are complete
     volatile uint32_t* head_word = async_word ? async_word : h->h_head.as<uint32_t>();
     *head_word = NONE32;
+    PE_TRY(run_deferred_at(h, 2));
     {
         ProfScope ps(h, PE_KERNEL_TREE);
         // the head index lands directly in host-coherent pinned memory: no D2H copy, just the stream sync
@@ -810,6 +811,7 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
         if (!find_block(h, h->justified.root, &tmp))
             return fail(h, PE_ERR_UNKNOWN_ROOT, "justified checkpoint root is not in the store");
     }
+    PE_TRY(run_deferred_at(h, 3));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
@@ -845,6 +847,7 @@ int pe_get_head_async(pe_engine* h, uint8_t out_root[32])
     OutBlock ob(h);
     const size_t off = ob.alloc(64);
     PE_TRY(ob.ensure());
+    PE_TRY(run_deferred_at(h, 3));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
