@@ -289,6 +289,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
+    if (const char* e = getenv("POSEVO_G1_S29")) h->g1_s29 = atoi(e) != 0;  // read per engine (A/B knob, off by default)
     if (const char* e = getenv("POSEVO_ROWS_STREAM")) h->rows_stream_on = atoi(e);  // read per engine (A/B knob, off by default)
     if (const char* e = getenv("POSEVO_PIPELINE_LAG")) {
         const int lag = atoi(e);
@@ -314,6 +315,7 @@ void pe_engine_destroy(pe_engine* h)
     h->rows_stream = nullptr;
     if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
     h->d_shuffle_scratch.release();
+    h->d_points29.release();
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
     if (h->comm_g1 && rccl().ok) (void)rccl().CommDestroy(h->comm_g1);
     h->d_xchg.release();

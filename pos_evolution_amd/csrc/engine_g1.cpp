@@ -34,10 +34,20 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
                            std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
     const size_t lane_bytes = (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan.n_slots + G1_WG - 1) / G1_WG);
     PE_TRY(ensure_quiesced(h, *lane_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, lane_bytes)));
+    const bool s29 = h->g1_s29 && d_points == h->d_points.as<uint32_t>() && h->n_val > 0;
+    if (s29 && !h->points29_valid) {  // the registry changed since the table of this form was built (or never was)
+        PE_TRY(ensure_quiesced(h, h->d_points29, 4ull * G1_ROW_WORDS * h->n_val));
+        launch_g1_table_s29(s, d_points, h->d_points29.as<uint32_t>(), h->n_val);
+        h->points29_valid = true;
+    }
     {
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s);
-        launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
+        if (s29)
+            launch_g1_accumulate_s29(s, h->d_points29.as<uint32_t>(), d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
+                                     lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
+        else
+            launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
+                                 lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
     }
     // POSEVO_G1_TREE_SERIAL=1: the tree stays on the accumulation's stream (the next accumulation starts behind it)
     static const bool tree_serial = [] { const char* e = getenv("POSEVO_G1_TREE_SERIAL"); return e && atoi(e) != 0; }();
@@ -205,6 +215,7 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
     if (n == 0) return PE_OK;
     HIP_TRY(h, h->d_points.ensure(4ull * G1_ROW_WORDS * n));
     h->have_points = false;
+    h->points29_valid = false;
     uint64_t n_bad = 0;
     int rc = g1_decompress_common(h, pubkeys48, n, h->d_points.as<uint32_t>(), nullptr, status, &n_bad);
     if (rc) return rc;

@@ -341,6 +341,9 @@ struct pe_engine {
     // POSEVO_ROWS_STREAM=1: the row chain of a streaming step's first device-row aggregate (copy, ingest, plan, members,
     // union) on a stream of its own -- it depends on nothing the previous step's fork-choice kernels produce, so it runs
     // beside them instead of behind them; the engine's stream takes over behind the union (engine_resident.cpp)
+    // POSEVO_G1_S29=1: k_g1_accumulate_s29 over d_points29 (built from d_points at the first use after the registry changed)
+    bool g1_s29 = false, points29_valid = false;
+    DevBuf d_points29;
     hipStream_t rows_stream = nullptr;
     hipEvent_t ev_rows = nullptr;
     int rows_stream_on = 0;  // 1: a stream of its own; 2: the state-transition stream carries the row chain

@@ -363,6 +363,7 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
     }
     if (pubkeys96 && n) {
         HIP_TRY(h, h->d_points.ensure(4ull * G1_ROW_WORDS * n));
+        h->points29_valid = false;
         // convert in chunks through a bounded device staging buffer
         const uint64_t chunk = std::min<uint64_t>(n, 1u << 20);
         HIP_TRY(h, h->d_tmp_be.ensure(96ull * chunk));

@@ -16,6 +16,7 @@
 // Bound: integer VALU (10 Montgomery products per mixed add = 5.8k v_mad_u64_u32/v_addc per
 // 100 bytes gathered), not HBM and not MFMA -- see DESIGN.md "G1 roofline".
 #include "g1.h"
+#include "g1_s29.h"
 #include "fp_sqrt.h"
 #include "kernels.h"
 
@@ -547,6 +548,122 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const ui
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), 0, s, points_mont24, members, bit_arena,
+                       groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
+}
+
+// ---------------------------------------------------------------- the accumulation over the S29 field form
+// (fp381_s29.h / g1_s29.h: 14 signed limbs of 29 bits, one v_mad_i64_i32 per limb product, no carry instructions).
+// POSEVO_G1_S29=1 routes launch_g1_planned's accumulation here; tree and finish are unchanged: a lane converts its
+// finished accumulator to the 48 words they read (four products + four exact reductions per lane).
+// The registry table of this form: one 128-byte row per validator like the 32-bit table -- x limbs in words 0..13,
+// y limbs in words 14..27 (canonical, Montgomery constant 2^406), word 28 = 1 when the row holds a point.
+__global__ void __launch_bounds__(256)
+k_g1_table_s29(const uint32_t* __restrict__ pts32, uint32_t* __restrict__ pts29, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* src = pts32 + (uint64_t)G1_ROW_WORDS * i;
+    uint32_t w[24], any = 0;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+    uint32_t* dst = pts29 + (uint64_t)G1_ROW_WORDS * i;
+    fq x, y;
+    fq_set_zero(x);
+    fq_set_zero(y);
+    if (any) {
+        fq_from_mont32(x, w);
+        fq_from_mont32(y, w + 12);
+    }
+#pragma unroll
+    for (int k = 0; k < FQ_N; ++k) { dst[k] = (uint32_t)x.l[k]; dst[FQ_N + k] = (uint32_t)y.l[k]; }
+    dst[28] = any ? 1u : 0u;
+    dst[29] = dst[30] = dst[31] = 0;
+}
+
+__device__ __forceinline__ bool load_point_s29(fq& x, fq& y, const uint32_t* __restrict__ pts29, uint32_t idx)
+{
+    const uint4* p = reinterpret_cast<const uint4*>(pts29 + (uint64_t)G1_ROW_WORDS * idx);  // one 128-byte line per point
+    const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4], v5 = p[5], v6 = p[6], v7 = p[7];
+    x.l[0] = v0.x; x.l[1] = v0.y; x.l[2] = v0.z; x.l[3] = v0.w;
+    x.l[4] = v1.x; x.l[5] = v1.y; x.l[6] = v1.z; x.l[7] = v1.w;
+    x.l[8] = v2.x; x.l[9] = v2.y; x.l[10] = v2.z; x.l[11] = v2.w;
+    x.l[12] = v3.x; x.l[13] = v3.y;
+    y.l[0] = v3.z; y.l[1] = v3.w;
+    y.l[2] = v4.x; y.l[3] = v4.y; y.l[4] = v4.z; y.l[5] = v4.w;
+    y.l[6] = v5.x; y.l[7] = v5.y; y.l[8] = v5.z; y.l[9] = v5.w;
+    y.l[10] = v6.x; y.l[11] = v6.y; y.l[12] = v6.z; y.l[13] = v6.w;
+    return v7.x != 0;  // the row holds a point
+}
+
+__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
+k_g1_accumulate_s29(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__ members,
+                    const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
+                    uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials,
+                    const AttPlan* __restrict__ plan_dev, const uint32_t* __restrict__ members1)
+{
+    const int tid = threadIdx.x;
+    if (plan_dev) {
+        n_groups = plan_dev->n_groups;
+        n_slots = plan_dev->n_slots;
+        if (blockIdx.x * G1_WG >= n_slots) return;
+    }
+    const uint32_t slot = blockIdx.x * G1_WG + tid;
+    g1q acc;
+    g1q_set_inf(acc);
+    uint32_t my_out, my_size, t;
+    G1Group d;
+    g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
+    if (slot < n_slots && t < d.n_tasks) {
+        const uint32_t gk = d.k & 0x7FFFFFFFu;
+        if (d.k >> 31) members = members1;
+        const uint32_t first = t * gk;
+        const uint32_t count = min(gk, d.n_members - first);
+        fq qx, qy, nx, ny;
+        bool have = false, nhave = false, qpoint = false, npoint = false;
+        auto fetch = [&](uint32_t j, fq& ox, fq& oy, bool& holds) -> bool {
+            const uint32_t i = first + j;
+            if (d.bits_word != NONE32) {
+                const uint32_t w = bit_arena[d.bits_word + (i >> 5)];
+                if (!((w >> (i & 31)) & 1u)) return false;
+            }
+            const uint32_t idx = members ? members[d.member_start + i] : d.member_start + i;
+            holds = load_point_s29(ox, oy, pts29, idx);
+            return true;
+        };
+        if (count > 0) have = fetch(0, qx, qy, qpoint);
+        for (uint32_t j = 0; j < count; ++j) {
+            nhave = false;
+            if (j + 1 < count) nhave = fetch(j + 1, nx, ny, npoint);
+            if (have) g1q_add_affine(acc, qx, qy, !qpoint);
+            qx = nx; qy = ny; have = nhave; qpoint = npoint;
+        }
+    }
+    // hand-over to the 12 x 32-bit words the tree reads
+    uint32_t w[G1X_WORDS];
+    g1q_to_words32(w, acc);
+    if (my_size == 1) {
+        uint32_t* dst = wg_partials + (size_t)G1X_WORDS * my_out;
+#pragma unroll
+        for (int k = 0; k < G1X_WORDS; ++k) dst[k] = w[k];
+    }
+    uint32_t* b = lane_partials + (size_t)blockIdx.x * G1X_WORDS * G1_WG + tid;
+#pragma unroll
+    for (int k = 0; k < G1X_WORDS; ++k) b[k * G1_WG] = w[k];
+}
+
+void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_g1_table_s29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, points_mont24, points_s29, n);
+}
+void launch_g1_accumulate_s29(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
+                              const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
+                              uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
+                              const uint32_t* members1)
+{
+    if (n_groups == 0 || n_slots == 0) return;
+    const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
+    hipLaunchKernelGGL(k_g1_accumulate_s29, dim3(blocks), dim3(G1_WG), 0, s, points_s29, members, bit_arena,
                        groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
 }
 

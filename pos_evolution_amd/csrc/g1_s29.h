@@ -1,0 +1,123 @@
+// g1_s29.h -- the accumulation side of g1.h over the S29 field form (fp381_s29.h): XYZZ accumulator += affine point,
+// and the hand-over of a finished accumulator to the 12 x 32-bit XYZZ words k_g1_tree / k_g1_finish read.
+//
+// Same formulas as g1.h (madd-2008-s / mmadd-2008-s / dbl-2008-s-1), same exact edge cases; what differs is the
+// bookkeeping of the lazy form: products come out in (-eps, p + eps) with balanced limbs (|limb| <= 2^28); a difference of
+// two such values goes into the next product as it is; X3 (three terms) and Y3 (stored, subtracted from a product in the next
+// add) take one carry pass each.  Two carry passes, six limb-wise subtractions, eight products and two squarings per
+// mixed add.  Infinity is a flag beside the accumulator, not a zero test.
+//
+// Host + device (see fp381_s29.h): tests/test_host_fp29.py runs these functions on the CPU against oracle/g1.py.
+#pragma once
+#include "fp381_s29.h"
+
+namespace posevo {
+
+struct g1q {
+    fq x, y, zz, zzz;
+    bool inf;     // the point at infinity (the coordinates are then meaningless)
+};
+
+PE_HD void g1q_set_inf(g1q& p)
+{
+    fq_set_zero(p.x);
+    fq_set_zero(p.y);
+    fq_set_zero(p.zz);
+    fq_set_zero(p.zzz);
+    p.inf = true;
+}
+
+// dbl-2008-s-1 (a = 0) of an XYZZ point.  Rare (an accumulator meets an equal point): carry passes used freely.
+PE_HD void g1q_double(g1q& p)
+{
+    if (p.inf) return;
+    if (fq_is_zero_modp(p.y)) {  // a point of order two: none on this curve, kept for exactness
+        g1q_set_inf(p);
+        return;
+    }
+    fq U, V, W, S, M, t, X3, Y3, yn, xn;
+    fq_norm(yn, p.y);
+    fq_norm(xn, p.x);
+    fq_add(U, yn, yn);           // 2 Y
+    fq_sqr(V, U);
+    fq_mul(W, U, V);
+    fq_mul(S, xn, V);
+    fq_sqr(M, xn);
+    fq_add(t, M, M);
+    fq_add(M, M, t);             // 3 X^2
+    fq_sqr(X3, M);
+#pragma unroll
+    for (int i = 0; i < FQ_N; ++i) t.l[i] = X3.l[i] - 2 * S.l[i];
+    fq_norm(X3, t);              // M^2 - 2 S
+    fq_sub_norm(t, S, X3);
+    fq_mul(Y3, M, t);
+    fq_mul(t, W, yn);
+    fq_sub_norm(Y3, Y3, t);
+    fq zz = p.zz, zzz = p.zzz;
+    fq_mul(p.zz, V, zz);
+    fq_mul(p.zzz, W, zzz);
+    p.x = X3;
+    p.y = Y3;
+}
+
+// acc += (qx, qy), an affine point with canonical limbs (the registry table's rows); q_none: the row encodes "no point".
+// acc.x / acc.y hold a table row (the first point) or carry-passed values (|limb| <= 2^28 + 4), acc.zz / acc.zzz products
+// (or the constant one).  The ten products sit in ONE basic block on purpose: hipcc selects v_mad_i64_i32 only where it
+// sees the 32 -> 64-bit sign extension next to the multiply; operands extended in another block (the first version of
+// this function branched around the ZZ / ZZZ products of a lane's first add) become generic 64 x 64 multiplies, four
+// instructions each.  A lane's first add therefore pays the four products by one (70 instead of 66 products per run of
+// eight).
+PE_HD void g1q_add_affine(g1q& acc, const fq& qx, const fq& qy, bool q_none)
+{
+    if (q_none) return;
+    if (acc.inf) {
+        acc.x = qx;
+        acc.y = qy;
+        fq_set_one(acc.zz);
+        fq_set_one(acc.zzz);
+        acc.inf = false;
+        return;
+    }
+    fq U2, S2, P, R;
+    fq_mul(U2, qx, acc.zz);
+    fq_mul(S2, qy, acc.zzz);
+    fq_sub(P, U2, acc.x);
+    fq_sub(R, S2, acc.y);
+    if (fq_maybe_zero_modp(P) && fq_is_zero_modp_exact(P)) {  // same x: the same point or its negative
+        if (fq_is_zero_modp(R)) g1q_double(acc);
+        else g1q_set_inf(acc);
+        return;
+    }
+    fq PP, PPP, Q, X3, t, u, zz, zzz;
+    fq_sqr(PP, P);
+    fq_mul(PPP, P, PP);
+    fq_mul(Q, acc.x, PP);
+    fq_sqr(X3, R);
+    fq_sub_sub2_norm(X3, X3, PPP, Q);  // R^2 - PPP - 2 Q: |limb| <= 2^30 before the pass
+    fq_sub(t, Q, X3);
+    fq_mul(t, R, t);
+    fq_mul(u, acc.y, PPP);
+    fq_sub_norm(acc.y, t, u);
+    fq_mul(zz, acc.zz, PP);
+    fq_mul(zzz, acc.zzz, PPP);
+    acc.zz = zz;
+    acc.zzz = zzz;
+    acc.x = X3;
+}
+
+// A finished accumulator as the 48 words of a g1x in the 12 x 32-bit Montgomery form (fp381.h): X, Y, ZZ, ZZZ, all
+// zero for infinity.  Four products and four exact reductions: once per lane.
+PE_HD void g1q_to_words32(uint32_t* w48, const g1q& p)
+{
+    if (p.inf) {
+#pragma unroll
+        for (int k = 0; k < 48; ++k) w48[k] = 0;
+        return;
+    }
+    fq_to_mont32(w48, p.x);
+    fq_to_mont32(w48 + 12, p.y);
+    fq_to_mont32(w48 + 24, p.zz);
+    fq_to_mont32(w48 + 36, p.zzz);
+}
+
+}  // namespace posevo

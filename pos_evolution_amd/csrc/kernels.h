@@ -59,6 +59,14 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const ui
                           const AttPlan* plan_dev = nullptr, const uint32_t* members1 = nullptr);
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
 // (group, workgroup) into wg_partials48.
+// The accumulation over the S29 field form (fp381_s29.h; POSEVO_G1_S29=1): its registry table (128-byte rows: 14 + 14
+// limbs of 29 bits, word 28 = the row holds a point) is built from the 32-bit table; the kernel hands the tree the same
+// lane partials as k_g1_accumulate.
+void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n);
+void launch_g1_accumulate_s29(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
+                              const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
+                              uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
+                              const uint32_t* members1);
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0, const AttPlan* plan_dev = nullptr);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or

@@ -1,0 +1,207 @@
+"""CPU: the S29 field form (pos_evolution_amd/csrc/fp381_s29.h: 14 signed limbs of 29 bits, lazy Montgomery with
+R' = 2^406) and the XYZZ accumulation over it (g1_s29.h), compiled for the HOST from the very source the gfx950 kernels
+use (tests/native/fp29_host.cpp) and held against Python integers and oracle/g1.py.  No GPU; the kernels that use the
+form are checked by the -m gpu tests through the C ABI like every other path."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import g1
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = g1.P
+B, N = 29, 14
+MASK = (1 << B) - 1
+RP = 1 << (B * N)
+R32 = 1 << 384
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = tmp_path_factory.mktemp("fp29") / "libfp29.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-Wno-unknown-pragmas", "-shared",
+                           "-fPIC", os.path.join(ROOT, "tests", "native", "fp29_host.cpp"), "-o", str(out)])
+    return C.CDLL(str(out))
+
+
+def limbs_of(v):
+    """Canonical limbs: 0..12 in [0, 2^29), the top one takes the rest (signed)."""
+    out = []
+    for _ in range(N - 1):
+        out.append(v & MASK)
+        v >>= B
+    out.append(v)
+    return np.array(out, dtype=np.int32)
+
+
+def value_of(l):
+    return sum(int(x) << (B * i) for i, x in enumerate(l))
+
+
+def loose(rng, v):
+    """A redundant representation of v with limbs of both signs, |limb| <= 2^29 + 16 (what limb-wise subtractions leave):
+    here and there limb i goes down by 2^29 and limb i + 1 up by one (or the other way round where limb i is tiny)."""
+    l = [int(x) for x in limbs_of(v)]
+    for i in range(N - 1):
+        if rng.random() < 0.5 and l[i] - (1 << B) >= -(1 << B) - 16:
+            l[i] -= 1 << B
+            l[i + 1] += 1
+        elif l[i] <= 16 and rng.random() < 0.5:
+            l[i] += 1 << B
+            l[i + 1] -= 1
+    assert value_of(l) == v and all(abs(x) <= (1 << B) + 16 for x in l[:-1])
+    return np.array(l, dtype=np.int32)
+
+
+def ptr(a, t=C.c_int32):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def test_product_and_square_against_python_integers(lib):
+    rng = random.Random(29)
+    out = np.zeros(N, dtype=np.int32)
+    cases = [(0, 0), (1, 1), (P - 1, P - 1), (-(P - 1), P - 1), (7 * P - 3, -5 * P + 11)]
+    for _ in range(3000):
+        cases.append((rng.randrange(-8 * P, 8 * P), rng.randrange(-8 * P, 8 * P)))
+    for a, b in cases:
+        for la, lb in ((limbs_of(a), limbs_of(b)), (loose(rng, a), loose(rng, b))):
+            lib.fq29_mul(ptr(la), ptr(lb), ptr(out))
+            r = value_of(out)
+            assert (r * RP - a * b) % P == 0                      # r = a b / R' mod p ...
+            assert a * b // RP - 1 <= r <= a * b // RP + P + 1     # ... lazily: within one p above a b / R'
+            assert all(-(1 << 28) <= int(x) < (1 << 28) for x in out[:-1]) and abs(int(out[-1])) < 64   # balanced digits
+        la = loose(rng, a)
+        lib.fq29_sqr(ptr(la), ptr(out))
+        r = value_of(out)
+        assert (r * RP - a * a) % P == 0 and 0 <= r <= a * a // RP + P + 1
+        assert all(-(1 << 28) <= int(x) < (1 << 28) for x in out[:-1])
+
+
+def test_worst_case_limbs_do_not_overflow_the_accumulator(lib):
+    """Every limb at the bound the formulas guarantee (|limb| <= 2^29 + 16, all signs alike): the 28-term column sum must
+    still be exact -- a wrapped 64-bit accumulator would break the congruence."""
+    out = np.zeros(N, dtype=np.int32)
+    top = (1 << B) + 16
+    for sa in (1, -1):
+        for sb in (1, -1):
+            la = np.full(N, sa * top, dtype=np.int32)
+            lb = np.full(N, sb * top, dtype=np.int32)
+            la[-1], lb[-1] = sa * 40, sb * 40   # top limbs stay small: they hold the value's excess over 2^377
+            a, b = value_of(la), value_of(lb)
+            lib.fq29_mul(ptr(la), ptr(lb), ptr(out))
+            assert (value_of(out) * RP - a * b) % P == 0
+            lib.fq29_sqr(ptr(la), ptr(out))
+            assert (value_of(out) * RP - a * a) % P == 0
+
+
+def test_carry_pass_canonical_forms_and_the_zero_test(lib):
+    rng = random.Random(5)
+    out = np.zeros(N, dtype=np.int32)
+    filt = C.c_int(0)
+    for _ in range(2000):
+        v = rng.randrange(-7 * P, 8 * P)
+        l = np.array([rng.randrange(-(3 << B) // 2, 1 << B) for _ in range(N - 1)] + [rng.randrange(-50, 50)], dtype=np.int32)
+        lib.fq29_norm(ptr(l), ptr(out))
+        assert value_of(out) == value_of(l) and all(abs(int(x)) <= (1 << 28) + 4 for x in out[:-1])
+        lv = loose(rng, v)
+        lib.fq29_canonical(ptr(lv), ptr(out), 0)
+        assert value_of(out) == v % P and np.array_equal(out, limbs_of(v % P))
+        w = rng.randrange(-P + 1, 2 * P)
+        lib.fq29_canonical(ptr(loose(rng, w)), ptr(out), 1)
+        assert np.array_equal(out, limbs_of(w % P))
+        assert lib.fq29_is_zero_modp(ptr(lv), C.byref(filt)) == (1 if v % P == 0 else 0)
+    for k in range(-8, 17):                      # every multiple of p a lazily reduced value can be
+        assert lib.fq29_is_zero_modp(ptr(loose(rng, k * P)), C.byref(filt)) == 1 and filt.value == 1
+        assert lib.fq29_is_zero_modp(ptr(loose(rng, k * P + 1)), C.byref(filt)) == 0
+    # the filter passes a non-multiple about 25 times in 2^29: it must then be caught by the exact test
+    v = 3 * P + (1 << B) * 12345          # same low 29 bits as 3p, not a multiple of p
+    assert lib.fq29_is_zero_modp(ptr(limbs_of(v)), C.byref(filt)) == 0 and filt.value == 1
+
+
+def test_hand_over_between_the_two_montgomery_forms(lib):
+    rng = random.Random(11)
+    w = np.zeros(12, dtype=np.uint32)
+    back = np.zeros(12, dtype=np.uint32)
+    out = np.zeros(N, dtype=np.int32)
+    for _ in range(500):
+        x = rng.randrange(P)
+        m32 = x * R32 % P
+        w[:] = [(m32 >> (32 * j)) & 0xFFFFFFFF for j in range(12)]
+        lib.fq29_words(ptr(w, C.c_uint32), ptr(out), ptr(back, C.c_uint32))
+        assert value_of(out) == m32 and np.array_equal(back, w)          # pure re-packing, both ways
+        lib.fq29_from_mont32(ptr(w, C.c_uint32), ptr(out))
+        assert np.array_equal(out, limbs_of(x * RP % P))                 # x 2^384 -> x R', canonical
+        lib.fq29_to_mont32(ptr(loose(rng, x * RP % P + rng.randrange(-3, 4) * P)), ptr(back, C.c_uint32))
+        assert np.array_equal(back, w)                                   # and back, from a lazy value
+
+
+def _row(pt):
+    """A registry row of the 32-bit form: x, y as 12-word Montgomery values; None -> all zero."""
+    if pt is None:
+        return [0] * 24
+    out = []
+    for c in pt:
+        m = c * R32 % P
+        out += [(m >> (32 * j)) & 0xFFFFFFFF for j in range(12)]
+    return out
+
+
+def _point_of(words48):
+    x, y, zz, zzz = (sum(int(words48[12 * c + j]) << (32 * j) for j in range(12)) for c in range(4))
+    if zz == 0:
+        return None
+    inv = pow(R32, -1, P)
+    x, y, zz, zzz = (v * inv % P for v in (x, y, zz, zzz))
+    assert pow(zz, 3, P) == pow(zzz, 2, P)
+    return (x * pow(zz, -1, P) % P, y * pow(zzz, -1, P) % P)
+
+
+def _run(lib, pts):
+    rows = np.array([w for pt in pts for w in _row(pt)], dtype=np.uint32)
+    out = np.zeros(48, dtype=np.uint32)
+    worst = C.c_int32(0)
+    lib.g1q_run(ptr(rows, C.c_uint32), len(pts), ptr(out, C.c_uint32), C.byref(worst))
+    assert worst.value <= (1 << B), worst.value          # a row's canonical limbs at most; everything computed is balanced
+    assert all(int(v) < P for v in [sum(int(out[12 * c + j]) << (32 * j) for j in range(12)) for c in range(4)])
+    return _point_of(out)
+
+
+def test_accumulation_against_the_oracle(lib):
+    rng = random.Random(3)
+    base = [g1.mul(rng.randrange(1, g1.R_ORDER), g1.G) for _ in range(24)]
+    for n in (1, 2, 3, 8, 24):
+        pts = base[:n]
+        assert _run(lib, pts) == g1.sum_points(pts)
+    # rows that hold no point are skipped wherever they stand
+    pts = [None, base[0], None, base[1], base[2], None]
+    assert _run(lib, pts) == g1.sum_points([p for p in pts if p])
+    assert _run(lib, [None, None]) is None and _run(lib, []) is None
+
+
+def test_accumulation_edge_cases_of_the_group_law(lib):
+    rng = random.Random(4)
+    A = g1.mul(rng.randrange(1, g1.R_ORDER), g1.G)
+    Bp = g1.mul(rng.randrange(1, g1.R_ORDER), g1.G)
+    assert _run(lib, [A, A]) == g1.double(A)                         # second point equals the (affine) accumulator
+    assert _run(lib, [A, g1.neg(A)]) is None                         # ... or its negative
+    assert _run(lib, [A, g1.neg(A), Bp]) == Bp                       # and the run goes on from infinity
+    assert _run(lib, [A, Bp, g1.add(A, Bp)]) == g1.double(g1.add(A, Bp))     # XYZZ accumulator meets an equal point
+    assert _run(lib, [A, Bp, g1.neg(g1.add(A, Bp))]) is None
+    assert _run(lib, [A, A, A, A]) == g1.mul(4, A)                   # double, then madd, then double again (3A + A)
+    seq = [g1.mul(i + 1, g1.G) for i in range(12)]                   # the structured keys of the synthetic registry
+    assert _run(lib, seq) == g1.mul(78, g1.G)
+    assert _run(lib, [g1.G] * 9) == g1.mul(9, g1.G)
+
+
+def test_generated_constants_are_current():
+    """fp381_s29_consts.inc is what tools/gen_fp29_consts.py prints (everything in it follows from the prime)."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fp29_consts.py")], capture_output=True, text=True,
+                         check=True).stdout
+    assert out == open(os.path.join(ROOT, "pos_evolution_amd", "csrc", "fp381_s29_consts.inc")).read()
+    n0 = int(out.split("FQ_N0INV = ")[1].split("u;")[0])
+    assert (n0 * P + 1) % (1 << B) == 0
