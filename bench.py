@@ -1024,7 +1024,9 @@ def main():
         "scaling": scaling,
         "vs_baseline": None,
         "dtype": "u32",
-        "dtype_detail": "12 x u32 Montgomery limbs (381-bit Fp, exact integer arithmetic); u64 Gwei weights",
+        "dtype_detail": ("12 x u32 Montgomery limbs (381-bit Fp, exact integer arithmetic); u64 Gwei weights"
+                         + ("; POSEVO_G1_S29=1: the accumulation in 14 signed 29-bit limbs (fp381_s29.h), same results"
+                            if os.environ.get("POSEVO_G1_S29", "0") not in ("", "0") else "")),
         "data": "synthetic",
         "config": {
             "workload": shape + f": {V_total} validators on {world} GPU(s) ({VL} per GPU), "
@@ -1036,6 +1038,7 @@ def main():
                             f"committees ({scaling} scaling)" if args.by_committee else
                             f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU"),
             "call_mode": mode,
+            "g1_field_form": "s29" if os.environ.get("POSEVO_G1_S29", "0") not in ("", "0") else "12x32",
             "inputs": (("attestation rows in host memory (grouped and validated by the host inside the timed step); "
                         if (args.host_rows or args.host_arena or (world > 1 and not engine_rccl)) else
                         "attestation rows resident in HBM before the timed region (grouped, resolved and validated on "
