@@ -16,6 +16,7 @@ namespace posevo {
 struct g1q {
     fq x, y, zz, zzz;
     bool inf;     // the point at infinity (the coordinates are then meaningless)
+    bool affine;  // x, y are a table row and zz = zzz = 1 is implied (zz / zzz do hold the constant): a lane's first point
 };
 
 PE_HD void g1q_set_inf(g1q& p)
@@ -25,6 +26,7 @@ PE_HD void g1q_set_inf(g1q& p)
     fq_set_zero(p.zz);
     fq_set_zero(p.zzz);
     p.inf = true;
+    p.affine = false;
 }
 
 // dbl-2008-s-1 (a = 0) of an XYZZ point.  Rare (an accumulator meets an equal point): carry passes used freely.
@@ -65,8 +67,7 @@ PE_HD void g1q_double(g1q& p)
 // (or the constant one).  The ten products sit in ONE basic block on purpose: hipcc selects v_mad_i64_i32 only where it
 // sees the 32 -> 64-bit sign extension next to the multiply; operands extended in another block (the first version of
 // this function branched around the ZZ / ZZZ products of a lane's first add) become generic 64 x 64 multiplies, four
-// instructions each.  A lane's first add therefore pays the four products by one (70 instead of 66 products per run of
-// eight).
+// instructions each.  A lane's first add (affine + affine, six products) is therefore a second straight-line body.
 PE_HD void g1q_add_affine(g1q& acc, const fq& qx, const fq& qy, bool q_none)
 {
     if (q_none) return;
@@ -76,6 +77,34 @@ PE_HD void g1q_add_affine(g1q& acc, const fq& qx, const fq& qy, bool q_none)
         fq_set_one(acc.zz);
         fq_set_one(acc.zzz);
         acc.inf = false;
+        acc.affine = true;
+        return;
+    }
+    if (acc.affine) {
+        // mmadd-2008-s, affine + affine (4M + 2S): a body of its own, straight-line like the general one below -- sharing
+        // the tail with it would put products and their operands' sign extensions into different basic blocks
+        fq P, R;
+        fq_sub(P, qx, acc.x);
+        fq_sub(R, qy, acc.y);
+        acc.affine = false;
+        if (fq_maybe_zero_modp(P) && fq_is_zero_modp_exact(P)) {
+            if (fq_is_zero_modp(R)) g1q_double(acc);
+            else g1q_set_inf(acc);
+            return;
+        }
+        fq PP, PPP, Q, X3, t, u;
+        fq_sqr(PP, P);
+        fq_mul(PPP, P, PP);
+        fq_mul(Q, acc.x, PP);
+        fq_sqr(X3, R);
+        fq_sub_sub2_norm(X3, X3, PPP, Q);
+        fq_sub(t, Q, X3);
+        fq_mul(t, R, t);
+        fq_mul(u, acc.y, PPP);
+        fq_sub_norm(acc.y, t, u);
+        acc.zz = PP;
+        acc.zzz = PPP;
+        acc.x = X3;
         return;
     }
     fq U2, S2, P, R;
