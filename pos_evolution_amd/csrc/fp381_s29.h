@@ -1,14 +1,19 @@
 // fp381_s29.h -- BLS12-381 base field in 14 signed limbs of 29 bits ("S29"), Montgomery constant R' = 2^406.
 //
-// Why a second form next to fp381.h (12 x 32 bits, R = 2^384): on gfx950 EVERY VALU instruction of a wave costs the same
-// issue slot -- tools/fpbench's 57 G products/s is exactly 689 instructions x 4 cycles per product (288 v_mad_u64_u32 +
-// 288 v_addc_co_u32 + ~113 moves / selects / the conditional subtraction), so the way to a faster product is FEWER
-// INSTRUCTIONS, and half of them are carry handling: v_mad_u64_u32 has a carry-out but no carry-in, a full 32 x 32
-// product plus a 64-bit accumulator overflows, every limb product pays a v_addc.  With 29-bit limbs a column of the
-// interleaved (FIPS) Montgomery product -- up to 14 a_i b_j + 14 m_i n_j terms of <= 2^58 -- fits a signed 64-bit
-// accumulator (28 x 2^58 < 2^63): one v_mad_i64_i32 per limb product and nothing else, 392 multiply-adds + ~100
-// instructions per product instead of 689, written in plain C++ (no inline assembly: the compiler sees the whole product
-// and the same source compiles for the host, where tests/test_host_fp29.py holds it against Python integers).
+// Why a second form next to fp381.h (12 x 32 bits, R = 2^384): half of that product's 689 instructions are carry
+// handling -- v_mad_u64_u32 has a carry-out but no carry-in, a full 32 x 32 product plus a 64-bit accumulator overflows,
+// every limb product pays a v_addc_co_u32 (288 per product), plus ~65 moves that slide the 96-bit column accumulator and
+// the conditional subtraction.  With 29-bit limbs a column of the interleaved (FIPS) Montgomery product -- up to 14
+// a_i b_j + 14 m_i n_j terms of <= 2^58 -- fits a signed 64-bit accumulator (28 x 2^58 < 2^63): one v_mad_i64_i32 per
+// limb product and nothing else, ~505 instructions per product instead of 689, written in plain C++ (no inline assembly:
+// the compiler sees the whole product and the same source compiles for the host, where tests/test_host_fp29.py holds it
+// against Python integers).
+// AN EXPERIMENT, NOT A CLAIM: the price is 392 multiply-adds per product instead of 288, and by the instruction timings
+// measured in round 1 (profiles/r01_ubench_valu_fpmul.log, 4 waves / SIMD: v_mad_u64_u32 2.45 ns, mad + addc pair 3.22 ns,
+// v_add_u32 1.2 ns, 64-bit shift 3.5 ns per instruction and SIMD) a multiply-add costs two simple instructions and the
+// carry behind it is three quarters hidden: 392 x 2.45 = 960 ns of multiply-adds alone against 927 ns for the 288 pairs
+// of the 32-bit form.  By instruction count this form is 0.75 x the work, by those timings ~10 % MORE; tools/fpbench29
+// settles it on hardware in seconds.  Until then POSEVO_G1_S29 stays off.
 //
 // Lazy, signed values.  R' / p > 2^25, so a product of operands of magnitude < 2^386 (32 p) comes out in (-eps, p + eps)
 // with no final subtraction; a - b is a plain limb-wise subtraction (limbs of both signs are fine in the next product as
