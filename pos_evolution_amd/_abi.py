@@ -28,9 +28,9 @@ PE_EXCHANGE_EXTRA = 512
 PE_DIST_ID_BYTES = 256
 (PE_KERNEL_G1_ACCUMULATE, PE_KERNEL_G1_NORMALISE, PE_KERNEL_VOTES, PE_KERNEL_TREE, PE_KERNEL_LMD,
  PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_G2_ACCUMULATE, PE_KERNEL_G2_NORMALISE,
- PE_KERNEL_G1_TREE, PE_KERNEL_COUNT) = range(11)
+ PE_KERNEL_G1_TREE, PE_KERNEL_ATT_GROUP, PE_KERNEL_ATT_VALIDATE, PE_KERNEL_COUNT) = range(13)
 KERNEL_NAMES = ["g1_accumulate", "g1_normalise", "votes", "tree", "lmd", "participation", "bits_union",
-                "g2_accumulate", "g2_normalise", "g1_tree"]
+                "g2_accumulate", "g2_normalise", "g1_tree", "att_group", "att_validate"]
 
 ATT_STATUS_NAMES = {
     0: "ok", 1: "target epoch not current or previous", 2: "target epoch != epoch(slot)",
@@ -181,6 +181,7 @@ SIGNATURES = {
     "pe_profile_enable": (C.c_int, [_H, C.c_int]),
     "pe_profile_reset": (C.c_int, [_H]),
     "pe_profile_get": (C.c_int, [_H, C.c_int, _u64p, _P(C.c_double)]),
+    "pe_profile_timeline": (C.c_int, [_H, _i32p, C.c_void_p, C.c_void_p, C.c_uint32, _P(C.c_uint32)]),
 }
 
 PE_ROWS_RESIDENT = 1  # include/posevo.h: "every group of the last pe_aggregate over rows in device memory"

@@ -314,6 +314,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->rows_stream && h->rows_stream != h->aux_stream) { (void)hipStreamSynchronize(h->rows_stream); (void)hipStreamDestroy(h->rows_stream); }
     h->rows_stream = nullptr;
     if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
+    if (h->prof_base) (void)hipEventDestroy(h->prof_base);
     h->d_shuffle_scratch.release();
     h->d_points29.release();
     if (h->comm && rccl().ok) (void)rccl().CommDestroy(h->comm);
@@ -486,6 +487,11 @@ int pe_profile_enable(pe_engine* h, int on)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     h->profiling = on != 0;
+    h->prof_timeline = on == 2;
+    if (h->prof_timeline && !h->prof_base && hipEventCreate(&h->prof_base) != hipSuccess) {
+        h->prof_base = nullptr;
+        h->prof_timeline = false;
+    }
     if (h->profiling)
         while (h->event_pool.size() < 4096) {
             hipEvent_t e = nullptr;
@@ -503,10 +509,20 @@ static void prof_drain(pe_engine* h)
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->rows_stream) (void)hipStreamSynchronize(h->rows_stream);
-    for (auto& p : h->prof) {
+    for (int k = 0; k < PE_KERNEL_COUNT; ++k) {
+        auto& p = h->prof[k];
         for (auto& ev : p.pending) {
             float ms = 0;
-            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { p.total_ms += ms; p.launches += 1; }
+            if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                p.total_ms += ms;
+                p.launches += 1;
+                float t0 = 0;
+                if (h->prof_timeline && h->prof_base && h->prof_tl.size() < (1u << 20) &&
+                    hipEventElapsedTime(&t0, h->prof_base, ev.first) == hipSuccess)
+                    h->prof_tl.push_back(pe_engine::TimelineEntry{k, t0, ms});
+                else
+                    (void)hipGetLastError();
+            }
             h->event_pool.push_back(ev.first);
             h->event_pool.push_back(ev.second);
         }
@@ -518,6 +534,20 @@ int pe_profile_reset(pe_engine* h)
     if (!h) return PE_ERR_INVALID_ARG;
     prof_drain(h);
     for (auto& p : h->prof) { p.launches = 0; p.total_ms = 0; }
+    h->prof_tl.clear();
+    if (h->prof_timeline && h->prof_base) HIP_TRY(h, hipEventRecord(h->prof_base, h->stream));  // time zero
+    return PE_OK;
+}
+int pe_profile_timeline(pe_engine* h, int32_t* kernel, double* start_ms, double* duration_ms, uint32_t cap, uint32_t* out_n)
+{
+    if (!h || !out_n || (cap && (!kernel || !start_ms || !duration_ms))) return PE_ERR_INVALID_ARG;
+    prof_drain(h);
+    *out_n = (uint32_t)h->prof_tl.size();
+    for (uint32_t i = 0; i < cap && i < h->prof_tl.size(); ++i) {
+        kernel[i] = h->prof_tl[i].kernel;
+        start_ms[i] = h->prof_tl[i].start_ms;
+        duration_ms[i] = h->prof_tl[i].dur_ms;
+    }
     return PE_OK;
 }
 int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms)

@@ -352,6 +352,11 @@ struct pe_engine {
     // ---- profiling ----
     bool profiling = false;
     KernelProfile prof[PE_KERNEL_COUNT];
+    // pe_profile_enable(h, 2): also a timeline of the bracketed launches (start relative to prof_base, duration)
+    bool prof_timeline = false;
+    hipEvent_t prof_base = nullptr;
+    struct TimelineEntry { int32_t kernel; float start_ms, dur_ms; };
+    std::vector<TimelineEntry> prof_tl;
     std::vector<hipEvent_t> event_pool;
     HostTrace trace;
 };
@@ -386,6 +391,7 @@ struct ProfScope {
     ProfScope(pe_engine* h_, int k_, hipStream_t s_ = nullptr) : h(h_), k(k_), s(s_ ? s_ : h_->stream)
     {
         if (!h->profiling) return;
+        if (k >= PE_KERNEL_ATT_GROUP && !h->prof_timeline) return;  // brackets that exist for the timeline only
         a = take(h);
         b = take(h);
         if (!a || !b) { a = b = nullptr; return; }

@@ -14,6 +14,8 @@
 // validate_on_attestation admits for gossip attestations); both must be partition tables (a real shuffling is).
 #include "engine_internal.h"
 
+#include <optional>
+
 using namespace posevo;
 
 namespace posevo {
@@ -297,6 +299,8 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                                   arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
     }
     lap.mark("ragg.2_bits");
+    std::optional<ProfScope> ps_group;  // timeline mode only: ingest + plan + members
+    ps_group.emplace(h, PE_KERNEL_ATT_GROUP, ms);
     uint32_t* cnt_tab = RS.tab.as<uint32_t>() + RS.tab_size;
     launch_att_ingest(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, RS.tab_size - 1, L.slot_of, arena_len, L.plan,
                       st.dev<uint8_t>(off_arena) + pad_at, n_dev);
@@ -330,6 +334,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     launch_att_plan(ms, pa);
     launch_att_members(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
                        L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev);
+    ps_group.reset();
     {
         ProfScope ps(h, PE_KERNEL_BITS_UNION, ms);
         launch_bits_union(ms, L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), RS.bits.as<uint32_t>(),
@@ -490,9 +495,12 @@ int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_
     // entries past the groups formed read "nothing applied"
     memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
     memset(ob.host<uint32_t>(off_count), 0, 4ull * cap);
-    launch_att_validate_fc(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), fc,
-                           RS.info.as<uint32_t>(), L.rows_fc, L.status_fc, ob.host<int32_t>(off_status),
-                           ob.host<uint32_t>(off_count), ob.host<uint32_t>(off_err));
+    {
+        ProfScope ps(h, PE_KERNEL_ATT_VALIDATE);  // timeline mode only
+        launch_att_validate_fc(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), fc,
+                               RS.info.as<uint32_t>(), L.rows_fc, L.status_fc, ob.host<int32_t>(off_status),
+                               ob.host<uint32_t>(off_count), ob.host<uint32_t>(off_err));
+    }
     {
         ProfScope ps(h, PE_KERNEL_LMD);
         launch_lmd_vm_tables(h->stream, L.rows_fc, h->rr.tables, L.crow_start, L.crow_list, L.plan,
@@ -569,9 +577,12 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
     memset(ob.host<uint64_t>(off_num), 0, 8ull * cap);  // k_participation_tables writes the rows it runs
     const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);
     hipStream_t ss = state_stream_begin(h);  // behind the unions and the plan; beside the next step's fork-choice chain
-    launch_att_validate_state(ss, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), S,
-                              RS.info.as<uint32_t>(), L.rows_st, L.status_st, ob.host<int32_t>(off_status),
-                              ob.host<uint32_t>(off_err));
+    {
+        ProfScope ps(h, PE_KERNEL_ATT_VALIDATE, ss);  // timeline mode only
+        launch_att_validate_state(ss, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), S,
+                                  RS.info.as<uint32_t>(), L.rows_st, L.status_st, ob.host<int32_t>(off_status),
+                                  ob.host<uint32_t>(off_err));
+    }
     {
         ProfScope ps(h, PE_KERNEL_PARTICIPATION, ss);
         launch_participation_tables(ss, L.rows_st, h->rr.tables, L.crow_start, L.crow_list, L.plan,

@@ -1006,8 +1006,22 @@ class Engine:
                     proposer_boost_root=bytes(boost))
 
     # -- profiling --------------------------------------------------------
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """0 / False off, 1 / True per-kernel totals, 2 totals + the timeline of profile_timeline()."""
         self._check(self._lib.pe_profile_enable(self._h, int(on)))
+
+    def profile_timeline(self):
+        """-> list of (kernel name, start_ms, duration_ms) of the launches bracketed since profile_reset(), by start time
+        (pe_profile_timeline; profile_enable(2))."""
+        n = C.c_uint32(0)
+        self._check(self._lib.pe_profile_timeline(self._h, None, None, None, 0, C.byref(n)))
+        k = np.zeros(max(n.value, 1), dtype=np.int32)
+        t0 = np.zeros(max(n.value, 1), dtype=np.float64)
+        dt = np.zeros(max(n.value, 1), dtype=np.float64)
+        self._check(self._lib.pe_profile_timeline(self._h, _ptr(k, C.c_int32), _ptr(t0, C.c_double), _ptr(dt, C.c_double),
+                                                  n.value, C.byref(n)))
+        rows = [(_abi.KERNEL_NAMES[int(k[i])], float(t0[i]), float(dt[i])) for i in range(min(n.value, k.size))]
+        return sorted(rows, key=lambda r: r[1])
 
     def profile_reset(self):
         self._check(self._lib.pe_profile_reset(self._h))

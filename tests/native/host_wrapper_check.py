@@ -194,4 +194,10 @@ assert calls() == ["pe_dist_init_custom", "pe_dist_set_max_groups", "pe_aggregat
 assert gx["n_groups"] == 0 and e._coll_keep is not None        # the callback table outlives the call
 e.dist_destroy()
 assert e._coll_keep is None
+# ---- profiling: per-kernel totals, and the timeline mode (the stub brackets nothing) ----
+lib.stub_reset()
+e.profile_enable(2)
+e.profile_reset()
+assert e.profile_timeline() == [] and set(e.profile()) >= {"g1_accumulate", "att_group", "att_validate"}
+assert calls()[:3] == ["pe_profile_enable", "pe_profile_reset", "pe_profile_timeline"]
 print("host wrapper ok")

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""In-situ kernel timeline of the streaming step from the ENGINE's own events (pe_profile_enable(h, 2) /
+pe_profile_timeline): every bracketed launch's start and end on the stream it ran on, without a profiler in the process
+-- rocprofv3 serialises enough to stretch the 0.28 ms step to 0.4 (profiles/r03_timeline.txt), which hides exactly the
+overlap one wants to see.
+
+    python tools/engine_timeline.py [--steps 24] [--show 3] [--lag 4] [--validators 1048576] > timeline.txt
+
+Builds bench.py's workload (BASELINE configs[3] shape by default), runs `--steps` streaming steps with rows + bits resident
+in HBM, and prints the launches of the last `--show` steps in time order, the period between consecutive
+k_g1_accumulate starts, and for each accumulate the gap since the previous one ended and which kernel ended last before
+it started (the candidate for what it waited for).  Brackets: att_group = ingest + plan + members, att_validate =
+validate_on_attestation / process_attestation asserts, bits_union, lmd, votes, tree, participation, g1_accumulate,
+g1_tree, g1_normalise (the finish).  Needs a GPU."""
+import argparse
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--show", type=int, default=3)
+    ap.add_argument("--lag", type=int, default=4)
+    ap.add_argument("--validators", type=int, default=1 << 20)
+    ap.add_argument("--committees", type=int, default=2048)
+    ap.add_argument("--blocks", type=int, default=4096)
+    ap.add_argument("--parts", type=int, default=4)
+    a = ap.parse_args()
+
+    import bench
+    import pos_evolution_amd as pea
+
+    args = types.SimpleNamespace(validators_local=a.validators, blocks=a.blocks, committees=a.committees, parts=a.parts,
+                                 mixed_balances=False, host_arena=False, host_rows=False, with_shuffle=False,
+                                 by_committee=False, world=1, shuffle_variant_from=a.steps)
+    e = pea.Engine(device=0, max_committee_tables=a.steps + 3)
+    w = bench.build_workload(e, args, 0, a.steps)
+    e.set_pipeline_lag(a.lag)
+    e.reuse_outputs(a.lag + 2)
+    warm = max(a.lag + 2, a.steps - a.show - a.lag - 2)
+    for s in range(warm):
+        bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False)
+    e.drain()
+    e.profile_enable(2)
+    e.profile_reset()              # time zero
+    for s in range(warm, a.steps):
+        bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False)
+    e.drain()
+    tl = e.profile_timeline()
+    e.profile_enable(0)
+    acc = [r for r in tl if r[0] == "g1_accumulate"]
+    if len(acc) < 2:
+        print("no accumulations bracketed", file=sys.stderr)
+        return 1
+    first = acc[max(0, len(acc) - a.show - 1)][1]
+    print(f"# {a.validators} validators, {a.committees} committees, {a.blocks} blocks, lag {a.lag}; times in us from the "
+          f"start of the accumulation {len(acc) - a.show - 1} of {len(acc)} timed steps")
+    print(f"{'kernel':16s} {'start':>9s} {'end':>9s} {'dur':>8s}")
+    for name, t0, dt in tl:
+        if t0 >= first - 1e-3:
+            print(f"{name:16s} {(t0 - first) * 1e3:9.1f} {(t0 + dt - first) * 1e3:9.1f} {dt * 1e3:8.1f}")
+    print()
+    print("accumulate  period_us  gap_after_previous_us  last_kernel_to_end_before_it (end -> accumulate start, us)")
+    for i in range(1, len(acc)):
+        t0 = acc[i][1]
+        prev_end = acc[i - 1][1] + acc[i - 1][2]
+        before = [(r[1] + r[2], r[0]) for r in tl if r[1] + r[2] <= t0 + 1e-6 and r[0] != "g1_accumulate"]
+        last = max(before) if before else (float("nan"), "-")
+        print(f"{i:10d} {(t0 - acc[i - 1][1]) * 1e3:10.1f} {(t0 - prev_end) * 1e3:22.1f}  {last[1]} ({(t0 - last[0]) * 1e3:.1f})")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -7,6 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 O=gpurun_out/r04first
 mkdir -p "$O"
+# 0. what the step waits for: the engine's own in-situ timeline (no profiler in the process)
+timeout 300 python tools/engine_timeline.py --steps 24 --show 3 > "$O/engine_timeline.txt" 2> "$O/engine_timeline.err"
+echo "[r04first] engine timeline rc $?"; tail -8 "$O/engine_timeline.txt"
 # 1. the S29 field form on hardware: device-vs-host check, products/s and mixed adds/s (tools/fpbench prints the 32-bit
 #    form's: 57 G products/s, 4.6-4.9 G mixed adds/s)
 ( cd tools && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../pos_evolution_amd/csrc -o fpbench29 fpbench29.hip \
