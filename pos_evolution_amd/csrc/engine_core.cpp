@@ -516,12 +516,13 @@ static void prof_drain(pe_engine* h)
             if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
                 p.total_ms += ms;
                 p.launches += 1;
-                float t0 = 0;
-                if (h->prof_timeline && h->prof_base && h->prof_tl.size() < (1u << 20) &&
-                    hipEventElapsedTime(&t0, h->prof_base, ev.first) == hipSuccess)
-                    h->prof_tl.push_back(pe_engine::TimelineEntry{k, t0, ms});
-                else
-                    (void)hipGetLastError();
+                if (h->prof_timeline && h->prof_base && h->prof_tl.size() < (1u << 20)) {
+                    float t0 = 0;
+                    if (hipEventElapsedTime(&t0, h->prof_base, ev.first) == hipSuccess)
+                        h->prof_tl.push_back(pe_engine::TimelineEntry{k, t0, ms});
+                    else
+                        (void)hipGetLastError();  // e.g. a launch bracketed before the reset that marked time zero
+                }
             }
             h->event_pool.push_back(ev.first);
             h->event_pool.push_back(ev.second);
