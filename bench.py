@@ -993,6 +993,9 @@ def main():
     products = 10.0 * att_per_launch - 4.0 * lane_runs
     valu_peak = 57.0e9
     valu_ach = products / (acc_ms * 1e-3) if acc_ms else 0.0
+    # the tree over the lanes' partials: one 14-product add per lane but one per committee; it runs on the same SIMDs
+    # beside the NEXT accumulation, so the step's VALU work is both
+    tree_products = 14.0 * max(lane_runs - C, 0)
     votes = prof["votes"]
     votes_ms = votes["total_ms"] / max(votes["launches"], 1)
     votes_bytes = 13.0 * VL + 32.0 * args.blocks
@@ -1068,6 +1071,15 @@ def main():
             "kernel": "k_g1_accumulate", "bound": "integer VALU (v_mad_u64_u32 Montgomery products)",
             "achieved": valu_ach / 1e9, "peak": valu_peak / 1e9, "unit": "G Fp-products/s", "frac": valu_ach / valu_peak,
             "products_per_launch": products,
+            "step_view": {
+                "tree_products_per_step": tree_products,
+                "products_per_step": products + tree_products,
+                "G_products_per_s_over_the_step": (products + tree_products) / (dt / args.steps) / 1e9,
+                "frac_of_peak_over_the_step": (products + tree_products) / (dt / args.steps) / valu_peak,
+                "note": "accumulation + tree products of one step over the whole step period: the fraction of the period "
+                        "the chip spends on this algorithm's Montgomery products at the multiplier's ceiling; the rest is "
+                        "the in-situ efficiency of the two kernels and the bubble between accumulations (DESIGN.md 8)",
+            },
             "peak_source": "tools/fpbench: this repository's own fp_mul in a dependent loop at 2 waves/SIMD -- a ceiling of the "
                            "multiplier as written, not of the chip",
             # the chip's own numbers (tools/ubench_valu, profiles/r01_ubench_valu_fpmul.log, 2 waves/SIMD): a product is 288
