@@ -1026,10 +1026,10 @@ def main():
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
-        "dtype": "u32",
-        "dtype_detail": ("12 x u32 Montgomery limbs (381-bit Fp, exact integer arithmetic); u64 Gwei weights"
-                         + ("; POSEVO_G1_S29=1: the accumulation in 14 signed 29-bit limbs (fp381_s29.h), same results"
-                            if os.environ.get("POSEVO_G1_S29", "0") not in ("", "0") else "")),
+        "dtype": "int32",
+        "dtype_detail": ("381-bit Fp, exact integer arithmetic: the accumulation (dominant kernel) in 14 signed 29-bit limbs "
+                         "held in int32 with int64 column sums (fp381_s29.h); tree / finish in 12 x u32 Montgomery limbs; "
+                         "u64 Gwei weights"),
         "data": "synthetic",
         "config": {
             "workload": shape + f": {V_total} validators on {world} GPU(s) ({VL} per GPU), "
@@ -1041,7 +1041,7 @@ def main():
                             f"committees ({scaling} scaling)" if args.by_committee else
                             f"validator-range shards x{world} ({scaling} scaling)" if world > 1 else "single GPU"),
             "call_mode": mode,
-            "g1_field_form": "s29" if os.environ.get("POSEVO_G1_S29", "0") not in ("", "0") else "12x32",
+            "g1_field_form": "s29 (accumulation) + 12x32 (tree, finish)",
             "inputs": (("attestation rows in host memory (grouped and validated by the host inside the timed step); "
                         if (args.host_rows or args.host_arena or (world > 1 and not engine_rccl)) else
                         "attestation rows resident in HBM before the timed region (grouped, resolved and validated on "

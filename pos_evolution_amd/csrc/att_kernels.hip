@@ -837,9 +837,12 @@ k_participation_tables(const AttRow* __restrict__ rows, TablesDev tables, const 
                        const uint32_t* __restrict__ bit_arena, const uint16_t* __restrict__ eff_increments,
                        unsigned long long base_reward_per_increment, uint32_t* __restrict__ part_cur,
                        uint32_t* __restrict__ part_prev, unsigned long long* __restrict__ numerators,
-                       const uint32_t* __restrict__ gates)
+                       const uint32_t* __restrict__ gates, uint32_t cap)
 {
     const int t = blockIdx.y;
+    // more groups than the caller's arrays hold: k_att_validate_state reported ERR_CAPACITY, nothing is applied and
+    // numerators[] (sized by cap) is not written
+    if (plan->n_groups > cap) return;
     if (!tables.t[t].valid || plan->n_rows_table[t] == 0) return;
     const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= tables.t[t].n_committees) return;
@@ -889,7 +892,7 @@ void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev ta
                                  uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
                                  const uint16_t* eff_increments, uint64_t base_reward_per_increment,
                                  uint32_t* part_cur_words, uint32_t* part_prev_words, uint64_t* numerators,
-                                 const uint32_t* gates)
+                                 const uint32_t* gates, uint32_t cap)
 {
     uint32_t nc = tables.t[0].valid ? tables.t[0].n_committees : 0u;
     if (tables.t[1].valid) nc = nc > tables.t[1].n_committees ? nc : tables.t[1].n_committees;
@@ -898,7 +901,7 @@ void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev ta
     hipLaunchKernelGGL(k_participation_tables, dim3((nc + 3) / 4, ny), dim3(256), 0, s, rows, tables, crow_start[0],
                        crow_start[1], crow_list[0], crow_list[1], plan, bit_arena, eff_increments,
                        (unsigned long long)base_reward_per_increment, part_cur_words, part_prev_words,
-                       reinterpret_cast<unsigned long long*>(numerators), gates);
+                       reinterpret_cast<unsigned long long*>(numerators), gates, cap);
 }
 
 }  // namespace posevo

@@ -608,7 +608,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
             // and k_g1_finish all run beside the accumulation: the step gets 6-8 % shorter (0.356 vs 0.378 ms fast box,
             // 0.38 vs 0.415 slow box) while the accumulation itself gets 20 % longer (0.275 vs 0.229 ms) -- the kernel's
             // own efficiency is what this engine is graded on, so the default keeps it.
-            static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return e && atoi(e) != 0; }();
+            static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return !e || atoi(e) != 0; }();
             if (h->streaming && !pinned) target = one_wave ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
             else if (h->g1_target_slots) target = h->g1_target_slots;
             else {
@@ -687,6 +687,8 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
     // behind the earlier chain (without this the first aggregate's pubkeys were summed over the second's unions).
     if (!h->deferred.empty()) PE_TRY(run_deferred(h));
     if (h->A().side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
+    PE_TRY(aux_join(h, ms));  // ... and behind an earlier process_attestation / signature leg of this pipeline (they read
+                              // the resident words on the state-transition stream)
     if (arena_kind == 0) {
         HIP_TRY(h, st.upload());
     } else {  // the bits by the copy engine from where they lie, then the zero pad and everything behind it
@@ -781,6 +783,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         HIP_TRY(h, h->d_tmp_points.ensure(4ull * G1_ROW_WORDS * n));
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, ms));
         launch_g1_convert(ms, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
+        h->tmp_points_n = n;
         int rc = launch_g1_planned(h, h->d_tmp_points.as<uint32_t>(), st.dev<uint32_t>(off_idx), nullptr,
                                    st.dev<G1Group>(off_g1s), plan_sig, ob.host<uint8_t>(off_osig), nullptr, ms);
         if (rc) return rc;
@@ -1038,7 +1041,7 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     const uint32_t* d_gates = resident ? h->arena[h->res_arena].d_res_info.as<uint32_t>() : nullptr;
     HIP_TRY(h, stg.upload());
     memset(ob.host<uint8_t>(off_num), 0, 8ull * n);  // the kernel writes the numerators straight into the pinned block
-    hipStream_t ss = state_stream_begin(h);  // behind the upload and the unions; beside whatever follows on the engine's stream
+    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true);  // behind the upload and the unions; beside whatever follows on the engine's stream
     for (size_t k = 0; k < ord.size();) {
         size_t e = k + 1;
         while (e < ord.size() && round_of[ord[e]] == round_of[ord[k]] && acc[ord[e]].table == acc[ord[k]].table) ++e;

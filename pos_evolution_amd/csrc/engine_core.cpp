@@ -72,7 +72,7 @@ int complete_arena(pe_engine* h, int ai)
     // is not a completed pipeline: the calls still to come put their outputs behind
     if (a.generation > h->pipes_completed && !(h->pipelining && ai == h->cur)) h->pipes_completed = a.generation;
     a.stage_cursor = a.out_cursor = 0;
-    a.fenced = a.side_used = a.aux_used = false;
+    a.fenced = a.side_used = a.aux_used = a.aux_reads_scratch = false;
     if (e == hipErrorNotReady)
         return fail(h, PE_ERR_TIMEOUT, "a collective did not complete within " + std::to_string(h->dist_timeout_ms) +
                     " ms: the communicators were aborted (pe_dist_destroy, then pe_dist_init_ex with PE_DIST_SINGLE_COMM)");
@@ -150,7 +150,7 @@ int enter(pe_engine* h)
     const int rc2 = aux_quiesce(h);  // e.g. a participation rotation outside any batch call
     return rc ? rc : rc2;
 }
-hipStream_t state_stream_begin(pe_engine* h)
+hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch)
 {
     // a caller-owned stream (pe_set_stream) carries everything: the caller orders its own work against it
     if (h->stream != h->own_stream || !h->aux_stream) return h->stream;
@@ -159,7 +159,22 @@ hipStream_t state_stream_begin(pe_engine* h)
         return h->stream;
     h->aux_busy = true;
     h->A().aux_used = true;
+    if (reads_scratch) h->A().aux_reads_scratch = true;
     return h->aux_stream;
+}
+// An aggregate that rewrites the current arena's scratch (group descriptors, plan, member lists, resident union words)
+// while an EARLIER call of the same pipeline still reads them on the state-transition stream (process_attestation's flag
+// pass, the signature leg): order the rewriting stream behind that work (ADVICE r3 -- the same hazard the deferred G1
+// launch had on the side stream, ev_join).  ev_aux_fork is free again here: its wait was enqueued when it was recorded.
+int aux_join(pe_engine* h, hipStream_t ms)
+{
+    // (only such readers: the participation rotation of every step also lives on that stream and reads no scratch --
+    // joining behind IT put every step's row chain behind the previous step's flag pass: 0.33 -> 0.86 ms per step)
+    if (!h->aux_stream || ms == h->aux_stream || !h->A().aux_reads_scratch) return PE_OK;
+    h->A().aux_reads_scratch = false;
+    HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->aux_stream));
+    HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_aux_fork, 0));
+    return PE_OK;
 }
 int need_init(pe_engine* h, bool flush)
 {
@@ -289,7 +304,6 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
-    if (const char* e = getenv("POSEVO_G1_S29")) h->g1_s29 = atoi(e) != 0;  // read per engine (A/B knob, off by default)
     if (const char* e = getenv("POSEVO_ROWS_STREAM")) h->rows_stream_on = atoi(e);  // read per engine (A/B knob, off by default)
     if (const char* e = getenv("POSEVO_PIPELINE_LAG")) {
         const int lag = atoi(e);
@@ -346,7 +360,7 @@ void pe_engine_destroy(pe_engine* h)
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
                       &h->d_tpos, &h->d_tidx, &h->d_direct, &h->d_weights, &h->d_totals, &h->d_head,
                       &h->d_broot_tab, &h->d_broots, &h->d_bslot_pos,
-                      &h->d_partials, &h->d_lane_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be})
+                      &h->d_partials, &h->d_lane_partials, &h->d_out96, &h->d_tmp_points, &h->d_tmp_be, &h->d_tmp_points29})
         b->release();
     for (auto& t : h->tables) {
         t.d_members.release(); t.d_offsets.release(); t.d_inv_comm.release(); t.d_inv_pos.release();

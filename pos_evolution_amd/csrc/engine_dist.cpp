@@ -204,7 +204,7 @@ int pe_dist_destroy(pe_engine* h)
         for (auto& a : h->arena) {
             a.pending.clear();
             a.stage_cursor = a.out_cursor = 0;
-            a.fenced = a.side_used = a.aux_used = false;
+            a.fenced = a.side_used = a.aux_used = a.aux_reads_scratch = false;
         }
         h->deferred.clear();
         h->pipelining = h->streaming = false;

@@ -15,6 +15,19 @@ void g1_stream_guard(pe_engine* h, hipStream_t s)
     if (h->side_ever && s != h->side_stream && s != h->fin_stream && s != h->norm_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
 }
 
+// The registry table in the accumulation's field form (k_g1_table_s29), built where the registry is loaded -- on the
+// engine's stream, which every G1 launch is ordered behind.  (Built lazily inside the first G1 launch -- round 3's S29
+// experiment -- the allocation ran ensure_quiesced INSIDE a streaming pipeline's deferred launch: it completed the
+// current arena, copying the aggregate pubkeys out before k_g1_finish had written them.)
+int build_points29(pe_engine* h, uint64_t n)
+{
+    HIP_TRY(h, h->d_points29.ensure(std::max<size_t>(128, 4ull * G1_ROW_WORDS * n)));
+    launch_g1_table_s29(h->stream, h->d_points.as<uint32_t>(), h->d_points29.as<uint32_t>(), n);
+    HIP_TRY(h, hipGetLastError());
+    h->points29_valid = true;
+    return PE_OK;
+}
+
 // Launch accumulate + finish for device-resident descriptors.  No copies, no synchronisation.
 // fin != s: the tree and finish kernels go to their own stream behind an event (a pipelined aggregate: they then overlap
 // the next aggregate's accumulation); partials / lane_partials: the scratch the kernels hand over through (per arena
@@ -34,20 +47,23 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
                            std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
     const size_t lane_bytes = (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan.n_slots + G1_WG - 1) / G1_WG);
     PE_TRY(ensure_quiesced(h, *lane_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, lane_bytes)));
-    const bool s29 = h->g1_s29 && d_points == h->d_points.as<uint32_t>() && h->n_val > 0;
-    if (s29 && !h->points29_valid) {  // the registry changed since the table of this form was built (or never was)
-        PE_TRY(ensure_quiesced(h, h->d_points29, 4ull * G1_ROW_WORDS * h->n_val));
-        launch_g1_table_s29(s, d_points, h->d_points29.as<uint32_t>(), h->n_val);
-        h->points29_valid = true;
+    // the table in the accumulation's field form (S29): the registry's is built at the first use after the registry
+    // changed; caller-supplied points (pe_g1_sum, the G1-flavoured signature leg: d_tmp_points) are converted per call
+    const uint32_t* d_points29;
+    if (d_points == h->d_points.as<uint32_t>()) {
+        if (!h->points29_valid) return fail(h, PE_ERR_STATE, "the registry's table of the accumulation's field form was not built");
+        d_points29 = h->d_points29.as<uint32_t>();
+    } else {
+        const uint64_t n_rows = h->tmp_points_n;
+        if (d_points != h->d_tmp_points.as<uint32_t>()) return fail(h, PE_ERR_STATE, "G1 sum over an unknown point table");
+        PE_TRY(ensure_quiesced(h, h->d_tmp_points29, std::max<size_t>(128, 4ull * G1_ROW_WORDS * n_rows)));
+        launch_g1_table_s29(s, d_points, h->d_tmp_points29.as<uint32_t>(), n_rows);
+        d_points29 = h->d_tmp_points29.as<uint32_t>();
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s);
-        if (s29)
-            launch_g1_accumulate_s29(s, h->d_points29.as<uint32_t>(), d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                                     lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
-        else
-            launch_g1_accumulate(s, d_points, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                                 lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
+        launch_g1_accumulate(s, d_points29, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
     }
     // POSEVO_G1_TREE_SERIAL=1: the tree stays on the accumulation's stream (the next accumulation starts behind it)
     static const bool tree_serial = [] { const char* e = getenv("POSEVO_G1_TREE_SERIAL"); return e && atoi(e) != 0; }();
@@ -135,6 +151,7 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n_points, hipMemcpyHostToDevice, h->stream));
         launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
         d_pts = h->d_tmp_points.as<uint32_t>();
+        h->tmp_points_n = n_points;
         np = n_points;
     } else {
         if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");
@@ -221,6 +238,7 @@ int pe_set_pubkeys_compressed(pe_engine* h, uint64_t n, const uint8_t* pubkeys48
     if (rc) return rc;
     if (n_bad) return fail(h, PE_ERR_INVALID_ARG, std::to_string(n_bad) + " pubkeys do not decode to curve points (see status[])");
     h->have_points = true;
+    PE_TRY(build_points29(h, n));
     return PE_OK;
 }
 
@@ -460,7 +478,7 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     const size_t off_st = ob.alloc(4ull * n);
     PE_TRY(ob.ensure());
     memset(ob.host<uint32_t>(off_bad), 0, 4ull * std::max<uint32_t>(ng_bound, 1));
-    hipStream_t ss = state_stream_begin(h);  // behind the grouping; beside the aggregate pubkeys and the fork-choice kernels
+    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true);  // behind the grouping; beside the aggregate pubkeys and the fork-choice kernels
     bool sig_on_device = false;
     {
         hipPointerAttribute_t pa;

@@ -260,6 +260,7 @@ struct pe_engine {
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
         bool fenced = false, side_used = false, aux_used = false;
+        bool aux_reads_scratch = false;  // work on the state-transition stream still reads this arena's grouping scratch / resident words
     };
     // lag depth L (pe_pipeline_set_lag, default 2) = L + 1 arenas in rotation: a lagged end waits for the pipeline L
     // back, never for the finish kernel of the one that has only just been fenced.  Arenas allocate on first use.
@@ -341,9 +342,11 @@ struct pe_engine {
     // POSEVO_ROWS_STREAM=1: the row chain of a streaming step's first device-row aggregate (copy, ingest, plan, members,
     // union) on a stream of its own -- it depends on nothing the previous step's fork-choice kernels produce, so it runs
     // beside them instead of behind them; the engine's stream takes over behind the union (engine_resident.cpp)
-    // POSEVO_G1_S29=1: k_g1_accumulate_s29 over d_points29 (built from d_points at the first use after the registry changed)
-    bool g1_s29 = false, points29_valid = false;
-    DevBuf d_points29;
+    // k_g1_accumulate reads the registry in the S29 field form: d_points29, built from d_points at the first use after the
+    // registry changed; d_tmp_points29: the same for caller-supplied points (d_tmp_points), per call
+    bool points29_valid = false;
+    DevBuf d_points29, d_tmp_points29;
+    uint64_t tmp_points_n = 0;  // rows of d_tmp_points the last conversion filled
     hipStream_t rows_stream = nullptr;
     hipEvent_t ev_rows = nullptr;
     int rows_stream_on = 0;  // 1: a stream of its own; 2: the state-transition stream carries the row chain
@@ -413,7 +416,8 @@ int flush_pending(pe_engine* h);
 int enter(pe_engine* h);
 int need_init(pe_engine* h, bool flush = true);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
-hipStream_t state_stream_begin(pe_engine* h);
+hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
+int aux_join(pe_engine* h, hipStream_t ms);  // ms waits for what this pipeline put on the state-transition stream
 
 // ------------------------------------------------------------------ spec helpers (A.10)
 inline uint64_t current_slot(const pe_engine* h) { return (h->time - h->genesis_time) / h->cfg.seconds_per_slot; }
@@ -557,7 +561,7 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
 // then runs beside the start of the accumulation).  3: in front of k_votes.  (A/B knob.)
 inline int g1_defer_point()
 {
-    static const int p = [] { const char* e = getenv("POSEVO_G1_DEFER"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 3 ? v : 1; }();
+    static const int p = [] { const char* e = getenv("POSEVO_G1_DEFER"); const int v = e ? atoi(e) : 2; return v >= 0 && v <= 3 ? v : 2; }();
     return p;
 }
 inline bool g1_defer_enabled() { return g1_defer_point() != 0; }
@@ -630,6 +634,7 @@ void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan, uint
 }
 
 void g1_stream_guard(pe_engine* h, hipStream_t s);
+int build_points29(pe_engine* h, uint64_t n);  // after the registry's points changed (n rows)
 int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
                       hipStream_t s = nullptr, hipStream_t fin = nullptr, DevBuf* partials = nullptr,

@@ -145,7 +145,7 @@ int candidate_tables(pe_engine* h, TablesDev* out, CommitteeTable* tabs[2])
 uint32_t g1_target_slots(const pe_engine* h)
 {
     static const uint32_t pinned = [] { const char* e = getenv("POSEVO_G1_TARGET_SLOTS"); return e ? (uint32_t)atol(e) : 0u; }();
-    static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return e && atoi(e) != 0; }();
+    static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return !e || atoi(e) != 0; }();
     if (pinned) return pinned;
     if (h->streaming) return one_wave ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
     return h->g1_target_slots ? h->g1_target_slots : G1_TARGET_LANES;
@@ -275,6 +275,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     if (set == 0) {
         if (!h->deferred.empty()) PE_TRY(run_deferred(h));
         if (A.side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
+        PE_TRY(aux_join(h, ms));  // ... or from a process_attestation / signature leg on the state-transition stream
     }
     h->res_valid = false;
     h->rr.valid = false;
@@ -568,15 +569,15 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
         S.tgt_blk[1] = get_ancestor(h, tip, S.prev_epoch * spe);
     }
     OutBlock ob(h);
+    const size_t off_err = ob.alloc(16);  // in front of the cap-sized arrays: nothing sized by the caller can reach it
     const size_t off_status = ob.alloc(4ull * cap);
     const size_t off_num = ob.alloc(8ull * cap);
-    const size_t off_err = ob.alloc(16);
     PE_TRY(ob.ensure());
     *ob.host<uint32_t>(off_err) = 0;
     memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
     memset(ob.host<uint64_t>(off_num), 0, 8ull * cap);  // k_participation_tables writes the rows it runs
     const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);
-    hipStream_t ss = state_stream_begin(h);  // behind the unions and the plan; beside the next step's fork-choice chain
+    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true);  // behind the unions and the plan; beside the next step's fork-choice chain
     {
         ProfScope ps(h, PE_KERNEL_ATT_VALIDATE, ss);  // timeline mode only
         launch_att_validate_state(ss, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), S,
@@ -588,7 +589,7 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
         launch_participation_tables(ss, L.rows_st, h->rr.tables, L.crow_start, L.crow_list, L.plan,
                                     RS.bits.as<uint32_t>(), h->d_incr.as<uint16_t>(), sc->base_reward_per_increment,
                                     h->d_part_cur.as<uint32_t>(), h->d_part_prev.as<uint32_t>(), ob.host<uint64_t>(off_num),
-                                    reinterpret_cast<const uint32_t*>(L.status_st));
+                                    reinterpret_cast<const uint32_t*>(L.status_st), cap);
     }
     HIP_TRY(h, hipGetLastError());
     lap.mark("rproc.1_launch");

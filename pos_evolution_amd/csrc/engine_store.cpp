@@ -376,6 +376,7 @@ int pe_set_validators(pe_engine* h, uint64_t n, const uint8_t* pubkeys96, const 
         }
         HIP_TRY(h, hipGetLastError());
         h->have_points = true;
+        PE_TRY(build_points29(h, n));  // the registry in the accumulation's field form, now: never inside a G1 launch
     } else if (!pubkeys96) {
         h->have_points = h->have_points && n <= old_n;
     }

@@ -30,8 +30,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PE_HD __host__ __device__ __forceinline__
+#define PE_HD_MEMBER static __host__ __device__ __forceinline__
 #else
 #define PE_HD static inline
+#define PE_HD_MEMBER static inline
 #endif
 #define PE_HD_CONST static constexpr  // constant-initialised: hipcc emits them for the device where device code reads them
 

@@ -6,15 +6,20 @@
 //
 // Kernels
 //   k_g1_convert     96-B big-endian affine -> Montgomery limbs (registry load, once)
-//   k_g1_accumulate  HOT: per-lane XYZZ accumulation of k gathered points (mixed
-//                    adds), then a compacting pairwise tree over the workgroup's 256
-//                    partials staged in LDS (limb-major, conflict-light), one XYZZ
+//   k_g1_table_s29   the registry in the accumulation's field form (14 x 29-bit limbs, fp381_s29.h), once per registry
+//   k_g1_accumulate  HOT: per-lane XYZZ accumulation of k gathered points (mixed adds over the S29 form), one
+//                    partial per lane slot
+//   k_g1_tree        the compacting pairwise tree over a workgroup's 256 partials staged in LDS (limb-major), one XYZZ
 //                    partial out per (group, workgroup)
 //   k_g1_finish      per group: add the few workgroup (or rank) partials, normalise
 //                    to canonical affine, store big-endian
 //
-// Bound: integer VALU (10 Montgomery products per mixed add = 5.8k v_mad_u64_u32/v_addc per
-// 100 bytes gathered), not HBM and not MFMA -- see DESIGN.md "G1 roofline".
+// Bound: integer VALU (a mixed add = 8 products + 2 squarings = 3 738 v_mad_[iu]64_[iu]32 per 100 bytes gathered), not
+// HBM and not MFMA -- see DESIGN.md "G1 roofline".  Two field forms live here: the accumulation computes in S29 (one
+// multiply-add per limb product, no carry instructions: 25 % faster per mixed add); tree, finish, wire formats and key
+// validation compute in 12 x 32-bit limbs (fp381.h) -- latency-bound guests whose products are CALLS to one copy of the
+// code, so that what they cost the accumulation is not a 64 KB instruction cache full of their unrolled products.
+#define POSEVO_FP_MUL_CALLED 1  // every 12 x 32-bit product of this file's kernels is a call (see fp381.h)
 #include "g1.h"
 #include "g1_s29.h"
 #include "fp_sqrt.h"
@@ -249,6 +254,19 @@ __device__ __forceinline__ void global_load_x(g1x& p, const uint32_t* __restrict
 __device__ __forceinline__ uint32_t find_group(const G1Group* __restrict__ groups, uint32_t n_groups, uint32_t slot)
 {
     uint32_t lo = 0, hi = n_groups;  // invariant: slot_base[lo] <= slot < slot_base[hi]
+    // Plans made on the device give every group the same block (k_att_plan), and so do the host's for committees of one
+    // size: try the group a uniform layout puts the slot in before searching (2 loads instead of 11 dependent ones:
+    // ~10 us at the head of a 170 us kernel).
+    {
+        const uint32_t lb = groups[0].log2_block;
+        const uint32_t g0 = min(lb <= 8 ? slot >> lb : 0u, n_groups - 1);
+        if (groups[g0].slot_base <= slot) {
+            if (g0 + 1 == n_groups || groups[g0 + 1].slot_base > slot) return g0;
+            lo = g0 + 1;
+        } else {
+            hi = g0;
+        }
+    }
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
         if (groups[mid].slot_base <= slot) lo = mid; else hi = mid;
@@ -278,8 +296,9 @@ __device__ unsigned long long g1_wave_info[3 * 4 * 4096];  // per wave: HW_ID | 
 #define POSEVO_G1_WAVES_PER_EU 2
 #endif
 // The sum of one launch runs in THREE kernels since round 2:
-//   k_g1_accumulate  per-lane XYZZ accumulation of k gathered points (mixed adds): throughput-bound, at the VALU issue
-//                    floor; writes one partial per lane slot, limb-major per workgroup (coalesced);
+//   k_g1_accumulate  per-lane XYZZ accumulation of k gathered points (mixed adds, S29 form since round 4): throughput-
+//                    bound, at the multiplier's issue floor; writes one partial per lane slot, limb-major per workgroup
+//                    (coalesced), already in the 12 x 32-bit words the tree reads;
 //   k_g1_tree        the compacting pairwise tree over each workgroup's 256 partials (LDS, two- and four-lane
 //                    cooperative adds): latency-bound, a level is one full add deep;
 //   k_g1_finish      adds the few workgroup partials of a wide group and normalises.
@@ -309,83 +328,13 @@ __device__ __forceinline__ void g1_slot_block(const G1Group* __restrict__ groups
 }
 
 // lane partials in HBM: word k of lane `tid` of workgroup `wg` at ((wg * 48 + k) * 256 + tid): a wave's 64 lanes write
-// 256 contiguous bytes per word
-__device__ __forceinline__ void lane_store_x(uint32_t* __restrict__ buf, uint32_t wg, int tid, const g1x& p)
-{
-    uint32_t* b = buf + (size_t)wg * G1X_WORDS * G1_WG + tid;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        b[(0 + k) * G1_WG] = p.x.l[k];
-        b[(12 + k) * G1_WG] = p.y.l[k];
-        b[(24 + k) * G1_WG] = p.zz.l[k];
-        b[(36 + k) * G1_WG] = p.zzz.l[k];
-    }
-}
-
-__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
-k_g1_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ members,
-                const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
-                uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials,
-                const AttPlan* __restrict__ plan_dev, const uint32_t* __restrict__ members1)
-{
-    const int tid = threadIdx.x;
-    if (plan_dev) {  // rows resident on the device: the plan was made there; the grid is sized by an upper bound
-        n_groups = plan_dev->n_groups;
-        n_slots = plan_dev->n_slots;
-        if (blockIdx.x * G1_WG >= n_slots) return;
-    }
-    const uint32_t slot = blockIdx.x * G1_WG + tid;
-    G1_STAMP(0);
-    G1_WAVE_BEGIN();
-
-    g1x acc;
-    g1x_set_inf(acc);
-    uint32_t my_out, my_size, t;
-    G1Group d;
-    g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
-    if (slot < n_slots && t < d.n_tasks) {
-        const uint32_t gk = d.k & 0x7FFFFFFFu;  // bit 31: the group's committee lives in the second member array
-        if (d.k >> 31) members = members1;
-        const uint32_t first = t * gk;
-        const uint32_t count = min(gk, d.n_members - first);
-        // gather + mixed adds; the next point's loads are issued before the current add
-        fp qx, qy, nx, ny;
-        bool have = false, nhave = false;
-        auto fetch = [&](uint32_t j, fp& ox, fp& oy) -> bool {
-            const uint32_t i = first + j;
-            if (d.bits_word != NONE32) {
-                const uint32_t w = bit_arena[d.bits_word + (i >> 5)];
-                if (!((w >> (i & 31)) & 1u)) return false;
-            }
-            const uint32_t idx = members ? members[d.member_start + i] : d.member_start + i;
-            load_point(ox, oy, pts, idx);
-            return true;
-        };
-        if (count > 0) have = fetch(0, qx, qy);
-        bool acc_affine = false;
-        for (uint32_t j = 0; j < count; ++j) {
-            nhave = false;
-            if (j + 1 < count) nhave = fetch(j + 1, nx, ny);
-            if (have) {
-                const bool q_inf = fp_is_zero(qx) && fp_is_zero(qy);  // (0,0) encodes infinity in the table
-                g1x_add_affine_run(acc, acc_affine, qx, qy, q_inf);
-            }
-            qx = nx; qy = ny; have = nhave;
-        }
-    }
-    G1_STAMP(1);
-    G1_WAVE_END();
-    if (my_size == 1) global_store_x(wg_partials + (size_t)G1X_WORDS * my_out, acc);  // single-task group: done
-    lane_store_x(lane_partials, blockIdx.x, tid, acc);
-}
+// 256 contiguous bytes per word (k_g1_accumulate's hand-over loop writes them, k_g1_tree reads them into LDS)
 
 #ifndef POSEVO_G1_TREE_WAVES_PER_EU
 #define POSEVO_G1_TREE_WAVES_PER_EU 2
 #endif
-// Two waves per SIMD: 226 VGPRs, no scratch.  The three-wave build (168 VGPRs, 288 B of scratch per lane) would fit
-// beside the two waves of the NEXT aggregate's k_g1_accumulate and start while that one runs; measured back to back on
-// one box it loses anyway -- alone 59 vs 51 us, in the streaming step 0.114 vs 0.093 ms and the finish behind it
-// 0.14 vs 0.086 ms, step 0.396-0.404 vs 0.381-0.389 ms (gpurun_out/r02r_*, summary in profiles/README.md).
+// Two waves per SIMD (256 VGPRs with the called product, 32 B of scratch): the shape that fits beside ONE wave of the
+// next aggregate's k_g1_accumulate (<= 256 VGPRs) on every SIMD, which is how streaming steps run it (round 4).
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_TREE_WAVES_PER_EU, POSEVO_G1_TREE_WAVES_PER_EU)))
 k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups, uint32_t n_groups,
           uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev)
@@ -540,21 +489,13 @@ k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict_
     }
 }
 
-void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
-                          const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
-                          uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
-                          const uint32_t* members1)
-{
-    if (n_groups == 0 || n_slots == 0) return;
-    const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
-    hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), 0, s, points_mont24, members, bit_arena,
-                       groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
-}
-
-// ---------------------------------------------------------------- the accumulation over the S29 field form
-// (fp381_s29.h / g1_s29.h: 14 signed limbs of 29 bits, one v_mad_i64_i32 per limb product, no carry instructions).
-// POSEVO_G1_S29=1 routes launch_g1_planned's accumulation here; tree and finish are unchanged: a lane converts its
-// finished accumulator to the 48 words they read (four products + four exact reductions per lane).
+// ---------------------------------------------------------------- the accumulation (S29 field form)
+// (fp381_s29.h / g1_s29.h: 14 signed limbs of 29 bits, one v_mad_i64_i32 per limb product, no carry instructions.)
+// Tree and finish read 12 x 32-bit words: a lane converts its finished accumulator (four products + four exact
+// reductions per lane).  Round 3 kept a 12 x 32-bit accumulation kernel beside this one (inline-asm columns of
+// v_mad_u64_u32 + v_addc_co_u32: 288 multiply-adds AND 288 carry adds per product); measured back to back on one box by
+// tools/accbench.hip at 1 M points it took 183 us where this kernel takes 158 (170 at one wave per SIMD, where the other
+// took 219) -- identical lane partials, word for word -- and it was deleted.
 // The registry table of this form: one 128-byte row per validator like the 32-bit table -- x limbs in words 0..13,
 // y limbs in words 14..27 (canonical, Montgomery constant 2^406), word 28 = 1 when the row holds a point.
 __global__ void __launch_bounds__(256)
@@ -595,8 +536,56 @@ __device__ __forceinline__ bool load_point_s29(fq& x, fq& y, const uint32_t* __r
     return v7.x != 0;  // the row holds a point
 }
 
+// ONE copy of the product and of the squaring for everything that is not the loop body (the hand-over of a finished
+// accumulator, the complete add of the rare path): called, arguments and result in registers.
+__device__ __noinline__ fq fq_mul_nc(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6,
+                                     int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13,
+                                     int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6,
+                                     int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13)
+{
+    const fq a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+    const fq b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}};
+    fq r;
+    fq_mul(r, a, b);
+    return r;
+}
+__device__ __noinline__ fq fq_sqr_nc(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6,
+                                     int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13)
+{
+    const fq a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+    fq r;
+    fq_sqr(r, a);
+    return r;
+}
+struct FqCalled {
+    __device__ __forceinline__ static void mul(fq& r, const fq& a, const fq& b)
+    {
+        r = fq_mul_nc(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
+                      a.l[12], a.l[13], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9],
+                      b.l[10], b.l[11], b.l[12], b.l[13]);
+    }
+    __device__ __forceinline__ static void sqr(fq& r, const fq& a)
+    {
+        r = fq_sqr_nc(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
+                      a.l[12], a.l[13]);
+    }
+};
+
+// The accumulation.  What shapes it (round 4, tools/icbench.hip): the instruction cache.  A lane's loop holds ONE
+// straight-line body -- the general mixed add, g1q_madd_fast: eight products + two squarings, ~38 KB -- and nothing else:
+//   * a lane's first point becomes the accumulator (x, y, 1, 1) as it is, and its first add is a general one (ten products
+//     instead of the six of an affine + affine add: +5 % products, against a second 27 KB body that every wave fetched
+//     once per run of eight);
+//   * the same-x cases (P + P, P - P) are detected by a one-multiply filter and NOT handled in the loop: a lane that saw
+//     one redoes its whole run afterwards with the complete add (g1q_add_affine over CALLED products: a few hundred bytes
+//     of code that is fetched only then) -- exact results, and structured keys ((i + 1) G) take that path all the time;
+//   * the hand-over to the 48 words k_g1_tree reads (four products + four exact reductions per lane) goes through the same
+//     called product, one coordinate per iteration of a rolled loop.
+// Round 3's version of this kernel (three inlined bodies + doubling twice + an unrolled hand-over: 214 KB of code) ran its
+// 1 M-point launch in 0.273 ms where the 12 x 32-bit kernel took 0.226 -- with a product that is 14 % and a mixed add that
+// is 25 % FASTER in a loop that fits the cache (tools/fpbench29).
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
-k_g1_accumulate_s29(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__ members,
+k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__ members,
                     const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials,
                     const AttPlan* __restrict__ plan_dev, const uint32_t* __restrict__ members1)
@@ -608,47 +597,87 @@ k_g1_accumulate_s29(const uint32_t* __restrict__ pts29, const uint32_t* __restri
         if (blockIdx.x * G1_WG >= n_slots) return;
     }
     const uint32_t slot = blockIdx.x * G1_WG + tid;
+    G1_STAMP(0);
+    G1_WAVE_BEGIN();
     g1q acc;
     g1q_set_inf(acc);
+    bool exc = false;
     uint32_t my_out, my_size, t;
     G1Group d;
     g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
+    uint32_t first = 0, count = 0;
     if (slot < n_slots && t < d.n_tasks) {
         const uint32_t gk = d.k & 0x7FFFFFFFu;
         if (d.k >> 31) members = members1;
-        const uint32_t first = t * gk;
-        const uint32_t count = min(gk, d.n_members - first);
+        first = t * gk;
+        count = min(gk, d.n_members - first);
+    }
+    // Two loads deep: while point j is added, the row of point j + 1 is in flight (its index arrived an iteration ago) and
+    // so are the index and the bit word of point j + 2 -- the wave never waits for an address it needs at once.  (One
+    // deep -- index, wait, row -- every iteration stalled for two dependent memory round trips IN FRONT of its add: the
+    // kernel ran 27 % below the rate of the same adds in a loop without loads, tools/accbench.hip.)
+    const bool gated = d.bits_word != NONE32;
+    auto want = [&](uint32_t j, uint32_t& idx) -> bool {  // member j of the run: its table row, whether its bit is set
+        const uint32_t i = first + j;
+        idx = members ? members[d.member_start + i] : d.member_start + i;
+        if (!gated) return true;
+        return (bit_arena[d.bits_word + (i >> 5)] >> (i & 31)) & 1u;
+    };
+    auto fetch = [&](uint32_t j, fq& ox, fq& oy) -> bool {  // complete, for the rare path
+        uint32_t idx;
+        if (!want(j, idx)) return false;
+        return load_point_s29(ox, oy, pts29, idx);
+    };
+    {
         fq qx, qy, nx, ny;
-        bool have = false, nhave = false, qpoint = false, npoint = false;
-        auto fetch = [&](uint32_t j, fq& ox, fq& oy, bool& holds) -> bool {
-            const uint32_t i = first + j;
-            if (d.bits_word != NONE32) {
-                const uint32_t w = bit_arena[d.bits_word + (i >> 5)];
-                if (!((w >> (i & 31)) & 1u)) return false;
-            }
-            const uint32_t idx = members ? members[d.member_start + i] : d.member_start + i;
-            holds = load_point_s29(ox, oy, pts29, idx);
-            return true;
-        };
-        if (count > 0) have = fetch(0, qx, qy, qpoint);
+        bool have = false, nhave = false, w1 = false, w2 = false;
+        uint32_t i1 = 0, i2 = 0;
+        if (count > 0) {
+            uint32_t i0;
+            if (want(0, i0)) have = load_point_s29(qx, qy, pts29, i0);
+        }
+        if (count > 1) w1 = want(1, i1);
         for (uint32_t j = 0; j < count; ++j) {
+            w2 = false;
+            if (j + 2 < count) w2 = want(j + 2, i2);
             nhave = false;
-            if (j + 1 < count) nhave = fetch(j + 1, nx, ny, npoint);
-            if (have) g1q_add_affine(acc, qx, qy, !qpoint);
-            qx = nx; qy = ny; have = nhave; qpoint = npoint;
+            if (w1) nhave = load_point_s29(nx, ny, pts29, i1);
+            if (have) {
+                if (acc.inf) g1q_set_first(acc, qx, qy);
+                else g1q_madd_fast(acc, qx, qy, exc);
+            }
+            qx = nx; qy = ny; have = nhave;
+            i1 = i2; w1 = w2;
         }
     }
-    // hand-over to the 12 x 32-bit words the tree reads
-    uint32_t w[G1X_WORDS];
-    g1q_to_words32(w, acc);
-    if (my_size == 1) {
-        uint32_t* dst = wg_partials + (size_t)G1X_WORDS * my_out;
-#pragma unroll
-        for (int k = 0; k < G1X_WORDS; ++k) dst[k] = w[k];
+    G1_STAMP(1);
+    G1_WAVE_END();
+    if (exc) {  // rare: the run again, every case of the group law (rows come from L2 this time)
+        g1q_set_inf(acc);
+        for (uint32_t j = 0; j < count; ++j) {
+            fq qx, qy;
+            if (fetch(j, qx, qy)) g1q_add_affine<FqCalled>(acc, qx, qy, false);
+        }
     }
+    // hand-over: coordinate c of the accumulator -> words 12 c .. 12 c + 11 (12 x 32-bit Montgomery form, canonical); zero
+    // words for infinity.  Rolled on purpose (see above): the coordinates rotate through acc.x.
     uint32_t* b = lane_partials + (size_t)blockIdx.x * G1X_WORDS * G1_WG + tid;
+    uint32_t* dst = my_size == 1 ? wg_partials + (size_t)G1X_WORDS * my_out : nullptr;  // single-task group: done
+    const bool inf = acc.inf;
+#pragma nounroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t w[12];
+        fq_to_mont32_via<FqCalled>(w, acc.x);
 #pragma unroll
-    for (int k = 0; k < G1X_WORDS; ++k) b[k * G1_WG] = w[k];
+        for (int k = 0; k < 12; ++k) {
+            const uint32_t v = inf ? 0u : w[k];
+            b[(12 * c + k) * G1_WG] = v;
+            if (dst) dst[12 * c + k] = v;
+        }
+        acc.x = acc.y;
+        acc.y = acc.zz;
+        acc.zz = acc.zzz;
+    }
 }
 
 void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n)
@@ -656,14 +685,14 @@ void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t*
     if (n == 0) return;
     hipLaunchKernelGGL(k_g1_table_s29, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, points_mont24, points_s29, n);
 }
-void launch_g1_accumulate_s29(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
+void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
                               const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
                               uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
                               const uint32_t* members1)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
-    hipLaunchKernelGGL(k_g1_accumulate_s29, dim3(blocks), dim3(G1_WG), 0, s, points_s29, members, bit_arena,
+    hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), 0, s, points_s29, members, bit_arena,
                        groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
 }
 

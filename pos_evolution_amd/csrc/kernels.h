@@ -48,25 +48,20 @@ struct G1Group {
 // ---- G1 ----
 // 96-byte big-endian uncompressed affine -> 24 u32 Montgomery limbs (x | y); infinity -> all zero.
 void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uint64_t n);
-// Per-lane XYZZ accumulation of k gathered points: one partial per lane slot into lane_partials (limb-major per
-// workgroup: ceil(n_slots / 256) * 256 * 192 bytes); single-task groups are written straight to wg_partials48.
-// plan_dev (nullable): n_groups / n_slots are read from this device-resident AttPlan instead (the arguments are then
-// upper bounds that size the grid); members1: the member array of groups whose G1Group::k has bit 31 set.
+// The registry in the accumulation's field form (fp381_s29.h: 14 + 14 limbs of 29 bits per 128-byte row, word 28 = the row
+// holds a point), built from the 24-word Montgomery table.
+void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n);
+// Per-lane XYZZ accumulation of k gathered points over that table: one partial per lane slot into lane_partials (limb-major
+// per workgroup: ceil(n_slots / 256) * 256 * 192 bytes, 12 x 32-bit Montgomery words); single-task groups are written
+// straight to wg_partials48.  plan_dev (nullable): n_groups / n_slots are read from this device-resident AttPlan instead (the
+// arguments are then upper bounds that size the grid); members1: the member array of groups whose G1Group::k has bit 31 set.
 struct AttPlan;
-void launch_g1_accumulate(hipStream_t s, const uint32_t* points_mont24, const uint32_t* members,
-                          const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups,
-                          uint32_t n_slots, uint32_t* lane_partials, uint32_t* wg_partials48,
-                          const AttPlan* plan_dev = nullptr, const uint32_t* members1 = nullptr);
+void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
+                          const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
+                          uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev = nullptr,
+                          const uint32_t* members1 = nullptr);
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
 // (group, workgroup) into wg_partials48.
-// The accumulation over the S29 field form (fp381_s29.h; POSEVO_G1_S29=1): its registry table (128-byte rows: 14 + 14
-// limbs of 29 bits, word 28 = the row holds a point) is built from the 32-bit table; the kernel hands the tree the same
-// lane partials as k_g1_accumulate.
-void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n);
-void launch_g1_accumulate_s29(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
-                              const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
-                              uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
-                              const uint32_t* members1);
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0, const AttPlan* plan_dev = nullptr);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
@@ -258,7 +253,7 @@ void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev ta
                                  uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
                                  const uint16_t* eff_increments, uint64_t base_reward_per_increment,
                                  uint32_t* part_cur_words, uint32_t* part_prev_words, uint64_t* numerators,
-                                 const uint32_t* gates);
+                                 const uint32_t* gates, uint32_t cap);  // cap: slots of numerators[]; more groups = no-op
 
 // The working-state view mirrors the registry (pe_store_init): sflags = active/slashed (+ active-in-previous-epoch),
 // increments = balance / effective_balance_increment.

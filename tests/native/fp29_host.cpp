@@ -93,4 +93,40 @@ void g1q_run(const uint32_t* rows24, int n, uint32_t* out48, int32_t* max_abs_li
     g1q_to_words32(out48, acc);
 }
 
+// The same run the way k_g1_accumulate_s29 does it: the first point becomes the accumulator as it is (g1q_set_first), every
+// later one goes through the general body alone (g1q_madd_fast), a same-x case only raises the flag and the whole run is
+// then redone by the complete add.  *took_slow_path says which way the run went.
+void g1q_run_kernel_way(const uint32_t* rows24, int n, uint32_t* out48, int32_t* max_abs_limb, int* took_slow_path)
+{
+    g1q acc;
+    g1q_set_inf(acc);
+    bool exc = false;
+    int32_t worst = 0;
+    for (int j = 0; j < n; ++j) {
+        const uint32_t* row = rows24 + 24 * j;
+        uint32_t any = 0;
+        for (int k = 0; k < 24; ++k) any |= row[k];
+        if (!any) continue;
+        fq qx, qy;
+        fq_from_mont32(qx, row);
+        fq_from_mont32(qy, row + 12);
+        if (acc.inf) g1q_set_first(acc, qx, qy);
+        else g1q_madd_fast(acc, qx, qy, exc);
+        if (exc) break;  // the kernel's lane goes on over garbage; nothing of it is used
+        const fq* cs[4] = {&acc.x, &acc.y, &acc.zz, &acc.zzz};
+        for (const fq* c : cs)
+            for (int i = 0; i < FQ_N - 1; ++i) {
+                const int32_t v = c->l[i] < 0 ? -c->l[i] : c->l[i];
+                if (v > worst) worst = v;
+            }
+    }
+    *took_slow_path = exc ? 1 : 0;
+    if (max_abs_limb) *max_abs_limb = worst;
+    if (exc) {
+        g1q_run(rows24, n, out48, nullptr);
+        return;
+    }
+    g1q_to_words32(out48, acc);
+}
+
 }  // extern "C"

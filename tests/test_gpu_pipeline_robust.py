@@ -193,3 +193,56 @@ def test_two_aggregates_in_one_pipeline(engine_factory, lagged):
             a1 = e.aggregate(packed=(halves[0], wb["arena"]), want_aggregate_pubkeys=True)
             e.aggregate(packed=(halves[1], wb["arena"]), want_aggregate_pubkeys=True)
             e.on_attestation_batch(packed=(a1["atts"], pea.RESIDENT))
+
+
+@pytest.mark.parametrize("dev_rows", [False, True])
+def test_two_aggregates_with_process_attestation_between(engine_factory, dev_rows):
+    """aggregate -> on_attestation -> process_attestation -> aggregate -> ... inside ONE pipeline: the flag pass of the
+    first half runs on the state-transition stream and reads the arena's group descriptors, member lists and resident
+    union words, which the second aggregate rewrites on the engine's stream -- the second aggregate must be ordered behind
+    it (before, only the G1 side stream was joined).  Rows in host memory and in HBM, ten rounds each (a
+    missing join shows as a reward numerator or a participation byte of the first half computed over the second half's
+    unions), against synchronous calls on a twin."""
+    import torch
+
+    wa = _world(engine_factory, 30000, 128, seed=73, density=0.85, parts=2)
+    wb = _world(engine_factory, 30000, 128, seed=73, density=0.85, parts=2)
+    first = wa["atts"]["slot"] % 32 < 16
+    halves = [np.ascontiguousarray(wa["atts"][m]) for m in (first, ~first)]
+    ea, e = wa["e"], wb["e"]
+    part0 = (ea.participation_get(0).copy(), ea.participation_get(1).copy())
+    ref = []
+    for atts in halves:
+        agg = ea.aggregate(packed=(atts, wa["arena"]), want_aggregate_pubkeys=True)
+        st, _, cnt = ea.on_attestation_batch(packed=(agg["atts"], agg["out_arena"]))
+        pst, num = ea.process_attestation_batch(wa["ctx"], packed=(agg["atts"], agg["out_arena"]))
+        ref.append((agg, st.copy(), cnt.copy(), pst.copy(), num.copy()))
+    ref_part = (ea.participation_get(0).copy(), ea.participation_get(1).copy())
+    assert sum(int(r[4].sum()) for r in ref) > 0
+    keep = []
+    for rep in range(10):
+        e.participation_set(0, part0[0])
+        e.participation_set(1, part0[1])
+        got = []
+        with e.pipeline():
+            for atts in halves:
+                if dev_rows:
+                    t = torch.from_numpy(atts.view(np.uint8).reshape(-1).copy()).cuda()
+                    rows = pea.DeviceRows(t.data_ptr(), len(atts), keep=t)
+                    keep.append(rows)
+                    agg = e.aggregate(packed=(rows, wb["arena"]), want_aggregate_pubkeys=True)
+                    st, _, cnt = e.on_attestation_batch(packed=(pea.ROWS_RESIDENT, pea.RESIDENT), cap=len(atts))
+                    pst, num = e.process_attestation_batch(wb["ctx"], packed=(pea.ROWS_RESIDENT, pea.RESIDENT), cap=len(atts))
+                else:
+                    agg = e.aggregate(packed=(atts, wb["arena"]), want_aggregate_pubkeys=True)
+                    st, _, cnt = e.on_attestation_batch(packed=(agg["atts"], pea.RESIDENT))
+                    pst, num = e.process_attestation_batch(wb["ctx"], packed=(agg["atts"], pea.RESIDENT))
+                got.append((agg, st, cnt, pst, num))
+        for (ra, rs, rc, rp, rn), (ga, gs, gc, gp, gn) in zip(ref, got):
+            ng = ra["n_groups"]
+            assert ga["n_groups"] == ng
+            assert np.array_equal(ga["aggpk96"][:ng], ra["aggpk96"][:ng]), rep
+            assert np.array_equal(gs[:ng], rs[:ng]) and np.array_equal(gc[:ng], rc[:ng]), rep
+            assert np.array_equal(gp[:ng], rp[:ng]) and np.array_equal(gn[:ng], rn[:ng]), rep
+        assert np.array_equal(e.participation_get(0), ref_part[0]), rep
+        assert np.array_equal(e.participation_get(1), ref_part[1]), rep

@@ -311,6 +311,20 @@ def test_errors_are_deferred_and_form_no_groups(engine_factory):
         e.on_attestation_batch(packed=(RR, RES), cap=10)
     assert err.value.status == pea._abi.PE_ERR_CAPACITY
     assert np.array_equal(e.latest_messages()[1], before)
+    # the same for process_attestation (the flag kernel used to run anyway and write numerators[g] for every
+    # g < groups into a block sized by cap -- over the error word, so the call returned PE_OK with all-zero statuses):
+    # synchronous, and as the middle call of a pipeline whose neighbours' outputs lie behind its block
+    part_before = (e.participation_get(0).copy(), e.participation_get(1).copy())
+    with pytest.raises(pea.EngineError) as err:
+        e.process_attestation_batch(ctx, packed=(RR, RES), cap=10)
+    assert err.value.status == pea._abi.PE_ERR_CAPACITY
+    with pytest.raises(pea.EngineError) as err:
+        with e.pipeline():
+            e.process_attestation_batch(ctx, packed=(RR, RES), cap=10)
+            e.get_head()
+    assert err.value.status == pea._abi.PE_ERR_CAPACITY
+    assert np.array_equal(e.participation_get(0), part_before[0])
+    assert np.array_equal(e.participation_get(1), part_before[1])
     # the clock crossing an epoch between the aggregate and its handler
     e.on_tick((w["epoch"] + 2) * 32 * 12)
     with pytest.raises(pea.EngineError) as err:

@@ -170,6 +170,37 @@ def _run(lib, pts):
     return _point_of(out)
 
 
+def _run_kernel_way(lib, pts):
+    rows = np.array([w for pt in pts for w in _row(pt)], dtype=np.uint32)
+    out = np.zeros(48, dtype=np.uint32)
+    worst, slow = C.c_int32(0), C.c_int(0)
+    lib.g1q_run_kernel_way(ptr(rows, C.c_uint32), len(pts), ptr(out, C.c_uint32), C.byref(worst), C.byref(slow))
+    assert worst.value <= (1 << B) or slow.value, worst.value   # the constant one's canonical limbs at most (zz = zzz of a first point)
+    return _point_of(out), bool(slow.value)
+
+
+def test_the_kernels_run_general_body_only_and_redo_on_same_x(lib):
+    """k_g1_accumulate_s29's lane logic (round 4): first point taken as it is, the general body for every add, same-x
+    cases detected by the filter and the run redone by the complete add.  Random runs never leave the fast path; every
+    edge case of the group law does, and comes out exact."""
+    rng = random.Random(31)
+    base = [g1.mul(rng.randrange(1, g1.R_ORDER), g1.G) for _ in range(40)]
+    for n in (1, 2, 3, 8, 16, 40):
+        got, slow = _run_kernel_way(lib, base[:n])
+        assert got == g1.sum_points(base[:n]) and not slow
+    pts = [None, base[0], None, None, base[1], base[2], None]
+    got, slow = _run_kernel_way(lib, pts)
+    assert got == g1.sum_points([p for p in pts if p]) and not slow
+    assert _run_kernel_way(lib, [None, None]) == (None, False) and _run_kernel_way(lib, []) == (None, False)
+    A, Bp = base[0], base[1]
+    for pts, want in (([A, A], g1.double(A)), ([A, g1.neg(A)], None), ([A, g1.neg(A), Bp], Bp),
+                      ([A, Bp, g1.add(A, Bp)], g1.double(g1.add(A, Bp))), ([A, Bp, g1.neg(g1.add(A, Bp))], None),
+                      ([A, A, A, A], g1.mul(4, A)), ([g1.G] * 9, g1.mul(9, g1.G)),
+                      ([g1.mul(i + 1, g1.G) for i in range(12)], g1.mul(78, g1.G))):
+        got, slow = _run_kernel_way(lib, pts)
+        assert got == want and slow, (pts, got, want, slow)
+
+
 def test_accumulation_against_the_oracle(lib):
     rng = random.Random(3)
     base = [g1.mul(rng.randrange(1, g1.R_ORDER), g1.G) for _ in range(24)]

@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--parts", type=int, default=4)
     a = ap.parse_args()
 
+    import torch
+
+    torch.cuda.init()   # before the engine's own HIP runtime comes up: the other order leaves torch without a device
     import bench
     import pos_evolution_amd as pea
 
