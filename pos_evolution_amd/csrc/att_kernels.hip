@@ -85,11 +85,23 @@ __device__ __forceinline__ bool same4(const uint4& a, const uint4& b)
 __global__ void __launch_bounds__(256)
 k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t* __restrict__ cnt_tab,
              uint32_t mask, uint32_t* __restrict__ slot_of, unsigned long long arena_len, AttPlan* __restrict__ plan,
-             uint4* __restrict__ arena_pad, const uint32_t* __restrict__ n_dev)
+             uint4* __restrict__ arena_pad, const uint32_t* __restrict__ n_dev, const uint4* __restrict__ arena_src,
+             uint4* __restrict__ arena_dst)
 {
     __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
     if (n_dev) n = min(n, *n_dev);  // the row count is itself a device result (pe_aggregate_exchange): n is its bound
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    // the caller's bits lie in device memory (16-byte aligned): this launch brings them into the staging arena itself -- a
+    // copy command in front of it cost the step's chain 10-13 us (profiles/r03_timeline.txt: __amd_rocclr_copyBuffer)
+    if (arena_src) {
+        const unsigned long long whole = arena_len >> 4;
+        for (unsigned long long q = i; q < whole; q += (unsigned long long)gridDim.x * 256) arena_dst[q] = arena_src[q];
+        if (i == 0 && (arena_len & 15)) {
+            const uint8_t* sb = reinterpret_cast<const uint8_t*>(arena_src + whole);
+            uint8_t* db = reinterpret_cast<uint8_t*>(arena_dst + whole);
+            for (uint32_t b = 0; b < (uint32_t)(arena_len & 15); ++b) db[b] = sb[b];
+        }
+    }
     if (i == 0 && arena_pad && n == 0) { arena_pad[0] = make_uint4(0, 0, 0, 0); arena_pad[1] = make_uint4(0, 0, 0, 0); }
     if (i >= n) return;
     // k_bits_union reads whole dwords: up to 8 bytes past the last member's bits, which must read zero (no copy command
@@ -119,22 +131,31 @@ k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ 
 }
 
 void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
-                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32, const uint32_t* n_dev)
+                       uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32, const uint32_t* n_dev,
+                       const void* arena_src, void* arena_dst)
 {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_att_ingest, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
-                       cnt_tab, tab_mask, slot_of, (unsigned long long)arena_len, plan, static_cast<uint4*>(arena_pad32), n_dev);
+    // with an arena to bring in: enough workgroups for the copy (one 16-byte word per lane and pass, at most 256 workgroups)
+    unsigned blocks = (n + 255) / 256;
+    if (arena_src) blocks = std::max(blocks, (unsigned)std::min<uint64_t>(256, ((arena_len >> 4) + 255) / 256));
+    hipLaunchKernelGGL(k_att_ingest, dim3(blocks), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
+                       cnt_tab, tab_mask, slot_of, (unsigned long long)arena_len, plan, static_cast<uint4*>(arena_pad32), n_dev,
+                       static_cast<const uint4*>(arena_src), static_cast<uint4*>(arena_dst));
 }
 
 // ------------------------------------------------------------------ plan: one workgroup
-// 512 lanes = two waves per SIMD of <= 88 registers: the workgroup must find room on a CU whose SIMDs already hold two
-// 168-register waves of the previous step's k_g1_accumulate (a 1024-lane build waited for that kernel to drain: +200 us
-// on every step).  The kernel is a chain of dependent round trips to L2 / HBM beside a kernel that saturates the chip, so
-// its shape is: coalesced chunk loops (lane = consecutive element, independent iterations the compiler can overlap),
-// wave-level prefix sums by shuffles, per-(chunk, wave) totals in an LDS matrix, ONE block scan per matrix.
-constexpr int PLAN_WG = 512;
+// 1024 lanes = four waves per SIMD of 64 registers (amdgpu_waves_per_eu(8, 8) caps them; 84 B of scratch per lane): the
+// workgroup must find room on a CU whose SIMDs already hold a wave of the previous step's k_g1_accumulate (232 registers;
+// rounds 2-3: two waves of 168, and 512 lanes of <= 88 here -- a 1024-lane build of 86 registers waits for that kernel to
+// drain: +200 us on every step).  The kernel is a chain of dependent round trips to L2 / HBM beside a kernel that saturates
+// the chip, so its shape is: coalesced chunk loops (lane = consecutive element, independent iterations the compiler can
+// overlap), wave-level prefix sums by shuffles, per-(chunk, wave) totals in an LDS matrix, ONE block scan per matrix; twice
+// the lanes = half the chunks of every phase.
+constexpr int PLAN_WG = 1024;
 constexpr int PLAN_WAVES = PLAN_WG / 64;
-constexpr uint32_t PLAN_SUPER = 32;  // chunks per super-chunk: 32 x 512 elements per LDS matrix of 256 totals
+constexpr uint32_t PLAN_SUPER = 32;  // chunks per super-chunk: 32 x 1024 elements per LDS matrix of 512 totals
+constexpr uint32_t PLAN_LDS_NC = 4096;  // committees per table up to which the rows-per-committee lists are built in LDS
+constexpr uint32_t PLAN_LDS_NG = 8192;  // groups up to which their (table, committee) keys are kept in LDS
 
 namespace {
 template <typename T>
@@ -185,7 +206,15 @@ __device__ __forceinline__ uint32_t scan_matrix(uint32_t* mat, uint32_t cnt, uin
 }
 }  // namespace
 
-__global__ void __launch_bounds__(PLAN_WG)
+// tools/build_variant.sh plantime -DPOSEVO_PLAN_TIMING: wall_clock64() (100 MHz) at the phase boundaries of the last launch,
+// read back through pe_debug_plan_stamps (tools/plan_phases.py)
+#ifdef POSEVO_PLAN_TIMING
+__device__ unsigned long long plan_stamps[16];
+#define PLAN_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) plan_stamps[i] = wall_clock64(); } while (0)
+#else
+#define PLAN_STAMP(i) do { } while (0)
+#endif
+__global__ void __launch_bounds__(PLAN_WG) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: see PLAN_WG
 k_att_plan(AttPlanArgs a)
 {
     __builtin_amdgcn_s_setprio(3);
@@ -193,6 +222,11 @@ k_att_plan(AttPlanArgs a)
     __shared__ unsigned long long wt64[PLAN_WAVES];
     __shared__ uint32_t matA[PLAN_SUPER * PLAN_WAVES], matB[PLAN_SUPER * PLAN_WAVES], matC[PLAN_SUPER * PLAN_WAVES];
     __shared__ uint32_t s_max_size, s_not_aligned, s_err, s_rows_t[2];
+    // rows per committee (phase 4 counts, phase 5 offsets and fill cursors) and the groups' (table, committee) keys: in LDS
+    // whenever the tables and the batch fit -- the global-memory form of these phases was 40 of the kernel's 73 us (a chain
+    // of dependent L2 round trips: count with atomics, read back, scan, write, read back, scatter)
+    __shared__ uint32_t s_cnt[2][PLAN_LDS_NC + 1];
+    __shared__ uint32_t s_key[PLAN_LDS_NG];
     const uint4* __restrict__ rows = static_cast<const uint4*>(a.rows);
     const uint32_t* __restrict__ tab = a.tab;
     const uint32_t* __restrict__ cnt_tab = a.cnt_tab;
@@ -204,6 +238,7 @@ k_att_plan(AttPlanArgs a)
     __syncthreads();
     const bool dead = s_err != 0;  // ingest refused a row: nothing downstream may touch the bits
 
+    PLAN_STAMP(0);
     // ---- 1. representatives -> group ids in order of first appearance
     uint32_t ng = 0;
     {
@@ -250,6 +285,7 @@ k_att_plan(AttPlanArgs a)
     if (dead) ng = 0;
     __syncthreads();  // rep_row / gid_of_row are re-read below by other lanes (workgroup-scope visibility)
 
+    PLAN_STAMP(1);
     // ---- 2. per group: committee resolution (get_beacon_committee's index arithmetic, A.6), sizes; wave-level partial
     //         prefix sums of union words / bytes / member counts, per-(chunk, wave) totals into the matrices
     const unsigned long long spe = a.tables.slots_per_epoch;
@@ -323,6 +359,7 @@ k_att_plan(AttPlanArgs a)
         // a tree of more than 32 chunks of groups (> 16384 groups) flushes the matrices: handled by the second pass's
         // running bases -- kept simple: one matrix generation must cover all chunks
     }
+    PLAN_STAMP(2);
     uint32_t word_total = 0, byte_total = 0, list_total = 0;
     unsigned long long total_members;
     (void)block_scan_512<unsigned long long>(my_members, wt64, &total_members);
@@ -332,6 +369,7 @@ k_att_plan(AttPlanArgs a)
     list_total = scan_matrix(matC, g_mats, 0, wt32);
     (void)list_total;
 
+    PLAN_STAMP(3);
     // ---- 3. one block size for every group: k members per lane, blocks of BL = 2^L lanes, group g at slot g * BL.  k
     // follows from the largest committee so that its tasks fill a block exactly or nearly (sizes that differ by one --
     // 511 / 512 members -- would otherwise put half of the lanes of every block to sleep)
@@ -346,11 +384,16 @@ k_att_plan(AttPlanArgs a)
         k = max(a.min_k, (max_size + (1u << L) - 1) >> L);
         if (k == 0) k = 1;
     }
+    PLAN_STAMP(4);
     // ---- 4. second pass over the groups: final offsets, union + G1 descriptors, committee row counts
+    bool lds_crow = ng <= PLAN_LDS_NG;
+    for (int t = 0; t < 2; ++t)
+        if (a.tables.t[t].valid && a.tables.t[t].n_committees > PLAN_LDS_NC) lds_crow = false;
     for (int t = 0; t < 2; ++t) {
         if (!a.tables.t[t].valid) continue;
         const uint32_t nc = a.tables.t[t].n_committees;
-        for (uint32_t c = tid; c <= nc; c += PLAN_WG) a.crow_cursor[t][c] = 0;
+        if (lds_crow) for (uint32_t c = tid; c <= nc; c += PLAN_WG) s_cnt[t][c] = 0;
+        else for (uint32_t c = tid; c <= nc; c += PLAN_WG) a.crow_cursor[t][c] = 0;
     }
     __syncthreads();
     for (uint32_t c = 0; c < g_chunks; ++c) {
@@ -379,13 +422,43 @@ k_att_plan(AttPlanArgs a)
         d.log2_block = L;
         d.out_base = g;
         a.g1[g] = d;
-        if (ok) atomicAdd(&a.crow_cursor[G.table][G.pos], 1u);
+        if (lds_crow) {
+            s_key[g] = ok ? ((G.table << 31) | G.pos) : NONE32;
+            if (ok) atomicAdd(&s_cnt[G.table][G.pos], 1u);
+        } else if (ok) {
+            atomicAdd(&a.crow_cursor[G.table][G.pos], 1u);
+        }
     }
     __syncthreads();
 
-    // ---- 5. rows per committee of each candidate table (unordered lists; consumers order by group id)
+    PLAN_STAMP(5);
+    // ---- 5. rows per committee of each candidate table (unordered lists; consumers order by group id).  A table without a
+    // row is skipped: its consumers (k_lmd_vm_tables, k_participation_tables) return on plan->n_rows_table[t] == 0.
+    if (lds_crow) {
+        for (int t = 0; t < 2; ++t) {
+            if (!a.tables.t[t].valid || s_rows_t[t] == 0) continue;
+            const uint32_t nc = a.tables.t[t].n_committees;
+            const uint32_t per = (nc + 1 + PLAN_WG - 1) / PLAN_WG;  // consecutive entries per lane (entry nc: the end mark)
+            const uint32_t b0 = min(tid * per, nc + 1), b1 = min(b0 + per, nc + 1);
+            uint32_t sum = 0;
+            for (uint32_t i = b0; i < b1; ++i) sum += i < nc ? s_cnt[t][i] : 0u;
+            uint32_t tot;
+            uint32_t run = block_scan_512<uint32_t>(sum, wt32, &tot);
+            for (uint32_t i = b0; i < b1; ++i) {
+                const uint32_t v = i < nc ? s_cnt[t][i] : 0u;
+                s_cnt[t][i] = run;  // becomes the fill cursor
+                a.crow_start[t][i] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        for (uint32_t g = tid; g < ng; g += PLAN_WG) {
+            const uint32_t key = s_key[g];
+            if (key != NONE32) a.crow_list[key >> 31][atomicAdd(&s_cnt[key >> 31][key & 0x7FFFFFFFu], 1u)] = g;
+        }
+    } else {
     for (int t = 0; t < 2; ++t) {
-        if (!a.tables.t[t].valid) continue;
+        if (!a.tables.t[t].valid || s_rows_t[t] == 0) continue;
         const uint32_t nc = a.tables.t[t].n_committees;
         const uint32_t c_chunks = (nc + 1 + PLAN_WG - 1) / PLAN_WG;
         uint32_t base = 0;
@@ -417,11 +490,13 @@ k_att_plan(AttPlanArgs a)
         const AttGroup& G = a.grp[g];
         if (G.status_agg == ST_OK) a.crow_list[G.table][atomicAdd(&a.crow_cursor[G.table][G.pos], 1u)] = g;
     }
+    }
 
+    PLAN_STAMP(6);
     // ---- 6. the plan, for the kernels that follow and (pinned mirror) for the host's completion
     if (tid == 0) {
         uint32_t err = s_err;
-        if (!err && g_chunks > PLAN_SUPER) err = ERR_CAPACITY;        // more than 16384 groups in one call
+        if (!err && g_chunks > PLAN_SUPER) err = ERR_CAPACITY;        // more than PLAN_SUPER x PLAN_WG (32768) groups in one call
         if (!err && byte_total > a.out_arena_cap) err = ERR_CAPACITY;  // "output bit arena too small"
         AttPlan p;
         p.n_groups = err ? 0u : ng;  // a failing aggregate forms no groups: the handlers behind it apply nothing
@@ -446,6 +521,14 @@ void launch_att_plan(hipStream_t s, const AttPlanArgs& a)
 {
     hipLaunchKernelGGL(k_att_plan, dim3(1), dim3(PLAN_WG), 0, s, a);
 }
+#ifdef POSEVO_PLAN_TIMING
+}  // namespace posevo
+extern "C" int pe_debug_plan_stamps(unsigned long long* out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(posevo::plan_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+namespace posevo {
+#endif
 
 // ------------------------------------------------------------------ members
 __global__ void __launch_bounds__(256)

@@ -716,7 +716,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
         uint32_t* jac = static_cast<uint32_t*>(dev_partials);
         // streaming pipelines launch the sums behind the step's fork-choice kernels (run_tree / pe_pipeline_end_lagged)
-            const bool defer = on_side && h->streaming && g1_defer_enabled();
+            const bool defer = on_side && h->streaming && g1_defer_enabled() && !g1_chain_idle(h);
         if (defer) tune_arm = -1;  // the autotune's event pair assumes launch and read-back in one call
         auto launch_g1 = [h, arena, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, on_side, gs, tune_arm]() -> int {
             hipStream_t ms_ = h->stream;

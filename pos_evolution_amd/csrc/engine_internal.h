@@ -561,10 +561,20 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
 // then runs beside the start of the accumulation).  3: in front of k_votes.  (A/B knob.)
 inline int g1_defer_point()
 {
-    static const int p = [] { const char* e = getenv("POSEVO_G1_DEFER"); const int v = e ? atoi(e) : 2; return v >= 0 && v <= 3 ? v : 2; }();
+    static const int p = [] { const char* e = getenv("POSEVO_G1_DEFER"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 3 ? v : 1; }();
     return p;
 }
 inline bool g1_defer_enabled() { return g1_defer_point() != 0; }
+// No G1 chain of an earlier step can still be running: every arena has been completed (the engine was drained) and this
+// pipeline has launched none.  The first step of a run then launches its accumulation with the aggregate instead of holding
+// it back behind k_tree: there is no predecessor on the side stream whose retiring workgroups it could pile onto, and a run
+// that starts from an idle device begins ~90 us earlier (tools/engine_timeline.py --cold 20).
+inline bool g1_chain_idle(const pe_engine* h)
+{
+    for (int i = 0; i < h->n_arenas; ++i)
+        if (h->arena[i].side_used) return false;
+    return h->deferred.empty();
+}
 inline int run_deferred_at(pe_engine* h, int point)  // the launch sites in front of k_votes (3) and k_tree (2)
 {
     return (h->streaming && g1_defer_point() == point) ? run_deferred(h) : PE_OK;

@@ -290,21 +290,25 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
         }
         ~Unwind() { if (armed) { join(); h->rr.valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
     } unwind{h, deferred_before, use_rows};
+    bool ingest_copies = false;
     if (arena_kind == 0) {
         memcpy(st.host<uint8_t>(off_arena), bits_arena, arena_len);
         memset(st.host<uint8_t>(off_arena) + arena_len, 0, pad_at + 32 - arena_len);
         HIP_TRY(h, st.upload());
     } else if (arena_len) {  // bytes [arena_len, pad_at) may keep old bits: they lie inside the last dword pair only when
                              // arena_len is not a multiple of 4, and then belong to no member (masked by n_bits)
-        HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena), bits_arena, arena_len,
-                                  arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
+        // device memory at a 16-byte boundary: k_att_ingest brings the bits in itself (no copy command in the chain)
+        if (arena_kind == 2 && (reinterpret_cast<uintptr_t>(bits_arena) & 15) == 0 && n > 0) ingest_copies = true;
+        else HIP_TRY(h, hipMemcpyAsync(st.dev<uint8_t>(off_arena), bits_arena, arena_len,
+                                       arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
     }
     lap.mark("ragg.2_bits");
     std::optional<ProfScope> ps_group;  // timeline mode only: ingest + plan + members
     ps_group.emplace(h, PE_KERNEL_ATT_GROUP, ms);
     uint32_t* cnt_tab = RS.tab.as<uint32_t>() + RS.tab_size;
     launch_att_ingest(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, RS.tab_size - 1, L.slot_of, arena_len, L.plan,
-                      st.dev<uint8_t>(off_arena) + pad_at, n_dev);
+                      st.dev<uint8_t>(off_arena) + pad_at, n_dev, ingest_copies ? bits_arena : nullptr,
+                      ingest_copies ? st.dev<uint8_t>(off_arena) : nullptr);
     AttPlanArgs pa;
     pa.rows = d_rows;
     pa.n = n;
@@ -378,7 +382,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
             }
             return PE_OK;
         };
-        if (on_side && h->streaming && g1_defer_enabled()) h->deferred.push_back(launch_g1);
+        if (on_side && h->streaming && g1_defer_enabled() && !g1_chain_idle(h)) h->deferred.push_back(launch_g1);
         else PE_TRY(launch_g1());
         lap.mark("ragg.4_g1");
     }

@@ -20,6 +20,7 @@
 // validation compute in 12 x 32-bit limbs (fp381.h) -- latency-bound guests whose products are CALLS to one copy of the
 // code, so that what they cost the accumulation is not a 64 KB instruction cache full of their unrolled products.
 #define POSEVO_FP_MUL_CALLED 1  // every 12 x 32-bit product of this file's kernels is a call (see fp381.h)
+#include <algorithm>
 #include "g1.h"
 #include "g1_s29.h"
 #include "fp_sqrt.h"
@@ -342,19 +343,20 @@ k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict_
     if (plan_dev) {
         n_groups = plan_dev->n_groups;
         n_slots = plan_dev->n_slots;
-        if (blockIdx.x * G1_WG >= n_slots) return;
     }
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 48*256 partial words + 2*256 block info
     uint32_t* lds_out = lds + G1X_WORDS * G1_WG;  // output slot of the block a partial belongs to
     uint32_t* lds_sz = lds_out + G1_WG;           // current block size (0 = empty / retired)
     const int tid = threadIdx.x;
-    const uint32_t slot = blockIdx.x * G1_WG + tid;
+    // a workgroup takes slabs wg, wg + gridDim.x, ... (launch_g1_tree starts one workgroup per slab)
+    for (uint32_t wg = blockIdx.x; wg * G1_WG < n_slots; wg += gridDim.x) {
+    const uint32_t slot = wg * G1_WG + tid;
     uint32_t my_out, my_size, t;
     G1Group d;
     g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
     if (my_size == 1) my_size = 0;  // written by k_g1_accumulate
     {
-        const uint32_t* b = lane_partials + (size_t)blockIdx.x * G1X_WORDS * G1_WG + tid;
+        const uint32_t* b = lane_partials + (size_t)wg * G1X_WORDS * G1_WG + tid;
 #pragma unroll
         for (int k = 0; k < G1X_WORDS; ++k) lds[k * G1_WG + tid] = b[k * G1_WG];
     }
@@ -487,6 +489,7 @@ k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict_
         ++g1_level;
 #endif
     }
+    }  // slabs (the level loop ends behind a barrier: the next slab may overwrite the LDS)
 }
 
 // ---------------------------------------------------------------- the accumulation (S29 field form)
@@ -696,18 +699,24 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
                        groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
 }
 
-// one_per_cu: ask for 77 KB of LDS instead of the 50 KB the kernel uses, so that a CU holds ONE of its workgroups and
-// keeps 83 KB free.  In a streaming pipeline the tree of step N runs when the accumulation of step N retires -- which
-// is when the fork-choice kernels of step N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096 blocks) then
-// found no CU with room until this kernel had drained: +60 us on every get_head (profiles/r02_timeline_tree_collision.txt).
+// one_per_cu (the tree of a streaming step, on its own stream): ask for 77 KB of LDS instead of the 50 KB the kernel uses,
+// so that a CU holding one of its workgroups keeps 83 KB free.  The tree of step N runs when the accumulation of step N
+// retires -- which is when the fork-choice kernels of step N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096
+// blocks) then found no CU with room until this kernel had drained: +60 us on every get_head
+// (profiles/r02_timeline_tree_collision.txt).
+// (Round 4 tried at most 128 workgroups x 84 KB -- never two per CU, half of the CUs free of them -- against the
+// accumulation's occasional 335-355 us launches (instead of 205-240: tools/engine_timeline.py --cold 20): no cure, the tree
+// took twice as long beside the accumulation and stretched it more.  Those launches come from the accumulation's OWN
+// placement: queued behind its predecessor on the side stream, its workgroups are dispatched as CUs free up, the first CUs
+// to finish take TWO (2 x 227 VGPRs fit) and their waves run at half speed; launched once the predecessor has retired
+// everywhere -- behind the step's k_tree -- it spreads one per CU.  Hence POSEVO_G1_DEFER's default.)
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
-    static const bool pad_ok = [] { const char* e = getenv("POSEVO_G1_TREE_PAD_LDS"); return !e || atoi(e) != 0; }();
-    if (one_per_cu && pad_ok) {
+    if (one_per_cu) {
         constexpr size_t padded = 77 * 1024;
         if (first_use_on_this_device<77>())
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_tree), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -210,7 +210,9 @@ struct StateCtxDev {              // the slice of BeaconState process_attestatio
 // left clean by k_att_members.  arena_pad32: 32 bytes behind the copied bit arena, zeroed here.
 void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
                        uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32,
-                       const uint32_t* n_dev = nullptr);  // n_dev: the row count lives on the device, n bounds it
+                       const uint32_t* n_dev = nullptr,  // n_dev: the row count lives on the device, n bounds it
+                       const void* arena_src = nullptr, void* arena_dst = nullptr);  // arena_src (device memory, 16-byte
+                                                          // aligned): the launch copies arena_len bytes to arena_dst itself
 struct AttPlanArgs {
     const void* rows; uint32_t n; const uint32_t* n_dev;
     const uint32_t* tab; const uint32_t* cnt_tab; const uint32_t* slot_of;

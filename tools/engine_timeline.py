@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--committees", type=int, default=2048)
     ap.add_argument("--blocks", type=int, default=4096)
     ap.add_argument("--parts", type=int, default=4)
+    ap.add_argument("--cold", type=int, default=0,
+                    help="K > 0: the picture of a K-step run that starts from a drained engine and ends with its drain (what a\n"
+                         "short timed region pays for ramp and drain): every accumulation's start / end and the last kernel's end")
     a = ap.parse_args()
 
     import torch
@@ -46,6 +49,8 @@ def main():
     e.set_pipeline_lag(a.lag)
     e.reuse_outputs(a.lag + 2)
     warm = max(a.lag + 2, a.steps - a.show - a.lag - 2)
+    if a.cold:
+        warm = a.steps - a.cold
     for s in range(warm):
         bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False)
     e.drain()
@@ -57,6 +62,21 @@ def main():
     tl = e.profile_timeline()
     e.profile_enable(0)
     acc = [r for r in tl if r[0] == "g1_accumulate"]
+    if a.cold and acc:
+        t00 = min(r[1] for r in tl)
+        end = max(r[1] + r[2] for r in tl)
+        print(f"# {a.cold} steps from a drained engine: first launch at 0, everything done at {(end - t00) * 1e3:.1f} us "
+              f"= {(end - t00) * 1e3 / a.cold:.1f} us per step")
+        print("step  accumulate_start  accumulate_end  dur")
+        for i, (_, t0, dt) in enumerate(acc):
+            print(f"{i:4d} {(t0 - t00) * 1e3:17.1f} {(t0 + dt - t00) * 1e3:15.1f} {dt * 1e3:6.1f}")
+        tail = sorted(((r[1] + r[2] - t00) * 1e3, r[0]) for r in tl)[-6:]
+        print("last kernels to end:", ", ".join(f"{n} {t:.0f}" for t, n in tail))
+        print()
+        print(f"{'kernel':16s} {'start':>9s} {'end':>9s} {'dur':>8s}")
+        for name, t0, dt in tl:
+            print(f"{name:16s} {(t0 - t00) * 1e3:9.1f} {(t0 + dt - t00) * 1e3:9.1f} {dt * 1e3:8.1f}")
+        return 0
     if len(acc) < 2:
         print("no accumulations bracketed", file=sys.stderr)
         return 1
