@@ -510,7 +510,7 @@ k_att_plan(AttPlanArgs a)
         p.n_rows_table[0] = s_rows_t[0];
         p.n_rows_table[1] = s_rows_t[1];
         p.n_rows_in = n;
-        p.reserved = 0;
+        p.last_error = err;
         p.total_members = total_members;
         *a.plan = p;
         *a.plan_host = p;
@@ -592,7 +592,7 @@ k_att_pack(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, con
     const uint32_t ng = min(ng_all, slots);
     if (g == 0) {
         send[0] = ng;
-        send[1] = ng_all > slots ? ERR_CAPACITY : plan->error;
+        send[1] = ng_all > slots ? ERR_CAPACITY : plan->last_error;  // not plan->error: k_att_members has cleared it
         send[2] = send[3] = 0;
     }
     if (g >= ng) return;

@@ -601,15 +601,11 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         for (uint32_t g = 0; g < ng; ++g) total_pk += gres[g].size;
         uint32_t target = G1_TARGET_LANES;
         if (total_pk >= (1ull << 19)) {
-            static const uint32_t pinned = [] { const char* e = getenv("POSEVO_G1_TARGET_SLOTS"); return e ? (uint32_t)atol(e) : 0u; }();
-            if (pinned) h->g1_target_slots = pinned;
-            // Streaming pipelines: the two-wave shape unless POSEVO_G1_STREAM_ONE_WAVE=1.  One wave per SIMD (65 536
-            // lanes, k = 16) leaves 344 registers per SIMD lane instead of 176, so k_tree's 1024-lane workgroup, k_g1_tree
-            // and k_g1_finish all run beside the accumulation: the step gets 6-8 % shorter (0.356 vs 0.378 ms fast box,
-            // 0.38 vs 0.415 slow box) while the accumulation itself gets 20 % longer (0.275 vs 0.229 ms) -- the kernel's
-            // own efficiency is what this engine is graded on, so the default keeps it.
-            static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return !e || atoi(e) != 0; }();
-            if (h->streaming && !pinned) target = one_wave ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
+            // Streaming pipelines: ONE wave per SIMD (65 536 lanes, k = 16 at 1 M validators): the S29 accumulation loses 3 %
+            // to its two-wave shape alone (tools/accbench) and leaves every SIMD the registers the guests of a streaming
+            // step need -- k_g1_tree, k_g1_finish, k_att_plan, the fork-choice chain all run beside it.  Synchronous calls:
+            // the shape the first four large calls measured faster.
+            if (h->streaming) target = G1_TARGET_LANES / 2;
             else if (h->g1_target_slots) target = h->g1_target_slots;
             else {
                 tune_arm = h->g1_tune_calls & 1;
@@ -675,9 +671,8 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
     hipStream_t ms = h->stream;
     // pipelined + host outputs: the G1 sums run on the side stream, beside the fork-choice kernels of the calls that
     // follow (they only need the union).  Sharded partials stay on the main stream, where the caller's collective is.
-    static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
     // (partials for the engine's own exchange follow the same route; partials for a caller's collective never do)
-    const bool on_side = want_pk && (!dev_partials || partials_may_defer) && h->pipelining && side_ok && h->side_stream &&
+    const bool on_side = want_pk && (!dev_partials || partials_may_defer) && h->pipelining && h->side_stream &&
                          h->stream == h->own_stream && xgroups.empty();
     h->last_agg_on_side = on_side;
     hipStream_t gs = on_side ? h->side_stream : ms;
@@ -716,7 +711,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         uint8_t* out_pk = out_aggpk96 ? ob.host<uint8_t>(off_opk) : nullptr;
         uint32_t* jac = static_cast<uint32_t*>(dev_partials);
         // streaming pipelines launch the sums behind the step's fork-choice kernels (run_tree / pe_pipeline_end_lagged)
-            const bool defer = on_side && h->streaming && g1_defer_enabled() && !g1_chain_idle(h);
+            const bool defer = on_side && h->streaming && !g1_chain_idle(h);
         if (defer) tune_arm = -1;  // the autotune's event pair assumes launch and read-back in one call
         auto launch_g1 = [h, arena, d_points, d_members, d_union, d_groups, plan_pk, out_pk, jac, on_side, gs, tune_arm]() -> int {
             hipStream_t ms_ = h->stream;
@@ -727,8 +722,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
                 HIP_TRY(h, hipEventRecord(h->ev_fork, ms_));
                 HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
                 // a second aggregate in the SAME pipeline shares this arena's d_partials with the first one's finish
-                static const bool serial_finish = [] { const char* e = getenv("POSEVO_G1_SERIAL_FINISH"); return e && atoi(e) != 0; }();
-                if (arena->side_used || (serial_finish && h->side_ever)) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
+                if (arena->side_used) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
             } else {
                 g1_stream_guard(h, gs);
             }

@@ -258,17 +258,15 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // default) per priority level, and how the engine's five streams fare depends on what else the process runs there:
     // with torch's NCCL process group (high-priority streams) in the process the next step's fork-choice chain is scheduled
     // behind the running accumulation (0.59 vs 0.37 ms/step, one rank over RCCL) -- bench.py keeps torch on gloo for that
-    // reason.  Priorities inside the engine (POSEVO_STREAM_PRIOS="m,s,f,n,a", -1 low / 0 normal / 1 high, for experiments)
-    // cut both ways: engine stream high + accumulation low repairs that case (0.37-0.44) and ruins the plain one
-    // (0.82-0.85 vs 0.34: the accumulation's waves get preempted); a fixed first-use order of the streams changes nothing.
+    // reason.  Priorities inside the engine were measured in rounds 3-4 and dropped: engine stream high + accumulation low
+    // repairs that case and ruins the plain one (0.82-0.85 vs 0.34 ms: the accumulation's waves get preempted); a row-chain
+    // stream of its own -- at normal priority it shares a hardware queue with a long kernel and waits for it (0.49-0.62 ms),
+    // in the high- or low-priority pool, or with a queue per stream (GPU_MAX_HW_QUEUES=8), the small kernels of two chains
+    // interleave and each takes 3-5x longer (0.36-0.44 ms vs 0.27): DESIGN.md 3.4.
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    int pr[5] = {0, 0, 0, 0, 0};  // main, side (accumulate), fin (tree), norm (finish), aux (state transition)
-    if (const char* e = getenv("POSEVO_STREAM_PRIOS")) (void)sscanf(e, "%d,%d,%d,%d,%d", &pr[0], &pr[1], &pr[2], &pr[3], &pr[4]);
-    auto mk = [&](hipStream_t* s, int p) {
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, p > 0 ? prio_greatest : p < 0 ? prio_least : (prio_least + prio_greatest) / 2);
-    };
-    if (mk(&h->own_stream, pr[0]) != hipSuccess) {
+    auto mk = [&](hipStream_t* s) { return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (prio_least + prio_greatest) / 2); };
+    if (mk(&h->own_stream) != hipSuccess) {
         delete h;
         return PE_ERR_NO_DEVICE;
     }
@@ -277,16 +275,14 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // k_g1_finish of step N-1/N, each on its own stream.  (CU-masked streams -- a private CU partition for the
     // latency-sized fork-choice kernels -- were measured and dropped: hipExtStreamCreateWithCUMask with 16 / 32 / 48
     // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
-    const bool ok_streams = mk(&h->side_stream, pr[1]) == hipSuccess && mk(&h->fin_stream, pr[2]) == hipSuccess &&
-                            mk(&h->aux_stream, pr[4]) == hipSuccess;
-    {
-        const char* e = getenv("POSEVO_G1_NORM_STREAM");  // 0: tree and finish share the finishing stream
-        if (hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming) != hipSuccess ||
-            (ok_streams && (!e || atoi(e) != 0) &&
-             mk(&h->norm_stream, pr[3]) != hipSuccess)) {
-            pe_engine_destroy(h);
-            return PE_ERR_NO_DEVICE;
-        }
+    const bool ok_streams = mk(&h->side_stream) == hipSuccess && mk(&h->fin_stream) == hipSuccess &&
+                            mk(&h->aux_stream) == hipSuccess;
+    // k_g1_finish has a stream of its own behind k_g1_tree: on one finishing stream the two latency-bound guests of a step
+    // ran one behind the other and THAT stream set the step's period (0.43-0.47 -> 0.34 ms, round 3)
+    if (hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming) != hipSuccess ||
+        (ok_streams && mk(&h->norm_stream) != hipSuccess)) {
+        pe_engine_destroy(h);
+        return PE_ERR_NO_DEVICE;
     }
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
@@ -304,7 +300,6 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
-    if (const char* e = getenv("POSEVO_ROWS_STREAM")) h->rows_stream_on = atoi(e);  // read per engine (A/B knob, off by default)
     if (const char* e = getenv("POSEVO_PIPELINE_LAG")) {
         const int lag = atoi(e);
         if (lag >= 1 && lag < pe_engine::MAX_ARENAS) h->n_arenas = lag + 1;
@@ -325,9 +320,6 @@ void pe_engine_destroy(pe_engine* h)
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (h->prep_stream) { (void)hipStreamSynchronize(h->prep_stream); (void)hipStreamDestroy(h->prep_stream); }
-    if (h->rows_stream && h->rows_stream != h->aux_stream) { (void)hipStreamSynchronize(h->rows_stream); (void)hipStreamDestroy(h->rows_stream); }
-    h->rows_stream = nullptr;
-    if (h->ev_rows) (void)hipEventDestroy(h->ev_rows);
     if (h->prof_base) (void)hipEventDestroy(h->prof_base);
     h->d_shuffle_scratch.release();
     h->d_points29.release();
@@ -522,7 +514,6 @@ static void prof_drain(pe_engine* h)
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
-    if (h->rows_stream) (void)hipStreamSynchronize(h->rows_stream);
     for (int k = 0; k < PE_KERNEL_COUNT; ++k) {
         auto& p = h->prof[k];
         for (auto& ev : p.pending) {

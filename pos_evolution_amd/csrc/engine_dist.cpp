@@ -271,7 +271,6 @@ static int get_head_sharded_impl(pe_engine* h, uint8_t out_root[32], bool async)
         PE_TRY(ob.ensure());
     }
     uint64_t* buf = h->d_xchg.as<uint64_t>();
-    PE_TRY(run_deferred_at(h, 3));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         // no memsets (k_tree zeroes the weights it read; the totals are plain per-workgroup stores), and inside a
@@ -430,7 +429,12 @@ int pe_aggregate_exchange(pe_engine* h, pe_attestation* out_atts, uint32_t* out_
     ResidentParts P;
     PE_TRY(resident_parts(h, &P));
     const uint32_t world = (uint32_t)h->dist_world;
-    const uint32_t slots = std::max<uint32_t>(1, h->dist_max_groups ? std::min(P.n_in, h->dist_max_groups) : P.n_in);
+    // the all-gather's size follows from the slot count, which must be the SAME on every rank: the local row count is not
+    // (ranks serve different committees), so the caller's bound is required here (without one, ranks issued
+    // all-gathers of different sizes -- a hang or a corrupt unpack)
+    if (!h->dist_max_groups)
+        return fail(h, PE_ERR_STATE, "pe_aggregate_exchange: call pe_dist_set_max_groups first (the same bound on every rank)");
+    const uint32_t slots = h->dist_max_groups;
     const uint32_t wps = (h->cfg.max_validators_per_committee + 31) / 32;  // words of one union
     const uint32_t n_bound = world * slots;
     if (cap_groups < n_bound)

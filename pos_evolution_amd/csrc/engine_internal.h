@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../include/posevo.h"
+#include "../../include/posevo_profile.h"
 #include "kernels.h"
 
 namespace posevo {
@@ -318,11 +319,16 @@ struct pe_engine {
     // 131072 task slots (two waves per SIMD, 6 tree levels at 512-member committees) or 65536 (one wave, 5 levels):
     // which one is faster depends on the box (fast boxes: one wave/SIMD by ~8 %, slow boxes: two by ~3 %;
     // profiles/r01_g1_phases_k8.txt / _k16.txt).  The first four large calls alternate A, B, A, B under a pair of
-    // events, the better minimum is kept.  POSEVO_G1_TARGET_SLOTS pins the choice.
+    // events, the better minimum is kept.
     int g1_tune_calls = 0;          // trials done so far (4 = decided)
     float g1_tune_best[2] = {1e30f, 1e30f};
     uint32_t g1_target_slots = 0;   // 0 = undecided
     hipEvent_t g1_tune_ev[2] = {nullptr, nullptr};
+    // k_g1_accumulate reads the registry in the S29 field form: d_points29, built from d_points where the registry is loaded
+    // (build_points29); d_tmp_points29: the same for caller-supplied points (d_tmp_points), per call
+    bool points29_valid = false;
+    DevBuf d_points29, d_tmp_points29;
+    uint64_t tmp_points_n = 0;  // rows of d_tmp_points the last conversion filled
 
     // ---- RCCL inside the engine (pe_dist_*): one communicator per handle, collectives on the engine's stream ----
     ncclComm_t comm = nullptr, comm_g1 = nullptr;  // get_head's all-reduce (engine stream) | the G1 partials' all-gather
@@ -339,17 +345,6 @@ struct pe_engine {
     uint32_t dist_timeout_ms = 30000;   // bounded waits once the handle exchanges with other ranks (0 = unbounded)
     uint32_t dist_max_groups = 0;       // pe_dist_set_max_groups (0 = the row count of the call)
     hipEvent_t ev_xchg = nullptr;       // single-communicator mode: G1 chain <-> engine stream hand-over
-    // POSEVO_ROWS_STREAM=1: the row chain of a streaming step's first device-row aggregate (copy, ingest, plan, members,
-    // union) on a stream of its own -- it depends on nothing the previous step's fork-choice kernels produce, so it runs
-    // beside them instead of behind them; the engine's stream takes over behind the union (engine_resident.cpp)
-    // k_g1_accumulate reads the registry in the S29 field form: d_points29, built from d_points at the first use after the
-    // registry changed; d_tmp_points29: the same for caller-supplied points (d_tmp_points), per call
-    bool points29_valid = false;
-    DevBuf d_points29, d_tmp_points29;
-    uint64_t tmp_points_n = 0;  // rows of d_tmp_points the last conversion filled
-    hipStream_t rows_stream = nullptr;
-    hipEvent_t ev_rows = nullptr;
-    int rows_stream_on = 0;  // 1: a stream of its own; 2: the state-transition stream carries the row chain
     bool dist_ready() const { return comm != nullptr || coll_custom; }
 
     // ---- profiling ----
@@ -555,16 +550,11 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
     size_t end() const { return base + used; }
 };
 
-// POSEVO_G1_DEFER: where a streaming pipeline's G1 sums go out.  1 (default): behind the step's k_tree.  0: with the
-// aggregate, behind its union -- the accumulations queue back to back and every fork-choice kernel of the step runs as
-// the guest of one (measured: 0.312 vs 0.285 ms/step).  2: behind k_votes, in front of k_tree (the one-workgroup tree
-// then runs beside the start of the accumulation).  3: in front of k_votes.  (A/B knob.)
-inline int g1_defer_point()
-{
-    static const int p = [] { const char* e = getenv("POSEVO_G1_DEFER"); const int v = e ? atoi(e) : 1; return v >= 0 && v <= 3 ? v : 1; }();
-    return p;
-}
-inline bool g1_defer_enabled() { return g1_defer_point() != 0; }
+// A streaming pipeline holds its G1 sums back and launches them BEHIND the step's k_tree (pe_get_head / _async), not with
+// the aggregate: queued behind its predecessor on the side stream an accumulation's workgroups are dispatched as CUs free
+// up, the first CUs to finish take two of them (2 x 232 registers fit) and their waves run at half speed -- 335-355 us
+// instead of 205-240 in five steps of twenty (tools/engine_timeline.py --cold 20; the same with the launch in front of
+// k_tree or k_votes) -- and every kernel of the engine stream's chain then runs as the guest of an accumulation.
 // No G1 chain of an earlier step can still be running: every arena has been completed (the engine was drained) and this
 // pipeline has launched none.  The first step of a run then launches its accumulation with the aggregate instead of holding
 // it back behind k_tree: there is no predecessor on the side stream whose retiring workgroups it could pile onto, and a run
@@ -575,10 +565,6 @@ inline bool g1_chain_idle(const pe_engine* h)
         if (h->arena[i].side_used) return false;
     return h->deferred.empty();
 }
-inline int run_deferred_at(pe_engine* h, int point)  // the launch sites in front of k_votes (3) and k_tree (2)
-{
-    return (h->streaming && g1_defer_point() == point) ? run_deferred(h) : PE_OK;
-}
 
 // Register a batch call's completion.  Outside a pipeline: wait now and run it (the call is synchronous, as
 // include/posevo.h promises).  Inside one: advance the cursors and return; pe_pipeline_end waits once.
@@ -588,6 +574,7 @@ int ensure_quiesced(pe_engine* h, DevBuf& b, size_t bytes);
 
 // ------------------------------------------------------------------ G1 plan
 constexpr uint32_t G1_TARGET_LANES = 131072;  // 2 waves per SIMD on 256 CUs
+constexpr uint32_t G1_MIN_K = 4;              // fewest members per accumulation lane (fewer: more tree levels than adds)
 struct G1Plan {
     uint32_t n_groups = 0, n_slots = 0, n_partials = 0;
 };
@@ -601,7 +588,7 @@ void plan_g1(uint32_t n_groups, SizeFn size_of, G1Group* out, G1Plan* plan, uint
 {
     uint64_t total = 0;
     for (uint32_t g = 0; g < n_groups; ++g) total += size_of(g);
-    static const uint32_t min_k = [] { const char* e = getenv("POSEVO_G1_MIN_K"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 4u; }();
+    const uint32_t min_k = G1_MIN_K;
     const uint32_t k = (uint32_t)std::max<uint64_t>(min_k, (total + target_slots - 1) / target_slots);
     uint32_t cursor = 0, outp = 0;
     for (uint32_t g = 0; g < n_groups; ++g) {

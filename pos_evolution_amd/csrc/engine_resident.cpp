@@ -144,10 +144,7 @@ int candidate_tables(pe_engine* h, TablesDev* out, CommitteeTable* tabs[2])
 
 uint32_t g1_target_slots(const pe_engine* h)
 {
-    static const uint32_t pinned = [] { const char* e = getenv("POSEVO_G1_TARGET_SLOTS"); return e ? (uint32_t)atol(e) : 0u; }();
-    static const bool one_wave = [] { const char* e = getenv("POSEVO_G1_STREAM_ONE_WAVE"); return !e || atoi(e) != 0; }();
-    if (pinned) return pinned;
-    if (h->streaming) return one_wave ? G1_TARGET_LANES / 2 : G1_TARGET_LANES;
+    if (h->streaming) return G1_TARGET_LANES / 2;  // one wave per SIMD: see aggregate_impl
     return h->g1_target_slots ? h->g1_target_slots : G1_TARGET_LANES;
 }
 
@@ -247,28 +244,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
             (void)hipGetLastError();
         }
     }
-    // The row chain reads the caller's rows and bits and this arena's scratch, nothing the store's kernels write: in a
-    // streaming step it may run on its own stream beside the PREVIOUS step's fork-choice kernels (the engine's stream
-    // holds them in order) -- for the first call into an arena only: a later aggregate of the same pipeline rewrites
-    // scratch whose readers are ordered on the engine's stream.
-    bool use_rows = h->rows_stream_on && h->streaming && set == 0 && !n_dev && arena_kind != 0 && !A.side_used &&
-                    A.pending.empty() && A.stage_cursor == 0 && A.out_cursor == 0 && h->stream == h->own_stream &&
-                    h->deferred.empty();
-    if (use_rows && !h->rows_stream) {
-        if (h->rows_stream_on == 2 && h->aux_stream) h->rows_stream = h->aux_stream;
-        if ((!h->rows_stream && hipStreamCreateWithFlags(&h->rows_stream, hipStreamNonBlocking) != hipSuccess) ||
-            hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            if (h->rows_stream && h->rows_stream != h->aux_stream) (void)hipStreamDestroy(h->rows_stream);
-            h->rows_stream = nullptr;
-            h->rows_stream_on = 0;
-            use_rows = false;
-        }
-    }
-    hipStream_t ms = use_rows ? h->rows_stream : h->stream;
-    if (use_rows)  // tables shuffled asynchronously: find_table made the ENGINE's stream wait for them
-        for (int t = 0; t < 2; ++t)
-            if (tabs[t] && tabs[t]->ev_ready) HIP_TRY(h, hipStreamWaitEvent(ms, tabs[t]->ev_ready, 0));
+    hipStream_t ms = h->stream;
     // an earlier aggregate of THIS pipeline still has to read the arena's resident words / descriptors from its G1 launch
     // (deferred in a streaming pipeline): issue it, then order this call's kernels behind that chain
     // The exchanged aggregate of a committee-sharded step has a scratch set of its own (set 1) precisely so as NOT to wait.
@@ -281,15 +257,9 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     h->rr.valid = false;
     const size_t deferred_before = h->deferred.size();
     struct Unwind {
-        pe_engine* h; size_t keep; bool rows; bool armed = true;
-        void join() const  // whatever reached the rows stream is ordered before the engine stream's next command
-        {
-            if (!rows) return;
-            (void)hipEventRecord(h->ev_rows, h->rows_stream);
-            (void)hipStreamWaitEvent(h->stream, h->ev_rows, 0);
-        }
-        ~Unwind() { if (armed) { join(); h->rr.valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
-    } unwind{h, deferred_before, use_rows};
+        pe_engine* h; size_t keep; bool armed = true;
+        ~Unwind() { if (armed) { h->rr.valid = false; if (h->deferred.size() > keep) h->deferred.resize(keep); } }
+    } unwind{h, deferred_before};
     bool ingest_copies = false;
     if (arena_kind == 0) {
         memcpy(st.host<uint8_t>(off_arena), bits_arena, arena_len);
@@ -332,8 +302,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     pa.out_arena_cap = out_arena_cap;
     pa.target_slots = target;
     pa.slot_cap = slot_cap;
-    static const uint32_t min_k = [] { const char* e = getenv("POSEVO_G1_MIN_K"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 4u; }();
-    pa.min_k = min_k;
+    pa.min_k = G1_MIN_K;
     pa.want_pk = want_pk ? 1u : 0u;
     pa.tables = tables;
     launch_att_plan(ms, pa);
@@ -346,11 +315,9 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                           RS.info.as<uint32_t>(), ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan);
     }
     HIP_TRY(h, hipGetLastError());
-    unwind.join();  // from here on the engine's stream carries the step: handlers, the head, the G1 launch's fork
     lap.mark("ragg.3_group_union");
     if (want_pk) {
-        static const bool side_ok = [] { const char* e = getenv("POSEVO_G1_SIDE_STREAM"); return !e || atoi(e) != 0; }();
-        const bool on_side = h->pipelining && side_ok && h->side_stream && h->stream == h->own_stream;
+        const bool on_side = h->pipelining && h->side_stream && h->stream == h->own_stream;
         h->last_agg_on_side = on_side;
         pe_engine::PipeArena* arena = &A;
         const uint32_t* d_points = h->d_points.as<uint32_t>();
@@ -382,7 +349,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
             }
             return PE_OK;
         };
-        if (on_side && h->streaming && g1_defer_enabled() && !g1_chain_idle(h)) h->deferred.push_back(launch_g1);
+        if (on_side && h->streaming && !g1_chain_idle(h)) h->deferred.push_back(launch_g1);
         else PE_TRY(launch_g1());
         lap.mark("ragg.4_g1");
     }

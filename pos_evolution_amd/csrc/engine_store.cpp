@@ -245,7 +245,6 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
     // the call's completion reads it when the pipeline's outputs are complete
     volatile uint32_t* head_word = async_word ? async_word : h->h_head.as<uint32_t>();
     *head_word = NONE32;
-    PE_TRY(run_deferred_at(h, 2));
     {
         ProfScope ps(h, PE_KERNEL_TREE);
         // the head index lands directly in host-coherent pinned memory: no D2H copy, just the stream sync
@@ -265,9 +264,8 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
     // k_tree's last act is a system-scope release store of the head index into this host-coherent word: polling it
     // sees the result a few microseconds before hipStreamSynchronize returns.  Bounded: after ~200 us (a hung or
     // faulted kernel) the stream sync takes over and reports the error.
-    static const bool spin = [] { const char* e = getenv("POSEVO_HEAD_SPIN"); return !e || atoi(e) != 0; }();
     bool seen = false;
-    if (spin) {
+    {
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t it = 0;; ++it) {
             if (*head_word != NONE32) { seen = true; break; }
@@ -683,14 +681,9 @@ static int compute_committees_impl(pe_engine* h, uint64_t epoch, const uint8_t s
         // staging pair (seed | offsets | active indices), the shuffle has its own stream and scratch, and the table's
         // event is what a later reader waits for (find_table).
         if (!h->prep_stream) {
-            static const int prio = [] { const char* e = getenv("POSEVO_PREP_PRIO"); return e ? atoi(e) : 0; }();
-            if (prio) {  // -1: the lowest priority the device offers, 1: the highest (each has hardware queues of its own)
-                int least = 0, greatest = 0;
-                (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-                HIP_TRY(h, hipStreamCreateWithPriority(&h->prep_stream, hipStreamNonBlocking, prio < 0 ? least : greatest));
-            } else {
-                HIP_TRY(h, hipStreamCreateWithFlags(&h->prep_stream, hipStreamNonBlocking));
-            }
+            // normal priority: neither the lowest nor the highest the device offers placed the shuffle any better beside a
+            // streaming step (0.56-0.72 ms with-shuffle against 0.55, round 3)
+            HIP_TRY(h, hipStreamCreateWithFlags(&h->prep_stream, hipStreamNonBlocking));
         }
         const size_t o_seed = 0, o_offs = 64, o_idx = (64 + 4ull * (n_committees + 1) + 63) & ~size_t(63);
         const size_t bytes = o_idx + (identity ? 0 : 4ull * n_active) + 64;
@@ -813,7 +806,6 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
         if (!find_block(h, h->justified.root, &tmp))
             return fail(h, PE_ERR_UNKNOWN_ROOT, "justified checkpoint root is not in the store");
     }
-    PE_TRY(run_deferred_at(h, 3));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
@@ -849,7 +841,6 @@ int pe_get_head_async(pe_engine* h, uint8_t out_root[32])
     OutBlock ob(h);
     const size_t off = ob.alloc(64);
     PE_TRY(ob.ensure());
-    PE_TRY(run_deferred_at(h, 3));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),

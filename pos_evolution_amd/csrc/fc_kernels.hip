@@ -168,15 +168,9 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
     // row w % 8, k_tree sums the rows) with 256 workgroups 40.8 us; four quads in flight per lane 30.0 vs 30.2 us (nothing);
     // k_tree launched BESIDE k_votes on a second stream and released by a device-side ticket 70 us -- the cross-stream
     // event that keeps the next call ordered costs more than the launch gap it removes (profiles/README.md);
-    // the count grows with the registry up to one workgroup per CU.  POSEVO_VOTES_WGS overrides it for tuning.
-    static const long forced = [] {
-        const char* e = getenv("POSEVO_VOTES_WGS");
-        const long v = e ? atol(e) : 0;
-        return (v >= 1 && v <= VOTES_MAX_WG) ? v : 0l;
-    }();
+    // the count grows with the registry up to one workgroup per CU.
     uint64_t cap = n_val / 16384;
     cap = cap < 64 ? 64 : cap > (uint64_t)VOTES_MAX_WG ? (uint64_t)VOTES_MAX_WG : cap;
-    if (forced) cap = (uint64_t)forced;
     if (blocks > cap) blocks = cap;
     if (first_use_on_this_device<0>()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes<2>), hipFuncAttributeMaxDynamicSharedMemorySize,

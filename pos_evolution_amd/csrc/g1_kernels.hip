@@ -293,9 +293,6 @@ __device__ unsigned long long g1_wave_info[3 * 4 * 4096];  // per wave: HW_ID | 
 #define G1_STAMP(i) do { } while (0)
 #endif
 
-#ifndef POSEVO_G1_WAVES_PER_EU
-#define POSEVO_G1_WAVES_PER_EU 2
-#endif
 // The sum of one launch runs in THREE kernels since round 2:
 //   k_g1_accumulate  per-lane XYZZ accumulation of k gathered points (mixed adds, S29 form since round 4): throughput-
 //                    bound, at the multiplier's issue floor; writes one partial per lane slot, limb-major per workgroup
@@ -331,12 +328,9 @@ __device__ __forceinline__ void g1_slot_block(const G1Group* __restrict__ groups
 // lane partials in HBM: word k of lane `tid` of workgroup `wg` at ((wg * 48 + k) * 256 + tid): a wave's 64 lanes write
 // 256 contiguous bytes per word (k_g1_accumulate's hand-over loop writes them, k_g1_tree reads them into LDS)
 
-#ifndef POSEVO_G1_TREE_WAVES_PER_EU
-#define POSEVO_G1_TREE_WAVES_PER_EU 2
-#endif
 // Two waves per SIMD (256 VGPRs with the called product, 32 B of scratch): the shape that fits beside ONE wave of the
 // next aggregate's k_g1_accumulate (<= 256 VGPRs) on every SIMD, which is how streaming steps run it (round 4).
-__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_TREE_WAVES_PER_EU, POSEVO_G1_TREE_WAVES_PER_EU)))
+__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups, uint32_t n_groups,
           uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev)
 {
@@ -587,7 +581,7 @@ struct FqCalled {
 // Round 3's version of this kernel (three inlined bodies + doubling twice + an unrolled hand-over: 214 KB of code) ran its
 // 1 M-point launch in 0.273 ms where the 12 x 32-bit kernel took 0.226 -- with a product that is 14 % and a mixed add that
 // is 25 % FASTER in a loop that fits the cache (tools/fpbench29).
-__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(POSEVO_G1_WAVES_PER_EU, POSEVO_G1_WAVES_PER_EU)))
+__global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__ members,
                     const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials,
@@ -733,7 +727,10 @@ k_g1_finish(const uint32_t* __restrict__ partials, const G1Group* __restrict__ g
             uint32_t n_parts_fixed, uint32_t part_stride, uint8_t* __restrict__ out_be96,
             uint32_t* __restrict__ out_jac, const AttPlan* __restrict__ plan_dev)
 {
-    if (plan_dev) n_groups = plan_dev->n_groups;
+    // the launch's n_groups BOUNDS the device-resident count: the output block (96 B per group) and, across ranks, the
+    // gathered partials' stride are sized by it (an aggregate that formed more groups than pe_dist_set_max_groups
+    // allows wrote past both; the completion reports PE_ERR_CAPACITY)
+    if (plan_dev) n_groups = min(n_groups, plan_dev->n_groups);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     // 32 waves of one long dependent chain each (the inversion).  In a stream of pipelined steps they run beside the

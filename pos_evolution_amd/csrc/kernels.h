@@ -171,7 +171,8 @@ struct AttPlan {                  // one per resident-rows aggregate: written by
     uint32_t packed_same;         // every union but the last is a whole number of words: word layout == byte layout
     uint32_t n_rows_table[2];     // groups resolved against each candidate table
     uint32_t n_rows_in;
-    uint32_t reserved;
+    uint32_t last_error;          // sticky copy of `error` (k_att_members clears `error` for the next call's ingest; the exchange
+                                  // kernel of a committee-sharded step runs after it and still has to tell the other ranks)
     unsigned long long total_members;
 };
 struct AttGroup {                 // one per group, in order of first appearance

@@ -241,9 +241,9 @@ int launch_shuffle(hipStream_t s, const uint32_t* d_seed_be, uint32_t n, uint32_
     if (hashes)
         hipLaunchKernelGGL(k_shuffle_tables, dim3((unsigned)((hashes + 255) / 256)), dim3(256), 0, s, d_seed_be, n, nb,
                            rounds, d_source, d_pivots);
-    // the LDS form needs n / 16 bytes (+ the ragged ends) of LDS: up to ~1.5 M indices inside 96 KB; larger lists and
-    // POSEVO_SHUFFLE_LDS=0 take the gather
-    static const bool lds_ok = [] { const char* e = getenv("POSEVO_SHUFFLE_LDS"); return !e || atoi(e) != 0; }();
+    // the LDS form needs n / 16 bytes (+ the ragged ends) of LDS: up to ~1.5 M indices inside 96 KB; larger (and tiny) lists
+    // take the gather
+    constexpr bool lds_ok = true;
     const size_t lds_bytes = 32ull * ((size_t)nb / 2 + 4);
     constexpr size_t LDS_CAP = SHUF_LDS_CAP;
     if (lds_ok && lds_bytes <= LDS_CAP && n >= 4096 && rounds > 0) {
