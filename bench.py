@@ -673,22 +673,189 @@ def replay_and_verify(pea, w, device, results, total):
     return same
 
 
+def slot_cadence(pea, w, device, n_epochs, lag):
+    """The same four functions at the cadence a client calls them (pe:934-944, 963, 1102, 1536): one step per SLOT -- on_tick
+    (which resets the proposer boost, pe:943), then the aggregates of the slot that just ended (64 committees x 4 partial
+    aggregates = 256 rows at configs[3]) through pe_aggregate -> pe_on_attestation_batch -> pe_get_head ->
+    pe_process_attestation_batch, 32 steps per epoch, the participation rotation at the epoch boundary and the NEXT epoch's
+    committee shuffle (pe_compute_committees_async) enqueued once per epoch, beside the slots' steps.  One warm-up epoch, then
+    n_epochs - 1 timed ones through streaming pipelines (throughput, per-step period), then one more epoch with the head
+    polled inside every step (the latency a client sees from its on_tick to the slot's head).  Every timed slot-step is
+    replayed with synchronous host-row calls on a fresh engine and compared by digest.  -> the `slot_cadence` object."""
+    import torch
+    from pos_evolution_amd import RESIDENT, ROWS_RESIDENT, DeviceArena, DeviceRows
+    from pos_evolution_amd._abi import pe_state_ctx
+
+    spe, tree = w["spe"], w["tree"]
+    epochs = w["steps"][:n_epochs + 1]           # + 1: the latency pass
+    keep = []
+
+    def make_engine():
+        e = pea.Engine(device=device, max_committee_tables=len(epochs) + 4)
+        e.store_init(0, 0, tree.roots[0].tobytes())
+        for i in range(1, tree.roots.shape[0]):
+            e.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+        e.set_validators(w["bal"], w["flags"], w["pts"])
+        for st in epochs:
+            e.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
+        return e
+
+    slots = []
+    for k, st in enumerate(epochs):
+        order = np.argsort(st["atts"]["slot"], kind="stable")
+        atts = np.ascontiguousarray(st["atts"][order])
+        rows_t = torch.from_numpy(atts.view(np.uint8).reshape(-1).copy()).cuda()
+        arena_t = torch.from_numpy(st["arena"]).cuda()
+        keep += [rows_t, arena_t]
+        arena_in = DeviceArena(arena_t.data_ptr(), arena_t.numel(), keep=arena_t)
+        bounds = np.searchsorted(atts["slot"], st["epoch"] * spe + np.arange(spe + 1))
+        cps = (st["comm"].offsets.size - 1) // spe
+        for s in range(spe):
+            lo, hi = int(bounds[s]), int(bounds[s + 1])
+            S = st["epoch"] * spe + s + 1           # the slot whose tick makes slot S - 1's attestations valid (pe:1411)
+            c = pe_state_ctx()
+            c.slot = S
+            c.chain_tip_root[:] = tree.roots[tree.roots.shape[0] - 1].tobytes()
+            c.current_justified_root[:] = tree.roots[0].tobytes()
+            c.previous_justified_root[:] = tree.roots[0].tobytes()
+            c.base_reward_per_increment = 2264
+            sl = dict(S=S, rotate=(S % spe == 0), atts=atts[lo:hi], arena=st["arena"], arena_in=arena_in, cap=cps, ctx=c,
+                      rows_in=DeviceRows(rows_t.data_ptr() + 144 * lo, hi - lo, keep=rows_t))
+            if s == 0 and k + 1 < len(epochs):     # MIN_SEED_LOOKAHEAD: epoch E's first slot can shuffle epoch E + 1
+                nxt = epochs[k + 1]
+                sl["shuffle"] = (nxt["epoch"], nxt["ep_seed"], w["bal"].size, nxt["comm"].offsets.size - 1, 90)
+            slots.append(sl)
+    torch.cuda.synchronize()
+
+    def step(e, sl, resident, lagged, sync_head):
+        e.on_tick(sl["S"] * 12)
+        if sl["rotate"]:
+            e.participation_rotate()
+        if resident and "shuffle" in sl:
+            e.compute_committees_async(*sl["shuffle"])
+        if not resident:
+            agg = e.aggregate(packed=(sl["atts"], sl["arena"]), want_aggregate_pubkeys=True)
+            rows = agg["atts"]
+            status, _, count = e.on_attestation_batch(packed=(rows, agg["out_arena"]))
+            st2, num = e.process_attestation_batch(sl["ctx"], packed=(rows, agg["out_arena"]))
+            return dict(agg=agg, status=status, count=count, pstatus=st2, numerators=num, head=e.get_head())
+        with e.pipeline(lagged=lagged):
+            agg = e.aggregate(packed=(sl["rows_in"], sl["arena_in"]), want_aggregate_pubkeys=True)
+            status, _, count = e.on_attestation_batch(packed=(ROWS_RESIDENT, RESIDENT), cap=sl["cap"])
+            head = e.get_head() if sync_head else e.get_head_async()
+            st2, num = e.process_attestation_batch(sl["ctx"], packed=(ROWS_RESIDENT, RESIDENT), cap=sl["cap"])
+        return dict(agg=agg, status=status, count=count, pstatus=st2, numerators=num, head=head)
+
+    e = make_engine()
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(len(slots) + 2)
+    n_warm, n_timed = spe, spe * (n_epochs - 1)
+    got = [step(e, sl, True, True, False) for sl in slots[:n_warm]]
+    e.drain()
+    e.fill_ring()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stamps = [t0]
+    for sl in slots[n_warm:n_warm + n_timed]:
+        got.append(step(e, sl, True, True, False))
+        stamps.append(time.perf_counter())
+    e.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_att = int(sum(int(np.asarray(r["count"]).sum()) for r in got[n_warm:]))
+    # the latency pass: one wait per slot, the head polled inside the step
+    lat = []
+    for sl in slots[n_warm + n_timed:]:
+        t = time.perf_counter()
+        e.on_tick(sl["S"] * 12)
+        if sl["rotate"]:
+            e.participation_rotate()
+        with e.pipeline(lagged=False):
+            agg = e.aggregate(packed=(sl["rows_in"], sl["arena_in"]), want_aggregate_pubkeys=True)
+            status, _, count = e.on_attestation_batch(packed=(ROWS_RESIDENT, RESIDENT), cap=sl["cap"])
+            head = e.get_head()
+            t_head = time.perf_counter()
+            st2, num = e.process_attestation_batch(sl["ctx"], packed=(ROWS_RESIDENT, RESIDENT), cap=sl["cap"])
+        got.append(dict(agg=agg, status=status, count=count, pstatus=st2, numerators=num, head=head))
+        lat.append(((t_head - t) * 1e6, (time.perf_counter() - t) * 1e6))
+    for r in got:
+        r["head"] = bytes(r["head"])
+    # on_attestation for ONE attestation (pe:963: the reference's handler takes them one at a time): a batch of one host row,
+    # synchronous -- rows of a slot already applied (the same latest messages again: nothing changes in the store)
+    single = []
+    one = slots[-2]
+    for i in range(min(100, len(one["atts"]))):
+        t = time.perf_counter()
+        st1, _, _ = e.on_attestation_batch(packed=(one["atts"][i:i + 1], one["arena"]))
+        single.append((time.perf_counter() - t) * 1e6)
+        assert int(st1[0]) == 0
+    single.sort()
+    e.close()
+    # every slot-step again: synchronous calls over host rows on a fresh engine
+    e2 = make_engine()
+    same = [step_digest(step(e2, sl, False, False, True)) == step_digest(r) for sl, r in zip(slots, got)]
+    e2.close()
+    per = np.diff(np.array(stamps)) * 1e6
+    to_head = np.sort(np.array([a for a, _ in lat]))
+    whole = np.sort(np.array([b for _, b in lat]))
+    rows_per_slot = int(np.mean([len(sl["atts"]) for sl in slots]))
+    out = {
+        "workload": (f"{n_timed} slot-steps ({n_epochs - 1} epochs x {spe}) after {n_warm} warm-up ones: per slot on_tick + "
+                     f"{rows_per_slot} partial aggregates of {slots[0]['cap']} committees -> pe_aggregate (union + aggregate "
+                     "pubkeys) -> pe_on_attestation_batch -> pe_get_head -> pe_process_attestation_batch; participation "
+                     "rotated and the next epoch's committees shuffled (pe_compute_committees_async) once per epoch; rows + "
+                     "bits resident in HBM, streaming pipelines"),
+        "attestations_per_s": n_att / dt,
+        "slot_step_us_mean": dt / n_timed * 1e6,
+        "slot_step_us_p50": float(np.median(per)), "slot_step_us_p99": float(np.percentile(per, 99)),
+        "slot_step_detail": "host stamps around each streaming slot-step (the host runs `lag` steps ahead of the device); "
+                            "the mean includes the final drain",
+        "tick_to_head_us_p50": float(to_head[len(to_head) // 2]), "tick_to_head_us_p99": float(to_head[-1]),
+        "tick_to_all_outputs_us_p50": float(whole[len(whole) // 2]),
+        "latency_detail": f"{len(lat)} further slots, one wait per slot: on_tick -> aggregate -> on_attestation -> pe_get_head "
+                          "returns the slot's head (polled) -> process_attestation -> pe_pipeline_end",
+        "on_attestation_single_us_p50": float(single[len(single) // 2]),
+        "on_attestation_single_detail": "pe_on_attestation_batch with ONE attestation in host memory, synchronous (validate, "
+                                        "upload, LMD update, wait): what forkchoice.on_attestation costs per call",
+        "fraction_of_the_slot": dt / n_timed / 12.0,
+        "slot_steps_verified": int(sum(same[n_warm:])), "slot_steps": len(slots) - n_warm,
+        "warmup_slot_steps_verified": int(sum(same[:n_warm])),
+    }
+    assert all(same), f"slot-steps differ from their synchronous replay: {[i for i, x in enumerate(same) if not x][:8]}"
+    return out
+
+
+# BASELINE.json configs[1..4] as written there (configs[0] is the CPU-only plumbing case: pyspec_c1 below)
+SHAPES = {
+    "configs1": dict(validators=1 << 16, committees=2048, blocks=512, mixed_balances=False),
+    "configs2": dict(validators=1 << 18, committees=2048, blocks=4096, mixed_balances=False),
+    "configs3": dict(validators=1 << 20, committees=2048, blocks=4096, mixed_balances=False),
+    "configs4": dict(validators=1 << 22, committees=2048, blocks=8192, mixed_balances=True),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--validators", type=int, default=1 << 20,
-                    help="registry size: the whole job's with --scaling strong, per GPU with --scaling weak")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
-                    help="N > 1: weak (default) = a registry shard of --validators per GPU (N x 1 048 576 validators in "
-                         "all, C committees x N x 512 members: per-GPU work fixed, the two exchange steps grow with N); "
-                         "strong = BASELINE configs[3] as written (the 1 048 576-validator registry range-sharded over "
-                         "the N GPUs, V/N validators and C committees x (V/N)/C local members per rank)")
-    ap.add_argument("--blocks", type=int, default=4096)
-    ap.add_argument("--committees", type=int, default=2048)
+    ap.add_argument("--shape", choices=sorted(SHAPES), default="configs3",
+                    help="the BASELINE.json config the job runs, as written there: configs3 (default) = configs[3], 1 048 576 "
+                         "validators, 2048 committees x 512, 4096-block tree; configs4 = configs[4], 4 194 304 validators "
+                         "(2048 x 2048), EIP-7251 mixed balances, 8192-block tree; configs1 / configs2 = the single-GPU "
+                         "parity shapes.  With --gpus N the SAME registry is divided over the N GPUs (--scaling strong)")
+    ap.add_argument("--validators", type=int, default=None,
+                    help="registry size (default: the shape's): the whole job's with --scaling strong, per GPU with "
+                         "--scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default) = the named config as written: ONE registry, range-sharded over the N GPUs (V/N "
+                         "validators and C committees x (V/N)/C local members per rank); weak = a registry shard of "
+                         "--validators per GPU (N x V validators in all: per-GPU work fixed, the two exchange steps grow "
+                         "with N) -- not a BASELINE config for N > 1")
+    ap.add_argument("--blocks", type=int, default=None)
+    ap.add_argument("--committees", type=int, default=None)
     ap.add_argument("--parts", type=int, default=4, help="partial aggregates per committee")
-    ap.add_argument("--mixed-balances", action="store_true")
+    ap.add_argument("--mixed-balances", action="store_true", default=None)
     ap.add_argument("--head-calls", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded-mode", choices=["engine", "torch", "committee"], default="engine",
@@ -720,12 +887,17 @@ def main():
                          "(ReplayCollectives).  A measurement of the per-rank step, not of a collective")
     ap.add_argument("--no-shuffle-variant", action="store_true",
                     help="skip the extra steps that report ms_per_step_with_shuffle")
+    ap.add_argument("--no-slot-cadence", action="store_true",
+                    help="skip the per-slot run that reports `slot_cadence` (one GPU)")
     ap.add_argument("--no-oracle-check", action="store_true",
                     help="N > 1: skip the check of the run's first step against the oracle")
     ap.add_argument("--lag", type=int, default=4,
                     help="lag depth of the streaming pipelines (pe_pipeline_set_lag): a step's outputs are complete when "
                          "the lag-th next step has been enqueued")
     args = ap.parse_args()
+    for key, val in SHAPES[args.shape].items():   # what the shape fixes, unless given explicitly
+        if getattr(args, key) is None:
+            setattr(args, key, val)
 
     import torch
 
@@ -983,31 +1155,38 @@ def main():
                 traffic, traffic_src = ent.get("k_g1_accumulate_bytes_per_launch"), ent.get("source")
         except Exception:
             traffic = None
-    # VALU view of the same kernel: Montgomery products per launch against the measured chip ceiling
-    # (tools/fpbench: 57 G products/s at the kernel's 2 waves/SIMD): 10 per mixed add (the 14-product tree adds run in
-    # k_g1_tree since the kernel was split)
-    # 10 per mixed add, 6 for the first add of a lane's run (affine + affine, round 3): k members per lane as the engine
-    # plans them (k = max(4, ceil(members / 131072)))
-    k_run = max(4, -(-VL // 131072))
+    # VALU view of the same kernel (round 4: the S29 field form, fp381_s29.h).  A lane takes its first point as it is and
+    # adds the others with the general mixed add: 8 products of 392 multiply-adds + 2 squarings of 301 = 3738
+    # v_mad_[iu]64_[iu]32 and nothing that carries; the hand-over to the tree's words costs 4 products per lane.  Lanes as the
+    # engine plans them in streaming steps: one wave per SIMD, k = max(4, ceil(members / 65536)) members per lane.
+    MACS_MUL, MACS_SQR = 392, 301
+    MACS_ADD = 8 * MACS_MUL + 2 * MACS_SQR
+    k_run = max(4, -(-VL // 65536))
     lane_runs = C * -(-(VL // C) // k_run)
-    products = 10.0 * att_per_launch - 4.0 * lane_runs
-    valu_peak = 57.0e9
-    valu_ach = products / (acc_ms * 1e-3) if acc_ms else 0.0
-    # the tree over the lanes' partials: one 14-product add per lane but one per committee; it runs on the same SIMDs
-    # beside the NEXT accumulation, so the step's VALU work is both
-    tree_products = 14.0 * max(lane_runs - C, 0)
+    mixed_adds = max(att_per_launch - lane_runs, 0.0)
+    macs = mixed_adds * MACS_ADD + lane_runs * 4 * MACS_MUL
+    # the multiplier's issue rate (tools/ubench_valu, profiles/r01_ubench_valu_fpmul.log: v_mad_u64_u32 every 2.496 ns per SIMD
+    # at two waves, 2.454 at four; v_mad_i64_i32 is the same unit): 1024 SIMDs x 64 lanes
+    MAC_PEAK = 1024 * 64 / 2.496e-9
+    valu_peak = MAC_PEAK / MACS_ADD              # mixed adds per second if the SIMDs issued nothing but multiply-adds
+    valu_ach = mixed_adds / (acc_ms * 1e-3) if acc_ms else 0.0
+    # the tree over the lanes' partials (12 x 32-bit form, 288 multiply-adds + 288 carry adds per product, 14 products per
+    # add): one add per lane but one per committee; it runs on the same SIMDs beside the NEXT accumulation
+    tree_macs = 14.0 * 288 * max(lane_runs - C, 0)
     votes = prof["votes"]
     votes_ms = votes["total_ms"] / max(votes["launches"], 1)
     votes_bytes = 13.0 * VL + 32.0 * args.blocks
     kernel_ms = {k: (v["total_ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()}
     per_step = np.diff(np.array(stamps)) * 1e3
     V_total = VL if args.by_committee else VL * world   # committee shards: one registry, on every rank
-    shape = ("BASELINE configs[3] shape on every GPU" if (world > 1 and (VL, C, args.blocks) == (1 << 20, 2048, 4096))
-             else "BASELINE configs[3] shape" if (V_total, C, args.blocks) == (1 << 20, 2048, 4096)
-             else "BASELINE configs[4] shape" if (V_total, args.blocks) == (1 << 22, 8192)
-             else "BASELINE configs[2] shape" if (V_total, args.blocks) == (1 << 18, 4096)
-             else "custom shape")
-    scaling = args.scaling  # weak (default): N = 1 is the per-GPU workload of every N
+    named = {(1 << 16, 2048, 512, False): 1, (1 << 18, 2048, 4096, False): 2, (1 << 20, 2048, 4096, False): 3,
+             (1 << 22, 2048, 8192, True): 4}.get((V_total, C, args.blocks, bool(args.mixed_balances)))
+    if named and world > 1 and args.scaling == "weak":
+        named = None
+    shape = (f"BASELINE configs[{named}]" + (f" over {world} GPUs" if world > 1 else " on one GPU") if named else
+             f"custom shape (weak scaling: a configs[3]-sized registry shard per GPU, {world} x {VL} validators)"
+             if (world > 1 and args.scaling == "weak" and (VL, C, args.blocks) == (1 << 20, 2048, 4096)) else "custom shape")
+    scaling = args.scaling  # strong (default): the named config's registry, whole on one GPU, divided over N
     mode = ("sharded, streaming pipelines, collectives issued by the engine between its kernels (" + exchange_how + ")"
             if engine_rccl else
             "sharded, synchronous calls, collectives through torch.distributed" if world > 1 else
@@ -1064,34 +1243,26 @@ def main():
             "kernel": "k_g1_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms, "launches": acc["launches"],
-            "note": "integer-VALU bound (10 Montgomery products per 100 B gathered), not HBM bound: "
-                    "see DESIGN.md; votes kernel below is the HBM-streaming one",
+            "note": "integer-VALU bound (3738 multiply-adds per 100 B gathered), not HBM bound: "
+                    "see roofline_valu and DESIGN.md; the votes kernel below is the HBM-streaming one",
         },
         "roofline_valu": {
-            "kernel": "k_g1_accumulate", "bound": "integer VALU (v_mad_u64_u32 Montgomery products)",
-            "achieved": valu_ach / 1e9, "peak": valu_peak / 1e9, "unit": "G Fp-products/s", "frac": valu_ach / valu_peak,
-            "products_per_launch": products,
+            "kernel": "k_g1_accumulate", "bound": "integer VALU: v_mad_i64_i32 / v_mad_u64_u32 issue (S29 field form)",
+            "achieved": valu_ach / 1e9, "peak": valu_peak / 1e9, "unit": "G mixed adds/s", "frac": valu_ach / valu_peak,
+            "mixed_adds_per_launch": mixed_adds, "multiply_adds_per_mixed_add": MACS_ADD,
+            "multiply_adds_per_launch": macs,
+            "peak_source": "instruction ceiling: one 32 x 32 -> 64 multiply-add per 2.496 ns and SIMD (tools/ubench_valu, "
+                           "profiles/r01_ubench_valu_fpmul.log) x 1024 SIMDs x 64 lanes / 3738 multiply-adds per mixed add = "
+                           "7.0 G/s; the same adds in a loop without loads reach 6.96 G/s (tools/icbench, "
+                           "profiles/r04_icbench.txt), the kernel alone 5.8 G/s (tools/accbench, profiles/r04_accbench.txt)",
             "step_view": {
-                "tree_products_per_step": tree_products,
-                "products_per_step": products + tree_products,
-                "G_products_per_s_over_the_step": (products + tree_products) / (dt / args.steps) / 1e9,
-                "frac_of_peak_over_the_step": (products + tree_products) / (dt / args.steps) / valu_peak,
-                "note": "accumulation + tree products of one step over the whole step period: the fraction of the period "
-                        "the chip spends on this algorithm's Montgomery products at the multiplier's ceiling; the rest is "
-                        "the in-situ efficiency of the two kernels and the bubble between accumulations (DESIGN.md 8)",
-            },
-            "peak_source": "tools/fpbench: this repository's own fp_mul in a dependent loop at 2 waves/SIMD -- a ceiling of the "
-                           "multiplier as written, not of the chip",
-            # the chip's own numbers (tools/ubench_valu, profiles/r01_ubench_valu_fpmul.log, 2 waves/SIMD): a product is 288
-            # multiply-accumulates; v_mad_u64_u32 issues every 2.496 ns per SIMD, the mad + v_addc_co pair every 3.600 ns
-            "instruction_ceilings": {
-                "mad_only_G_products_per_s": 1024 * 64 / (288 * 2.496),
-                "mad_plus_addc_G_products_per_s": 1024 * 64 / (288 * 3.600),
-                "frac_of_mad_only": valu_ach / 1e9 / (1024 * 64 / (288 * 2.496)),
-                "frac_of_mad_plus_addc": valu_ach / 1e9 / (1024 * 64 / (288 * 3.600)),
-                "note": "v_mad_u64_u32 has a carry-out but no carry-in: each of the 288 MACs of a 12 x 12-limb Montgomery "
-                        "product pays a v_addc_co_u32 for the third accumulator word; the mad-only figure is what a "
-                        "carry-free multiplier could reach, the mad + addc figure is the bound of this algorithm",
+                "tree_multiply_adds_per_step": tree_macs,
+                "multiply_adds_per_step": macs + tree_macs,
+                "frac_of_multiplier_over_the_step": (macs + tree_macs) / (dt / args.steps) / MAC_PEAK,
+                "note": "multiply-adds of the accumulation + the tree of one step over the whole step period: the fraction of "
+                        "the period the chip's multipliers spend on this algorithm; the rest is the tree's carry adds, the "
+                        "in-situ efficiency of the two kernels and the chain of small kernels that paces the step "
+                        "(DESIGN.md 8)",
             },
         },
         "roofline_votes": {
@@ -1148,6 +1319,9 @@ def main():
             out["steps_verified_with_shuffle"] = int(sum(same[total:]))
             assert out["steps_verified_with_shuffle"] == n_var, "with-shuffle steps differ from their synchronous replay"
         assert out["steps_verified"] == args.steps, f"timed steps differ from their synchronous replay: {same}"
+    if world == 1 and not emulate and not args.no_slot_cadence and not args.no_pipeline and not args.host_rows \
+            and not args.host_arena and len(w["steps"]) >= 4 and C % w["spe"] == 0:
+        out["slot_cadence"] = slot_cadence(pea, w, local_rank, 3, args.lag)
     if not args.no_cpu_baseline and world == 1:
         base, chk = cpu_baseline(w, w["steps"][0])
         out["cpu_baseline"] = base

@@ -614,38 +614,13 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n,
  * apply the whole epoch's votes and flags to this rank's copy of the store, and pe_get_head (the plain one: no weight
  * exchange) returns the same head on every rank.  Outputs: the gathered aggregates, rank after rank (out_atts rows with
  * bits_offset into out_bits_arena, out_count), cap_groups entries each -- cap_groups >= world x the bound of
- * pe_dist_set_max_groups (or x the local row count when no bound is set).  Every rank calls it once per step; inside a
+ * pe_dist_set_max_groups (required, and the same on every rank: PE_ERR_STATE without one -- the exchange is sized by it).  Every rank calls it once per step; inside a
  * pipeline nothing waits (with RCCL) and the local aggregate's G1 sums keep running beside the exchange.  A union may be
  * at most max_validators_per_committee bits (pe_config). */
 int pe_aggregate_exchange(pe_engine* h, pe_attestation* out_atts, uint32_t* out_n_groups, uint8_t* out_bits_arena,
                           uint64_t out_arena_cap, uint32_t* out_count, uint32_t cap_groups);
 
-/* ---- profiling hooks (bench.py roofline leg) ----------------------------- */
-/* When enabled, the engine brackets each launch of its kernels with HIP events on
- * the launch stream and accumulates per-kernel launch counts and durations. */
-#define PE_KERNEL_G1_ACCUMULATE 0
-#define PE_KERNEL_G1_NORMALISE  1
-#define PE_KERNEL_VOTES         2
-#define PE_KERNEL_TREE          3
-#define PE_KERNEL_LMD           4
-#define PE_KERNEL_PARTICIPATION 5
-#define PE_KERNEL_BITS_UNION    6
-#define PE_KERNEL_G2_ACCUMULATE 7
-#define PE_KERNEL_G2_NORMALISE  8
-#define PE_KERNEL_G1_TREE       9   /* the LDS tree over the lane partials: its own kernel since round 2 */
-#define PE_KERNEL_ATT_GROUP     10  /* rows in device memory: ingest + plan + members (bracketed in timeline mode only) */
-#define PE_KERNEL_ATT_VALIDATE  11  /* rows in device memory: the validate_on_attestation / process_attestation kernels (ditto) */
-#define PE_KERNEL_COUNT         12
-/* on = 0 off, 1 per-kernel totals, 2 totals + a timeline: every bracketed launch's start (relative to the last
- * pe_profile_reset, which marks time zero on the engine's stream) and duration, read with pe_profile_timeline.  The
- * events are the engine's own, on the streams the kernels run on: an in-situ picture of a streaming step without a
- * profiler's serialisation (rocprofv3 stretches the 0.28 ms step to 0.4). */
-int pe_profile_enable(pe_engine* h, int on);
-int pe_profile_reset(pe_engine* h);
-int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms);
-/* The launches bracketed since the last pe_profile_reset, in the order they were drained (per kernel kind, launch order
- * inside a kind): kernel id, start and duration in ms.  At most cap entries are written; *out_n = how many exist. */
-int pe_profile_timeline(pe_engine* h, int32_t* kernel, double* start_ms, double* duration_ms, uint32_t cap, uint32_t* out_n);
+/* Measurement hooks (per-kernel event brackets, the in-situ timeline) are not part of the boundary: include/posevo_profile.h. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,41 @@
+/* posevo_profile.h -- measurement hooks of libposevo.so: per-kernel launch counts / durations from HIP events the engine
+ * records around its own launches, and an in-situ timeline of a streaming step.  NOT part of the drop-in boundary
+ * (include/posevo.h): nothing a client of the reference's functions needs; bench.py's `roofline` leg and
+ * tools/engine_timeline.py use them. */
+#ifndef POSEVO_PROFILE_H
+#define POSEVO_PROFILE_H
+#include "posevo.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* When enabled, the engine brackets each launch of its kernels with HIP events on
+ * the launch stream and accumulates per-kernel launch counts and durations. */
+#define PE_KERNEL_G1_ACCUMULATE 0
+#define PE_KERNEL_G1_NORMALISE  1
+#define PE_KERNEL_VOTES         2
+#define PE_KERNEL_TREE          3
+#define PE_KERNEL_LMD           4
+#define PE_KERNEL_PARTICIPATION 5
+#define PE_KERNEL_BITS_UNION    6
+#define PE_KERNEL_G2_ACCUMULATE 7
+#define PE_KERNEL_G2_NORMALISE  8
+#define PE_KERNEL_G1_TREE       9   /* the LDS tree over the lane partials: its own kernel since round 2 */
+#define PE_KERNEL_ATT_GROUP     10  /* rows in device memory: ingest + plan + members (bracketed in timeline mode only) */
+#define PE_KERNEL_ATT_VALIDATE  11  /* rows in device memory: the validate_on_attestation / process_attestation kernels (ditto) */
+#define PE_KERNEL_COUNT         12
+/* on = 0 off, 1 per-kernel totals, 2 totals + a timeline: every bracketed launch's start (relative to the last
+ * pe_profile_reset, which marks time zero on the engine's stream) and duration, read with pe_profile_timeline.  The
+ * events are the engine's own, on the streams the kernels run on: an in-situ picture of a streaming step without a
+ * profiler's serialisation (rocprofv3 stretches the 0.28 ms step to 0.4). */
+int pe_profile_enable(pe_engine* h, int on);
+int pe_profile_reset(pe_engine* h);
+int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_ms);
+/* The launches bracketed since the last pe_profile_reset, in the order they were drained (per kernel kind, launch order
+ * inside a kind): kernel id, start and duration in ms.  At most cap entries are written; *out_n = how many exist. */
+int pe_profile_timeline(pe_engine* h, int32_t* kernel, double* start_ms, double* duration_ms, uint32_t cap, uint32_t* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEVO_PROFILE_H */

@@ -8,15 +8,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "posevo.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(pe_[a-z0-9_]+)\s*\(", text)))
+def header_symbols(names=("posevo.h", "posevo_profile.h")):
+    """Every entry point declared under include/: the boundary (posevo.h) and the measurement hooks (posevo_profile.h)."""
+    out = set()
+    for name in names:
+        text = open(os.path.join(ROOT, "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(pe_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_and_binding_agree():
     from pos_evolution_amd import _abi
-    assert header_symbols() == sorted(_abi.SIGNATURES), "include/posevo.h and _abi.SIGNATURES list different entry points"
+    assert header_symbols() == sorted(_abi.SIGNATURES), "include/*.h and _abi.SIGNATURES list different entry points"
+    assert not [n for n in header_symbols(("posevo.h",)) if n.startswith("pe_profile")]   # measurement is not boundary
 
 
 def test_library_exports_every_symbol():

@@ -152,6 +152,10 @@ def test_aggregate_exchange_needs_its_preconditions(engine_factory):
         e.aggregate_exchange(cap_groups=64)
     assert err.value.status == pea._abi.PE_ERR_STATE
     e.aggregate(packed=(_dev_rows(atts), _dev_arena(arena)))
+    with pytest.raises(pea.EngineError) as err:      # no bound on the groups: ranks would size the all-gather differently
+        e.aggregate_exchange(cap_groups=len(atts))
+    assert err.value.status == pea._abi.PE_ERR_STATE and "pe_dist_set_max_groups" in str(err.value)
+    e.dist_set_max_groups(len(atts))
     with pytest.raises(pea.EngineError) as err:      # output arrays smaller than world x bound
         e.aggregate_exchange(cap_groups=3)
     assert err.value.status == pea._abi.PE_ERR_CAPACITY

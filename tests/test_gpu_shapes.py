@@ -122,3 +122,54 @@ def test_config5_shape_aggregate_2048_committees_of_2048_over_4m_registry(engine
     for g in range(agg["n_groups"]):
         mem = comm.members[comm.offsets[pos[g]]:comm.offsets[pos[g] + 1]]
         assert agg["aggpk96"][g].tobytes() == synth.registry_closed_form(mem[agg["bits"][g]]), g
+
+
+@pytest.mark.parametrize("shape,lag,n_epochs", [("configs1", 2, 3), ("configs1", 4, 5), ("configs2", 2, 3), ("configs2", 4, 3),
+                                                ("configs3", 2, 3), ("configs3", 4, 3), ("configs4", 4, 2)])
+def test_the_timed_path_against_the_oracle(shape, lag, n_epochs):
+    """The path bench.py TIMES -- attestation rows and bits resident in HBM (PE_ROWS_RESIDENT: grouped, resolved and validated
+    on the device), streaming pipelines whose outputs complete `lag` steps later, pe_get_head_async -- held against the C
+    oracle DIRECTLY, on bench.build_workload's own workload at the BASELINE configs[1..4] shapes (configs[2] with its
+    4096-block tree, configs[4] with mixed balances and 8192 blocks): consecutive epochs, every step's union bits, counts,
+    aggregate pubkeys, statuses, head and reward numerators, and the store behind the last one (latest messages, all
+    weights, both participation arrays).  (until now only bench.py's own step-0 check compared this path with
+    the oracle; the -m gpu tests held it against the host-row path.)"""
+    import types
+
+    cfg = bench.SHAPES[shape]
+    args = types.SimpleNamespace(validators_local=cfg["validators"], blocks=cfg["blocks"], committees=cfg["committees"], parts=4,
+                                 mixed_balances=cfg["mixed_balances"], host_arena=False, host_rows=False, with_shuffle=False,
+                                 by_committee=False, world=1, shuffle_variant_from=n_epochs)
+    e = pea.Engine(max_committee_tables=n_epochs + 3)
+    w = bench.build_workload(e, args, 0, n_epochs)
+    assert all("rows_in" in st and "arena_in" in st for st in w["steps"])
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(n_epochs + 2)
+    got = [bench.run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=False) for st in w["steps"]]
+    e.drain()
+    V = w["bal"].size
+    C = cfg["committees"]
+    vote_epoch, vote_block = np.zeros(V, dtype=np.uint64), np.full(V, 0xFFFFFFFF, dtype=np.uint32)
+    for k, (st, r) in enumerate(zip(w["steps"], got)):
+        want = bench.cpu_step(w, st, bench.cpu_step_inputs(w, st), True, vote_epoch, vote_block)
+        agg = r["agg"]
+        assert int(agg["n_groups"]) == C
+        rows = agg["atts"]
+        pos = ((rows["slot"] % 32) * (C // 32) + rows["index"]).astype(np.int64)
+        inv = np.argsort(pos)
+        assert np.array_equal(pos[inv], np.arange(C)), k
+        assert np.array_equal(np.asarray(agg["count"])[inv], want["count"]), k
+        assert np.array_equal(np.asarray(r["count"])[:C][inv], want["count"]), k
+        assert np.array_equal(np.concatenate([np.packbits(agg["bits"][g], bitorder="little") for g in inv]), want["union"]), k
+        assert np.array_equal(np.asarray(agg["aggpk96"])[inv], want["aggpk"]), (k, "aggregate pubkeys")
+        assert (np.asarray(r["status"])[:C] == 0).all() and (np.asarray(r["pstatus"])[:C] == 0).all(), k
+        assert bytes(r["head"]) == want["head"], k
+        assert np.array_equal(np.asarray(r["numerators"])[:C][inv], want["numerators"]), k
+        last = want
+    assert np.array_equal(e.latest_messages()[1], last["vote_block"])
+    assert np.array_equal(e.get_weights(), last["weights"])
+    # the state's slot is the first of the NEXT epoch (bench.state_ctx): the step's attestations are previous-epoch ones, their
+    # flags land in the previous-epoch array on top of what the rotation left there (nothing: the current-epoch array stays empty)
+    assert np.array_equal(e.participation_get(0), last["part_cur"]) and not last["part_cur"].any()
+    assert np.array_equal(e.participation_get(1), last["part_prev"]) and last["part_prev"].any()
+    e.close()

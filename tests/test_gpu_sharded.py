@@ -202,7 +202,7 @@ def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--validators", "65536", "--blocks", "512", "--committees", "256", "--head-calls", "5", "--no-cpu-baseline",
-           "--scaling", scaling]
+           "--scaling", scaling]   # a small custom shape, both ways of dividing it
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -215,6 +215,31 @@ def test_bench_two_ranks_dry_run_on_one_gpu(scaling):
     # every rank (shard-local state, head + weights over the gathered vote tables, all aggregate pubkeys)
     assert "pe_dist_init_custom" in d["config"]["call_mode"]
     assert d["checked_against_oracle"] is True and d["oracle_check"]["aggregate_pubkeys"] and d["oracle_check"]["weights"]
+
+
+@pytest.mark.parametrize("shape,index,validators,blocks", [("configs3", 3, 1 << 20, 4096), ("configs4", 4, 1 << 22, 8192)])
+def test_bench_two_ranks_run_the_named_configs_by_default(shape, index, validators, blocks):
+    """What the round driver launches for N > 1 -- `bench.py --gpus N` with no shape flags -- is BASELINE configs[3] AS
+    WRITTEN (one 1 048 576-validator registry divided over the N GPUs, strong scaling), and `--shape configs4` is
+    configs[4] (4 194 304 validators, mixed balances, 8192 blocks): two ranks sharing this GPU (gloo, host-staged
+    collectives), the first step held against the oracle on every rank, `roofline` in the line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEVO_DIST_BACKEND="gloo", POSEVO_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29560 + index), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--head-calls", "5", "--no-cpu-baseline"] + ([] if shape == "configs3" else ["--shape", shape])
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["workload"].startswith(f"BASELINE configs[{index}] over 2 GPUs"), d["config"]["workload"]
+    assert d["config"]["validators_total"] == validators and d["config"]["validators_per_gpu"] == validators // 2
+    assert d["config"]["blocks"] == blocks
+    assert d["checked_against_oracle"] is True and d["oracle_check"]["aggregate_pubkeys"] and d["oracle_check"]["weights"]
+    assert d["roofline"]["kernel"] == "k_g1_accumulate" and d["roofline"]["achieved"] > 0
 
 
 def test_bench_two_ranks_committee_sharded_dry_run_on_one_gpu():
