@@ -1100,7 +1100,10 @@ int pe_participation_rotate(pe_engine* h)
     (void)hipSetDevice(h->device);
     std::swap(h->d_part_cur, h->d_part_prev);  // previous = current
     // on the state stream, behind the flag passes that still write the old arrays (and off the fork-choice stream)
-    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), state_stream_begin(h)));  // current = 0
+    // The array that becomes "current" was "previous": its last readers and writers are the flag passes of earlier steps, on
+    // this stream; synchronous readers on the engine's stream (pe_participation_get, pe_ffg_balances) complete before they
+    // return.  So the memset needs no ordering against the engine's stream.
+    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), state_stream_unordered(h)));  // current = 0
     return PE_OK;
 }
 

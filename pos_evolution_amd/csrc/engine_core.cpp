@@ -150,6 +150,16 @@ int enter(pe_engine* h)
     const int rc2 = aux_quiesce(h);  // e.g. a participation rotation outside any batch call
     return rc ? rc : rc2;
 }
+// The same stream for work that depends on NOTHING the engine's stream holds (the participation rotation of a new epoch:
+// it follows the previous flag passes on this very stream): no fork event -- every event record on the engine's stream is
+// one more packet in the chain of small kernels that paces a streaming step.
+hipStream_t state_stream_unordered(pe_engine* h)
+{
+    if (h->stream != h->own_stream || !h->aux_stream) return h->stream;
+    h->aux_busy = true;
+    h->A().aux_used = true;
+    return h->aux_stream;
+}
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch)
 {
     // a caller-owned stream (pe_set_stream) carries everything: the caller orders its own work against it

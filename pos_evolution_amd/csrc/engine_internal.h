@@ -412,6 +412,7 @@ int enter(pe_engine* h);
 int need_init(pe_engine* h, bool flush = true);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
+hipStream_t state_stream_unordered(pe_engine* h);  // the same stream, not ordered behind the engine's
 int aux_join(pe_engine* h, hipStream_t ms);  // ms waits for what this pipeline put on the state-transition stream
 
 // ------------------------------------------------------------------ spec helpers (A.10)

@@ -693,17 +693,22 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
                        groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
 }
 
-// one_per_cu (the tree of a streaming step, on its own stream): ask for 77 KB of LDS instead of the 50 KB the kernel uses,
-// so that a CU holding one of its workgroups keeps 83 KB free.  The tree of step N runs when the accumulation of step N
-// retires -- which is when the fork-choice kernels of step N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096
-// blocks) then found no CU with room until this kernel had drained: +60 us on every get_head
-// (profiles/r02_timeline_tree_collision.txt).
-// (Round 4 tried at most 128 workgroups x 84 KB -- never two per CU, half of the CUs free of them -- against the
-// accumulation's occasional 335-355 us launches (instead of 205-240: tools/engine_timeline.py --cold 20): no cure, the tree
-// took twice as long beside the accumulation and stretched it more.  Those launches come from the accumulation's OWN
-// placement: queued behind its predecessor on the side stream, its workgroups are dispatched as CUs free up, the first CUs
-// to finish take TWO (2 x 227 VGPRs fit) and their waves run at half speed; launched once the predecessor has retired
-// everywhere -- behind the step's k_tree -- it spreads one per CU.  Hence POSEVO_G1_DEFER's default.)
+// one_per_cu (the tree of a streaming step, on its own stream): ask for 84 KB of LDS instead of the 50 KB the kernel uses,
+// so that a CU (160 KB) never holds two of its workgroups.  Two reasons, one per round:
+//  * round 2: the tree of step N runs when the accumulation of step N retires -- which is when the fork-choice kernels of step
+//    N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096 blocks) found no CU with room until this kernel had
+//    drained (+60 us on every get_head, profiles/r02_timeline_tree_collision.txt).  With the accumulation launched behind
+//    k_tree the two now rarely meet; k_tree measured 22-28 us in every step of the runs below.
+//  * round 4: the accumulation runs ONE 4-wave workgroup per CU (232 registers per wave) and this kernel's waves take 256:
+//    two tree workgroups fill a CU's registers, the dispatcher skips that CU and puts a second accumulate workgroup on
+//    another one, whose waves then run at half speed -- 330-360 us instead of 205-240 in up to five steps of twenty
+//    (tools/engine_timeline.py --cold 20, 77 KB: two per CU fit); with at most one tree workgroup per CU every CU keeps room
+//    for its accumulate workgroup: 0-1 such steps in twenty over four runs, 291-297 us per step instead of 289-323.
+//    (At most 128 tree workgroups of two slabs each -- half of the CUs free of them -- was tried first: the tree took
+//    twice as long beside the accumulation and stretched it more.)
+// The accumulation has the same problem with ITSELF when it is queued behind its predecessor on the side stream: its
+// workgroups are dispatched as CUs free up and the first CUs to finish take two; hence its launch behind the step's k_tree
+// (engine_internal.h, g1_chain_idle).
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev)
 {
@@ -711,8 +716,8 @@ void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group*
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
     size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
     if (one_per_cu) {
-        constexpr size_t padded = 77 * 1024;
-        if (first_use_on_this_device<77>())
+        constexpr size_t padded = 84 * 1024;
+        if (first_use_on_this_device<84>())
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_tree), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)padded);
         lds_bytes = padded;
