@@ -13,8 +13,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out
 mkdir -p $OUT/prof_$TAG $OUT/pmc_$TAG
 [ -n "${SKIP_FULL:-}" ] || python bench.py > $OUT/${TAG}_bench_full.json 2> $OUT/${TAG}_bench_full.err
+# (--no-verify-steps --no-shuffle-variant --no-oracle-check: the replays run the same kernels ALONE (synchronous calls), the
+# variant steps beside a shuffle; with them in the trace rocprof's per-kernel average is over three different workloads and
+# cannot be held against the bench line's own average over the timed steps)
 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o $TAG -- python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-slot-cadence \
-    > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_$TAG/err.log
+    --no-verify-steps --no-shuffle-variant --no-oracle-check > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_$TAG/err.log
 python tools/rocpd_stats.py $OUT/prof_$TAG/${TAG}_results.db $OUT/${TAG}_kernel_stats.txt > /dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -o fetch -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-slot-cadence \
     > $OUT/pmc_$TAG/fetch.log 2>&1
