@@ -144,7 +144,7 @@ def test_the_timed_path_against_the_oracle(shape, lag, n_epochs):
     w = bench.build_workload(e, args, 0, n_epochs)
     assert all("rows_in" in st and "arena_in" in st for st in w["steps"])
     e.set_pipeline_lag(lag)
-    e.reuse_outputs(n_epochs + 2)
+    e.reuse_outputs(max(n_epochs, lag) + 2)   # the output ring must be deeper than the lag
     got = [bench.run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=False) for st in w["steps"]]
     e.drain()
     V = w["bal"].size
