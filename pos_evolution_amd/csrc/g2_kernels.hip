@@ -10,6 +10,9 @@
 //   k_g2_finish      per group: add the workgroup partials, normalise to canonical affine, store big-endian
 //
 // Bound: integer VALU, 36 Montgomery products per gathered 192-byte point.
+// (Round 4 measured this file's kernels with their Fp products as CALLS, like g1_kernels.hip's -- DESIGN.md 3.8: k_g2_accumulate
+// 1.222 ms against 1.218 ms inlined, 2048 x 512 points (gpurun_out/r04g2): its five LDS tree levels of 26 dependent products
+// are what it waits for, not instruction fetch.  The inlined form stays: no scratch.)
 #include "g2.h"
 #include "fp_sqrt.h"
 #include "kernels.h"
