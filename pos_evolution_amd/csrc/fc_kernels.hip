@@ -272,8 +272,9 @@ __device__ __forceinline__ void block_exclusive_scan2(const unsigned long long (
     __syncthreads();
 }
 
-// LEAN: the form that fits beside a running k_g1_accumulate (two waves of 168 VGPRs per SIMD leave 176 registers per
-// SIMD lane; a 512-lane workgroup = two waves per SIMD of 64 here).  Parent, rank and block index are loaded where they
+// LEAN: the form that fits beside a running k_g1_accumulate (one wave of 232 VGPRs per SIMD in streaming steps leaves
+// 280 registers per SIMD lane -- rounds 2-3: two waves of 168, 176 left; a 512-lane workgroup = two waves per SIMD of <= 88
+// here, where the 1024-lane shapes take 4 x 84).  Parent, rank and block index are loaded where they
 // are used instead of up front -- three more round trips to L2, ~6 us -- so only pipelined calls use it.
 // lds_entries: skewed index range of this launch (the host sizes the dynamic LDS for the block count at hand, not for
 // the 8192-block maximum: 82 KB at 4096 blocks leaves room for another kernel's workgroup on the CU).

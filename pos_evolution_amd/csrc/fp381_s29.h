@@ -1,6 +1,6 @@
 // fp381_s29.h -- BLS12-381 base field in 14 signed limbs of 29 bits ("S29"), Montgomery constant R' = 2^406.
 //
-// Why a second form next to fp381.h (12 x 32 bits, R = 2^384): half of that product's 689 instructions are carry
+// Why this form next to fp381.h (12 x 32 bits, R = 2^384): half of that product's 689 instructions are carry
 // handling -- v_mad_u64_u32 has a carry-out but no carry-in, a full 32 x 32 product plus a 64-bit accumulator overflows,
 // every limb product pays a v_addc_co_u32 (288 per product), plus ~65 moves that slide the 96-bit column accumulator and
 // the conditional subtraction.  With 29-bit limbs a column of the interleaved (FIPS) Montgomery product -- up to 14
@@ -8,12 +8,12 @@
 // limb product and nothing else, ~505 instructions per product instead of 689, written in plain C++ (no inline assembly:
 // the compiler sees the whole product and the same source compiles for the host, where tests/test_host_fp29.py holds it
 // against Python integers).
-// AN EXPERIMENT, NOT A CLAIM: the price is 392 multiply-adds per product instead of 288, and by the instruction timings
-// measured in round 1 (profiles/r01_ubench_valu_fpmul.log, 4 waves / SIMD: v_mad_u64_u32 2.45 ns, mad + addc pair 3.22 ns,
-// v_add_u32 1.2 ns, 64-bit shift 3.5 ns per instruction and SIMD) a multiply-add costs two simple instructions and the
-// carry behind it is three quarters hidden: 392 x 2.45 = 960 ns of multiply-adds alone against 927 ns for the 288 pairs
-// of the 32-bit form.  By instruction count this form is 0.75 x the work, by those timings ~10 % MORE; tools/fpbench29
-// settles it on hardware in seconds.  Until then POSEVO_G1_S29 stays off.
+// The price is 392 multiply-adds per product instead of 288.  Round 3 wrote this form and could not run it; by the
+// per-instruction timings of round 1 it predicted a wash (the carry add behind a multiply-add "three quarters hidden").
+// Round 4 measured (tools/fpbench29, tools/icbench, tools/accbench): 14 % more dependent products per second,
+// 25 % more mixed adds (the squaring is 301 multiply-adds), and the accumulation kernel 158 us against 183 for a million
+// points -- a mixed add of 3 738 multiply-adds runs at the multiplier's issue rate, the simple instructions around them are
+// free and carries are not.  It is the accumulation's form; tree, finish and the wire formats stay in fp381.h.
 //
 // Lazy, signed values.  R' / p > 2^25, so a product of operands of magnitude < 2^386 (32 p) comes out in (-eps, p + eps)
 // with no final subtraction; a - b is a plain limb-wise subtraction (limbs of both signs are fine in the next product as

@@ -109,57 +109,6 @@ __device__ __forceinline__ void g1x_add_affine(g1x& acc, const fp& qx, const fp&
     acc.x = X3;
 }
 
-// acc += q inside a lane's run of mixed adds.  `affine` says that acc still is the run's first point, (x, y, 1, 1): the add
-// is then affine + affine (mmadd-2008-s, 4M + 2S) -- the four products by ZZ1 = ZZZ1 = 1 are branched around, not
-// executed.  In the iteration where most lanes of a wave hold exactly one point no lane needs them (a lane is affine or
-// still empty), so the wave skips them: 66 instead of 70 products for a run of eight.  Same results as g1x_add_affine.
-__device__ __forceinline__ void g1x_add_affine_run(g1x& acc, bool& affine, const fp& qx, const fp& qy, bool q_inf)
-{
-    if (q_inf) return;
-    if (g1x_is_inf(acc)) {
-        acc.x = qx;
-        acc.y = qy;
-        fp_set_one(acc.zz);
-        fp_set_one(acc.zzz);
-        affine = true;
-        return;
-    }
-    fp U2 = qx, S2 = qy, P, R;
-    if (!affine) {
-        fp_mul(U2, qx, acc.zz);
-        fp_mul(S2, qy, acc.zzz);
-    }
-    fp_sub(P, U2, acc.x);
-    fp_sub(R, S2, acc.y);
-    if (fp_is_zero(P)) {
-        if (fp_is_zero(R)) acc = g1x_double(acc);
-        else g1x_set_inf(acc);
-        affine = false;
-        return;
-    }
-    fp PP, PPP, Q, X3, t;
-    fp_sqr(PP, P);
-    fp_mul(PPP, P, PP);
-    fp_mul(Q, acc.x, PP);
-    fp_sqr(X3, R);
-    fp_sub(X3, X3, PPP);
-    fp_dbl(t, Q);
-    fp_sub(X3, X3, t);
-    fp_sub(t, Q, X3);
-    fp_mul(t, R, t);
-    fp_mul(Q, acc.y, PPP);
-    fp_sub(acc.y, t, Q);
-    if (affine) {
-        acc.zz = PP;
-        acc.zzz = PPP;
-    } else {
-        fp_mul(acc.zz, acc.zz, PP);
-        fp_mul(acc.zzz, acc.zzz, PPP);
-    }
-    acc.x = X3;
-    affine = false;
-}
-
 // p += q, both XYZZ (add-2008-s: 12M + 2S), single lane, all edge cases
 __device__ __forceinline__ void g1x_add(g1x& p, const g1x& q)
 {
