@@ -1027,7 +1027,20 @@ def main():
                 e.set_pipeline_lag(args.lag)
             e.reuse_outputs(total_all + 2 if verify else lag + 2)
         kept, sharded_chk = [], None
+        import gc
+
+        def quiet_the_host():
+            # Python's cyclic collector is paused over the timed steps: with torch loaded a full collection walks ~10^6
+            # objects (tens of ms) and, landing inside a 20-step window, would be charged to the engine as +2 ms per step.
+            # Collected HERE -- in front of the last warm-up steps, not between them and the clock: tens of milliseconds of
+            # idle GPU in front of a 6 ms timed region is a cold start, which is not what W warm-up steps are for.
+            gc.collect()
+            gc.disable()
+            e.profile_enable(True)
+
         for s in range(args.warmup):
+            if s == 1:
+                quiet_the_host()
             kept.append(step(w["steps"][s]))
             if s == 0:
                 e.drain()
@@ -1038,14 +1051,10 @@ def main():
                     # N > 1: the first step of the run (a fresh store on every rank) against the oracle, before the clock
                     sharded_chk = (committee_step_check if args.by_committee else sharded_step_check)(
                         e, w, w["steps"][0], kept[0], rank, world, dist, args)
+        if args.warmup < 2:
+            quiet_the_host()
         e.drain()
-        e.profile_enable(True)
-        e.profile_reset()
-        # Python's cyclic collector is paused over the timed steps: with torch loaded a full collection walks ~10^6
-        # objects (tens of ms) and, landing inside a 20-step window, would be charged to the engine as +2 ms per step.
-        import gc
-        gc.collect()
-        gc.disable()
+        e.profile_reset()   # the warm-up launches are not part of the per-kernel averages
         barrier()
         t0 = time.perf_counter()
         inflight = []

@@ -11,7 +11,7 @@
 #   trace            quick under POSEVO_HOST_TRACE=1                              -> host_trace.txt
 #   timeline         rocprofv3 --kernel-trace of 30 steps                         -> timeline.txt, kernel_stats.txt
 #   pmc              FETCH_SIZE / WRITE_SIZE passes (kernel-trace only)           -> pmc_fetch.json, pmc_write.json
-#   env:<NAME>=<V>   export a variable for the actions that follow (e.g. env:POSEVO_G1_MIN_K=8)
+#   env:<NAME>=<V>   export a variable for the actions that follow (e.g. env:POSEVO_PIPELINE_LAG=3)
 #   label:<name>     suffix for the output files of the actions that follow
 set -u
 TAG=${1:?tag}; shift
