@@ -605,6 +605,8 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
             // to its two-wave shape alone (tools/accbench) and leaves every SIMD the registers the guests of a streaming
             // step need -- k_g1_tree, k_g1_finish, k_att_plan, the fork-choice chain all run beside it.  Synchronous calls:
             // the shape the first four large calls measured faster.
+            // (also at configs[4], where the accumulation is 0.89 of the 0.95 ms step: two waves per SIMD measured 1.00-1.05 ms
+            // there -- the accumulation 0.92-0.99 ms instead of 0.89, k_g1_tree 0.75 ms waiting for registers)
             if (h->streaming) target = G1_TARGET_LANES / 2;
             else if (h->g1_target_slots) target = h->g1_target_slots;
             else {
