@@ -56,7 +56,9 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     } else {
         const uint64_t n_rows = h->tmp_points_n;
         if (d_points != h->d_tmp_points.as<uint32_t>()) return fail(h, PE_ERR_STATE, "G1 sum over an unknown point table");
-        PE_TRY(ensure_quiesced(h, h->d_tmp_points29, std::max<size_t>(128, 4ull * G1_ROW_WORDS * n_rows)));
+        // sized like d_tmp_points, by its callers' rule: engine-owned scratch of calls that complete before they return (a
+        // flush from here could complete the current arena in the middle of the call that is filling it)
+        HIP_TRY(h, h->d_tmp_points29.ensure(std::max<size_t>(128, 4ull * G1_ROW_WORDS * n_rows)));
         launch_g1_table_s29(s, d_points, h->d_tmp_points29.as<uint32_t>(), n_rows);
         d_points29 = h->d_tmp_points29.as<uint32_t>();
     }

@@ -1,0 +1,59 @@
+"""CPU: what bench.py promises the round driver without running anything on a GPU -- its named shapes are BASELINE.json's
+configs as written, `--gpus N` alone means configs[3] under strong scaling, and the JSON keys the contract names exist in
+the line's template."""
+import ast
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_source():
+    return open(os.path.join(ROOT, "bench.py")).read()
+
+
+def _shapes():
+    tree = ast.parse(_bench_source())
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == "SHAPES":
+            return eval(compile(ast.Expression(node.value), "bench.SHAPES", "eval"))   # a literal dict of dict(...) calls
+    raise AssertionError("bench.SHAPES not found")
+
+
+def _number(text, pattern):
+    m = re.search(pattern, text)
+    assert m, (pattern, text)
+    return int(m.group(1).replace(" ", "").replace(" ", ""))
+
+
+def test_named_shapes_are_the_baseline_configs_as_written():
+    cfgs = json.load(open(os.path.join(ROOT, "BASELINE.json")))["configs"]
+    shapes = _shapes()
+    for k in (1, 2, 3, 4):
+        sh = shapes[f"configs{k}"]
+        assert sh["validators"] == _number(cfgs[k], r"^([\d ]+) validators"), cfgs[k]
+    assert shapes["configs1"]["committees"] == 64 * 32                      # "64 committees/slot"
+    assert shapes["configs2"]["blocks"] == _number(cfgs[2], r"deep ([\d ]+)-block")
+    assert shapes["configs4"]["blocks"] == _number(cfgs[4], r", ([\d ]+)-block tree")
+    assert shapes["configs4"]["mixed_balances"] is True and "mixed balances" in cfgs[4]
+    assert shapes["configs3"]["validators"] // shapes["configs3"]["committees"] == 512
+
+
+def test_gpus_n_alone_is_a_named_config_under_strong_scaling():
+    src = _bench_source()
+    assert re.search(r'"--shape".*default="configs3"', src)
+    assert re.search(r'"--scaling", choices=\["strong", "weak"\], default="strong"', src)
+    # the workload string of a named shape starts the way the driver's reader expects
+    assert 'f"BASELINE configs[{named}]"' in src
+
+
+def test_the_contract_keys_are_in_the_line():
+    src = _bench_source()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert f'"{key}"' in src, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert f'"{key}"' in src, key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert f'"{key}"' in src or f"{key}=" in src, key
