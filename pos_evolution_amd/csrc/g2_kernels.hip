@@ -409,11 +409,38 @@ void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* 
 }
 
 // ---------------------------------------------------------------- subgroup check
-// r * P == infinity for every decoded point (is_valid_indexed_attestation, pe:736 / pe:976, presumes signatures in G2:
-// a point of the curve outside the r-torsion is not a BLSSignature).  Lane pair per point, left-to-right double-and-add
-// over the 255 bits of r (uniform control flow: r is a constant), mixed adds of the affine input.  ~6.4 k Montgomery
-// products per lane: an explicit validation step (PE_SIG_CHECK_SUBGROUP), not part of the default hot path.
+// Membership of G2 for every decoded point (is_valid_indexed_attestation, pe:736 / pe:976, presumes signatures in G2: a point
+// of the curve outside the r-torsion is not a BLSSignature) by the endomorphism test (round 4; M. Scott, "A note on group
+// membership tests for G1, G2 and GT on BLS pairing-friendly curves", 2021):   P in G2  <=>  psi(P) = [z] P,   z = the curve's
+// parameter -0xd201000000010000, psi = untwist-Frobenius-twist: psi(x, y) = (c_x conj(x), c_y conj(y)) with
+// c_x = 1 / (1 + u)^((p - 1) / 3), c_y = 1 / (1 + u)^((p - 1) / 2).  63 doublings + 5 mixed adds (|z| has six bits set) + six
+// Fp2 products instead of the 254 doublings + 127 adds of r * P == infinity (rounds 1-3): ~1.6 k instead of ~6.4 k Montgomery
+// products per lane.  Lane pair per point, uniform control flow (z is a constant).  The constants and the criterion are
+// derived and checked against oracle/g2.py in tests/test_oracle_g2_psi.py (CPU): psi(P) == [z]P on multiples of the generator,
+// psi(P) != [z]P on curve points outside the subgroup, exactly where r * P != infinity.
 // status[i]: 0 stays 0 when the point is in G2 (or is infinity), becomes 3 otherwise; non-zero entries are left alone.
+namespace {
+// Montgomery limbs (R = 2^384) of c_x = (0, CX1) and c_y = (CY0, CY1)
+__device__ __forceinline__ constexpr uint32_t psi_cx1_limb(int j)
+{
+    return j == 0 ? 0x867545c3u : j == 1 ? 0x890dc9e4u : j == 2 ? 0x3285a5d5u : j == 3 ? 0x2af32253u
+         : j == 4 ? 0x309b7e2cu : j == 5 ? 0x50880866u : j == 6 ? 0x7e881024u : j == 7 ? 0xa20d1b8cu
+         : j == 8 ? 0xe2db9068u : j == 9 ? 0x14e4f04fu : j == 10 ? 0x1564853au : 0x14e56d3fu;
+}
+__device__ __forceinline__ constexpr uint32_t psi_cy0_limb(int j)
+{
+    return j == 0 ? 0xa55c9ad1u : j == 1 ? 0x3e2f585du : j == 2 ? 0x86c18183u : j == 3 ? 0x4294213du
+         : j == 4 ? 0x8b623732u : j == 5 ? 0x382844c8u : j == 6 ? 0x19103e18u : j == 7 ? 0x92ad2afdu
+         : j == 8 ? 0xac7cf0b9u : j == 9 ? 0x1d794e4fu : j == 10 ? 0x7d825ec8u : 0x0bd592fcu;
+}
+__device__ __forceinline__ constexpr uint32_t psi_cy1_limb(int j)
+{
+    return j == 0 ? 0x5aa30fdau : j == 1 ? 0x7bcfa7a2u : j == 2 ? 0x2a927e7cu : j == 3 ? 0xdc17dec1u
+         : j == 4 ? 0x6b4ebef1u : j == 5 ? 0x2f088dd8u : j == 6 ? 0xda74d4a7u : j == 7 ? 0xd1ca2087u
+         : j == 8 ? 0x96cebc1du : j == 9 ? 0x2da25966u : j == 10 ? 0xbbfd87d2u : 0x0e2b7eedu;
+}
+}  // namespace
+
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g2_subgroup_check(const uint32_t* __restrict__ pts, uint64_t n, int32_t* __restrict__ status)
 {
@@ -427,18 +454,38 @@ k_g2_subgroup_check(const uint32_t* __restrict__ pts, uint64_t n, int32_t* __res
     ld12(px, p);
     ld12(py, p + 24);
     if (pair_and(fp_is_zero(px) && fp_is_zero(py))) return;  // infinity: in every subgroup
-    // r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, most significant word first
-    const uint32_t R[8] = {0x73EDA753u, 0x299D7D48u, 0x3339D808u, 0x09A1D805u, 0x53BDA402u, 0xFFFE5BFEu, 0xFFFFFFFFu, 0x00000001u};
+    // Q = [|z|] P, left to right over |z| = 0xd201000000010000 (bit 63 is the leading one)
+    const uint32_t Z_HI = 0xd2010000u, Z_LO = 0x00010000u;
     g2x acc;
     g2x_set_inf(acc);
-    g2x_add_affine(acc, px, py, false, role);  // the leading one of r (bit 254)
-    for (int w = 0; w < 8; ++w) {
-        for (int b = (w == 0 ? 29 : 31); b >= 0; --b) {  // word 0 holds bits 254 .. 224: bit 254 = its bit 30
-            acc = g2x_double(acc, role);
-            if ((R[w] >> b) & 1u) g2x_add_affine(acc, px, py, false, role);
-        }
+    g2x_add_affine(acc, px, py, false, role);
+    for (int b = 62; b >= 0; --b) {
+        acc = g2x_double(acc, role);
+        const uint32_t w = b >= 32 ? Z_HI : Z_LO;
+        if ((w >> (b & 31)) & 1u) g2x_add_affine(acc, px, py, false, role);
     }
-    if (!g2x_is_inf(acc) && !role) status[i] = 3;
+    // psi(P): conjugate (the c1 lane negates its half), times the constants
+    fp xc, yc, cx, cy, nx, ny, X, Y;
+    fp_neg(nx, px);
+    fp_neg(ny, py);
+    fp_select(xc, role, nx, px);
+    fp_select(yc, role, ny, py);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        cx.l[j] = role ? psi_cx1_limb(j) : 0u;
+        cy.l[j] = role ? psi_cy1_limb(j) : psi_cy0_limb(j);
+    }
+    f2_mul(X, xc, cx, role);
+    f2_mul(Y, yc, cy, role);
+    // psi(P) == [z] P = -Q   <=>   Q.X == X ZZ   and   Q.Y + Y ZZZ == 0   (Q = (X/ZZ, Y/ZZZ), not infinity)
+    fp t1, t2, d1, d2;
+    f2_mul(t1, X, acc.zz, role);
+    f2_mul(t2, Y, acc.zzz, role);
+    fp_sub(d1, acc.x, t1);
+    fp_add(d2, acc.y, t2);
+    const bool q_inf = g2x_is_inf(acc);
+    const bool same = f2_is_zero(d1) & f2_is_zero(d2);   // both exchanges executed by both lanes
+    if ((q_inf || !same) && !role) status[i] = 3;
 }
 
 void launch_g2_subgroup_check(hipStream_t s, const uint32_t* points_mont48, uint64_t n, int32_t* status)
