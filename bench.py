@@ -22,6 +22,7 @@ exchange steps are one RCCL all-gather of G1 XYZZ partials (192 B per committee)
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import functools
 import json
 import os
 import sys
@@ -142,8 +143,9 @@ def _timed(name, fn, *a, **k):
     return r
 
 
-def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
-    """One epoch through the per-function C ABI.  pipelined: the three batch calls enqueue and return, the aggregate's
+def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True, sigs=None):
+    """One epoch through the per-function C ABI (sigs: one compressed BLSSignature per row -> pe_aggregate_signed in
+    pe_aggregate's place).  pipelined: the three batch calls enqueue and return, the aggregate's
     rows + OR-ed bits stay on the device for the two handlers (PE_BITS_RESIDENT), get_head polls its head word, and
     pe_pipeline_end waits ONCE for every output (include/posevo.h "pipelined calls").  Same results either way
     (tests/test_gpu_pipeline.py)."""
@@ -152,6 +154,7 @@ def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
     ep = st["epoch"]
     e.on_tick((ep + 1) * w["spe"] * 12)
     e.participation_rotate()
+    aggregate = e.aggregate if sigs is None else functools.partial(e.aggregate_signed, sigs)
     if "rows_in" in st and pipelined:
         # rows + bits resident in HBM: the host enqueues a fixed sequence of launches and reads nothing of the rows
         cap = st["comm"].offsets.size - 1   # one AttestationData per committee in this workload: groups <= committees
@@ -161,7 +164,7 @@ def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
             # beside this step's kernels
             _timed("compute_committees", e.compute_committees_async, *st["next_shuffle"])
         with e.pipeline(lagged=lagged):
-            agg = _timed("aggregate", e.aggregate, packed=(st["rows_in"], st["arena_in"]), want_aggregate_pubkeys=True)
+            agg = _timed("aggregate", aggregate, packed=(st["rows_in"], st["arena_in"]), want_aggregate_pubkeys=True)
             status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
             # the root arrives with the step's other outputs (two steps behind, like them): the loop never blocks on the
             # device inside a step; --sync-head polls for it as pe_get_head does
@@ -170,7 +173,7 @@ def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
                               packed=(ROWS_RESIDENT, RESIDENT), cap=cap)
         return dict(agg=agg, rows=None, status=status, count=count, pstatus=st2, numerators=num, head=head)
     if not pipelined:
-        agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
+        agg = _timed("aggregate", aggregate, packed=(st["atts"], st["arena"]), want_aggregate_pubkeys=True)
         rows = agg["atts"]
         status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, agg["out_arena"]))
         st2, num = _timed("process_attestation", e.process_attestation_batch, st["ctx"],
@@ -180,7 +183,7 @@ def run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=True):
     # lagged: this step's outputs are complete when the NEXT step's block exits (the last one at e.drain(), inside the
     # timed region): the G1 sums of step N run on the second stream while the host prepares step N+1
     with e.pipeline(lagged=lagged):
-        agg = _timed("aggregate", e.aggregate, packed=(st["atts"], st.get("arena_in", st["arena"])),
+        agg = _timed("aggregate", aggregate, packed=(st["atts"], st.get("arena_in", st["arena"])),
                      want_aggregate_pubkeys=True)
         rows = agg["atts"]
         status, _, count = _timed("on_attestation", e.on_attestation_batch, packed=(rows, RESIDENT))
@@ -650,6 +653,9 @@ def step_digest(r):
     for a in (r["status"][:g], r["count"][:g], r["pstatus"][:g], r["numerators"][:g], agg["atts"][:g], agg["out_arena"],
               agg["aggpk96"][:g], agg["count"][:g], agg["group_of"]):
         h.update(np.ascontiguousarray(a).tobytes())
+    if "_raw" in agg and "sig96c" in agg["_raw"]:   # pe_aggregate_signed: the aggregate signatures, per-row statuses
+        h.update(np.ascontiguousarray(agg["sig96c"]).tobytes())
+        h.update(np.ascontiguousarray(agg["sig_status"]).tobytes())
     return h.digest()
 
 
@@ -671,6 +677,89 @@ def replay_and_verify(pea, w, device, results, total):
         same.append(step_digest(r) == step_digest(results[s]))
     e2.close()
     return same
+
+
+def signed_steps(pea, w, device, n_warm, n_timed, lag):
+    """The step with the signature leg of the aggregation (pe:659, pe:717, pe:1536: bls.Aggregate over the members'
+    BLSSignatures): pe_aggregate_signed in pe_aggregate's place -- one 96-byte compressed signature per partial aggregate
+    (8192 a step at configs[3]), resident in HBM like the rows, decompressed on the device (one Fp2 square root each), summed
+    per group and handed back compressed.  Same streaming pipelines as the headline steps, on a fresh engine; afterwards every
+    step is replayed with synchronous host-row calls (digest equality, signatures and per-row statuses included) and a
+    sample of step 0's aggregate signatures is held against the oracle's closed form.  -> the `with_signatures` object."""
+    import torch
+    from oracle import g2   # the checker of the sampled aggregate signatures
+    from pos_evolution_amd import DeviceArena
+    import pos_evolution_amd.synth as synth
+
+    steps = w["steps"][:n_warm + n_timed]
+    tree = w["tree"]
+
+    def make_engine():
+        e = pea.Engine(device=device, max_committee_tables=len(steps) + 2)
+        e.store_init(0, 0, tree.roots[0].tobytes())
+        for i in range(1, tree.roots.shape[0]):
+            e.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+        e.set_validators(w["bal"], w["flags"], w["pts"])
+        for st in steps:
+            e.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
+        return e
+
+    e = make_engine()
+    n_rows = len(steps[0]["atts"])
+    assert all(len(st["atts"]) == n_rows for st in steps)
+    a, b = 0xABCDEF12345, 0x1357
+    sigs = synth.signature_points(e, n_rows, a, b)            # row i signs with (a + i * b) * G2
+    sig_t = torch.from_numpy(sigs.reshape(-1).copy()).cuda()
+    sig_dev = DeviceArena(sig_t.data_ptr(), sig_t.numel(), keep=sig_t)
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(len(steps) + 2)
+    got = [run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev) for st in steps[:n_warm]]
+    e.drain()
+    e.fill_ring()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for st in steps[n_warm:]:
+        got.append(run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev))
+    e.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_att = int(sum(int(np.asarray(r["count"]).sum()) for r in got[n_warm:]))
+    for r in got:
+        r["head"] = bytes(r["head"])
+    bad_rows = int(sum(int((np.asarray(r["agg"]["sig_status"]) != 0).sum()) for r in got))
+    e.close()
+    # a sample of step 0's groups against the closed form (|S| a + b sum(i)) G2 of their member rows
+    agg0 = got[0]["agg"]
+    gof = np.asarray(agg0["group_of"])[:n_rows]
+    ng = int(agg0["n_groups"])
+    sample = sorted(set(int(x) for x in np.linspace(0, ng - 1, 32)))
+    ok = True
+    for k in sample:
+        rows = np.nonzero(gof == k)[0]
+        want = g2.compress(g2.mul((len(rows) * a + b * int(rows.sum())) % g2.R_ORDER, g2.G2))
+        ok = ok and bytes(agg0["sig96c"][k]) == want
+    # every step again: synchronous calls over host rows and host signatures on a fresh engine
+    e2 = make_engine()
+    same = []
+    for st, r in zip(steps, got):
+        host_st = {k: v for k, v in st.items() if k not in ("rows_in", "arena_in")}
+        same.append(step_digest(run_step_single(e2, w, host_st, pipelined=False, sigs=sigs)) == step_digest(r))
+    e2.close()
+    assert ok, "aggregate signatures differ from the oracle's closed form"
+    assert all(same), f"signed steps differ from their synchronous replay: {[i for i, x in enumerate(same) if not x][:8]}"
+    assert bad_rows == 0
+    return {
+        "ms_per_step_with_signatures": dt / n_timed * 1e3,
+        "attestations_per_s": n_att / dt,
+        "signatures_per_step": n_rows,
+        "steps": n_timed, "warmup": n_warm,
+        "detail": ("pe_aggregate_signed in pe_aggregate's place: one compressed BLSSignature (96 B, resident in HBM) per partial "
+                   "aggregate -> k_g2_decompress (an Fp2 square root each) -> per-group G2 sums -> compressed aggregate "
+                   "signatures, on the state-transition stream beside the aggregate pubkeys and the fork choice; the rest of "
+                   "the step as the headline's; streaming pipelines, drain included"),
+        "steps_verified": int(sum(same[n_warm:])),
+        "aggregate_signatures_checked_against_oracle": len(sample),
+    }
 
 
 def slot_cadence(pea, w, device, n_epochs, lag):
@@ -887,6 +976,8 @@ def main():
                          "(ReplayCollectives).  A measurement of the per-rank step, not of a collective")
     ap.add_argument("--no-shuffle-variant", action="store_true",
                     help="skip the extra steps that report ms_per_step_with_shuffle")
+    ap.add_argument("--no-signed-steps", action="store_true",
+                    help="skip the steps with the signature leg (pe_aggregate_signed): the `with_signatures` object")
     ap.add_argument("--no-slot-cadence", action="store_true",
                     help="skip the per-slot run that reports `slot_cadence` (one GPU)")
     ap.add_argument("--no-oracle-check", action="store_true",
@@ -1331,6 +1422,15 @@ def main():
     if world == 1 and not emulate and not args.no_slot_cadence and not args.no_pipeline and not args.host_rows \
             and not args.host_arena and len(w["steps"]) >= 4 and C % w["spe"] == 0:
         out["slot_cadence"] = slot_cadence(pea, w, local_rank, 3, args.lag)
+    if world == 1 and not emulate and not args.no_signed_steps and not args.no_pipeline and not args.host_rows \
+            and not args.host_arena and not args.no_lag:
+        n_signed = min(20, args.steps)
+        try:
+            out["with_signatures"] = signed_steps(pea, w, local_rank, min(3, len(w["steps"]) - n_signed), n_signed, args.lag)
+            out["ms_per_step_with_signatures"] = out["with_signatures"]["ms_per_step_with_signatures"]
+        except (AssertionError, pea.EngineError) as err:   # an extra leg: reported, never at the cost of the headline line
+            print(f"[bench] with_signatures failed: {err!r}", file=sys.stderr)
+            out["with_signatures"] = {"error": repr(err)}
     if not args.no_cpu_baseline and world == 1:
         base, chk = cpu_baseline(w, w["steps"][0])
         out["cpu_baseline"] = base

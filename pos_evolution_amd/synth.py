@@ -267,3 +267,86 @@ def registry_closed_form(indices, a: int = 0x1234567, b: int = 0x89ABCDE) -> byt
     r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
     idx = [int(i) for i in indices]
     return _enc96(_ec_mul((len(idx) * a + sum(idx) * b) % r, _G))
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic BLSSignatures S_i = (a + i*b) * G2 for the signature leg of the aggregation (pe:659, pe:717), built the
+# same way: two short pure-Python progressions on the twist E'/Fp2: y^2 = x^3 + 4(1 + u), the engine's G2 sum for the
+# pairs.  A group's aggregate signature then has the closed form (|S|*a + b*sum(i)) * G2.
+# ---------------------------------------------------------------------------------------------
+_G2 = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+        0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+       (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+        0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
+
+
+def _f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % _P, (a[0] * b[1] + a[1] * b[0]) % _P)
+
+
+def _f2_inv(a):
+    t = pow(a[0] * a[0] + a[1] * a[1], -1, _P)
+    return (a[0] * t % _P, -a[1] * t % _P)
+
+
+def _ec2_add(p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    (x1, y1), (x2, y2) = p, q
+    if x1 == x2:
+        if ((y1[0] + y2[0]) % _P, (y1[1] + y2[1]) % _P) == (0, 0):
+            return None
+        xx = _f2_mul(x1, x1)
+        lam = _f2_mul((3 * xx[0] % _P, 3 * xx[1] % _P), _f2_inv((2 * y1[0] % _P, 2 * y1[1] % _P)))
+    else:
+        lam = _f2_mul(((y2[0] - y1[0]) % _P, (y2[1] - y1[1]) % _P), _f2_inv(((x2[0] - x1[0]) % _P, (x2[1] - x1[1]) % _P)))
+    ll = _f2_mul(lam, lam)
+    x3 = ((ll[0] - x1[0] - x2[0]) % _P, (ll[1] - x1[1] - x2[1]) % _P)
+    t = _f2_mul(lam, ((x1[0] - x3[0]) % _P, (x1[1] - x3[1]) % _P))
+    return (x3, ((t[0] - y1[0]) % _P, (t[1] - y1[1]) % _P))
+
+
+def _ec2_mul(k, p):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _ec2_add(acc, p)
+        p = _ec2_add(p, p)
+        k >>= 1
+    return acc
+
+
+def _enc192(p) -> bytes:
+    """ZCash order: x.c1 || x.c0 || y.c1 || y.c0 (include/posevo.h, PE_SIG_G2_UNCOMPRESSED)."""
+    if p is None:
+        return bytes([0x40]) + bytes(191)
+    (x0, x1), (y0, y1) = p
+    return x1.to_bytes(48, "big") + x0.to_bytes(48, "big") + y1.to_bytes(48, "big") + y0.to_bytes(48, "big")
+
+
+def signature_points(engine, n: int, a: int = 0xABCDEF12345, b: int = 0x1357) -> np.ndarray:
+    """(n, 96) uint8: row i = the compressed BLSSignature (a + i*b) * G2.  i = i0 + 128*i1, n <= 16384."""
+    assert n <= 128 * 128
+    A, B = _ec2_mul(a, _G2), _ec2_mul(b, _G2)
+    t0, cur = [], A
+    for _ in range(128):
+        t0.append(cur)
+        cur = _ec2_add(cur, B)
+    t1, cur, step = [], None, _ec2_mul(128, B)
+    for _ in range(128):
+        t1.append(cur)
+        cur = _ec2_add(cur, step)
+    table = np.frombuffer(b"".join(_enc192(p) for p in t0 + t1), dtype=np.uint8).reshape(-1, 192)
+    i = np.arange(n, dtype=np.uint32)
+    idx = np.stack([i & 127, 128 + (i >> 7)], axis=1).reshape(-1)
+    pts = engine.g2_sum(table, np.arange(0, 2 * n + 1, 2, dtype=np.uint32), index=idx)
+    return engine.g2_compress(pts)
+
+
+def signature_closed_form(rows, a: int = 0xABCDEF12345, b: int = 0x1357):
+    """The affine point sum_{i in rows} (a + i*b) * G2 (x, y as (c0, c1) pairs; None = infinity), pure Python."""
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    rows = [int(i) for i in rows]
+    return _ec2_mul((len(rows) * a + sum(rows) * b) % r, _G2)

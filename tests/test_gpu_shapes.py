@@ -173,3 +173,21 @@ def test_the_timed_path_against_the_oracle(shape, lag, n_epochs):
     assert np.array_equal(e.participation_get(0), last["part_cur"]) and not last["part_cur"].any()
     assert np.array_equal(e.participation_get(1), last["part_prev"]) and last["part_prev"].any()
     e.close()
+
+
+def test_the_signed_steps_of_the_bench():
+    """bench.py's `with_signatures` leg at the configs[1] shape: streaming steps whose aggregate is pe_aggregate_signed over
+    signatures resident in HBM -- its own checks (every step == its synchronous host-row replay, signatures and statuses
+    included; sampled aggregate signatures == the oracle's closed form) are assertions inside."""
+    import types
+
+    cfg = bench.SHAPES["configs1"]
+    args = types.SimpleNamespace(validators_local=cfg["validators"], blocks=cfg["blocks"], committees=cfg["committees"], parts=4,
+                                 mixed_balances=False, host_arena=False, host_rows=False, with_shuffle=False,
+                                 by_committee=False, world=1, shuffle_variant_from=6)
+    e = pea.Engine(max_committee_tables=8)
+    w = bench.build_workload(e, args, 0, 6)
+    e.close()
+    out = bench.signed_steps(pea, w, 0, 2, 4, 4)
+    assert out["steps_verified"] == 4 and out["signatures_per_step"] == 8192
+    assert out["aggregate_signatures_checked_against_oracle"] == 32 and out["ms_per_step_with_signatures"] > 0

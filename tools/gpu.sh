@@ -34,7 +34,7 @@ for act in "$@"; do
       timeout 900 python bench.py $BENCH_ARGS > "$O/bench_full$SFX.json" 2> "$O/bench_full$SFX.err"
       echo "[gpu.sh] bench rc $?"; line "$O/bench_full$SFX.json";;
     quick)
-      timeout 600 python bench.py --steps "$STEPS" --warmup 6 --no-cpu-baseline --no-slot-cadence $BENCH_ARGS > "$O/bench_quick$SFX.json" 2> "$O/bench_quick$SFX.err"
+      timeout 600 python bench.py --steps "$STEPS" --warmup 6 --no-cpu-baseline --no-slot-cadence --no-signed-steps $BENCH_ARGS > "$O/bench_quick$SFX.json" 2> "$O/bench_quick$SFX.err"
       echo "[gpu.sh] quick$SFX rc $?"; line "$O/bench_quick$SFX.json";;
     driver)
       timeout 600 python bench.py --steps 20 --warmup 5 $BENCH_ARGS > "$O/bench_driver$SFX.json" 2> "$O/bench_driver$SFX.err"
@@ -47,7 +47,7 @@ for act in "$@"; do
     timeline)
       rm -rf "$O/prof"; mkdir -p "$O/prof"
       timeout 600 rocprofv3 --kernel-trace --stats -d "$O/prof" -o tl -- python bench.py --steps 30 --warmup 6 --no-cpu-baseline \
-        --no-verify-steps --no-slot-cadence $BENCH_ARGS > "$O/bench_under_rocprof$SFX.json" 2> "$O/prof_err$SFX.log"
+        --no-verify-steps --no-slot-cadence --no-signed-steps $BENCH_ARGS > "$O/bench_under_rocprof$SFX.json" 2> "$O/prof_err$SFX.log"
       timeout 120 python tools/rocpd_timeline.py "$O/prof/tl_results.db" 20 2 > "$O/timeline$SFX.txt" 2>&1
       timeout 120 python tools/rocpd_stats.py "$O/prof/tl_results.db" "$O/kernel_stats$SFX.txt" > /dev/null 2>&1
       cat "$O/timeline$SFX.txt"; cut -c1-130 "$O/kernel_stats$SFX.txt" | head -24; line "$O/bench_under_rocprof$SFX.json"
@@ -56,7 +56,7 @@ for act in "$@"; do
       for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf "$O/pmc"; mkdir -p "$O/pmc"
         timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$O/pmc" -o p -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline \
-          --no-verify-steps --no-slot-cadence $BENCH_ARGS > "$O/pmc_$c$SFX.log" 2>&1
+          --no-verify-steps --no-slot-cadence --no-signed-steps $BENCH_ARGS > "$O/pmc_$c$SFX.log" 2>&1
         timeout 120 python tools/rocpd_pmc.py "$O/pmc/p_results.db" $c > "$O/pmc_$c$SFX.json" 2>> "$O/pmc_$c$SFX.log"
         rm -rf "$O/pmc"
       done

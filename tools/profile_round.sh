@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/profile_round.sh r01'
 # 1. bench.py full line (with cpu_baseline)         -> gpurun_out/<tag>_bench_full.json
 # 2. rocprofv3 --kernel-trace --stats of bench.py   -> gpurun_out/<tag>_kernel_stats.txt (+ the bench line under rocprof)
-#    (--no-slot-cadence: the per-slot run launches the same kernels at 1/32 of the size; mixed in, the per-kernel averages
+#    (--no-slot-cadence --no-signed-steps: the per-slot run launches the same kernels at 1/32 of the size; mixed in, the per-kernel averages
 #    and the PMC medians would describe neither workload)
 # 3. PMC passes FETCH_SIZE / WRITE_SIZE (separate runs, kernel-trace only) -> gpurun_out/<tag>_pmc_{fetch,write}.json
 set -u
@@ -16,12 +16,12 @@ mkdir -p $OUT/prof_$TAG $OUT/pmc_$TAG
 # (--no-verify-steps --no-shuffle-variant --no-oracle-check: the replays run the same kernels ALONE (synchronous calls), the
 # variant steps beside a shuffle; with them in the trace rocprof's per-kernel average is over three different workloads and
 # cannot be held against the bench line's own average over the timed steps)
-rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o $TAG -- python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-slot-cadence \
+rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o $TAG -- python bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-slot-cadence --no-signed-steps \
     --no-verify-steps --no-shuffle-variant --no-oracle-check > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof_$TAG/err.log
 python tools/rocpd_stats.py $OUT/prof_$TAG/${TAG}_results.db $OUT/${TAG}_kernel_stats.txt > /dev/null
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -o fetch -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-slot-cadence \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_$TAG -o fetch -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-slot-cadence --no-signed-steps \
     > $OUT/pmc_$TAG/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_$TAG -o write -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-slot-cadence \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_$TAG -o write -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-slot-cadence --no-signed-steps \
     > $OUT/pmc_$TAG/write.log 2>&1
 python tools/rocpd_pmc.py $OUT/pmc_$TAG/fetch_results.db FETCH_SIZE > $OUT/${TAG}_pmc_fetch.json
 python tools/rocpd_pmc.py $OUT/pmc_$TAG/write_results.db WRITE_SIZE > $OUT/${TAG}_pmc_write.json
