@@ -295,4 +295,29 @@ PE_HD void fq_to_mont32(uint32_t* w, const fq& a)
     fq_to_words32(w, c);
 }
 
+// ---- a^((p-3)/4): the exponentiation under every square root of the decompression kernels (fp_sqrt.h) ----
+// One lane per point there, a few thousand points a call: a single wave per SIMD and nothing beside it to hide the carry chains
+// of the 12 x 32 product (~2 us per dependent product).  This form's column sums are independent multiply-adds: the same
+// chain runs at the multiplier's issue rate (301 / 392 multiply-adds per squaring / product).
+// Fixed 4-bit windows over the 379-bit exponent (wave-uniform branches and table index; the table a^1 .. a^15 is indexed at
+// run time, i.e. lives in scratch: 14 dwords read per window): 14 + 376 + at most 94 products.
+PE_HD_CONST uint32_t FQ_PM3D4_EXP[12] = {0xffffeaaau, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                         0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};  // (p-3)/4
+PE_HD void fq_pow_pm3d4(fq& w, const fq& a)  // a: limbs as the products accept them (|limb| <= 2^29 + 16), any residue
+{
+    fq tab[16];
+    fq_norm(tab[1], a);  // balanced digits: signed x signed multiplies below
+#pragma nounroll
+    for (int k = 2; k < 16; ++k) fq_mul(tab[k], tab[k - 1], tab[1]);
+    fq acc = tab[(FQ_PM3D4_EXP[11] >> 24) & 15u];  // bits 376..378: the top (non-zero) window
+#pragma nounroll
+    for (int i = 93; i >= 0; --i) {
+#pragma nounroll
+        for (int k = 0; k < 4; ++k) fq_sqr(acc, acc);
+        const uint32_t nb = (FQ_PM3D4_EXP[i >> 3] >> ((i & 7) * 4)) & 15u;
+        if (nb) fq_mul(acc, acc, tab[nb]);
+    }
+    w = acc;
+}
+
 }  // namespace posevo

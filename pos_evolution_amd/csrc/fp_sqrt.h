@@ -1,11 +1,10 @@
 // fp_sqrt.h -- square roots in Fp381 (p = 3 mod 4) for the point decompression kernels, device only.
 #pragma once
 #include "g1.h"
+#include "fp381_s29.h"
 
 namespace posevo {
 
-static __device__ const uint32_t FP_PM3D4_EXP[12] = {0xffffeaaau, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
-                                                     0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};  // (p-3)/4
 static __device__ const uint32_t FP_HALF[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
                                                 0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};     // (p-1)/2
 
@@ -47,24 +46,14 @@ __device__ __forceinline__ void fp_half(fp& r, const fp& a)
 // w = a^((p-3)/4).  With it: a * w = a^((p+1)/4) is the square root of a when a is a quadratic residue (the caller checks
 // its square), and then w = 1 / sqrt(a) as well ((a w) w = a^((p-1)/2) = 1) -- the G2 decompression needs both.  When a is NOT a
 // residue, (a w)^2 = -a and (a w) w = -1.
-// Fixed 4-bit windows over the 379-bit exponent (wave-uniform branches and table index; the table of a^1 .. a^15 lives in
-// scratch, 12 dwords read per window): 14 + 376 squarings-or-products for the windows + at most 94 table products = 484,
-// against 606 for bit-by-bit square-and-multiply.
+// The chain itself runs in the 29-bit form (fp381_s29.h, fq_pow_pm3d4: why, and the windows); Montgomery words in, canonical
+// Montgomery words out, one product each way.
 __device__ __noinline__ void fp_pow_pm3d4(fp& w, const fp& a)
 {
-    fp tab[16];
-    tab[1] = a;
-#pragma nounroll
-    for (int k = 2; k < 16; ++k) fp_mul(tab[k], tab[k - 1], a);
-    fp acc = tab[(FP_PM3D4_EXP[11] >> 24) & 15u];  // bits 376..378: the top (non-zero) window
-#pragma nounroll
-    for (int i = 93; i >= 0; --i) {
-#pragma nounroll
-        for (int k = 0; k < 4; ++k) fp_sqr(acc, acc);
-        const uint32_t nb = (FP_PM3D4_EXP[i >> 3] >> ((i & 7) * 4)) & 15u;
-        if (nb) fp_mul(acc, acc, tab[nb]);
-    }
-    w = acc;
+    fq x, r;
+    fq_from_mont32(x, a.l);
+    fq_pow_pm3d4(r, x);
+    fq_to_mont32(w.l, r);
 }
 __device__ __forceinline__ void fp_sqrt_candidate(fp& r, const fp& a)
 {

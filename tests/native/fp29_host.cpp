@@ -129,4 +129,19 @@ void g1q_run_kernel_way(const uint32_t* rows24, int n, uint32_t* out48, int32_t*
     g1q_to_words32(out48, acc);
 }
 
+// fp_sqrt.h's fp_pow_pm3d4 as the decompression kernels run it: Montgomery words (R = 2^384) in and out
+void fq29_pow_pm3d4_words(const uint32_t* in12, uint32_t* out12, int32_t* max_abs_limb)
+{
+    fq x, r;
+    fq_from_mont32(x, in12);
+    fq_pow_pm3d4(r, x);
+    int32_t worst = 0;
+    for (int i = 0; i < FQ_N - 1; ++i) {
+        const int32_t v = r.l[i] < 0 ? -r.l[i] : r.l[i];
+        if (v > worst) worst = v;
+    }
+    if (max_abs_limb) *max_abs_limb = worst;
+    fq_to_mont32(out12, r);
+}
+
 }  // extern "C"

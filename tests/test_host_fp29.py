@@ -139,6 +139,30 @@ def test_hand_over_between_the_two_montgomery_forms(lib):
         assert np.array_equal(back, w)                                   # and back, from a lazy value
 
 
+def test_the_square_root_exponentiation_against_python_integers(lib):
+    """fq_pow_pm3d4 between the two hand-overs, as fp_sqrt.h's fp_pow_pm3d4 runs it under every square root of the G1 / G2
+    decompression kernels: x 2^384 in, x^((p-3)/4) 2^384 out (canonical words) -- residues, non-residues, 0, 1, p - 1; and
+    the identities the G2 decompression builds on (x w = sqrt(x) and w = 1 / sqrt(x) for a residue; (x w)^2 = -x otherwise)."""
+    rng = random.Random(17)
+    E = (P - 3) // 4
+    w_in = np.zeros(12, dtype=np.uint32)
+    w_out = np.zeros(12, dtype=np.uint32)
+    worst = C.c_int32(0)
+    inv32 = pow(R32, -1, P)
+    for x in [0, 1, 2, P - 1, P - 2, (P - 1) // 2] + [rng.randrange(P) for _ in range(60)]:
+        m = x * R32 % P
+        w_in[:] = [(m >> (32 * j)) & 0xFFFFFFFF for j in range(12)]
+        lib.fq29_pow_pm3d4_words(ptr(w_in, C.c_uint32), ptr(w_out, C.c_uint32), C.byref(worst))
+        got = sum(int(w_out[j]) << (32 * j) for j in range(12))
+        assert got < P and got * inv32 % P == pow(x, E, P), hex(x)
+        assert worst.value <= (1 << (B - 1)) + 64
+        w = got * inv32 % P
+        if x and pow(x, (P - 1) // 2, P) == 1:
+            assert (x * w) ** 2 % P == x and x * w * w % P == 1
+        elif x:
+            assert (x * w) ** 2 % P == P - x and x * w * w % P == P - 1
+
+
 def _row(pt):
     """A registry row of the 32-bit form: x, y as 12-word Montgomery values; None -> all zero."""
     if pt is None:
