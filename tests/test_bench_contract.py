@@ -51,7 +51,8 @@ def test_gpus_n_alone_is_a_named_config_under_strong_scaling():
 def test_the_contract_keys_are_in_the_line():
     src = _bench_source()
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "slot_cadence", "with_signatures",
+                "ms_per_step_with_signatures"):
         assert f'"{key}"' in src, key
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert f'"{key}"' in src, key
