@@ -596,6 +596,9 @@ k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__
     const uint32_t slot = blockIdx.x * G1_WG + tid;
     G1_STAMP(0);
     G1_WAVE_BEGIN();
+#ifdef POSEVO_ACC_PRIO_LEVEL   // tools/build_variant.sh accprio -DPOSEVO_ACC_PRIO_LEVEL=1: an experiment for the signed step
+    __builtin_amdgcn_s_setprio(POSEVO_ACC_PRIO_LEVEL);
+#endif
     g1q acc;
     g1q_set_inf(acc);
     bool exc = false;
