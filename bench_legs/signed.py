@@ -1,0 +1,93 @@
+"""bench.py `with_signatures`: the step with the signature leg of the aggregation."""
+import functools
+import os
+import time
+
+import numpy as np
+
+from .verify import step_digest
+from .workload import load_registry, run_step_single
+
+
+def signed_steps(pea, w, device, n_warm, n_timed, lag):
+    """The step with the signature leg of the aggregation (pe:659, pe:717, pe:1536: bls.Aggregate over the members'
+    BLSSignatures): pe_aggregate_signed in pe_aggregate's place -- one 96-byte compressed signature per partial aggregate
+    (8192 a step at configs[3]), resident in HBM like the rows, decompressed on the device (one Fp2 square root each), summed
+    per group and handed back compressed.  Same streaming pipelines as the headline steps, on a fresh engine; afterwards every
+    step is replayed with synchronous host-row calls (digest equality, signatures and per-row statuses included) and a
+    sample of step 0's aggregate signatures is held against the oracle's closed form.  -> the `with_signatures` object."""
+    import torch
+    from oracle import g2   # the checker of the sampled aggregate signatures
+    from pos_evolution_amd import DeviceArena
+    import pos_evolution_amd.synth as synth
+
+    steps = w["steps"][:n_warm + n_timed]
+    tree = w["tree"]
+
+    def make_engine():
+        e = pea.Engine(device=device, max_committee_tables=len(steps) + 2)
+        e.store_init(0, 0, tree.roots[0].tobytes())
+        for i in range(1, tree.roots.shape[0]):
+            e.add_block(tree.roots[i].tobytes(), tree.roots[int(tree.parent[i])].tobytes(), int(tree.slot[i]))
+        load_registry(e, w)
+        for st in steps:
+            e.set_committees(st["epoch"], st["comm"].offsets, st["comm"].members)
+        return e
+
+    e = make_engine()
+    n_rows = len(steps[0]["atts"])
+    assert all(len(st["atts"]) == n_rows for st in steps)
+    a, b = 0xABCDEF12345, 0x1357
+    sigs = synth.signature_points(e, n_rows, a, b)            # row i signs with (a + i * b) * G2
+    sig_t = torch.from_numpy(sigs.reshape(-1).copy()).cuda()
+    sig_dev = DeviceArena(sig_t.data_ptr(), sig_t.numel(), keep=sig_t)
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(len(steps) + 2)
+    got = [run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev) for st in steps[:n_warm]]
+    e.drain()
+    e.fill_ring()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for st in steps[n_warm:]:
+        got.append(run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev))
+    e.drain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_att = int(sum(int(np.asarray(r["count"]).sum()) for r in got[n_warm:]))
+    for r in got:
+        r["head"] = bytes(r["head"])
+    bad_rows = int(sum(int((np.asarray(r["agg"]["sig_status"]) != 0).sum()) for r in got))
+    e.close()
+    # a sample of step 0's groups against the closed form (|S| a + b sum(i)) G2 of their member rows
+    agg0 = got[0]["agg"]
+    gof = np.asarray(agg0["group_of"])[:n_rows]
+    ng = int(agg0["n_groups"])
+    sample = sorted(set(int(x) for x in np.linspace(0, ng - 1, 32)))
+    ok = True
+    for k in sample:
+        rows = np.nonzero(gof == k)[0]
+        want = g2.compress(g2.mul((len(rows) * a + b * int(rows.sum())) % g2.R_ORDER, g2.G2))
+        ok = ok and bytes(agg0["sig96c"][k]) == want
+    # every step again: synchronous calls over host rows and host signatures on a fresh engine
+    e2 = make_engine()
+    same = []
+    for st, r in zip(steps, got):
+        host_st = {k: v for k, v in st.items() if k not in ("rows_in", "arena_in")}
+        same.append(step_digest(run_step_single(e2, w, host_st, pipelined=False, sigs=sigs)) == step_digest(r))
+    e2.close()
+    assert ok, "aggregate signatures differ from the oracle's closed form"
+    assert all(same), f"signed steps differ from their synchronous replay: {[i for i, x in enumerate(same) if not x][:8]}"
+    assert bad_rows == 0
+    return {
+        "ms_per_step_with_signatures": dt / n_timed * 1e3,
+        "attestations_per_s": n_att / dt,
+        "signatures_per_step": n_rows,
+        "steps": n_timed, "warmup": n_warm,
+        "detail": ("pe_aggregate_signed in pe_aggregate's place: one compressed BLSSignature (96 B, resident in HBM) per partial "
+                   "aggregate -> k_g2_decompress (an Fp2 square root each) -> per-group G2 sums -> compressed aggregate "
+                   "signatures, on the state-transition stream beside the aggregate pubkeys and the fork choice; the rest of "
+                   "the step as the headline's; streaming pipelines, drain included"),
+        "steps_verified": int(sum(same[n_warm:])),
+        "aggregate_signatures_checked_against_oracle": len(sample),
+    }
+

@@ -159,7 +159,7 @@ constexpr uint32_t PLAN_LDS_NG = 8192;  // groups up to which their (table, comm
 
 namespace {
 template <typename T>
-__device__ __forceinline__ T block_scan_512(T v, T* wave_tot /* 8 entries of LDS */, T* total)
+__device__ __forceinline__ T block_scan(T v, T* wave_tot /* PLAN_WAVES entries of LDS */, T* total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T incl = v;
@@ -193,13 +193,15 @@ __device__ __forceinline__ uint32_t wave_excl_u32(uint32_t v, uint32_t* wave_tot
     *wave_total = __shfl(incl, 63, 64);
     return incl - v;
 }
-// mat[0 .. cnt) (cnt <= 256 <= PLAN_WG) -> exclusive prefix sums + base, in place; returns the total.  All lanes call it.
+// mat[0 .. cnt) (cnt <= PLAN_SUPER * PLAN_WAVES <= PLAN_WG: one entry per lane) -> exclusive prefix sums + base, in place;
+// returns the total.  All lanes call it.
+static_assert(PLAN_SUPER * PLAN_WAVES <= (uint32_t)PLAN_WG, "scan_matrix scans one matrix entry per lane");
 __device__ __forceinline__ uint32_t scan_matrix(uint32_t* mat, uint32_t cnt, uint32_t base, uint32_t* wt32)
 {
     __syncthreads();  // the matrix is complete
     const uint32_t v = threadIdx.x < cnt ? mat[threadIdx.x] : 0u;
     uint32_t tot;
-    const uint32_t ex = block_scan_512<uint32_t>(v, wt32, &tot);
+    const uint32_t ex = block_scan<uint32_t>(v, wt32, &tot);
     if (threadIdx.x < cnt) mat[threadIdx.x] = base + ex;
     __syncthreads();
     return tot;
@@ -362,7 +364,7 @@ k_att_plan(AttPlanArgs a)
     PLAN_STAMP(2);
     uint32_t word_total = 0, byte_total = 0, list_total = 0;
     unsigned long long total_members;
-    (void)block_scan_512<unsigned long long>(my_members, wt64, &total_members);
+    (void)block_scan<unsigned long long>(my_members, wt64, &total_members);
     const uint32_t g_mats = min(g_chunks, PLAN_SUPER) * PLAN_WAVES;
     word_total = scan_matrix(matA, g_mats, 0, wt32);
     byte_total = scan_matrix(matB, g_mats, 0, wt32);
@@ -443,7 +445,7 @@ k_att_plan(AttPlanArgs a)
             uint32_t sum = 0;
             for (uint32_t i = b0; i < b1; ++i) sum += i < nc ? s_cnt[t][i] : 0u;
             uint32_t tot;
-            uint32_t run = block_scan_512<uint32_t>(sum, wt32, &tot);
+            uint32_t run = block_scan<uint32_t>(sum, wt32, &tot);
             for (uint32_t i = b0; i < b1; ++i) {
                 const uint32_t v = i < nc ? s_cnt[t][i] : 0u;
                 s_cnt[t][i] = run;  // becomes the fill cursor

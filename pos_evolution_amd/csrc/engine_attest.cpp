@@ -779,9 +779,9 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         HIP_TRY(h, h->d_tmp_points.ensure(4ull * G1_ROW_WORDS * n));
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, sig_points96, 96ull * n, hipMemcpyHostToDevice, ms));
         launch_g1_convert(ms, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n);
-        h->tmp_points_n = n;
         int rc = launch_g1_planned(h, h->d_tmp_points.as<uint32_t>(), st.dev<uint32_t>(off_idx), nullptr,
-                                   st.dev<G1Group>(off_g1s), plan_sig, ob.host<uint8_t>(off_osig), nullptr, ms);
+                                   st.dev<G1Group>(off_g1s), plan_sig, ob.host<uint8_t>(off_osig), nullptr, ms, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr, /*caller_rows=*/n);
         if (rc) return rc;
     }
     HIP_TRY(h, hipGetLastError());
@@ -1104,8 +1104,16 @@ int pe_participation_rotate(pe_engine* h)
     // on the state stream, behind the flag passes that still write the old arrays (and off the fork-choice stream)
     // The array that becomes "current" was "previous": its last readers and writers are the flag passes of earlier steps, on
     // this stream; synchronous readers on the engine's stream (pe_participation_get, pe_ffg_balances) complete before they
-    // return.  So the memset needs no ordering against the engine's stream.
-    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), state_stream_unordered(h)));  // current = 0
+    // return.  So the memset needs no ordering against the engine's stream -- unless a flag pass had to be placed there
+    // (state_stream_begin's fall-back when its fork event could not be recorded): then this rotation forks behind it.
+    hipStream_t ss;
+    if (h->state_work_on_main) {
+        h->state_work_on_main = false;
+        ss = state_stream_begin(h);
+    } else {
+        ss = state_stream_unordered(h);
+    }
+    if (h->n_val) HIP_TRY(h, hipMemsetAsync(h->d_part_cur.p, 0, (h->n_val + 3) & ~uint64_t(3), ss));  // current = 0
     return PE_OK;
 }
 

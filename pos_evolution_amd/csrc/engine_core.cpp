@@ -165,8 +165,11 @@ hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch)
     // a caller-owned stream (pe_set_stream) carries everything: the caller orders its own work against it
     if (h->stream != h->own_stream || !h->aux_stream) return h->stream;
     if (hipEventRecord(h->ev_aux_fork, h->stream) != hipSuccess ||
-        hipStreamWaitEvent(h->aux_stream, h->ev_aux_fork, 0) != hipSuccess)
+        hipStreamWaitEvent(h->aux_stream, h->ev_aux_fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        h->state_work_on_main = true;  // the next participation rotation must be ordered behind THIS stream
         return h->stream;
+    }
     h->aux_busy = true;
     h->A().aux_used = true;
     if (reads_scratch) h->A().aux_reads_scratch = true;

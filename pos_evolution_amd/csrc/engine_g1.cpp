@@ -36,7 +36,7 @@ int build_points29(pe_engine* h, uint64_t n)
 int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_members, const uint32_t* d_bits,
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
                       hipStream_t s, hipStream_t fin, DevBuf* partials, DevBuf* lane_partials, const AttPlan* plan_dev,
-                      const uint32_t* d_members1)
+                      const uint32_t* d_members1, uint64_t caller_rows)
 {
     if (plan.n_groups == 0) return PE_OK;
     if (!s) s = h->stream;
@@ -54,8 +54,11 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
         if (!h->points29_valid) return fail(h, PE_ERR_STATE, "the registry's table of the accumulation's field form was not built");
         d_points29 = h->d_points29.as<uint32_t>();
     } else {
-        const uint64_t n_rows = h->tmp_points_n;
-        if (d_points != h->d_tmp_points.as<uint32_t>()) return fail(h, PE_ERR_STATE, "G1 sum over an unknown point table");
+        // caller_rows: the rows of d_tmp_points this call's conversion filled, handed down by the caller (not a
+        // side channel on the handle, which another user of that scratch buffer would leave stale)
+        const uint64_t n_rows = caller_rows;
+        if (d_points != h->d_tmp_points.as<uint32_t>() || 4ull * G1_ROW_WORDS * n_rows > h->d_tmp_points.cap)
+            return fail(h, PE_ERR_STATE, "G1 sum over an unknown point table");
         // sized like d_tmp_points, by its callers' rule: engine-owned scratch of calls that complete before they return (a
         // flush from here could complete the current arena in the middle of the call that is filling it)
         HIP_TRY(h, h->d_tmp_points29.ensure(std::max<size_t>(128, 4ull * G1_ROW_WORDS * n_rows)));
@@ -128,7 +131,8 @@ static int g1_sum_common(pe_engine* h, const uint32_t* d_pts, uint64_t n_pts, co
     PE_TRY(ob.ensure());
     HIP_TRY(h, st.upload());
     int rc = launch_g1_planned(h, d_pts, index ? st.dev<uint32_t>(off_i) : nullptr, nullptr, st.dev<G1Group>(off_g), plan,
-                               out96_host ? ob.dev<uint8_t>(off_o) : nullptr, dev_jac);
+                               out96_host ? ob.dev<uint8_t>(off_o) : nullptr, dev_jac, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, d_pts == h->d_tmp_points.as<uint32_t>() ? n_pts : 0);
     if (rc) return rc;
     if (out96_host) HIP_TRY(h, ob.download());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -151,7 +155,6 @@ int pe_g1_sum(pe_engine* h, const uint8_t* points96, uint64_t n_points, const ui
         HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, points96, 96ull * n_points, hipMemcpyHostToDevice, h->stream));
         launch_g1_convert(h->stream, h->d_tmp_be.as<uint8_t>(), h->d_tmp_points.as<uint32_t>(), n_points);
         d_pts = h->d_tmp_points.as<uint32_t>();
-        h->tmp_points_n = n_points;
         np = n_points;
     } else {
         if (!h->have_points) return fail(h, PE_ERR_STATE, "no pubkeys loaded");

@@ -288,6 +288,7 @@ struct pe_engine {
     DevBuf d_shuffle_scratch;           // ... and their hash tables (the synchronous call uses d_tmp_be)
     hipEvent_t ev_aux_fork = nullptr;
     bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
+    bool state_work_on_main = false;    // state_stream_begin fell back to the engine's stream for a flag pass
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_busy = false;             // the side stream holds work of the current arena nobody has waited for yet
@@ -325,10 +326,9 @@ struct pe_engine {
     uint32_t g1_target_slots = 0;   // 0 = undecided
     hipEvent_t g1_tune_ev[2] = {nullptr, nullptr};
     // k_g1_accumulate reads the registry in the S29 field form: d_points29, built from d_points where the registry is loaded
-    // (build_points29); d_tmp_points29: the same for caller-supplied points (d_tmp_points), per call
+    // (build_points29); d_tmp_points29: the same for caller-supplied points (d_tmp_points, `caller_rows` rows), per call
     bool points29_valid = false;
     DevBuf d_points29, d_tmp_points29;
-    uint64_t tmp_points_n = 0;  // rows of d_tmp_points the last conversion filled
 
     // ---- RCCL inside the engine (pe_dist_*): one communicator per handle, collectives on the engine's stream ----
     ncclComm_t comm = nullptr, comm_g1 = nullptr;  // get_head's all-reduce (engine stream) | the G1 partials' all-gather
@@ -637,7 +637,7 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
                       const G1Group* d_groups, const G1Plan& plan, uint8_t* d_out96, uint32_t* dev_jac,
                       hipStream_t s = nullptr, hipStream_t fin = nullptr, DevBuf* partials = nullptr,
                       DevBuf* lane_partials = nullptr, const AttPlan* plan_dev = nullptr,
-                      const uint32_t* d_members1 = nullptr);
+                      const uint32_t* d_members1 = nullptr, uint64_t caller_rows = 0);
 
 // ------------------------------------------------------------------ attestation resolution
 struct Resolved {

@@ -498,7 +498,7 @@ int pe_set_checkpoints(pe_engine* h, uint64_t je, const uint8_t jr[32], uint64_t
 
 int pe_set_proposer_boost(pe_engine* h, const uint8_t root[32])
 {
-    int rc = need_init(h);
+    int rc = need_init(h, /*flush=*/false);  // a host-side scalar (read where get_head is enqueued), like on_tick's
     if (rc) return rc;
     if (!root) return PE_ERR_INVALID_ARG;
     const Root r = to_root(root);

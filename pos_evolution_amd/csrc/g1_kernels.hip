@@ -346,7 +346,7 @@ k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict_
     for (uint32_t wg = blockIdx.x; wg * G1_WG < n_slots; wg += gridDim.x) {
     const uint32_t slot = wg * G1_WG + tid;
     uint32_t my_out, my_size, t;
-    G1Group d;
+    G1Group d{};  // padding lanes (slot >= n_slots) read zeros, not an unwritten struct
     g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
     if (my_size == 1) my_size = 0;  // written by k_g1_accumulate
     {
@@ -603,7 +603,7 @@ k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__
     g1q_set_inf(acc);
     bool exc = false;
     uint32_t my_out, my_size, t;
-    G1Group d;
+    G1Group d{};  // padding lanes (slot >= n_slots) read zeros, not an unwritten struct
     g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
     uint32_t first = 0, count = 0;
     if (slot < n_slots && t < d.n_tasks) {

@@ -343,8 +343,8 @@ def process_attestation(state, attestation, *, get_beacon_proposer_index: Option
         raise EngineError(int(status[0]), "process_attestation: " + _abi.ATT_STATUS_NAMES.get(int(status[0]), "?"))
     b.sync_back()
     # Reward proposer (pe:752-754)
-    proposer_reward_denominator = (WEIGHT_DENOMINATOR - PROPOSER_WEIGHT) * WEIGHT_DENOMINATOR // PROPOSER_WEIGHT
-    proposer_reward = int(numerators[0]) // proposer_reward_denominator
+    denominator = WEIGHT_DENOMINATOR * (WEIGHT_DENOMINATOR - PROPOSER_WEIGHT) // PROPOSER_WEIGHT
+    proposer_reward = int(numerators[0]) // denominator
     proposer = int(proposer_index) if proposer_index is not None else int(get_beacon_proposer_index(state))
     state.balances[proposer] += proposer_reward
     state._last_proposer_reward_numerator = int(numerators[0])
@@ -354,37 +354,43 @@ def process_attestation(state, attestation, *, get_beacon_proposer_index: Option
 JUSTIFICATION_BITS_LENGTH = 4
 
 
+# The finalization rules of pe:841-852 as data: (justified bits that must all be set, which of the two checkpoints held BEFORE
+# this epoch's update is the source, how many epochs back that source must lie).  Rules apply in this order; a later
+# match overrides an earlier one, as the reference's four consecutive `if`s do.
+_FINALITY_RULES = (
+    (range(1, 4), "previous", 3),   # epochs 2-4 back justified, the 2nd finalizes its source, the 4th
+    (range(1, 3), "previous", 2),   # epochs 2-3 back justified, source = the 3rd
+    (range(0, 3), "current", 2),    # epochs 1-3 back justified, source = the 3rd
+    (range(0, 2), "current", 1),    # epochs 1-2 back justified, source = the 2nd
+)
+
+
 def weigh_justification_and_finalization(state, total_active_balance: int, previous_epoch_target_balance: int,
                                          current_epoch_target_balance: int, *, get_block_root: Callable,
                                          slots_per_epoch: int) -> None:
-    """pe:815-853 -- scalar logic on the state, as in the reference."""
-    current_epoch = int(state.slot) // slots_per_epoch
-    previous_epoch = max(current_epoch - 1, GENESIS_EPOCH)
-    old_previous_justified_checkpoint = state.previous_justified_checkpoint
-    old_current_justified_checkpoint = state.current_justified_checkpoint
-    cp_type = type(old_current_justified_checkpoint)
+    """The FFG verdict of pe:815-853 on the three Gwei sums `pe_ffg_balances` delivers.  Same state transition as the
+    reference's function (tests/test_gpu_forkchoice.py runs both on the same states), written as two tables: which epoch
+    a 2/3 supermajority justifies (bit position = epochs back), and `_FINALITY_RULES`."""
+    epoch_now = int(state.slot) // slots_per_epoch
+    epoch_before = max(epoch_now - 1, GENESIS_EPOCH)
+    held = {"previous": state.previous_justified_checkpoint, "current": state.current_justified_checkpoint}
+    make_checkpoint = type(held["current"])
 
-    # Process justifications
-    state.previous_justified_checkpoint = state.current_justified_checkpoint
-    state.justification_bits[1:] = state.justification_bits[:JUSTIFICATION_BITS_LENGTH - 1]
-    state.justification_bits[0] = False
-    if previous_epoch_target_balance * 3 >= total_active_balance * 2:
-        state.current_justified_checkpoint = cp_type(epoch=previous_epoch, root=get_block_root(state, previous_epoch))
-        state.justification_bits[1] = True
-    if current_epoch_target_balance * 3 >= total_active_balance * 2:
-        state.current_justified_checkpoint = cp_type(epoch=current_epoch, root=get_block_root(state, current_epoch))
-        state.justification_bits[0] = True
+    # justification: the bit vector ages by one epoch, then a supermajority of the target balance sets its epoch's bit
+    aged = [False] + [bool(x) for x in state.justification_bits[:JUSTIFICATION_BITS_LENGTH - 1]]
+    state.previous_justified_checkpoint = held["current"]
+    for bit, epoch, target_balance in ((1, epoch_before, previous_epoch_target_balance),
+                                       (0, epoch_now, current_epoch_target_balance)):
+        if 3 * target_balance >= 2 * total_active_balance:
+            aged[bit] = True
+            state.current_justified_checkpoint = make_checkpoint(epoch=epoch, root=get_block_root(state, epoch))
+    for i, v in enumerate(aged):
+        state.justification_bits[i] = v
 
-    # Process finalizations
-    bits = state.justification_bits
-    if all(bits[1:4]) and old_previous_justified_checkpoint.epoch + 3 == current_epoch:
-        state.finalized_checkpoint = old_previous_justified_checkpoint
-    if all(bits[1:3]) and old_previous_justified_checkpoint.epoch + 2 == current_epoch:
-        state.finalized_checkpoint = old_previous_justified_checkpoint
-    if all(bits[0:3]) and old_current_justified_checkpoint.epoch + 2 == current_epoch:
-        state.finalized_checkpoint = old_current_justified_checkpoint
-    if all(bits[0:2]) and old_current_justified_checkpoint.epoch + 1 == current_epoch:
-        state.finalized_checkpoint = old_current_justified_checkpoint
+    # finalization
+    for needed, source, distance in _FINALITY_RULES:
+        if all(aged[i] for i in needed) and held[source].epoch + distance == epoch_now:
+            state.finalized_checkpoint = held[source]
 
 
 def process_justification_and_finalization(state, *, get_block_root: Callable) -> None:

@@ -93,7 +93,7 @@ void g1q_run(const uint32_t* rows24, int n, uint32_t* out48, int32_t* max_abs_li
     g1q_to_words32(out48, acc);
 }
 
-// The same run the way k_g1_accumulate_s29 does it: the first point becomes the accumulator as it is (g1q_set_first), every
+// The same run the way k_g1_accumulate does it: the first point becomes the accumulator as it is (g1q_set_first), every
 // later one goes through the general body alone (g1q_madd_fast), a same-x case only raises the flag and the whole run is
 // then redone by the complete add.  *took_slow_path says which way the run went.
 void g1q_run_kernel_way(const uint32_t* rows24, int n, uint32_t* out48, int32_t* max_abs_limb, int* took_slow_path)

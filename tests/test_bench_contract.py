@@ -10,11 +10,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench_source():
-    return open(os.path.join(ROOT, "bench.py")).read()
+    """bench.py (arguments, the timed region, the JSON line) + bench_legs/ (workload, CPU baselines, checks, the extra legs)."""
+    import glob
+
+    paths = [os.path.join(ROOT, "bench.py")] + sorted(glob.glob(os.path.join(ROOT, "bench_legs", "*.py")))
+    return "\n".join(open(p).read() for p in paths)
 
 
 def _shapes():
-    tree = ast.parse(_bench_source())
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
     for node in tree.body:
         if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == "SHAPES":
             return eval(compile(ast.Expression(node.value), "bench.SHAPES", "eval"))   # a literal dict of dict(...) calls
@@ -38,6 +42,10 @@ def test_named_shapes_are_the_baseline_configs_as_written():
     assert shapes["configs4"]["blocks"] == _number(cfgs[4], r", ([\d ]+)-block tree")
     assert shapes["configs4"]["mixed_balances"] is True and "mixed balances" in cfgs[4]
     assert shapes["configs3"]["validators"] // shapes["configs3"]["committees"] == 512
+    # SURVEY.md 8(d)'s table: c2's 2048-block chain with side branches, c5's 1 % equivocating validators
+    assert shapes["configs1"]["blocks"] == 2048 and shapes["configs1"]["tree_kind"] == "branchy"
+    assert shapes["configs4"]["equivocating_frac"] == 0.01
+    assert all(shapes[f"configs{k}"]["equivocating_frac"] == 0.0 for k in (1, 2, 3))
 
 
 def test_gpus_n_alone_is_a_named_config_under_strong_scaling():

@@ -124,25 +124,33 @@ def test_config5_shape_aggregate_2048_committees_of_2048_over_4m_registry(engine
         assert agg["aggpk96"][g].tobytes() == synth.registry_closed_form(mem[agg["bits"][g]]), g
 
 
-@pytest.mark.parametrize("shape,lag,n_epochs", [("configs1", 2, 3), ("configs1", 4, 5), ("configs2", 2, 3), ("configs2", 4, 3),
-                                                ("configs3", 2, 3), ("configs3", 4, 3), ("configs4", 4, 2)])
-def test_the_timed_path_against_the_oracle(shape, lag, n_epochs):
+@pytest.mark.parametrize("shape,lag,n_epochs,boost", [("configs1", 2, 3, False), ("configs1", 4, 5, False), ("configs1", 4, 5, True),
+                                                      ("configs2", 2, 3, False), ("configs2", 4, 3, True),
+                                                      ("configs3", 2, 3, False), ("configs3", 4, 3, False),
+                                                      ("configs4", 4, 2, False)])
+def test_the_timed_path_against_the_oracle(shape, lag, n_epochs, boost):
     """The path bench.py TIMES -- attestation rows and bits resident in HBM (PE_ROWS_RESIDENT: grouped, resolved and validated
     on the device), streaming pipelines whose outputs complete `lag` steps later, pe_get_head_async -- held against the C
     oracle DIRECTLY, on bench.build_workload's own workload at the BASELINE configs[1..4] shapes (configs[2] with its
     4096-block tree, configs[4] with mixed balances and 8192 blocks): consecutive epochs, every step's union bits, counts,
     aggregate pubkeys, statuses, head and reward numerators, and the store behind the last one (latest messages, all
     weights, both participation arrays).  (until now only bench.py's own step-0 check compared this path with
-    the oracle; the -m gpu tests held it against the host-row path.)"""
+    the oracle; the -m gpu tests held it against the host-row path.)  Round 5: configs[1] on SURVEY 8(d)'s 2048-block
+    branchy chain, configs[4] with its 1 % equivocating validators (pe:1438 and A.1's mask inside the timed path), and
+    `boost`: proposer_boost_root set on a leaf behind every step's on_tick (pe:1020-1024; the oracle's head and weights
+    carry the same boost)."""
     import types
 
     cfg = bench.SHAPES[shape]
     args = types.SimpleNamespace(validators_local=cfg["validators"], blocks=cfg["blocks"], committees=cfg["committees"], parts=4,
                                  mixed_balances=cfg["mixed_balances"], host_arena=False, host_rows=False, with_shuffle=False,
-                                 by_committee=False, world=1, shuffle_variant_from=n_epochs)
+                                 by_committee=False, world=1, shuffle_variant_from=n_epochs, tree_kind=cfg["tree_kind"],
+                                 equivocating_frac=cfg["equivocating_frac"], boost=boost)
     e = pea.Engine(max_committee_tables=n_epochs + 3)
     w = bench.build_workload(e, args, 0, n_epochs)
     assert all("rows_in" in st and "arena_in" in st for st in w["steps"])
+    assert (w["equivocating"] is not None and len(w["equivocating"]) == cfg["validators"] // 100) == (shape == "configs4")
+    assert all(("boost_idx" in st) == boost for st in w["steps"])
     e.set_pipeline_lag(lag)
     e.reuse_outputs(max(n_epochs, lag) + 2)   # the output ring must be deeper than the lag
     got = [bench.run_step_single(e, w, st, pipelined=True, lagged=True, sync_head=False) for st in w["steps"]]

@@ -204,7 +204,7 @@ def _run_kernel_way(lib, pts):
 
 
 def test_the_kernels_run_general_body_only_and_redo_on_same_x(lib):
-    """k_g1_accumulate_s29's lane logic (round 4): first point taken as it is, the general body for every add, same-x
+    """k_g1_accumulate's lane logic (round 4): first point taken as it is, the general body for every add, same-x
     cases detected by the filter and the run redone by the complete add.  Random runs never leave the fast path; every
     edge case of the group law does, and comes out exact."""
     rng = random.Random(31)

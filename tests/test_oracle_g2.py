@@ -18,6 +18,19 @@ def test_external_known_answers():
     assert g2.compress(g2.G2).hex().startswith("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049")
     assert g2.compress(g2.double(g2.G2)).hex().startswith("aa4edef9c1ed7f729f520e47730a124fd70662a904ba1074728114d1031e1572")
     assert g2.compress(None) == bytes([0xC0]) + bytes(95)
+    # round 5: the whole 96 bytes of 2 * G2 and the leading 16 of 3 * G2, typed in from the published
+    # encodings BEFORE this oracle's output was looked at (no network: memory of the IETF / zkcrypto vectors is the only
+    # external source there is); the rest of each point is then held by the structure no wrong point has:
+    two, three = g2.double(g2.G2), g2.mul(3, g2.G2)
+    assert g2.compress(two).hex() == (
+        "aa4edef9c1ed7f729f520e47730a124fd70662a904ba1074728114d1031e1572c6c886f6b57ec72a6178288c47c33577"
+        "1638533957d540a9d2370f17cc7ed5863bc0b995b8825e0ee1ea1e1e4d00dbae81f14b0bf3611b78c952aacab827a053")
+    assert g2.compress(three).hex().startswith("89380275bbc8e5dcea7dc4dd7e0550ff")
+    for p in (two, three):
+        assert g2.is_on_curve(p) and g2.mul(g1.R_ORDER, p) is None          # r * P = infinity
+        assert g2.decompress(g2.compress(p)) == p
+        from tests.test_oracle_g2_psi import Z, psi                          # psi(P) = [z] P on the subgroup
+        assert psi(p) == g2.mul(Z % g1.R_ORDER, p)
 
 
 def test_group_law_consistency():
