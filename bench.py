@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (guide: ~6290 GB/s achievable)
 from bench_legs.cpu import cpu_baseline, cpu_step, cpu_step_inputs, pyspec_c1_baseline  # noqa: E402,F401
 from bench_legs.sharded import (ReplayCollectives, _SoloDist, committee_step_check, run_step_committee,  # noqa: E402,F401
                                 run_step_sharded, run_step_sharded_pipelined, sharded_step_check)
-from bench_legs.signed import signed_steps  # noqa: E402,F401
+from bench_legs.signed import signed_steps, unaggregated_signatures  # noqa: E402,F401
 from bench_legs.slots import slot_cadence  # noqa: E402,F401
 from bench_legs.verify import replay_and_verify, step_digest, whole_step_check  # noqa: E402,F401
 from bench_legs.workload import _BREAKDOWN, build_workload, load_registry, run_step_single, state_ctx  # noqa: E402,F401
@@ -361,6 +361,16 @@ def main():
         e.get_head() if (ex is None or args.by_committee) else ex.get_head()
         lat.append((time.perf_counter() - t) * 1e6)
     lat = np.sort(np.array(lat))
+    # k_votes / k_tree alone (in the timed steps they run as halves of paired launches, engine_pair.cpp): their own durations
+    # from a few more synchronous heads under the engine's event brackets, after the latency calls
+    prof_head = None
+    if ex is None or args.by_committee:
+        e.profile_enable(True)
+        e.profile_reset()
+        for _ in range(50):
+            e.get_head()
+        prof_head = e.profile()
+        e.profile_enable(False)
 
     if dist is not None:
         t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda" if torch_backend == "nccl" else "cpu")
@@ -416,7 +426,7 @@ def main():
     # the tree over the lanes' partials (12 x 32-bit form, 288 multiply-adds + 288 carry adds per product, 14 products per
     # add): one add per lane but one per committee; it runs on the same SIMDs beside the NEXT accumulation
     tree_macs = 14.0 * 288 * max(lane_runs - C, 0)
-    votes = prof["votes"]
+    votes = prof_head["votes"] if prof_head is not None and prof_head["votes"]["launches"] else prof["votes"]
     votes_ms = votes["total_ms"] / max(votes["launches"], 1)
     votes_bytes = 13.0 * VL + 32.0 * args.blocks
     kernel_ms = {k: (v["total_ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()}
@@ -436,7 +446,9 @@ def main():
             "sharded, synchronous calls, collectives through torch.distributed" if world > 1 else
             "synchronous calls" if args.no_pipeline else
             "pipelined calls (one wait per step)" if args.no_lag else
-            "streaming pipelines (pe_pipeline_begin_streaming / _end_lagged: a step's G1 sums overlap the next step)")
+            "streaming pipelines (pe_pipeline_begin_streaming / _end_lagged: a step's G1 sums overlap the next step"
+            + (")" if os.environ.get("POSEVO_PAIR") == "0" else
+               "; its fork-choice kernels are launched pairwise with the next step's row kernels, engine_pair.cpp)"))
 
     out = {
         "metric": "attestations aggregated/sec + get_head() p50 latency at 1M validators",
@@ -490,6 +502,8 @@ def main():
             "kernel": "k_g1_accumulate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms, "launches": acc["launches"],
+            "launches_detail": "launches bracketed with HIP events on the kernel's own stream inside the timed region: one in "
+                               "four (every event record on that stream is step time since the accumulation paces the step)",
             "note": "integer-VALU bound (3738 multiply-adds per 100 B gathered), not HBM bound: "
                     "see roofline_valu and DESIGN.md; the votes kernel below is the HBM-streaming one",
         },
@@ -517,8 +531,12 @@ def main():
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": (votes_bytes / (votes_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if votes_ms else 0.0,
             "avg_launch_ms": votes_ms, "launches": votes["launches"],
+            "measured": ("stand-alone launches of 50 synchronous pe_get_head calls after the timed region (in the streaming steps "
+                         "k_votes runs as one half of a paired launch: kernel_avg_ms.pair_members_votes)"
+                         if votes is not prof["votes"] else "the timed steps' own launches"),
         },
         "kernel_avg_ms": kernel_ms,
+        "kernel_launches": {k: v["launches"] for k, v in prof.items()},
     }
     if emulate:
         g0 = kept[0]["gx"]
@@ -582,6 +600,12 @@ def main():
         except Exception as err:   # an extra leg: reported (here and on stderr), never at the cost of the headline line
             print(f"[bench] with_signatures failed: {err!r}", file=sys.stderr)
             out["with_signatures"] = {"error": repr(err)}
+    if world == 1 and not emulate and not args.no_signed_steps:
+        try:
+            out["with_unaggregated_signatures"] = unaggregated_signatures(pea, w, local_rank)
+        except Exception as err:   # as above
+            print(f"[bench] with_unaggregated_signatures failed: {err!r}", file=sys.stderr)
+            out["with_unaggregated_signatures"] = {"error": repr(err)}
     if not args.no_cpu_baseline and world == 1:
         base, chk = cpu_baseline(w, w["steps"][0])
         out["cpu_baseline"] = base

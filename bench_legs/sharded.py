@@ -6,6 +6,7 @@ import time
 import numpy as np
 
 from .cpu import cpu_step, cpu_step_inputs
+from .workload import load_registry
 
 
 def run_step_sharded_pipelined(e, w, st, lagged=True):

@@ -91,3 +91,81 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
         "aggregate_signatures_checked_against_oracle": len(sample),
     }
 
+
+
+def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32):
+    """The epoch's UNAGGREGATED signatures (pe:717: every attester signs; pe:474 / pe:659 / pe:1536: aggregated per committee):
+    one compressed 96-byte BLSSignature per validator resident in HBM (V x 96 bytes), the attesters of every committee as an
+    index list resident in HBM -> pe_aggregate_signatures: k_g2_decompress over the whole chip (an Fp2 square root per
+    signature), k_g2_accumulate / k_g2_finish per committee, the 2048 aggregates handed back compressed.  Synchronous calls,
+    one epoch per call; every call's aggregates are sampled against the oracle's closed form.
+    -> the `with_unaggregated_signatures` object."""
+    import torch
+    from oracle import cport, g2
+    from pos_evolution_amd import DeviceArena
+    import pos_evolution_amd.synth as synth
+    from .cpu import cpu_step_inputs
+
+    steps = w["steps"][:n_warm + n_timed]
+    V = w["bal"].size
+    e = pea.Engine(device=device)
+    a, b, period = 0xABCDEF12345, 0x1357, 16384
+    base = synth.signature_points(e, min(V, period), a, b)              # validator v signs with (a + (v mod 16384) b) G2
+    sigs = np.ascontiguousarray(np.tile(base, (-(-V // base.shape[0]), 1))[:V])
+    sig_t = torch.from_numpy(sigs.reshape(-1)).cuda()
+    sig_dev = DeviceArena(sig_t.data_ptr(), sig_t.numel(), keep=sig_t)
+    prepared = []
+    for st in steps:   # who attested: the union of the committee's partial aggregates (the oracle's), as an index list per committee
+        inp = cpu_step_inputs(w, st)
+        union, count = cport.bits_union(inp["group_start"], inp["order"], st["atts"]["bits_offset"], st["arena"], inp["sizes"],
+                                        inp["out_off"][:-1], int(inp["out_off"][-1]), mt=True)
+        comm, off = st["comm"], inp["out_off"]
+        lists = []
+        for c in range(inp["n_comm"]):
+            bits = np.unpackbits(union[off[c]:off[c + 1]], bitorder="little")[:inp["sizes"][c]].astype(bool)
+            lists.append(comm.members[comm.offsets[c]:comm.offsets[c + 1]][bits])
+        offsets = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint32)
+        index = np.concatenate(lists).astype(np.uint32)
+        idx_t = torch.from_numpy(index).cuda()
+        prepared.append(dict(lists=lists, offsets=offsets, index=DeviceArena(idx_t.data_ptr(), idx_t.numel() * 4, keep=idx_t),
+                             n=int(index.size)))
+    torch.cuda.synchronize()
+    got = []
+    for p in prepared[:n_warm]:
+        got.append(e.aggregate_signatures(sig_dev, p["offsets"], index=p["index"]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for p in prepared[n_warm:]:
+        got.append(e.aggregate_signatures(sig_dev, p["offsets"], index=p["index"]))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_sig = int(sum(p["n"] for p in prepared[n_warm:]))
+    e.close()
+    # a sample of every call's committees against the closed form (|S| a + b sum(v mod 16384)) G2
+    verified = 0
+    for p, (agg, status, bad) in zip(prepared, got):
+        ok = not status.any() and not bad.any()
+        ng = len(p["lists"])
+        for c in sorted(set(int(x) for x in np.linspace(0, ng - 1, check_groups))):
+            m = p["lists"][c].astype(np.int64) % period
+            want = g2.compress(g2.mul((len(m) * a + b * int(m.sum())) % g2.R_ORDER, g2.G2))
+            ok = ok and bytes(agg[c]) == want
+        verified += int(ok)
+    assert verified == len(prepared), "aggregates of the unaggregated signatures differ from the oracle's closed form"
+    products = 1010.0   # two windowed Fp exponentiations of <= 484 products + ~40 around them (g2_kernels.hip, fp_sqrt.h)
+    ceiling = 68.6e9    # dependent S29 products per second, chip-wide (tools/fpbench29, profiles/r04_fpbench29.txt)
+    return {
+        "ms_per_epoch": dt / n_timed * 1e3,
+        "signatures_per_s": n_sig / dt,
+        "signatures_per_epoch": n_sig // n_timed,
+        "committees": len(prepared[0]["lists"]),
+        "epochs": n_timed, "warmup": n_warm,
+        "epochs_verified": verified - n_warm,
+        "checked_per_epoch": check_groups,
+        "roofline_valu": {"bound": "integer VALU (the S29 Fp product of the square roots)", "products_per_signature": products,
+                          "achieved_G_products_per_s": n_sig * products / dt / 1e9, "peak_G_products_per_s": ceiling / 1e9,
+                          "frac": n_sig * products / dt / ceiling},
+        "detail": ("pe_aggregate_signatures: V compressed BLSSignatures + the attesters' index lists resident in HBM -> "
+                   "k_g2_decompress (whole chip) -> k_g2_accumulate -> k_g2_finish -> 2048 compressed aggregates; synchronous, "
+                   "one epoch per call; each call's aggregates sampled against oracle/g2.py's closed form"),
+    }

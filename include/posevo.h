@@ -432,6 +432,18 @@ int pe_g2_decompress(pe_engine* h, const uint8_t* in96, uint64_t n, uint8_t* out
 int pe_g2_compress(const uint8_t* in192, uint64_t n, uint8_t* out96);
 int pe_g2_sum(pe_engine* h, const uint8_t* points192, uint64_t n_points,
               const uint32_t* index, const uint32_t* offsets, uint32_t n_groups, uint8_t* out192);
+/* bls.Aggregate per committee over the UNAGGREGATED signatures of an epoch (pe:717: one BLSSignature per attester; pe:474,
+ * pe:659, pe:1536: aggregated per committee): signatures96 = n compressed signatures (host or DEVICE memory; device memory
+ * at a 16-byte boundary is read in place), aggregate g = sum of signatures96[index[j]] for j in [offsets[g], offsets[g+1])
+ * (index: host or device memory, NULL = identity; offsets: host), decompressed on the whole chip (k_g2_decompress: an Fp2
+ * square root each, curve membership checked; PE_SIG_CHECK_SUBGROUP adds the endomorphism test), summed (k_g2_accumulate /
+ * k_g2_finish) and handed back compressed in out_signatures96 (n_groups x 96 bytes, host).  sig_status (nullable, n entries,
+ * host): 0 ok, 1 malformed, 2 not on the curve, 3 outside G2; a signature that does not decode is left out of its sum and
+ * counted in out_bad[g] (nullable, n_groups entries).  Synchronous.  1 048 576 signatures in 2048 committees: ~1 k
+ * Fp products per signature against ~10 per addition -- the decompression is the cost of the call. */
+int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t n, const uint32_t* index,
+                            const uint32_t* offsets, uint32_t n_groups, uint32_t sig_flags, uint8_t* out_signatures96,
+                            int32_t* sig_status, uint32_t* out_bad);
 
 /* ---- inspection (parity checks) ---------------------------------------- */
 uint32_t pe_num_blocks(const pe_engine* h);

@@ -23,7 +23,13 @@ extern "C" {
 #define PE_KERNEL_G1_TREE       9   /* the LDS tree over the lane partials: its own kernel since round 2 */
 #define PE_KERNEL_ATT_GROUP     10  /* rows in device memory: ingest + plan + members (bracketed in timeline mode only) */
 #define PE_KERNEL_ATT_VALIDATE  11  /* rows in device memory: the validate_on_attestation / process_attestation kernels (ditto) */
-#define PE_KERNEL_COUNT         12
+/* paired launches of a streaming caller (round 5): the fork-choice kernel of step N and the row kernel of step N + 1 as block
+ * ranges of one grid (pair_kernels.hip); the stand-alone ids above count only the launches that ran alone */
+#define PE_KERNEL_PAIR_INGEST_VALIDATE 12
+#define PE_KERNEL_PAIR_PLAN_LMD        13
+#define PE_KERNEL_PAIR_MEMBERS_VOTES   14
+#define PE_KERNEL_PAIR_UNION_TREE      15
+#define PE_KERNEL_COUNT         16
 /* on = 0 off, 1 per-kernel totals, 2 totals + a timeline: every bracketed launch's start (relative to the last
  * pe_profile_reset, which marks time zero on the engine's stream) and duration, read with pe_profile_timeline.  The
  * events are the engine's own, on the streams the kernels run on: an in-situ picture of a streaming step without a

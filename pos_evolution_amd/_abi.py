@@ -28,9 +28,11 @@ PE_EXCHANGE_EXTRA = 512
 PE_DIST_ID_BYTES = 256
 (PE_KERNEL_G1_ACCUMULATE, PE_KERNEL_G1_NORMALISE, PE_KERNEL_VOTES, PE_KERNEL_TREE, PE_KERNEL_LMD,
  PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_G2_ACCUMULATE, PE_KERNEL_G2_NORMALISE,
- PE_KERNEL_G1_TREE, PE_KERNEL_ATT_GROUP, PE_KERNEL_ATT_VALIDATE, PE_KERNEL_COUNT) = range(13)
+ PE_KERNEL_G1_TREE, PE_KERNEL_ATT_GROUP, PE_KERNEL_ATT_VALIDATE, PE_KERNEL_PAIR_INGEST_VALIDATE,
+ PE_KERNEL_PAIR_PLAN_LMD, PE_KERNEL_PAIR_MEMBERS_VOTES, PE_KERNEL_PAIR_UNION_TREE, PE_KERNEL_COUNT) = range(17)
 KERNEL_NAMES = ["g1_accumulate", "g1_normalise", "votes", "tree", "lmd", "participation", "bits_union",
-                "g2_accumulate", "g2_normalise", "g1_tree", "att_group", "att_validate"]
+                "g2_accumulate", "g2_normalise", "g1_tree", "att_group", "att_validate", "pair_ingest_validate",
+                "pair_plan_lmd", "pair_members_votes", "pair_union_tree"]
 
 ATT_STATUS_NAMES = {
     0: "ok", 1: "target epoch not current or previous", 2: "target epoch != epoch(slot)",
@@ -149,6 +151,8 @@ SIGNATURES = {
     "pe_g2_decompress": (C.c_int, [_H, _u8p, C.c_uint64, _u8p, _i32p]),
     "pe_g2_compress": (C.c_int, [_u8p, C.c_uint64, _u8p]),
     "pe_g2_sum": (C.c_int, [_H, _u8p, C.c_uint64, _u32p, _u32p, C.c_uint32, _u8p]),
+    "pe_aggregate_signatures": (C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_void_p, _u32p, C.c_uint32, C.c_uint32, _u8p, _i32p,
+                                         _u32p]),
     "pe_num_blocks": (C.c_uint32, [_H]),
     "pe_num_validators": (C.c_uint64, [_H]),
     "pe_block_root_at": (C.c_int, [_H, C.c_uint32, _u8p]),

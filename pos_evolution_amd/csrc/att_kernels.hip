@@ -82,20 +82,29 @@ __device__ __forceinline__ bool same4(const uint4& a, const uint4& b)
 }  // namespace
 
 // ------------------------------------------------------------------ ingest: hash + insert
-__global__ void __launch_bounds__(256)
-k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t* __restrict__ cnt_tab,
-             uint32_t mask, uint32_t* __restrict__ slot_of, unsigned long long arena_len, AttPlan* __restrict__ plan,
-             uint4* __restrict__ arena_pad, const uint32_t* __restrict__ n_dev, const uint4* __restrict__ arena_src,
-             uint4* __restrict__ arena_dst)
+// (Bodies take their block index and grid size as arguments: the same code runs as a kernel of its own and as one block
+// range of a paired launch, pair_kernels.hip.)
+namespace {
+__device__ __forceinline__ void att_ingest_body(const uint32_t bid, const uint32_t nblk, const IngestArgs& a)
 {
-    __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
-    if (n_dev) n = min(n, *n_dev);  // the row count is itself a device result (pe_aggregate_exchange): n is its bound
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint4* __restrict__ rows = static_cast<const uint4*>(a.rows);
+    uint32_t* __restrict__ tab = a.tab;
+    uint32_t* __restrict__ cnt_tab = a.cnt_tab;
+    uint32_t* __restrict__ slot_of = a.slot_of;
+    AttPlan* __restrict__ plan = a.plan;
+    uint4* __restrict__ arena_pad = static_cast<uint4*>(a.arena_pad32);
+    const uint4* __restrict__ arena_src = static_cast<const uint4*>(a.arena_src);
+    uint4* __restrict__ arena_dst = static_cast<uint4*>(a.arena_dst);
+    const uint32_t mask = a.tab_mask;
+    const unsigned long long arena_len = a.arena_len;
+    uint32_t n = a.n;
+    if (a.n_dev) n = min(n, *a.n_dev);  // the row count is itself a device result (pe_aggregate_exchange): n is its bound
+    const uint32_t i = bid * 256 + threadIdx.x;
     // the caller's bits lie in device memory (16-byte aligned): this launch brings them into the staging arena itself -- a
     // copy command in front of it cost the step's chain 10-13 us (profiles/r03_timeline.txt: __amd_rocclr_copyBuffer)
     if (arena_src) {
         const unsigned long long whole = arena_len >> 4;
-        for (unsigned long long q = i; q < whole; q += (unsigned long long)gridDim.x * 256) arena_dst[q] = arena_src[q];
+        for (unsigned long long q = i; q < whole; q += (unsigned long long)nblk * 256) arena_dst[q] = arena_src[q];
         if (i == 0 && (arena_len & 15)) {
             const uint8_t* sb = reinterpret_cast<const uint8_t*>(arena_src + whole);
             uint8_t* db = reinterpret_cast<uint8_t*>(arena_dst + whole);
@@ -129,19 +138,36 @@ k_att_ingest(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ 
     slot_of[i] = h;
     atomicAdd(&cnt_tab[h], 1u);  // members of the class: k_att_plan reads the group's size here instead of counting
 }
+// with an arena to bring in: enough workgroups for the copy (one 16-byte word per lane and pass, at most 256 workgroups)
+inline unsigned att_ingest_blocks(const IngestArgs& a)
+{
+    unsigned blocks = (a.n + 255) / 256;
+    if (a.arena_src) blocks = std::max(blocks, (unsigned)std::min<uint64_t>(256, ((a.arena_len >> 4) + 255) / 256));
+    return blocks;
+}
+}  // namespace
 
+#ifndef POSEVO_BODIES_ONLY
+__global__ void __launch_bounds__(256)
+k_att_ingest(const IngestArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
+    att_ingest_body(blockIdx.x, gridDim.x, a);
+}
+
+void launch_att_ingest(hipStream_t s, const IngestArgs& a)
+{
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_att_ingest, dim3(att_ingest_blocks(a)), dim3(256), 0, s, a);
+}
 void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, uint32_t tab_mask,
                        uint32_t* slot_of, uint64_t arena_len, AttPlan* plan, void* arena_pad32, const uint32_t* n_dev,
                        const void* arena_src, void* arena_dst)
 {
-    if (n == 0) return;
-    // with an arena to bring in: enough workgroups for the copy (one 16-byte word per lane and pass, at most 256 workgroups)
-    unsigned blocks = (n + 255) / 256;
-    if (arena_src) blocks = std::max(blocks, (unsigned)std::min<uint64_t>(256, ((arena_len >> 4) + 255) / 256));
-    hipLaunchKernelGGL(k_att_ingest, dim3(blocks), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
-                       cnt_tab, tab_mask, slot_of, (unsigned long long)arena_len, plan, static_cast<uint4*>(arena_pad32), n_dev,
-                       static_cast<const uint4*>(arena_src), static_cast<uint4*>(arena_dst));
+    launch_att_ingest(s, IngestArgs{rows, n, tab, cnt_tab, tab_mask, slot_of, arena_len, plan, arena_pad32, n_dev, arena_src,
+                                    arena_dst});
 }
+#endif
 
 // ------------------------------------------------------------------ plan: one workgroup
 // 1024 lanes = four waves per SIMD of 64 registers (amdgpu_waves_per_eu(8, 8) caps them; 84 B of scratch per lane): the
@@ -216,10 +242,9 @@ __device__ unsigned long long plan_stamps[16];
 #else
 #define PLAN_STAMP(i) do { } while (0)
 #endif
-__global__ void __launch_bounds__(PLAN_WG) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: see PLAN_WG
-k_att_plan(AttPlanArgs a)
+namespace {
+__device__ __forceinline__ void att_plan_body(const AttPlanArgs& a)  // ONE workgroup of PLAN_WG lanes
 {
-    __builtin_amdgcn_s_setprio(3);
     __shared__ uint32_t wt32[PLAN_WAVES];
     __shared__ unsigned long long wt64[PLAN_WAVES];
     __shared__ uint32_t matA[PLAN_SUPER * PLAN_WAVES], matB[PLAN_SUPER * PLAN_WAVES], matC[PLAN_SUPER * PLAN_WAVES];
@@ -518,12 +543,22 @@ k_att_plan(AttPlanArgs a)
         *a.plan_host = p;
     }
 }
+}  // namespace
+
+#ifndef POSEVO_BODIES_ONLY
+__global__ void __launch_bounds__(PLAN_WG) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: see PLAN_WG
+k_att_plan(const AttPlanArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);
+    att_plan_body(a);
+}
 
 void launch_att_plan(hipStream_t s, const AttPlanArgs& a)
 {
     hipLaunchKernelGGL(k_att_plan, dim3(1), dim3(PLAN_WG), 0, s, a);
 }
-#ifdef POSEVO_PLAN_TIMING
+#endif
+#if defined(POSEVO_PLAN_TIMING) && !defined(POSEVO_BODIES_ONLY)
 }  // namespace posevo
 extern "C" int pe_debug_plan_stamps(unsigned long long* out16)
 {
@@ -533,16 +568,23 @@ namespace posevo {
 #endif
 
 // ------------------------------------------------------------------ members
-__global__ void __launch_bounds__(256)
-k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__ tab, uint32_t* __restrict__ cnt_tab,
-              const uint32_t* __restrict__ slot_of,
-              const uint32_t* __restrict__ rep_of, const uint32_t* __restrict__ gid_of_row, AttGroup* __restrict__ grp,
-              AttPlan* __restrict__ plan, uint32_t* __restrict__ ubytes, uint32_t* __restrict__ member_row,
-              uint32_t* __restrict__ host_group_of, uint4* __restrict__ host_out_rows, const uint32_t* __restrict__ n_dev)
+namespace {
+__device__ __forceinline__ void att_members_body(const uint32_t i /* input row of this lane */, const MembersArgs& a)
 {
-    __builtin_amdgcn_s_setprio(3);
-    if (n_dev) n = min(n, *n_dev);
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint4* __restrict__ rows = static_cast<const uint4*>(a.rows);
+    uint32_t* __restrict__ tab = a.tab;
+    uint32_t* __restrict__ cnt_tab = a.cnt_tab;
+    const uint32_t* __restrict__ slot_of = a.slot_of;
+    const uint32_t* __restrict__ rep_of = a.rep_of;
+    const uint32_t* __restrict__ gid_of_row = a.gid_of_row;
+    AttGroup* __restrict__ grp = a.grp;
+    AttPlan* __restrict__ plan = a.plan;
+    uint32_t* __restrict__ ubytes = a.ubytes;
+    uint32_t* __restrict__ member_row = a.member_row;
+    uint32_t* __restrict__ host_group_of = a.host_group_of;
+    uint4* __restrict__ host_out_rows = static_cast<uint4*>(a.host_out_rows);
+    uint32_t n = a.n;
+    if (a.n_dev) n = min(n, *a.n_dev);
     if (i == 0 && n == 0) plan->error = 0;
     if (i >= n) return;
     const uint32_t slot = slot_of[i];
@@ -567,23 +609,37 @@ k_att_members(const uint4* __restrict__ rows, uint32_t n, uint32_t* __restrict__
     cnt_tab[slot] = 0;
     if (i == 0) plan->error = 0;  // consumed by k_att_plan (mirrored to the host): k_att_ingest of the next call starts clean
 }
+}  // namespace
 
+#ifndef POSEVO_BODIES_ONLY
+__global__ void __launch_bounds__(256)
+k_att_members(const MembersArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);
+    att_members_body(blockIdx.x * 256 + threadIdx.x, a);
+}
+
+void launch_att_members(hipStream_t s, const MembersArgs& a)
+{
+    if (a.n == 0) return;
+    hipLaunchKernelGGL(k_att_members, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
 void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
                         const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
                         uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows,
                         const uint32_t* n_dev)
 {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_att_members, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), n, tab,
-                       cnt_tab, slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row, host_group_of,
-                       static_cast<uint4*>(host_out_rows), n_dev);
+    launch_att_members(s, MembersArgs{rows, n, tab, cnt_tab, slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row,
+                                      host_group_of, host_out_rows, n_dev});
 }
+#endif
 
 // ------------------------------------------------------------------ committee-sharded exchange (pe_aggregate_exchange)
 // Every rank aggregates the rows of ITS committees; what the other ranks need of the result -- the aggregate attestation
 // itself: AttestationData + OR-ed bits (pe:714-717), its attester count and its verdict flags -- is packed into fixed
 // slots, all-gathered, and unpacked into one dense batch that the receiving rank ingests like any batch of rows.
 //   send buffer: [0] groups packed, [1] error, [2..3] reserved | slot g: 36 words row, count, reserved, `wps` words of bits
+#ifndef POSEVO_BODIES_ONLY
 __global__ void __launch_bounds__(256)
 k_att_pack(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
            const uint32_t* __restrict__ res_bits, const uint32_t* __restrict__ res_info, uint32_t slots, uint32_t wps,
@@ -669,6 +725,7 @@ void launch_att_unpack(hipStream_t s, const uint32_t* recv, uint32_t world, uint
     hipLaunchKernelGGL(k_att_unpack, dim3((n + 255) / 256), dim3(256), 0, s, recv, world, slots, wps,
                        static_cast<uint32_t*>(out_rows), out_bits, n_dev, err_host);
 }
+#endif
 
 // ------------------------------------------------------------------ block lookups
 namespace {
@@ -692,14 +749,21 @@ __device__ __forceinline__ bool root_equals(const uint8_t* root32, const uint4& 
 }  // namespace
 
 // ------------------------------------------------------------------ validate_on_attestation (A.4) per group
-__global__ void __launch_bounds__(256)
-k_att_validate_fc(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
-                  uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* __restrict__ union_info,
-                  AttRow* __restrict__ out_rows, int32_t* __restrict__ status_dev, int32_t* __restrict__ status_host,
-                  uint32_t* __restrict__ count_host, uint32_t* __restrict__ err_host)
+namespace {
+__device__ __forceinline__ void att_validate_fc_body(const uint32_t g /* group of this lane */, const ValidateFcArgs& a)
 {
-    __builtin_amdgcn_s_setprio(3);
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint4* __restrict__ rows = static_cast<const uint4*>(a.rows);
+    const AttGroup* __restrict__ grp = a.grp;
+    const AttPlan* __restrict__ plan = a.plan;
+    const uint32_t cap = a.cap;
+    const BlockTableDev& bt = a.bt;
+    const FcCtx& fc = a.fc;
+    const uint32_t* __restrict__ union_info = a.union_info;
+    AttRow* __restrict__ out_rows = a.out_rows;
+    int32_t* __restrict__ status_dev = a.status_dev;
+    int32_t* __restrict__ status_host = a.status_host;
+    uint32_t* __restrict__ count_host = a.count_host;
+    uint32_t* __restrict__ err_host = a.err_host;
     const uint32_t ng = plan->n_groups;
     if (ng > cap) {  // the caller's status / count arrays hold fewer entries than groups were formed: nothing applies
         if (g < ng) status_dev[g] = -1;
@@ -762,17 +826,32 @@ k_att_validate_fc(const uint4* __restrict__ rows, const AttGroup* __restrict__ g
     status_host[g] = st;
     if (count_host) count_host[g] = st == ST_OK ? cnt : 0u;
 }
+}  // namespace
 
+#ifndef POSEVO_BODIES_ONLY
+__global__ void __launch_bounds__(256)
+k_att_validate_fc(const ValidateFcArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);
+    att_validate_fc_body(blockIdx.x * 256 + threadIdx.x, a);
+}
+
+void launch_att_validate_fc(hipStream_t s, const ValidateFcArgs& a)
+{
+    if (a.n_bound == 0) return;
+    hipLaunchKernelGGL(k_att_validate_fc, dim3((a.n_bound + 255) / 256), dim3(256), 0, s, a);
+}
 void launch_att_validate_fc(hipStream_t s, const void* rows, const AttGroup* grp, const AttPlan* plan, uint32_t n_bound,
                             uint32_t cap, BlockTableDev bt, FcCtx fc, const uint32_t* union_info, AttRow* out_rows,
                             int32_t* status_dev, int32_t* status_host, uint32_t* count_host, uint32_t* err_host)
 {
-    if (n_bound == 0) return;
-    hipLaunchKernelGGL(k_att_validate_fc, dim3((n_bound + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows), grp,
-                       plan, cap, bt, fc, union_info, out_rows, status_dev, status_host, count_host, err_host);
+    launch_att_validate_fc(s, ValidateFcArgs{rows, grp, plan, n_bound, cap, bt, fc, union_info, out_rows, status_dev,
+                                             status_host, count_host, err_host});
 }
+#endif
 
 // ------------------------------------------------------------------ process_attestation's asserts + flag indices per group
+#ifndef POSEVO_BODIES_ONLY
 __global__ void __launch_bounds__(256)
 k_att_validate_state(const uint4* __restrict__ rows, const AttGroup* __restrict__ grp, const AttPlan* __restrict__ plan,
                      uint32_t cap, BlockTableDev bt, const StateCtxDev S,
@@ -849,21 +928,29 @@ void launch_att_validate_state(hipStream_t s, const void* rows, const AttGroup* 
     hipLaunchKernelGGL(k_att_validate_state, dim3((n_bound + 255) / 256), dim3(256), 0, s, static_cast<const uint4*>(rows),
                        grp, plan, cap, bt, st, union_info, out_rows, status_dev, status_host, err_host);
 }
+#endif
 
 // ------------------------------------------------------------------ LMD update, validator-major, both tables
 // One lane per validator walks the rows of ITS committee.  The lists are unordered, so the spec's sequential rule
 // (pe:1435-1441: a later target epoch wins; among equal epochs the first in batch order, and only against a stored vote
 // of a strictly earlier epoch) is applied by comparing (epoch, order) explicitly.
-__global__ void __launch_bounds__(256)
-k_lmd_vm_tables(const AttRow* __restrict__ rows, TablesDev tables, const uint32_t* __restrict__ cs0,
-                const uint32_t* __restrict__ cs1, const uint32_t* __restrict__ cl0, const uint32_t* __restrict__ cl1,
-                const AttPlan* __restrict__ plan, const uint32_t* __restrict__ bit_arena,
-                const uint8_t* __restrict__ flags, unsigned long long n_val, unsigned long long* __restrict__ vote_key,
-                uint32_t* __restrict__ vote_block, uint32_t* __restrict__ vote_slot, const uint32_t* __restrict__ gates)
+namespace {
+__device__ __forceinline__ void lmd_vm_tables_body(const unsigned long long v /* validator of this lane */, const LmdVmArgs& a)
 {
-    __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
-    const unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_val) return;
+    const AttRow* __restrict__ rows = a.rows;
+    const TablesDev& tables = a.tables;
+    const uint32_t* __restrict__ cs0 = a.crow_start[0];
+    const uint32_t* __restrict__ cs1 = a.crow_start[1];
+    const uint32_t* __restrict__ cl0 = a.crow_list[0];
+    const uint32_t* __restrict__ cl1 = a.crow_list[1];
+    const AttPlan* __restrict__ plan = a.plan;
+    const uint32_t* __restrict__ bit_arena = a.bit_arena;
+    const uint8_t* __restrict__ flags = a.flags;
+    unsigned long long* __restrict__ vote_key = reinterpret_cast<unsigned long long*>(a.vote_key);
+    uint32_t* __restrict__ vote_block = a.vote_block;
+    uint32_t* __restrict__ vote_slot = a.vote_slot;
+    const uint32_t* __restrict__ gates = a.gates;
+    if (v >= a.n_val) return;
     // a validator sits in one committee of EACH epoch: the same lane walks both tables, one after the other (two lanes
     // would race on its latest message)
     uint32_t best_e = 0, best_order = NONE32, new_block = NONE32, new_slot = 0;
@@ -901,20 +988,33 @@ k_lmd_vm_tables(const AttRow* __restrict__ rows, TablesDev tables, const uint32_
         if (vote_slot) vote_slot[v] = new_slot;
     }
 }
+}  // namespace
 
+#ifndef POSEVO_BODIES_ONLY
+__global__ void __launch_bounds__(256)
+k_lmd_vm_tables(const LmdVmArgs a)
+{
+    __builtin_amdgcn_s_setprio(3);  // in front of a head, beside the previous step's G1 kernels (see fc_kernels.hip)
+    lmd_vm_tables_body((unsigned long long)blockIdx.x * 256 + threadIdx.x, a);
+}
+
+void launch_lmd_vm_tables(hipStream_t s, const LmdVmArgs& a)
+{
+    if (a.n_val == 0) return;
+    hipLaunchKernelGGL(k_lmd_vm_tables, dim3((unsigned)((a.n_val + 255) / 256)), dim3(256), 0, s, a);
+}
 void launch_lmd_vm_tables(hipStream_t s, const AttRow* rows, TablesDev tables, uint32_t* const crow_start[2],
                           uint32_t* const crow_list[2], const AttPlan* plan, const uint32_t* bit_arena,
                           const uint8_t* flags, uint64_t n_val, uint64_t* vote_key, uint32_t* vote_block,
                           uint32_t* vote_slot, const uint32_t* gates)
 {
-    if (n_val == 0) return;
-    hipLaunchKernelGGL(k_lmd_vm_tables, dim3((unsigned)((n_val + 255) / 256)), dim3(256), 0, s, rows, tables,
-                       crow_start[0], crow_start[1], crow_list[0], crow_list[1], plan, bit_arena, flags,
-                       (unsigned long long)n_val, reinterpret_cast<unsigned long long*>(vote_key), vote_block, vote_slot,
-                       gates);
+    launch_lmd_vm_tables(s, LmdVmArgs{rows, tables, {crow_start[0], crow_start[1]}, {crow_list[0], crow_list[1]}, plan,
+                                      bit_arena, flags, n_val, vote_key, vote_block, vote_slot, gates});
 }
+#endif
 
 // ------------------------------------------------------------------ participation flags, one wave per committee
+#ifndef POSEVO_BODIES_ONLY
 __global__ void __launch_bounds__(256)
 k_participation_tables(const AttRow* __restrict__ rows, TablesDev tables, const uint32_t* __restrict__ cs0,
                        const uint32_t* __restrict__ cs1, const uint32_t* __restrict__ cl0,
@@ -988,5 +1088,6 @@ void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev ta
                        (unsigned long long)base_reward_per_increment, part_cur_words, part_prev_words,
                        reinterpret_cast<unsigned long long*>(numerators), gates, cap);
 }
+#endif
 
 }  // namespace posevo

@@ -87,7 +87,7 @@ extern "C" {
 int pe_on_attestation_batch(pe_engine* h, const pe_attestation* atts, uint32_t n, const uint8_t* bits_arena,
                             uint64_t arena_len, int32_t* status, uint8_t* out_aggpk96, uint32_t* out_count)
 {
-    int rc = need_init(h, /*flush=*/false);
+    int rc = need_init(h, /*flush=*/false, /*keep_held=*/atts == PE_ROWS_RESIDENT);  // (that path holds or issues itself)
     if (rc) return rc;
     if (n && (!atts || !bits_arena || !status)) return PE_ERR_INVALID_ARG;
     if (atts == PE_ROWS_RESIDENT) {  // the groups of the last pe_aggregate over rows in device memory, validated there
@@ -432,6 +432,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
         return aggregate_resident(h, atts, n, bits_arena, arena_len, out_atts, out_n_groups, group_of, out_bits_arena,
                                   out_arena_cap, out_aggpk96, out_count);
     }
+    if (h->held.active) PE_TRY(held_issue(h));  // host rows: nothing to pair the held-back launches with
     HostLap lap(&h->trace);
     auto stp = std::make_shared<AggState>();
     AggState& A = *stp;
@@ -875,7 +876,8 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
                                  const uint8_t* bits_arena, uint64_t arena_len, int32_t* status,
                                  uint64_t* out_numerators)
 {
-    int rc = need_init(h, /*flush=*/false);
+    // (over device rows the flag pass runs on the state-transition stream and shares nothing with held-back fork-choice launches)
+    int rc = need_init(h, /*flush=*/false, /*keep_held=*/atts == PE_ROWS_RESIDENT);
     if (rc) return rc;
     if (!st || (n && (!atts || !bits_arena || !status || !out_numerators))) return PE_ERR_INVALID_ARG;
     if (atts == PE_ROWS_RESIDENT) {

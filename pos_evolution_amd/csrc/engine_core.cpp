@@ -38,7 +38,11 @@ int complete_arena(pe_engine* h, int ai)
 {
     pe_engine::PipeArena& a = h->arena[ai];
     if (a.pending.empty() && !a.fenced && a.stage_cursor == 0 && a.out_cursor == 0) return PE_OK;
+    // fork-choice launches of this arena's pipeline still held back for a next aggregate (engine_pair.cpp): nobody waits for
+    // work that has not been launched
+    if (h->held.active && h->held.arena == ai) PE_TRY(held_issue(h));
     if (ai == h->cur) PE_TRY(run_deferred(h));  // deferred launches belong to the arena the calls are going into
+    if (a.fence_pending) PE_TRY(fence_arena(h, a));  // (cannot happen behind held_issue; kept as the invariant's last line)
     hipError_t e = hipSuccess;
     if (a.fenced) {  // a lagged pipeline: its end was marked on every stream it used
         e = bounded_event_sync(h, a.ev_main);
@@ -72,7 +76,7 @@ int complete_arena(pe_engine* h, int ai)
     // is not a completed pipeline: the calls still to come put their outputs behind
     if (a.generation > h->pipes_completed && !(h->pipelining && ai == h->cur)) h->pipes_completed = a.generation;
     a.stage_cursor = a.out_cursor = 0;
-    a.fenced = a.side_used = a.aux_used = a.aux_reads_scratch = false;
+    a.fenced = a.side_used = a.aux_used = a.aux_reads_scratch = a.fence_pending = false;
     if (e == hipErrorNotReady)
         return fail(h, PE_ERR_TIMEOUT, "a collective did not complete within " + std::to_string(h->dist_timeout_ms) +
                     " ms: the communicators were aborted (pe_dist_destroy, then pe_dist_init_ex with PE_DIST_SINGLE_COMM)");
@@ -92,7 +96,7 @@ void complete_oldest_if_ready(pe_engine* h)
 {
     const int ai = (h->cur + 1) % h->n_arenas;
     pe_engine::PipeArena& a = h->arena[ai];
-    if (!a.fenced || a.pending.empty()) return;
+    if (!a.fenced || a.fence_pending || a.pending.empty()) return;
     if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess) ||
         (a.aux_used && hipEventQuery(a.ev_aux) != hipSuccess)) {
         (void)hipGetLastError();  // hipErrorNotReady is not an error here
@@ -106,6 +110,10 @@ int flush_pending(pe_engine* h)
 {
     int rc = h->early_rc;
     h->early_rc = PE_OK;
+    if (h->held.active) {  // launches held back for a next aggregate that is not coming now
+        const int r = held_issue(h);
+        if (r && !rc) rc = r;
+    }
     for (int k = 1; k <= h->n_arenas; ++k) {  // oldest first, the current one last
         const int r = complete_arena(h, (h->cur + k) % h->n_arenas);
         if (r && !rc) rc = r;
@@ -189,11 +197,12 @@ int aux_join(pe_engine* h, hipStream_t ms)
     HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_aux_fork, 0));
     return PE_OK;
 }
-int need_init(pe_engine* h, bool flush)
+int need_init(pe_engine* h, bool flush, bool keep_held)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     if (!h->initialised) return fail(h, PE_ERR_STATE, "store not initialised: call pe_store_init first");
     (void)hipSetDevice(h->device);
+    if (!keep_held && h->held.active) PE_TRY(held_issue(h));
     if (!flush) return PE_OK;
     const int rc = flush_pending(h);
     const int rc2 = aux_quiesce(h);
@@ -318,6 +327,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
         if (lag >= 1 && lag < pe_engine::MAX_ARENAS) h->n_arenas = lag + 1;
     }
     h->tables.reserve(c.max_committee_tables ? c.max_committee_tables : 4u);
+    if (h->pairing) pair_kernels_preload();
     *out = h;
     return PE_OK;
 }
@@ -482,13 +492,22 @@ int pe_pipeline_end_lagged(pe_engine* h)
     h->pipelining = false;
     h->streaming = false;
     HostLap lap(&h->trace);
-    PE_TRY(run_deferred(h));  // the step's G1 sums start now, behind its fork-choice kernels
-    lap.mark("pipe.end_lagged_launch_g1");
     pe_engine::PipeArena& a = h->A();
-    // mark the end of this pipeline on both streams; its completions run when the NEXT lagged end (or any
-    // synchronous call) has waited for the marks
-    HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
-    if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->g1_tail()));  // the last kernel of the G1 chain runs there
+    const bool held = h->held.active && h->held.arena == h->cur;
+    if (held) {
+        // the step's fork-choice launches wait for the next aggregate (engine_pair.cpp); what the step launches BEHIND its
+        // k_tree -- its G1 sums and this pipeline's marks on the engine's and the G1 streams -- goes with them
+        for (auto& f : h->deferred) h->held.g1.push_back(std::move(f));
+        h->deferred.clear();
+        h->held.fence_pending = true;
+        a.fence_pending = true;
+    } else {
+        PE_TRY(run_deferred(h));  // the step's G1 sums start now, behind its fork-choice kernels
+        lap.mark("pipe.end_lagged_launch_g1");
+        // mark the end of this pipeline on both streams; its completions run when the NEXT lagged end (or any
+        // synchronous call) has waited for the marks
+        PE_TRY(fence_arena(h, a));
+    }
     if (a.aux_used) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));
     h->aux_busy = false;    // accounted for by the fence
     a.fenced = true;

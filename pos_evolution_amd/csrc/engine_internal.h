@@ -261,6 +261,8 @@ struct pe_engine {
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
         bool fenced = false, side_used = false, aux_used = false;
+        bool fence_pending = false;  // fenced by pe_pipeline_end_lagged, but ev_main / ev_side are still to be recorded: behind the
+                                     // pipeline's held-back fork-choice launches (engine_pair.cpp)
         bool aux_reads_scratch = false;  // work on the state-transition stream still reads this arena's grouping scratch / resident words
     };
     // lag depth L (pe_pipeline_set_lag, default 2) = L + 1 arenas in rotation: a lagged end waits for the pipeline L
@@ -295,6 +297,24 @@ struct pe_engine {
     bool side_ever = false;             // ev_join has been recorded at least once
     bool streaming = false;             // pe_pipeline_begin_streaming: G1 launches are deferred to the pipeline's end
     std::vector<std::function<int()>> deferred;  // ... these
+    // ---- the fork-choice launches of a streaming step, held back for the next aggregate (engine_pair.cpp) ----
+    // In a streaming pipeline over rows in device memory pe_on_attestation_batch and pe_get_head_async do not launch: their
+    // kernels' argument blocks wait here until the NEXT step's pe_aggregate arrives and are then launched pairwise with its
+    // row kernels (pair_kernels.hip) -- or alone, in order, the moment anything else needs the stream (held_issue).
+    struct HeldFc {
+        bool active = false;
+        int arena = -1;               // the arena (pipeline) the launches belong to
+        bool have_fc = false;         // validate + lmd (pe_on_attestation_batch)
+        bool have_head = false;       // votes + tree (pe_get_head_async)
+        ValidateFcArgs validate{};
+        LmdVmArgs lmd{};
+        VotesArgs votes{};
+        TreeArgs tree{};
+        std::vector<std::function<int()>> g1;  // the step's G1 launches: behind its k_tree, as without the holding
+        bool fence_pending = false;   // pe_pipeline_end_lagged has closed the pipeline: its fence follows these launches
+    } held;
+    bool pairing = std::getenv("POSEVO_PAIR") == nullptr || std::atoi(std::getenv("POSEVO_PAIR")) != 0;
+
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
     // tag: a fold of the group's AttestationData -- a row handed over as resident must BE a row of the resident aggregate,
     // not merely sit at the same offset as one (two aggregates of equal shape lay their unions out alike)
@@ -349,6 +369,7 @@ struct pe_engine {
 
     // ---- profiling ----
     bool profiling = false;
+    uint64_t acc_launches = 0;  // k_g1_accumulate launches: totals mode brackets every 4th one (launch_g1_planned)
     KernelProfile prof[PE_KERNEL_COUNT];
     // pe_profile_enable(h, 2): also a timeline of the bracketed launches (start relative to prof_base, duration)
     bool prof_timeline = false;
@@ -386,10 +407,10 @@ struct ProfScope {
         hipEvent_t e = nullptr;
         return hipEventCreate(&e) == hipSuccess ? e : nullptr;
     }
-    ProfScope(pe_engine* h_, int k_, hipStream_t s_ = nullptr) : h(h_), k(k_), s(s_ ? s_ : h_->stream)
+    ProfScope(pe_engine* h_, int k_, hipStream_t s_ = nullptr, bool sampled_out = false) : h(h_), k(k_), s(s_ ? s_ : h_->stream)
     {
-        if (!h->profiling) return;
-        if (k >= PE_KERNEL_ATT_GROUP && !h->prof_timeline) return;  // brackets that exist for the timeline only
+        if (!h->profiling || sampled_out) return;
+        if ((k == PE_KERNEL_ATT_GROUP || k == PE_KERNEL_ATT_VALIDATE) && !h->prof_timeline) return;  // timeline-only brackets
         a = take(h);
         b = take(h);
         if (!a || !b) { a = b = nullptr; return; }
@@ -409,7 +430,18 @@ int complete_arena(pe_engine* h, int ai);
 void complete_oldest_if_ready(pe_engine* h);
 int flush_pending(pe_engine* h);
 int enter(pe_engine* h);
-int need_init(pe_engine* h, bool flush = true);
+// keep_held: the call does not touch what the held-back fork-choice launches read or write and enqueues nothing that must
+// follow them (host-side scalars; the calls that hold or pair themselves): everything else issues them first
+int need_init(pe_engine* h, bool flush = true, bool keep_held = false);
+// ---- held-back fork-choice launches (engine_pair.cpp)
+bool hold_eligible(const pe_engine* h);
+int held_issue(pe_engine* h);  // each kernel alone, in order, then what waits behind the step's k_tree
+// the row kernels of an aggregate, pairwise with the held launches of the previous step where there are any
+int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa, const MembersArgs& ma, const UnionArgs& ua);
+int fence_arena(pe_engine* h, pe_engine::PipeArena& a);  // ev_main / ev_side of a lagged pipeline's end
+// get_head's tree launch as an argument block (engine_store.cpp)
+int tree_args(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_word, TreeArgs* out);
+VotesArgs votes_args(const pe_engine* h);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
 hipStream_t state_stream_unordered(pe_engine* h);  // the same stream, not ordered behind the engine's

@@ -1,0 +1,150 @@
+// engine_pair.cpp -- the fork-choice launches of a streaming step held back and paired with the next step's row kernels.
+//
+// A streaming caller (pe_pipeline_begin_streaming / _end_lagged over rows in device memory) runs, per step, on the engine's
+// stream:  ingest -> plan -> members -> union   (pe_aggregate: grouping of the step's rows, pe:474 / pe:659)
+//          validate -> LMD                      (pe_on_attestation_batch: A.4, pe:1435-1441)
+//          votes -> tree                        (pe_get_head_async: A.1, pe:1102-1116)
+// The first chain of step N + 1 needs nothing the other two of step N produce, and each is ~120 us of latency-sized
+// kernels.  So the handlers of step N do not launch when they are called: their argument blocks are kept on the handle
+// (pe_engine::held) and go out when step N + 1's pe_aggregate arrives, each one as a block range of the same grid as a row
+// kernel of that aggregate (pair_kernels.hip).  Everything the step launched BEHIND its k_tree follows the pair that
+// carries the tree: the step's G1 sums (deferred as before) and the fence of its lagged pipeline.
+//
+// Nothing changes for the caller: the per-function ABI, the order of effects on the store (the held kernels run in the
+// same order on the same stream, merely later), the lag contract (a step's outputs are complete when the lag-th next
+// pipeline has ended: the launches are out by the NEXT aggregate at the latest, or at any call that needs the stream --
+// held_issue runs them alone, in order -- pe_pipeline_end, pe_get_head, every synchronous entry point).
+// POSEVO_PAIR=0 disables the holding (A/B).
+#include "engine_internal.h"
+
+using namespace posevo;
+
+namespace posevo {
+
+// The calls of a streaming pipeline on the engine's own stream, one rank: only there is a next aggregate to wait for.
+bool hold_eligible(const pe_engine* h)
+{
+    return h->pairing && h->streaming && h->pipelining && h->stream == h->own_stream && !h->dist_ready() &&
+           h->side_stream != nullptr;
+}
+
+int fence_arena(pe_engine* h, pe_engine::PipeArena& a)
+{
+    HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
+    if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->g1_tail()));  // the last kernel of the G1 chain runs there
+    a.fence_pending = false;
+    return PE_OK;
+}
+
+// What a step launches behind its k_tree: its G1 sums (on their own streams, ordered behind the engine's stream by the
+// launch closures), then -- if its pipeline has ended meanwhile -- the pipeline's fence.
+static int after_tree(pe_engine* h, pe_engine::HeldFc& L)
+{
+    int rc = PE_OK;
+    for (auto& f : L.g1) {
+        const int r = f();
+        if (r && !rc) rc = r;
+    }
+    L.g1.clear();
+    if (L.fence_pending && L.arena >= 0) {
+        pe_engine::PipeArena& a = h->arena[L.arena];
+        const int r = fence_arena(h, a);
+        if (r && !rc) rc = r;
+        if (L.arena != h->cur) h->side_busy = false;  // accounted for by that fence (the current pipeline has launched no G1 yet)
+    }
+    return rc;
+}
+
+int held_issue(pe_engine* h)
+{
+    if (!h->held.active) return PE_OK;
+    pe_engine::HeldFc L = std::move(h->held);
+    h->held = pe_engine::HeldFc{};
+    hipStream_t s = h->stream;
+    if (L.have_fc) {
+        {
+            ProfScope ps(h, PE_KERNEL_ATT_VALIDATE);  // timeline mode only
+            launch_att_validate_fc(s, L.validate);
+        }
+        ProfScope ps(h, PE_KERNEL_LMD);
+        launch_lmd_vm_tables(s, L.lmd);
+    }
+    if (L.have_head) {
+        {
+            ProfScope ps(h, PE_KERNEL_VOTES);
+            launch_votes(s, L.votes, /*lean=*/1);
+        }
+        ProfScope ps(h, PE_KERNEL_TREE);
+        launch_tree(s, L.tree, /*lean=*/1);
+    }
+    const hipError_t e = hipGetLastError();
+    const int rc = after_tree(h, L);
+    if (e != hipSuccess) return hip_fail(h, e, "launching the held-back fork-choice kernels");
+    return rc;
+}
+
+int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa, const MembersArgs& ma, const UnionArgs& ua)
+{
+    hipStream_t s = h->stream;
+    if (!h->held.active) {  // nothing held: the row chain alone
+        {
+            ProfScope ps(h, PE_KERNEL_ATT_GROUP, s);  // timeline mode only: ingest + plan + members
+            launch_att_ingest(s, ia);
+            launch_att_plan(s, pa);
+            launch_att_members(s, ma);
+        }
+        ProfScope ps(h, PE_KERNEL_BITS_UNION, s);
+        launch_bits_union(s, ua);
+        return PE_OK;
+    }
+    pe_engine::HeldFc L = std::move(h->held);
+    h->held = pe_engine::HeldFc{};
+    // a pair without a common shape goes out as two launches (the two are independent: any order)
+    if (L.have_fc) {
+        {
+            ProfScope ps(h, PE_KERNEL_PAIR_INGEST_VALIDATE, s);
+            if (!launch_pair_ingest_validate(s, ia, L.validate)) {
+                launch_att_validate_fc(s, L.validate);
+                launch_att_ingest(s, ia);
+            }
+        }
+        ProfScope ps(h, PE_KERNEL_PAIR_PLAN_LMD, s);
+        if (!launch_pair_plan_lmd(s, pa, L.lmd)) {
+            launch_lmd_vm_tables(s, L.lmd);
+            launch_att_plan(s, pa);
+        }
+    } else {
+        ProfScope ps(h, PE_KERNEL_ATT_GROUP, s);
+        launch_att_ingest(s, ia);
+        launch_att_plan(s, pa);
+    }
+    if (L.have_head) {
+        {
+            ProfScope ps(h, PE_KERNEL_PAIR_MEMBERS_VOTES, s);
+            if (!launch_pair_members_votes(s, ma, L.votes)) {
+                launch_votes(s, L.votes, /*lean=*/1);
+                launch_att_members(s, ma);
+            }
+        }
+        ProfScope ps(h, PE_KERNEL_PAIR_UNION_TREE, s);
+        if (!launch_pair_union_tree(s, ua, L.tree)) {
+            launch_tree(s, L.tree, /*lean=*/1);
+            launch_bits_union(s, ua);
+        }
+    } else {
+        {
+            ProfScope ps(h, PE_KERNEL_ATT_GROUP, s);
+            launch_att_members(s, ma);
+        }
+        ProfScope ps(h, PE_KERNEL_BITS_UNION, s);
+        launch_bits_union(s, ua);
+    }
+    const hipError_t e = hipGetLastError();
+    const int rc = after_tree(h, L);
+    if (e != hipSuccess) return hip_fail(h, e, "launching the paired kernels");
+    if (h->streaming) complete_oldest_if_ready(h);  // as pe_get_head_async did behind its k_tree: the copy-out of the oldest
+                                                    // pipeline, if the device is through with it
+    return rc;
+}
+
+}  // namespace posevo

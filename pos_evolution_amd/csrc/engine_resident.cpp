@@ -14,7 +14,6 @@
 // validate_on_attestation admits for gossip attestations); both must be partition tables (a real shuffling is).
 #include "engine_internal.h"
 
-#include <optional>
 
 using namespace posevo;
 
@@ -82,34 +81,48 @@ RrLayout rr_of(pe_engine::PipeArena& a, int set = 0)
     return rr_layout(s.rr.as<uint8_t>(), s.rows_cap, s.comm_cap);
 }
 
-// The arena's scratch for n input rows and tables of up to n_comm committees.  Growing waits for everything enqueued.
+// The arena's scratch for n input rows and tables of up to n_comm committees.  Growing waits for everything enqueued --
+// so when one arena has to grow, every arena of the rotation grows with it: the steps of a stream look alike, and an arena
+// that grew at ITS first use would drain the pipeline once per arena (and with it the fork-choice launches held back for
+// pairing, engine_pair.cpp: the first lag + 1 steps of a run went out unpaired).
 int rr_ensure(pe_engine* h, pe_engine::PipeArena& arena, int set, uint32_t n, uint32_t n_comm)
 {
-    struct View { DevBuf &d_rr_tab, &d_rr; uint32_t &rr_rows_cap, &rr_comm_cap, &rr_tab_size; };
-    const RrSet rs = rr_set(arena, set);
-    View a{rs.tab, rs.rr, rs.rows_cap, rs.comm_cap, rs.tab_size};
-    if (n <= a.rr_rows_cap && n_comm <= a.rr_comm_cap && a.d_rr.p && a.d_rr_tab.p) return PE_OK;
+    {
+        const RrSet rs = rr_set(arena, set);
+        if (n <= rs.rows_cap && n_comm <= rs.comm_cap && rs.rr.p && rs.tab.p) return PE_OK;
+    }
     PE_TRY(flush_pending(h));
     HIP_TRY(h, hipDeviceSynchronize());
-    uint32_t cap_n = std::max<uint32_t>(a.rr_rows_cap, 1024), cap_c = std::max<uint32_t>(a.rr_comm_cap, 64);
+    uint32_t cap_n = 1024, cap_c = 64;
+    for (int i = 0; i < h->n_arenas; ++i) {
+        const RrSet o = rr_set(h->arena[i], set);
+        cap_n = std::max(cap_n, o.rows_cap);
+        cap_c = std::max(cap_c, o.comm_cap);
+    }
     while (cap_n < n) cap_n *= 2;
     while (cap_c < n_comm) cap_c *= 2;
     uint32_t tab = 2048;
     while (tab < 2 * cap_n) tab <<= 1;
     const RrLayout L = rr_layout(nullptr, cap_n, cap_c);
-    a.d_rr.release();
-    a.d_rr_tab.release();
-    HIP_TRY(h, a.d_rr.ensure(L.bytes));
-    HIP_TRY(h, a.d_rr_tab.ensure(8ull * tab));  // slot -> first row | slot -> class size
-    // the grouping table is kept empty by its users (k_att_members clears what k_att_ingest filled); the plan's error
-    // word starts at zero
-    HIP_TRY(h, hipMemsetAsync(a.d_rr_tab.p, 0xFF, 4ull * tab, h->stream));
-    HIP_TRY(h, hipMemsetAsync(a.d_rr_tab.as<uint8_t>() + 4ull * tab, 0, 4ull * tab, h->stream));
-    HIP_TRY(h, hipMemsetAsync(a.d_rr.p, 0, L.bytes, h->stream));
+    for (int i = 0; i < h->n_arenas; ++i) {
+        pe_engine::PipeArena& other = h->arena[i];
+        if (set != 0 && &other != &arena) continue;  // the exchanged aggregate's set: where it is used
+        const RrSet a = rr_set(other, set);
+        if (cap_n <= a.rows_cap && cap_c <= a.comm_cap && a.rr.p && a.tab.p) continue;
+        a.rr.release();
+        a.tab.release();
+        HIP_TRY(h, a.rr.ensure(L.bytes));
+        HIP_TRY(h, a.tab.ensure(8ull * tab));  // slot -> first row | slot -> class size
+        // the grouping table is kept empty by its users (k_att_members clears what k_att_ingest filled); the plan's error
+        // word starts at zero
+        HIP_TRY(h, hipMemsetAsync(a.tab.p, 0xFF, 4ull * tab, h->stream));
+        HIP_TRY(h, hipMemsetAsync(a.tab.as<uint8_t>() + 4ull * tab, 0, 4ull * tab, h->stream));
+        HIP_TRY(h, hipMemsetAsync(a.rr.p, 0, L.bytes, h->stream));
+        a.rows_cap = cap_n;
+        a.comm_cap = cap_c;
+        a.tab_size = tab;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    a.rr_rows_cap = cap_n;
-    a.rr_comm_cap = cap_c;
-    a.rr_tab_size = tab;
     return PE_OK;
 }
 
@@ -245,6 +258,11 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
         }
     }
     hipStream_t ms = h->stream;
+    // Fork-choice launches held back by the PREVIOUS step of a streaming caller go out pairwise with this aggregate's row
+    // kernels (engine_pair.cpp).  Anything else that is held -- launches of THIS pipeline (they read the scratch this
+    // call rewrites), or an aggregate in a form that is not the plain streaming one -- goes out first, alone and in order.
+    const bool pair_ok = h->held.active && h->held.arena != h->cur && set == 0 && !n_dev && !dev_partials && hold_eligible(h);
+    if (h->held.active && !pair_ok) PE_TRY(held_issue(h));
     // an earlier aggregate of THIS pipeline still has to read the arena's resident words / descriptors from its G1 launch
     // (deferred in a streaming pipeline): issue it, then order this call's kernels behind that chain
     // The exchanged aggregate of a committee-sharded step has a scratch set of its own (set 1) precisely so as NOT to wait.
@@ -273,12 +291,10 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                                        arena_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ms));
     }
     lap.mark("ragg.2_bits");
-    std::optional<ProfScope> ps_group;  // timeline mode only: ingest + plan + members
-    ps_group.emplace(h, PE_KERNEL_ATT_GROUP, ms);
     uint32_t* cnt_tab = RS.tab.as<uint32_t>() + RS.tab_size;
-    launch_att_ingest(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, RS.tab_size - 1, L.slot_of, arena_len, L.plan,
-                      st.dev<uint8_t>(off_arena) + pad_at, n_dev, ingest_copies ? bits_arena : nullptr,
-                      ingest_copies ? st.dev<uint8_t>(off_arena) : nullptr);
+    const IngestArgs ia{d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, RS.tab_size - 1, L.slot_of, arena_len, L.plan,
+                        st.dev<uint8_t>(off_arena) + pad_at, n_dev, ingest_copies ? bits_arena : nullptr,
+                        ingest_copies ? st.dev<uint8_t>(off_arena) : nullptr};
     AttPlanArgs pa;
     pa.rows = d_rows;
     pa.n = n;
@@ -305,15 +321,12 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     pa.min_k = G1_MIN_K;
     pa.want_pk = want_pk ? 1u : 0u;
     pa.tables = tables;
-    launch_att_plan(ms, pa);
-    launch_att_members(ms, d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
-                       L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev);
-    ps_group.reset();
-    {
-        ProfScope ps(h, PE_KERNEL_BITS_UNION, ms);
-        launch_bits_union(ms, L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), RS.bits.as<uint32_t>(),
-                          RS.info.as<uint32_t>(), ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan);
-    }
+    const MembersArgs ma{d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
+                         L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev};
+    const UnionArgs ua{L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), RS.bits.as<uint32_t>(), RS.info.as<uint32_t>(),
+                       ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan};
+    // ingest -> plan -> members -> union, each one beside the held-back fork-choice kernel of the previous step if there is one
+    PE_TRY(launch_rows_paired(h, ia, pa, ma, ua));
     HIP_TRY(h, hipGetLastError());
     lap.mark("ragg.3_group_union");
     if (want_pk) {
@@ -446,6 +459,9 @@ int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_
 {
     PE_TRY(resident_precheck(h, "pe_on_attestation_batch"));
     if (cap == 0) return PE_OK;
+    // launches held back by an earlier pipeline, or already some of this one (a second batch, a head in front of it): out
+    // first, in order
+    if (h->held.active && (h->held.arena != h->cur || h->held.have_fc || h->held.have_head)) PE_TRY(held_issue(h));
     HostLap lap(&h->trace);
     PE_TRY(refresh_tree(h));
     pe_engine::PipeArena& RA = h->arena[h->rr.arena];
@@ -467,19 +483,28 @@ int on_attestation_resident(pe_engine* h, uint32_t cap, int32_t* status, uint32_
     // entries past the groups formed read "nothing applied"
     memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
     memset(ob.host<uint32_t>(off_count), 0, 4ull * cap);
-    {
-        ProfScope ps(h, PE_KERNEL_ATT_VALIDATE);  // timeline mode only
-        launch_att_validate_fc(h->stream, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), fc,
-                               RS.info.as<uint32_t>(), L.rows_fc, L.status_fc, ob.host<int32_t>(off_status),
-                               ob.host<uint32_t>(off_count), ob.host<uint32_t>(off_err));
-    }
-    {
+    const ValidateFcArgs va{h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), fc, RS.info.as<uint32_t>(), L.rows_fc,
+                            L.status_fc, ob.host<int32_t>(off_status), ob.host<uint32_t>(off_count), ob.host<uint32_t>(off_err)};
+    const LmdVmArgs la{L.rows_fc, h->rr.tables, {L.crow_start[0], L.crow_start[1]}, {L.crow_list[0], L.crow_list[1]}, L.plan,
+                       RS.bits.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
+                       h->d_vote_block.as<uint32_t>(), h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr,
+                       reinterpret_cast<const uint32_t*>(L.status_fc)};
+    if (hold_eligible(h) && h->rr.arena == h->cur && h->rr.set == 0 && h->n_val) {
+        // a streaming step: validate + LMD go out with the NEXT aggregate's row kernels (engine_pair.cpp); they read this
+        // arena's scratch and unions, which stay untouched until the arena comes round again (lag depth + 1 steps)
+        h->held.validate = va;
+        h->held.lmd = la;
+        h->held.have_fc = true;
+        h->held.active = true;
+        h->held.arena = h->cur;
+    } else {
+        if (h->held.active) PE_TRY(held_issue(h));
+        {
+            ProfScope ps(h, PE_KERNEL_ATT_VALIDATE);  // timeline mode only
+            launch_att_validate_fc(h->stream, va);
+        }
         ProfScope ps(h, PE_KERNEL_LMD);
-        launch_lmd_vm_tables(h->stream, L.rows_fc, h->rr.tables, L.crow_start, L.crow_list, L.plan,
-                             RS.bits.as<uint32_t>(), h->d_flags.as<uint8_t>(), h->n_val, h->d_vote_key.as<uint64_t>(),
-                             h->d_vote_block.as<uint32_t>(),
-                             h->cfg.vote_expiry_slots ? h->d_vote_slot.as<uint32_t>() : nullptr,
-                             reinterpret_cast<const uint32_t*>(L.status_fc));
+        launch_lmd_vm_tables(h->stream, la);
     }
     HIP_TRY(h, hipGetLastError());
     lap.mark("ratt.1_launch");

@@ -16,6 +16,7 @@ namespace posevo {
 int refresh_tree(pe_engine* h)
 {
     if (!h->tree_dirty) return PE_OK;
+    if (h->held.active) PE_TRY(held_issue(h));  // held-back launches read the tables this upload rewrites
     const uint32_t n = (uint32_t)h->blocks.size();
     if (n > (uint32_t)TREE_MAX_BLOCKS)
         return fail(h, PE_ERR_CAPACITY, "block table exceeds the LDS-resident tree capacity (8192)");
@@ -229,9 +230,9 @@ int upload_balances(pe_engine* h, uint64_t n, const uint64_t* bal, const uint8_t
     return PE_OK;
 }
 
-// get_head's device part on arbitrary weight buffer.
-int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out,
-             uint32_t* async_word)
+// get_head's tree launch as an argument block: the store's scalars of NOW (justified root, proposer boost) by value, the
+// head index into head_word (host-coherent pinned memory: no D2H copy), which reads NONE32 until the kernel has run.
+int tree_args(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_word, TreeArgs* out)
 {
     uint32_t just_idx;
     if (!find_block(h, h->justified.root, &just_idx))
@@ -241,17 +242,32 @@ int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int c
         uint32_t bi;
         if (find_block(h, h->boost_root, &bi)) boost_pos = h->h_pos_of_idx[bi];
     }
+    *const_cast<volatile uint32_t*>(head_word) = NONE32;
+    *out = TreeArgs{tree_dev(h), d_direct, d_totals, 0, 0, 0, h->h_pos_of_idx[just_idx], boost_pos, h->cfg.slots_per_epoch,
+                    h->cfg.proposer_score_boost, h->cfg.effective_balance_increment, h->d_weights.as<uint64_t>(), head_word,
+                    clear_direct};
+    return PE_OK;
+}
+// ... and its votes launch over the engine's own weight buffer
+VotesArgs votes_args(const pe_engine* h)
+{
+    return VotesArgs{h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(), h->n_val,
+                     h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(), h->d_direct.as<uint64_t>(),
+                     h->d_totals.as<VoteTotals>(), expiry_slots_ptr(h), min_vote_slot(h)};
+}
+
+// get_head's device part on arbitrary weight buffer.
+int run_tree(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_out,
+             uint32_t* async_word)
+{
     // async_word: a slot of the pinned output block instead of the engine's head word -- pe_get_head_async: nobody polls,
     // the call's completion reads it when the pipeline's outputs are complete
     volatile uint32_t* head_word = async_word ? async_word : h->h_head.as<uint32_t>();
-    *head_word = NONE32;
+    TreeArgs ta;
+    PE_TRY(tree_args(h, d_direct, d_totals, clear_direct, const_cast<uint32_t*>(head_word), &ta));
     {
         ProfScope ps(h, PE_KERNEL_TREE);
-        // the head index lands directly in host-coherent pinned memory: no D2H copy, just the stream sync
-        launch_tree(h->stream, tree_dev(h), d_direct, d_totals, 0, 0, 0, h->h_pos_of_idx[just_idx], boost_pos,
-                    h->cfg.slots_per_epoch, h->cfg.proposer_score_boost, h->cfg.effective_balance_increment,
-                    h->d_weights.as<uint64_t>(), const_cast<uint32_t*>(head_word), clear_direct,
-                    /*lean=*/h->pipelining ? 1 : 0);  // inside a pipeline: the shape that fits beside an accumulation
+        launch_tree(h->stream, ta, /*lean=*/h->pipelining ? 1 : 0);  // inside a pipeline: the shape that fits beside an accumulation
     }
     HIP_TRY(h, hipGetLastError());
     // a streaming pipeline's G1 sums go out now, ordered behind k_tree on the device: they start the moment the head
@@ -394,7 +410,7 @@ int pe_set_balances(pe_engine* h, uint64_t n, const uint64_t* effective_balance,
 
 int pe_on_tick(pe_engine* h, uint64_t time)
 {
-    int rc = need_init(h, /*flush=*/false);  // host-side scalars only
+    int rc = need_init(h, /*flush=*/false, /*keep_held=*/true);  // host-side scalars only
     if (rc) return rc;
     if (time < h->genesis_time) return fail(h, PE_ERR_INVALID_ARG, "time before genesis");
     const uint64_t previous_slot = current_slot(h);
@@ -498,7 +514,7 @@ int pe_set_checkpoints(pe_engine* h, uint64_t je, const uint8_t jr[32], uint64_t
 
 int pe_set_proposer_boost(pe_engine* h, const uint8_t root[32])
 {
-    int rc = need_init(h, /*flush=*/false);  // a host-side scalar (read where get_head is enqueued), like on_tick's
+    int rc = need_init(h, /*flush=*/false, /*keep_held=*/true);  // a host-side scalar (read where get_head is enqueued), like on_tick's
     if (rc) return rc;
     if (!root) return PE_ERR_INVALID_ARG;
     const Root r = to_root(root);
@@ -826,10 +842,12 @@ int pe_get_head(pe_engine* h, uint8_t out_root[32])
 // G1 sums behind them) are enqueued, nothing is polled.  The caller's loop then never blocks on the GPU inside a step.
 int pe_get_head_async(pe_engine* h, uint8_t out_root[32])
 {
-    int rc = need_init(h, /*flush=*/false);
+    int rc = need_init(h, /*flush=*/false, /*keep_held=*/true);
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
     if (!h->pipelining) return pe_get_head(h, out_root);  // outside a pipeline every call is synchronous
+    // launches held back by an EARLIER pipeline, or a head already held for this one: out first, in order
+    if (h->held.active && (h->held.arena != h->cur || h->held.have_head)) PE_TRY(held_issue(h));
     HostLap lap(&h->trace);
     PE_TRY(refresh_tree(h));
     {
@@ -841,15 +859,24 @@ int pe_get_head_async(pe_engine* h, uint8_t out_root[32])
     OutBlock ob(h);
     const size_t off = ob.alloc(64);
     PE_TRY(ob.ensure());
-    {
-        ProfScope ps(h, PE_KERNEL_VOTES);
-        launch_votes(h->stream, h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
-                     h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), (uint32_t)h->blocks.size(),
-                     h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 0, expiry_slots_ptr(h),
-                     min_vote_slot(h), /*lean=*/1);
+    if (hold_eligible(h) && h->n_val) {
+        // a streaming step: votes + tree (and, behind them, the step's G1 sums) go out with the NEXT aggregate's row kernels
+        // (engine_pair.cpp) -- the store's scalars are read now, the vote tables when the kernels run, behind this step's
+        // LMD update either way
+        PE_TRY(tree_args(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 1, ob.host<uint32_t>(off), &h->held.tree));
+        h->held.votes = votes_args(h);
+        h->held.have_head = true;
+        h->held.active = true;
+        h->held.arena = h->cur;
+    } else {
+        if (h->held.active) PE_TRY(held_issue(h));
+        {
+            ProfScope ps(h, PE_KERNEL_VOTES);
+            launch_votes(h->stream, votes_args(h), /*lean=*/1);
+        }
+        uint32_t unused;
+        PE_TRY(run_tree(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 1, &unused, ob.host<uint32_t>(off)));
     }
-    uint32_t unused;
-    PE_TRY(run_tree(h, h->d_direct.as<uint64_t>(), h->d_totals.as<VoteTotals>(), 1, &unused, ob.host<uint32_t>(off)));
     lap.mark("head.async_launch");
     const size_t base = ob.base;
     const int ai = h->cur;

@@ -57,24 +57,32 @@ constexpr int VOTES_PER_THREAD = 4;
 // 1: the lean form for pipelined steps, where this kernel runs BESIDE k_g1_accumulate of the previous aggregate:
 // that kernel's two waves per SIMD hold 464 of the 512 registers, and only a wave of <= 48 fits into the rest and can
 // start before the accumulation's last workgroup retires.
+// (body: block index and grid size are arguments, hist = the workgroup's n_blocks bins of LDS -- the same code runs as a
+// kernel of its own and as one block range of a paired launch, pair_kernels.hip)
 template <int QUADS>
-__global__ void __launch_bounds__(VOTES_WG)
-k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ eff_balance,
-        const uint8_t* __restrict__ flags, uint64_t n_val, uint32_t filter_slashed,
-        const uint32_t* __restrict__ pos_of_idx, uint32_t n_blocks, unsigned long long* __restrict__ direct,
-        VoteTotals* __restrict__ totals, const uint32_t* __restrict__ vote_slot, uint32_t min_vote_slot)
+__device__ __forceinline__ void votes_body(const uint32_t bid, const uint32_t nblk, const VotesArgs& a,
+                                           unsigned long long* __restrict__ hist)
 {
-    POSEVO_FC_PRIO();
-    extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];  // n_blocks bins, by insertion index
+    const uint32_t* __restrict__ vote_block = a.vote_block;
+    const uint64_t* __restrict__ eff_balance = a.eff_balance;
+    const uint8_t* __restrict__ flags = a.flags;
+    const uint64_t n_val = a.n_val;
+    const uint32_t filter_slashed = a.filter_slashed;
+    const uint32_t* __restrict__ pos_of_idx = a.pos_of_idx;
+    const uint32_t n_blocks = a.n_blocks;
+    unsigned long long* __restrict__ direct = reinterpret_cast<unsigned long long*>(a.direct);
+    VoteTotals* __restrict__ totals = a.totals;
+    const uint32_t* __restrict__ vote_slot = a.vote_slot;
+    const uint32_t min_vote_slot = a.min_vote_slot;
     for (uint32_t b = threadIdx.x; b < n_blocks; b += VOTES_WG) hist[b] = 0;
     __syncthreads();
 
     unsigned long long act_bal = 0;
     uint32_t act_num = 0;
     const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
-    const uint64_t stride = (uint64_t)gridDim.x * VOTES_WG;
+    const uint64_t stride = (uint64_t)nblk * VOTES_WG;
     // QUADS quads (4 validators each: 16 + 32 + 4 bytes of vector loads) in flight per lane per iteration
-    for (uint64_t q0 = (uint64_t)blockIdx.x * VOTES_WG + threadIdx.x; q0 < n_quads; q0 += QUADS * stride) {
+    for (uint64_t q0 = (uint64_t)bid * VOTES_WG + threadIdx.x; q0 < n_quads; q0 += QUADS * stride) {
         uint32_t vb[4 * QUADS];
         unsigned long long bal[4 * QUADS];
         uint32_t fl[4 * QUADS];
@@ -132,14 +140,14 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        totals[blockIdx.x].total_active_balance = wg_tot[0];
-        totals[blockIdx.x].num_active = wg_tot[1];
+        totals[bid].total_active_balance = wg_tot[0];
+        totals[bid].num_active = wg_tot[1];
     }
     // The slots no workgroup of THIS launch owns must read zero: after an in-place all-reduce they hold the other ranks'
     // sums of the previous round (ranks with unequal shards launch different grids), and a shrinking registry leaves
     // stale partials behind (the sharded head double-counted them).  Workgroup 0 clears them: no memset.
-    if (blockIdx.x == 0)
-        for (uint32_t j = gridDim.x + threadIdx.x; j < (uint32_t)VOTES_MAX_WG; j += VOTES_WG) {
+    if (bid == 0)
+        for (uint32_t j = nblk + threadIdx.x; j < (uint32_t)VOTES_MAX_WG; j += VOTES_WG) {
             totals[j].total_active_balance = 0;
             totals[j].num_active = 0;
         }
@@ -149,7 +157,34 @@ k_votes(const uint32_t* __restrict__ vote_block, const uint64_t* __restrict__ ef
         if (w) atomicAdd(&direct[pos_of_idx[b]], w);
     }
 }
+// workgroups of a votes launch over n_val validators
+inline unsigned votes_blocks(uint64_t n_val)
+{
+    const uint64_t n_quads = (n_val + VOTES_PER_THREAD - 1) / VOTES_PER_THREAD;
+    uint64_t blocks = (n_quads + VOTES_WG - 1) / VOTES_WG;
+    // Grid-stride over few, fat workgroups: every workgroup zeroes, scans and flushes a whole n_blocks histogram, so
+    // at 1 M validators 64 workgroups (16 K validators each) beat 256 (k_votes 16 us vs 23 us, get_head p50 46 vs 53 us);
+    // the count grows with the registry up to one workgroup per CU (launch_votes has the measured alternatives).
+    uint64_t cap = n_val / 16384;
+    cap = cap < 64 ? 64 : cap > (uint64_t)VOTES_MAX_WG ? (uint64_t)VOTES_MAX_WG : cap;
+    return (unsigned)(blocks > cap ? cap : blocks);
+}
 
+#ifndef POSEVO_BODIES_ONLY
+template <int QUADS>
+__global__ void __launch_bounds__(VOTES_WG)
+k_votes(const VotesArgs a)
+{
+    POSEVO_FC_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];  // n_blocks bins, by insertion index
+    votes_body<QUADS>(blockIdx.x, gridDim.x, a, hist);
+}
+
+void launch_votes(hipStream_t s, const VotesArgs& a, int lean)
+{
+    launch_votes(s, a.vote_block, a.eff_balance, a.flags, a.n_val, a.filter_slashed, a.pos_of_idx, a.n_blocks, a.direct,
+                 a.totals, 0, a.vote_slot, a.min_vote_slot, lean);
+}
 void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff_balance, const uint8_t* flags,
                   uint64_t n_val, uint32_t filter_slashed, const uint32_t* pos_of_idx, uint32_t n_blocks,
                   uint64_t* direct, VoteTotals* totals, int zero_first, const uint32_t* vote_slot, uint32_t min_vote_slot,
@@ -178,15 +213,14 @@ void launch_votes(hipStream_t s, const uint32_t* vote_block, const uint64_t* eff
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_votes<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(uint64_t) * TREE_MAX_BLOCKS));
     }
+    const VotesArgs a{vote_block, eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks, direct, totals, vote_slot,
+                      min_vote_slot};
     if (lean)
-        hipLaunchKernelGGL(k_votes<1>, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
-                           eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
-                           reinterpret_cast<unsigned long long*>(direct), totals, vote_slot, min_vote_slot);
+        hipLaunchKernelGGL(k_votes<1>, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, a);
     else
-        hipLaunchKernelGGL(k_votes<2>, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, vote_block,
-                           eff_balance, flags, n_val, filter_slashed, pos_of_idx, n_blocks,
-                           reinterpret_cast<unsigned long long*>(direct), totals, vote_slot, min_vote_slot);
+        hipLaunchKernelGGL(k_votes<2>, dim3((unsigned)blocks), dim3(VOTES_WG), sizeof(uint64_t) * n_blocks, s, a);
 }
+#endif
 
 // ------------------------------------------------------------------ tree
 // (A fused get_head -- votes phase in every workgroup, tree phase in the last one to pass a device-scope ticket --
@@ -279,16 +313,20 @@ __device__ __forceinline__ void block_exclusive_scan2(const unsigned long long (
 // lds_entries: skewed index range of this launch (the host sizes the dynamic LDS for the block count at hand, not for
 // the 8192-block maximum: 82 KB at 4096 blocks leaves room for another kernel's workgroup on the CU).
 template <int TREE_WG, int TREE_PER_THREAD, bool LEAN = false>
-__global__ void __launch_bounds__(TREE_WG)
-k_tree(TreeDev tree, uint32_t lds_entries, unsigned long long* __restrict__ direct, const VoteTotals* __restrict__ totals,
-       unsigned long long ov_balance, unsigned long long ov_num, int use_override, uint32_t justified_pos,
-       uint32_t boost_pos, unsigned long long slots_per_epoch, unsigned long long boost_percent,
-       unsigned long long balance_increment, unsigned long long* __restrict__ weights_by_idx,
-       uint32_t* __restrict__ head_idx, int clear_direct)
+__device__ __forceinline__ void tree_body(const TreeArgs& a, const uint32_t lds_entries, unsigned char* smem)  // ONE workgroup
 {
-    POSEVO_FC_PRIO();
+    const TreeDev& tree = a.tree;
+    unsigned long long* __restrict__ direct = reinterpret_cast<unsigned long long*>(a.direct);
+    const VoteTotals* __restrict__ totals = a.totals;
+    const unsigned long long ov_balance = a.ov_balance, ov_num = a.ov_num;
+    const int use_override = a.use_override;
+    const uint32_t justified_pos = a.justified_pos, boost_pos = a.boost_pos;
+    const unsigned long long slots_per_epoch = a.slots_per_epoch, boost_percent = a.boost_percent,
+                             balance_increment = a.balance_increment;
+    unsigned long long* __restrict__ weights_by_idx = reinterpret_cast<unsigned long long*>(a.weights_by_idx);
+    uint32_t* __restrict__ head_idx = a.head_idx;
+    const int clear_direct = a.clear_direct;
     // LDS plan (n <= 8192, skewed indices):  S u64 (later bestW) | L u32 (later bestRank) | jump u32 | scratch
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // u64 regions first so that every 64-bit LDS access (ds_*_b64, ds_add_u64, ds_max_u64) is 8-byte aligned
     unsigned long long* S = reinterpret_cast<unsigned long long*>(smem);
     unsigned long long* wave_tot64 = S + lds_entries;         // 16 waves
@@ -452,44 +490,56 @@ k_tree(TreeDev tree, uint32_t lds_entries, unsigned long long* __restrict__ dire
     if (tid == 0)  // host-coherent pinned word polled by the host: system-scope release
         __hip_atomic_store(head_idx, tree.idx_of_pos[head_pos[0]], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// dynamic LDS of a tree launch: skewed index of the last entry (n) of the shape, + 1, rounded up to keep the u32 regions
+// 16-byte aligned; the bytes that go with it; the most any launch asks for (the opt-in beyond 64 KiB)
+template <int PER>
+inline uint32_t tree_lds_entries(uint32_t n) { return std::min<uint32_t>(TREE_LDS_ENTRIES, ((SKT<PER>(n + 1) + 2) + 3u) & ~3u); }
+inline size_t tree_lds_bytes(uint32_t entries) { return sizeof(uint64_t) * ((size_t)entries + 18) + sizeof(uint32_t) * (2 * (size_t)entries + 16); }
+constexpr size_t TREE_LDS_MAX = sizeof(uint64_t) * (TREE_LDS_ENTRIES + 18) + sizeof(uint32_t) * (2 * TREE_LDS_ENTRIES + 16);
 
-template <int WG, int PER, bool LEAN = false>
-static void launch_tree_shape(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
-                              uint64_t ovb, uint64_t ovn, int use_override, uint32_t justified_pos, uint32_t boost_pos,
-                              uint64_t slots_per_epoch, uint64_t boost_percent, uint64_t balance_increment,
-                              uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct)
+#ifndef POSEVO_BODIES_ONLY
+template <int TREE_WG, int TREE_PER_THREAD, bool LEAN = false>
+__global__ void __launch_bounds__(TREE_WG)
+k_tree(const TreeArgs a, const uint32_t lds_entries)
 {
-    constexpr size_t lds_max = sizeof(uint64_t) * (TREE_LDS_ENTRIES + 18) + sizeof(uint32_t) * (2 * TREE_LDS_ENTRIES + 16);
-    if (first_use_on_this_device<1000 + WG + PER + (LEAN ? 5000 : 0)>()) {  // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<WG, PER, LEAN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    }
-    // skewed index of the last entry (n) of this shape, + 1, rounded up to keep the u32 regions 16-byte aligned
-    const uint32_t entries = std::min<uint32_t>(TREE_LDS_ENTRIES, ((SKT<PER>(tree.n + 1) + 2) + 3u) & ~3u);
-    const size_t lds = sizeof(uint64_t) * ((size_t)entries + 18) + sizeof(uint32_t) * (2 * (size_t)entries + 16);
-    hipLaunchKernelGGL((k_tree<WG, PER, LEAN>), dim3(1), dim3(WG), lds, s, tree, entries,
-                       reinterpret_cast<unsigned long long*>(direct), totals, (unsigned long long)ovb,
-                       (unsigned long long)ovn, use_override, justified_pos, boost_pos, (unsigned long long)slots_per_epoch,
-                       (unsigned long long)boost_percent, (unsigned long long)balance_increment,
-                       reinterpret_cast<unsigned long long*>(weights_by_idx), head_idx, clear_direct);
+    POSEVO_FC_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    tree_body<TREE_WG, TREE_PER_THREAD, LEAN>(a, lds_entries, smem);
 }
 
+template <int WG, int PER, bool LEAN = false>
+static void launch_tree_shape(hipStream_t s, const TreeArgs& a)
+{
+    if (first_use_on_this_device<1000 + WG + PER + (LEAN ? 5000 : 0)>()) {  // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_tree<WG, PER, LEAN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)TREE_LDS_MAX);
+    }
+    const uint32_t entries = tree_lds_entries<PER>(a.tree.n);
+    hipLaunchKernelGGL((k_tree<WG, PER, LEAN>), dim3(1), dim3(WG), tree_lds_bytes(entries), s, a, entries);
+}
+
+void launch_tree(hipStream_t s, const TreeArgs& a, int lean)
+{
+    const uint32_t n = a.tree.n;
+    if (n <= 1024) launch_tree_shape<1024, 1>(s, a);  // 40 VGPRs x 4 waves per SIMD: lean as it is
+    else if (lean && n <= 2048) launch_tree_shape<512, 4, true>(s, a);
+    else if (lean && n <= 4096) launch_tree_shape<512, 8, true>(s, a);
+    else if (n <= 2048) launch_tree_shape<1024, 2>(s, a);
+    else if (n <= 4096) launch_tree_shape<1024, 4>(s, a);
+    else launch_tree_shape<1024, 8>(s, a);
+}
 void launch_tree(hipStream_t s, const TreeDev& tree, uint64_t* direct, const VoteTotals* totals,
                  uint64_t totals_override_balance, uint64_t totals_override_num, int use_override,
                  uint32_t justified_pos, uint32_t boost_pos, uint64_t slots_per_epoch, uint64_t boost_percent,
                  uint64_t balance_increment, uint64_t* weights_by_idx, uint32_t* head_idx, int clear_direct, int lean)
 {
-#define POSEVO_TREE_ARGS s, tree, direct, totals, totals_override_balance, totals_override_num, use_override, justified_pos, \
-        boost_pos, slots_per_epoch, boost_percent, balance_increment, weights_by_idx, head_idx, clear_direct
-    if (tree.n <= 1024) launch_tree_shape<1024, 1>(POSEVO_TREE_ARGS);  // 40 VGPRs x 4 waves per SIMD: lean as it is
-    else if (lean && tree.n <= 2048) launch_tree_shape<512, 4, true>(POSEVO_TREE_ARGS);
-    else if (lean && tree.n <= 4096) launch_tree_shape<512, 8, true>(POSEVO_TREE_ARGS);
-    else if (tree.n <= 2048) launch_tree_shape<1024, 2>(POSEVO_TREE_ARGS);
-    else if (tree.n <= 4096) launch_tree_shape<1024, 4>(POSEVO_TREE_ARGS);
-    else launch_tree_shape<1024, 8>(POSEVO_TREE_ARGS);
-#undef POSEVO_TREE_ARGS
+    launch_tree(s, TreeArgs{tree, direct, totals, totals_override_balance, totals_override_num, use_override, justified_pos,
+                            boost_pos, slots_per_epoch, boost_percent, balance_increment, weights_by_idx, head_idx,
+                            clear_direct}, lean);
 }
+#endif
 
+#ifndef POSEVO_BODIES_ONLY
 // ------------------------------------------------------------------ LMD update
 // One wave per attestation; lane l walks bit words l, l+64, ...
 __device__ __forceinline__ unsigned long long lmd_key(uint32_t epoch_p1, uint32_t order)
@@ -797,20 +847,24 @@ void launch_state_view_from_registry(hipStream_t s, const uint8_t* flags, const 
                        sflags, increments);
 }
 
+#endif  // POSEVO_BODIES_ONLY
+
 // ------------------------------------------------------------------ bitfield union
 // One wave per group.  The members' bitfields are read straight from the caller's arena as uploaded (byte offsets:
 // an aligned dword pair + v_alignbyte_b32), so the host packs nothing.  Besides the OR and its popcount the wave sums
 // the members' own popcounts: sum > popcount(OR) <=> two members share a bit (A.8: such aggregates are not merged --
 // the aggregate signature would count that validator twice).
-__global__ void __launch_bounds__(256)
-k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ att_bytes,
-             const uint8_t* __restrict__ bit_arena, uint32_t* __restrict__ out_arena,
-             uint32_t* __restrict__ out_info, uint32_t* __restrict__ host_arena, uint32_t* __restrict__ host_info,
-             const AttPlan* __restrict__ plan_dev)
+__device__ __forceinline__ void bits_union_body(const uint32_t g /* group of this WAVE */, const UnionArgs& a)
 {
-    POSEVO_FC_PRIO();
-    if (plan_dev) n_groups = plan_dev->n_groups;  // groups formed on the device: the grid covers an upper bound
-    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const UnionGroup* __restrict__ groups = a.groups;
+    const uint32_t* __restrict__ att_bytes = a.att_bytes;
+    const uint8_t* __restrict__ bit_arena = a.bit_arena;
+    uint32_t* __restrict__ out_arena = a.out_arena;
+    uint32_t* __restrict__ out_info = a.out_info;
+    uint32_t* __restrict__ host_arena = a.host_arena;
+    uint32_t* __restrict__ host_info = a.host_info;
+    uint32_t n_groups = a.n_groups;
+    if (a.plan_dev) n_groups = a.plan_dev->n_groups;  // groups formed on the device: the grid covers an upper bound
     if (g >= n_groups) return;
     const int lane = threadIdx.x & 63;
     const UnionGroup d = groups[g];
@@ -846,13 +900,25 @@ k_bits_union(const UnionGroup* __restrict__ groups, uint32_t n_groups, const uin
     }
 }
 
+#ifndef POSEVO_BODIES_ONLY
+__global__ void __launch_bounds__(256)
+k_bits_union(const UnionArgs a)
+{
+    POSEVO_FC_PRIO();
+    bits_union_body(blockIdx.x * 4 + (threadIdx.x >> 6), a);
+}
+
+void launch_bits_union(hipStream_t s, const UnionArgs& a)
+{
+    if (a.n_groups == 0) return;
+    hipLaunchKernelGGL(k_bits_union, dim3((a.n_groups + 3) / 4), dim3(256), 0, s, a);
+}
 void launch_bits_union(hipStream_t s, const UnionGroup* groups, uint32_t n_groups, const uint32_t* att_bytes,
                        const uint8_t* bit_arena, uint32_t* out_arena, uint32_t* out_info, uint32_t* host_arena,
                        uint32_t* host_info, const AttPlan* plan_dev)
 {
-    if (n_groups == 0) return;
-    hipLaunchKernelGGL(k_bits_union, dim3((n_groups + 3) / 4), dim3(256), 0, s, groups, n_groups, att_bytes,
-                       bit_arena, out_arena, out_info, host_arena, host_info, plan_dev);
+    launch_bits_union(s, UnionArgs{groups, n_groups, att_bytes, bit_arena, out_arena, out_info, host_arena, host_info, plan_dev});
 }
+#endif
 
 }  // namespace posevo

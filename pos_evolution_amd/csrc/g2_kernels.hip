@@ -494,6 +494,22 @@ void launch_g2_subgroup_check(hipStream_t s, const uint32_t* points_mont48, uint
     hipLaunchKernelGGL(k_g2_subgroup_check, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, s, points_mont48, n, status);
 }
 
+// Rows whose status is not 0 become the (0, 0) row = infinity, so that a plain sum leaves them out (pe_aggregate_signatures:
+// a signature outside G2 keeps its decoded point until here; undecodable ones are zero rows already).
+__global__ void __launch_bounds__(256)
+k_g2_mask_bad(uint32_t* __restrict__ points_mont48, uint64_t n, const int32_t* __restrict__ status)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // 12 lanes of 16 bytes per 192-byte row
+    const uint64_t i = t / 12;
+    if (i >= n || status[i] == 0) return;
+    reinterpret_cast<uint4*>(points_mont48)[t] = make_uint4(0, 0, 0, 0);
+}
+void launch_g2_mask_bad(hipStream_t s, uint32_t* points_mont48, uint64_t n, const int32_t* status)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_g2_mask_bad, dim3((unsigned)((12 * n + 255) / 256)), dim3(256), 0, s, points_mont48, n, status);
+}
+
 // ---------------------------------------------------------------- the signature leg of pe_aggregate
 // bls.Aggregate (pe:659, pe:714-717) per aggregate: group g's signature = the sum of its members' signature points,
 // members listed by input row (member_row[list_start .. + n_atts), the lists the bitfield union runs over).  One lane

@@ -258,6 +258,61 @@ void launch_participation_tables(hipStream_t s, const AttRow* rows, TablesDev ta
                                  uint32_t* part_cur_words, uint32_t* part_prev_words, uint64_t* numerators,
                                  const uint32_t* gates, uint32_t cap);  // cap: slots of numerators[]; more groups = no-op
 
+// ---- paired launches (pair_kernels.hip) --------------------------------------------------------------------------
+// A streaming caller's engine stream carries two independent chains: the fork-choice chain of step N (validate ->
+// LMD -> votes -> tree) and the row chain of step N + 1 (ingest -> plan -> members -> union).  Side by side on two
+// streams the command processor's queue interleaving costs more than the overlap gives; launched as ONE
+// kernel per pair -- block ranges of one grid, each range running the body of its own kernel -- they overlap without a
+// second queue.  The argument blocks below are the stand-alone kernels' parameters, so that a held-back launch can be
+// issued either way (engine_pair.cpp).
+struct IngestArgs {
+    const void* rows; uint32_t n; uint32_t* tab; uint32_t* cnt_tab; uint32_t tab_mask; uint32_t* slot_of;
+    uint64_t arena_len; AttPlan* plan; void* arena_pad32; const uint32_t* n_dev; const void* arena_src; void* arena_dst;
+};
+struct ValidateFcArgs {
+    const void* rows; const AttGroup* grp; const AttPlan* plan; uint32_t n_bound, cap; BlockTableDev bt; FcCtx fc;
+    const uint32_t* union_info; AttRow* out_rows; int32_t* status_dev; int32_t* status_host; uint32_t* count_host;
+    uint32_t* err_host;
+};
+struct LmdVmArgs {
+    const AttRow* rows; TablesDev tables; const uint32_t* crow_start[2]; const uint32_t* crow_list[2];
+    const AttPlan* plan; const uint32_t* bit_arena; const uint8_t* flags; uint64_t n_val; uint64_t* vote_key;
+    uint32_t* vote_block; uint32_t* vote_slot; const uint32_t* gates;
+};
+struct MembersArgs {
+    const void* rows; uint32_t n; uint32_t* tab; uint32_t* cnt_tab; const uint32_t* slot_of; const uint32_t* rep_of;
+    const uint32_t* gid_of_row; AttGroup* grp; AttPlan* plan; uint32_t* ubytes; uint32_t* member_row;
+    uint32_t* host_group_of; void* host_out_rows; const uint32_t* n_dev;
+};
+struct VotesArgs {
+    const uint32_t* vote_block; const uint64_t* eff_balance; const uint8_t* flags; uint64_t n_val;
+    uint32_t filter_slashed; const uint32_t* pos_of_idx; uint32_t n_blocks; uint64_t* direct; VoteTotals* totals;
+    const uint32_t* vote_slot; uint32_t min_vote_slot;
+};
+struct UnionArgs {
+    const UnionGroup* groups; uint32_t n_groups; const uint32_t* att_bytes; const uint8_t* bit_arena;
+    uint32_t* out_arena; uint32_t* out_info; uint32_t* host_arena; uint32_t* host_info; const AttPlan* plan_dev;
+};
+struct TreeArgs {
+    TreeDev tree; uint64_t* direct; const VoteTotals* totals; uint64_t ov_balance, ov_num; int use_override;
+    uint32_t justified_pos, boost_pos; uint64_t slots_per_epoch, boost_percent, balance_increment;
+    uint64_t* weights_by_idx; uint32_t* head_idx; int clear_direct;
+};
+// the stand-alone launches over the same argument blocks (lean: the shapes that fit beside a running accumulation)
+void launch_att_ingest(hipStream_t s, const IngestArgs& a);
+void launch_att_validate_fc(hipStream_t s, const ValidateFcArgs& a);
+void launch_lmd_vm_tables(hipStream_t s, const LmdVmArgs& a);
+void launch_att_members(hipStream_t s, const MembersArgs& a);
+void launch_votes(hipStream_t s, const VotesArgs& a, int lean);
+void launch_bits_union(hipStream_t s, const UnionArgs& a);
+void launch_tree(hipStream_t s, const TreeArgs& a, int lean);
+// ... and pairwise.  Each returns false when the pair has no common shape (the caller then launches the two alone).
+bool launch_pair_ingest_validate(hipStream_t s, const IngestArgs& rows_next, const ValidateFcArgs& fc_prev);
+bool launch_pair_plan_lmd(hipStream_t s, const AttPlanArgs& rows_next, const LmdVmArgs& fc_prev);
+bool launch_pair_members_votes(hipStream_t s, const MembersArgs& rows_next, const VotesArgs& fc_prev);
+bool launch_pair_union_tree(hipStream_t s, const UnionArgs& rows_next, const TreeArgs& fc_prev);
+void pair_kernels_preload();  // resolve the pair kernels' code object now rather than inside the first streaming step
+
 // The working-state view mirrors the registry (pe_store_init): sflags = active/slashed (+ active-in-previous-epoch),
 // increments = balance / effective_balance_increment.
 void launch_state_view_from_registry(hipStream_t s, const uint8_t* flags, const uint64_t* balance, uint64_t increment,
@@ -280,6 +335,8 @@ void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* 
                       uint8_t* out_be192);
 // r * P == infinity per decoded point: status 0 -> 3 where it fails (non-zero entries are left alone)
 void launch_g2_subgroup_check(hipStream_t s, const uint32_t* points_mont48, uint64_t n, int32_t* status);
+// rows with a non-zero status become the (0, 0) row (infinity): a plain sum then leaves them out
+void launch_g2_mask_bad(hipStream_t s, uint32_t* points_mont48, uint64_t n, const int32_t* status);
 // the signature leg of pe_aggregate: per group the sum of its members' signature points (rows member_row[list_start ..
 // + n_atts) of `ug`), compressed to the 96-byte BLSSignature wire form; out_bad[g] = members that did not decode
 struct UnionGroup;

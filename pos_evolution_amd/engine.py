@@ -723,6 +723,34 @@ class Engine:
                                         _ptr(off, C.c_uint32), n_groups, _ptr(out, C.c_uint8)))
         return out[:n_groups]
 
+    def aggregate_signatures(self, signatures, offsets, index=None, check_subgroup: bool = False):
+        """pe_aggregate_signatures: bls.Aggregate per committee over an epoch's unaggregated compressed signatures
+        (pe:717, pe:659, pe:1536).  signatures: (n, 96) uint8 array or a DeviceArena of n * 96 bytes; index: uint32 array
+        or a DeviceArena of 4-byte entries (None = contiguous groups).
+        -> (aggregates (n_groups, 96) uint8, per-signature status int32 (n,), undecodable members per group uint32)."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint32)
+        n_groups = off.size - 1
+        if isinstance(signatures, DeviceArena):
+            sig_ptr, n = signatures.ptr, signatures.size // 96
+        else:
+            sig = np.ascontiguousarray(signatures, dtype=np.uint8)
+            sig_ptr, n = sig.ctypes.data, sig.size // 96
+        if index is None:
+            idx_ptr = None
+        elif isinstance(index, DeviceArena):
+            idx_ptr = index.ptr
+        else:
+            idx = np.ascontiguousarray(index, dtype=np.uint32)
+            idx_ptr = idx.ctypes.data
+        out = np.empty((max(n_groups, 1), 96), dtype=np.uint8)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        bad = np.zeros(max(n_groups, 1), dtype=np.uint32)
+        flags = _abi.PE_SIG_CHECK_SUBGROUP if check_subgroup else 0
+        self._check(self._lib.pe_aggregate_signatures(self._h, C.c_void_p(sig_ptr), n, C.c_void_p(idx_ptr) if idx_ptr else None,
+                                                      _ptr(off, C.c_uint32), n_groups, flags, _ptr(out, C.c_uint8),
+                                                      _ptr(status, C.c_int32), _ptr(bad, C.c_uint32)))
+        return out[:n_groups], status[:n], bad[:n_groups]
+
     # -- multi-GPU exchange inside the C ABI (RCCL owned by the engine) -------
     def dist_unique_id(self) -> bytes:
         """rank 0: the PE_DIST_ID_BYTES (two RCCL unique ids) to ship to the other ranks (pe_dist_unique_id)."""

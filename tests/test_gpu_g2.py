@@ -245,3 +245,87 @@ def test_g2_subgroup_check(engine_factory):
     st = e.g2_subgroup_check(pts)
     want = [0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 3]
     assert st.tolist() == want
+
+
+# ---------------------------------------------------------------- pe_aggregate_signatures: an epoch's unaggregated signatures
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_aggregate_signatures_vs_oracle(engine_factory, where):
+    """bls.Aggregate per committee over compressed signatures (pe:717 one BLSSignature per attester; pe:659 / pe:1536 summed
+    per committee): ragged groups over an index list, an empty group, members that do not decode (malformed, off the curve,
+    off the subgroup with the check on) left out of their sums and counted, an infinity member -- against oracle/g2.py."""
+    import torch
+
+    import pos_evolution_amd as pea
+
+    e = engine_factory()
+    n = 700
+    pts = g2.synthetic_points(n, 0x5151, 0x77)
+    comp = [g2.compress(p) for p in pts]
+    off_sub = _off_subgroup_point()
+    comp[5] = bytes(96)                         # malformed (no compression flag)
+    comp[6] = _off_curve_x()                    # not on the curve
+    comp[7] = g2.compress(off_sub)              # on the curve, outside G2
+    comp[8] = g2.compress(None)                 # the identity: a valid encoding, adds nothing
+    sig = np.frombuffer(b"".join(comp), dtype=np.uint8).reshape(-1, 96).copy()
+    rng = np.random.default_rng(3)
+    index = rng.permutation(n).astype(np.uint32)
+    cuts = np.sort(rng.choice(np.arange(1, n), size=9, replace=False))
+    offsets = np.concatenate([[0], cuts[:4], [cuts[3]], cuts[4:], [n]]).astype(np.uint32)   # one empty group
+    if where == "device":
+        st = torch.from_numpy(sig.reshape(-1)).cuda()
+        it = torch.from_numpy(index).cuda()
+        sig_in = pea.DeviceArena(st.data_ptr(), st.numel(), keep=st)
+        idx_in = pea.DeviceArena(it.data_ptr(), it.numel() * 4, keep=it)
+    else:
+        sig_in, idx_in = sig, index
+    for check in (False, True):
+        agg, status, bad = e.aggregate_signatures(sig_in, offsets, index=idx_in, check_subgroup=check)
+        want_status = np.zeros(n, dtype=np.int32)
+        want_status[5], want_status[6] = 1, 2
+        if check:
+            want_status[7] = 3
+        assert np.array_equal(status, want_status)
+        for g in range(offsets.size - 1):
+            members = index[offsets[g]:offsets[g + 1]]
+            good = [int(i) for i in members if want_status[i] == 0]
+            total = g2.sum_points([off_sub if i == 7 else None if i == 8 else pts[i] for i in good])
+            assert bytes(agg[g]) == g2.compress(total), (check, g)
+            assert bad[g] == len(members) - len(good)
+    # contiguous groups (index NULL) and the degenerate calls
+    agg, status, bad = e.aggregate_signatures(sig[20:84], [0, 64])
+    assert bytes(agg[0]) == g2.compress(g2.sum_points(pts[20:84])) and not status.any() and not bad.any()
+    agg, _, _ = e.aggregate_signatures(np.zeros((0, 96), dtype=np.uint8), [0, 0])
+    assert bytes(agg[0]) == g2.compress(None)
+    with pytest.raises(AssertionError):
+        e.aggregate_signatures(sig, [0, 10], index=np.array([n] * 10, dtype=np.uint32))
+
+
+def test_aggregate_signatures_of_a_whole_epoch(engine_factory):
+    """BASELINE configs[3]'s epoch at full size: 1 048 576 compressed signatures resident in HBM, 2048 committees of 512 by
+    a random partition, every committee's aggregate against the closed form (validator v signs with (a + (v mod 16384) b) G2:
+    sum = (|S| a + b sum(v mod 16384)) G2, computed by oracle/g2.py's own double-and-add) -- all 2048 of them."""
+    import torch
+
+    import pos_evolution_amd as pea
+    import pos_evolution_amd.synth as synth
+
+    e = engine_factory()
+    V, C, period = 1 << 20, 2048, 16384
+    a, b = 0xABCDEF12345, 0x1357
+    base = synth.signature_points(e, period, a, b)
+    sig = np.ascontiguousarray(np.tile(base, (V // period, 1)))
+    st = torch.from_numpy(sig.reshape(-1)).cuda()
+    rng = np.random.default_rng(20)
+    perm = rng.permutation(V).astype(np.uint32)
+    attests = rng.random(V) < 0.99
+    lists = [perm[c * 512:(c + 1) * 512][attests[c * 512:(c + 1) * 512]] for c in range(C)]
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.uint32)
+    index = np.concatenate(lists).astype(np.uint32)
+    it = torch.from_numpy(index).cuda()
+    agg, status, bad = e.aggregate_signatures(pea.DeviceArena(st.data_ptr(), st.numel(), keep=st), offsets,
+                                              index=pea.DeviceArena(it.data_ptr(), it.numel() * 4, keep=it))
+    assert not status.any() and not bad.any()
+    for c in range(C):
+        m = lists[c].astype(np.int64) % period
+        want = g2.compress(g2.mul((len(m) * a + b * int(m.sum())) % R_ORDER, g2.G2))
+        assert bytes(agg[c]) == want, c
