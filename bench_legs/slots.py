@@ -90,6 +90,10 @@ def slot_cadence(pea, w, device, n_epochs, lag):
     e.drain()
     e.fill_ring()
     torch.cuda.synchronize()
+    timeline_path = os.environ.get("POSEVO_SLOT_TIMELINE")   # diagnostic: the engine's own event timeline of the timed slots
+    if timeline_path:
+        e.profile_enable(2)
+        e.profile_reset()
     t0 = time.perf_counter()
     stamps = [t0]
     for sl in slots[n_warm:n_warm + n_timed]:
@@ -98,6 +102,13 @@ def slot_cadence(pea, w, device, n_epochs, lag):
     e.drain()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if timeline_path:
+        tl = e.profile_timeline()
+        e.profile_enable(0)
+        with open(timeline_path, "w") as f:
+            f.write(f"# slot cadence, {n_timed} slot-steps in {dt * 1e3:.2f} ms; kernel start end dur (us)\n")
+            for name, a0, d0 in tl:
+                f.write(f"{name:22s} {a0 * 1e3:10.1f} {(a0 + d0) * 1e3:10.1f} {d0 * 1e3:8.1f}\n")
     n_att = int(sum(int(np.asarray(r["count"]).sum()) for r in got[n_warm:]))
     # the latency pass: one wait per slot, the head polled inside the step
     lat = []

@@ -309,6 +309,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_sig, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         false) {
@@ -391,6 +392,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
+    if (h->ev_sig) (void)hipEventDestroy(h->ev_sig);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
     if (h->ev_xchg) (void)hipEventDestroy(h->ev_xchg);
@@ -508,7 +510,6 @@ int pe_pipeline_end_lagged(pe_engine* h)
         // synchronous call) has waited for the marks
         PE_TRY(fence_arena(h, a));
     }
-    if (a.aux_used) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));
     h->aux_busy = false;    // accounted for by the fence
     a.fenced = true;
     h->side_busy = false;   // accounted for by the fence from here on
@@ -572,6 +573,7 @@ int pe_profile_reset(pe_engine* h)
     if (!h) return PE_ERR_INVALID_ARG;
     prof_drain(h);
     for (auto& p : h->prof) { p.launches = 0; p.total_ms = 0; }
+    h->acc_launches = 0;  // the first accumulation behind a reset is bracketed (one in four is, engine_g1.cpp)
     h->prof_tl.clear();
     if (h->prof_timeline && h->prof_base) HIP_TRY(h, hipEventRecord(h->prof_base, h->stream));  // time zero
     return PE_OK;

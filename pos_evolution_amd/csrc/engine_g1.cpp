@@ -579,31 +579,60 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     const size_t off_st = ob.alloc(4ull * n);
     PE_TRY(ob.ensure());
     memset(ob.host<uint32_t>(off_bad), 0, 4ull * std::max<uint32_t>(ng_bound, 1));
-    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true);  // behind the grouping; beside the aggregate pubkeys and the fork-choice kernels
     bool sig_on_device = false;
     {
         hipPointerAttribute_t pa;
         if (hipPointerGetAttributes(&pa, signatures) == hipSuccess) sig_on_device = pa.type == hipMemoryTypeDevice;
         else (void)hipGetLastError();
     }
-    HIP_TRY(h, hipMemcpyAsync(A.d_sig_in.p, signatures, sig_bytes * n,
-                              sig_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ss));
+    // The leg as a launch sequence on the state-transition stream.  Where the aggregate's pubkey sums run on the G1 streams
+    // (pipelined calls) the leg goes BEHIND the accumulation (ev_acc) and the NEXT accumulation behind the leg (ev_sig):
+    // k_g2_decompress holds an eighth of the chip's SIMDs for ~0.95 ms, and an accumulation that runs beside it ends when the
+    // decompression ends (0.84 ms instead of 0.2: the SIMDs' arbiters serve the older wave first) -- one behind the other the
+    // two cost their sum, 1.15 ms per signed step instead of 1.56 (profiles/r04_signed_timeline.txt).
+    pe_engine::PipeArena* arena = &A;
+    const uint8_t* d_sig_in = A.d_sig_in.as<uint8_t>();
     int32_t* d_status = A.d_sig_status.as<int32_t>();
     uint32_t* d_pts = A.d_sig_pts.as<uint32_t>();
-    if (fmt == PE_SIG_G2_COMPRESSED) {
-        launch_g2_decompress(ss, A.d_sig_in.as<uint8_t>(), n, d_pts, nullptr, d_status);
-    } else {
-        HIP_TRY(h, hipMemsetAsync(d_status, 0, 4ull * n, ss));
-        launch_g2_convert(ss, A.d_sig_in.as<uint8_t>(), d_pts, n);
-    }
-    if (sig_format_flags & PE_SIG_CHECK_SUBGROUP) launch_g2_subgroup_check(ss, d_pts, n, d_status);
-    {
-        ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
-        launch_g2_aggregate_rows(ss, d_pts, d_status, d_ug, d_member_row, ng_bound, plan_dev, ob.host<uint8_t>(off_sig),
-                                 ob.host<uint32_t>(off_bad));
-    }
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(ob.host<int32_t>(off_st), d_status, 4ull * n, hipMemcpyDeviceToHost, ss));
+    uint8_t* o_sig = ob.host<uint8_t>(off_sig);
+    uint32_t* o_bad = ob.host<uint32_t>(off_bad);
+    int32_t* o_st = ob.host<int32_t>(off_st);
+    const bool behind_acc = h->last_agg_on_side && out_aggpk96 != nullptr && h->ev_sig != nullptr;
+    auto leg = [h, arena, behind_acc, signatures, sig_bytes, n, sig_on_device, fmt, sig_format_flags, d_sig_in, d_status, d_pts,
+                d_ug, d_member_row, ng_bound, plan_dev, o_sig, o_bad, o_st]() -> int {
+        hipStream_t ss = h->aux_stream && h->stream == h->own_stream ? h->aux_stream : h->stream;
+        if (ss != h->stream) {  // behind the grouping (state_stream_begin's fork, on behalf of the leg's own arena)
+            HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
+            HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
+            h->aux_busy = true;
+            arena->aux_used = true;
+            arena->aux_reads_scratch = true;
+            if (behind_acc) HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_acc, 0));  // the accumulation of this aggregate, just launched
+        }
+        HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(d_sig_in), signatures, sig_bytes * n,
+                                  sig_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ss));
+        if (fmt == PE_SIG_G2_COMPRESSED) {
+            launch_g2_decompress(ss, d_sig_in, n, d_pts, nullptr, d_status);
+        } else {
+            HIP_TRY(h, hipMemsetAsync(d_status, 0, 4ull * n, ss));
+            launch_g2_convert(ss, d_sig_in, d_pts, n);
+        }
+        if (sig_format_flags & PE_SIG_CHECK_SUBGROUP) launch_g2_subgroup_check(ss, d_pts, n, d_status);
+        if (behind_acc && ss != h->stream) {  // the next accumulation may start: what follows is latency-sized
+            HIP_TRY(h, hipEventRecord(h->ev_sig, ss));
+            h->sig_leg_open = true;
+        }
+        {
+            ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
+            launch_g2_aggregate_rows(ss, d_pts, d_status, d_ug, d_member_row, ng_bound, plan_dev, o_sig, o_bad);
+        }
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(o_st, d_status, 4ull * n, hipMemcpyDeviceToHost, ss));
+        return PE_OK;
+    };
+    // a streaming pipeline holds the aggregate's G1 launch back (behind the step's k_tree): the leg follows it, in the same list
+    if (behind_acc && !h->deferred.empty()) h->deferred.push_back(leg);
+    else PE_TRY(leg());
     const size_t base = ob.base;
     const int ai = h->cur;
     auto complete = [h, ai, base, off_sig, off_bad, off_st, n, ng_bound, dev_rows, out_n_groups, out_atts, out_signatures96,

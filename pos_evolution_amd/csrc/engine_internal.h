@@ -292,6 +292,8 @@ struct pe_engine {
     bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
     bool state_work_on_main = false;    // state_stream_begin fell back to the engine's stream for a flag pass
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
+    hipEvent_t ev_sig = nullptr;        // pe_aggregate_signed: the decompression of a step's signatures is done -> the next
+    bool sig_leg_open = false;          // ... accumulation may start (engine_g1.cpp); set while such an event is outstanding
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_busy = false;             // the side stream holds work of the current arena nobody has waited for yet
     bool side_ever = false;             // ev_join has been recorded at least once

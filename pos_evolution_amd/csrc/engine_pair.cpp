@@ -32,6 +32,7 @@ int fence_arena(pe_engine* h, pe_engine::PipeArena& a)
 {
     HIP_TRY(h, hipEventRecord(a.ev_main, h->stream));
     if (a.side_used) HIP_TRY(h, hipEventRecord(a.ev_side, h->g1_tail()));  // the last kernel of the G1 chain runs there
+    if (a.aux_used) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));    // flag pass, signature leg
     a.fence_pending = false;
     return PE_OK;
 }

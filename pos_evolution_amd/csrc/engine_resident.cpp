@@ -348,6 +348,10 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
                 HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
                 HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
                 if (arena->side_used) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
+                if (h->sig_leg_open) {  // the previous step's signature decompression first (pe_aggregate_signed)
+                    HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_sig, 0));
+                    h->sig_leg_open = false;
+                }
             } else {
                 g1_stream_guard(h, gs);
             }
