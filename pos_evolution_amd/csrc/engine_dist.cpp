@@ -234,9 +234,11 @@ int pe_dist_destroy(pe_engine* h)
 static int get_head_sharded_impl(pe_engine* h, uint8_t out_root[32], bool async)
 {
     // inside a pipeline the call is ordered behind the enqueued batch calls on the stream, like pe_get_head
-    int rc = need_init(h, /*flush=*/!(h && h->pipelining));
+    int rc = need_init(h, /*flush=*/!(h && h->pipelining), /*keep_held=*/async && h && h->pipelining);
     if (rc) return rc;
     if (!out_root) return PE_ERR_INVALID_ARG;
+    // launches held back by an EARLIER pipeline, or a head already held for this one: out first, in order
+    if (h->held.active && (h->held.arena != h->cur || h->held.have_head)) PE_TRY(held_issue(h));
     if (!h->dist_ready()) return fail(h, PE_ERR_STATE, "pe_get_head_sharded: call pe_dist_init first");
     if (h->dist_wedged)  // before anything is launched: k_votes / the unions would otherwise run with no exchange to follow
         return fail(h, PE_ERR_TIMEOUT, "an earlier exchange timed out on this handle: pe_dist_destroy, then initialise again");
@@ -271,6 +273,29 @@ static int get_head_sharded_impl(pe_engine* h, uint8_t out_root[32], bool async)
         PE_TRY(ob.ensure());
     }
     uint64_t* buf = h->d_xchg.as<uint64_t>();
+    if (async && hold_eligible(h) && h->n_val) {
+        // a streaming step: votes -> all-reduce -> tree go out with the NEXT aggregate's row kernels (engine_pair.cpp); every
+        // rank holds and issues alike, so the all-reduce keeps its place in the order of this communicator's collectives
+        PE_TRY(tree_args(h, buf, reinterpret_cast<const VoteTotals*>(buf + nb), /*clear_direct=*/1, ob.host<uint32_t>(off),
+                         &h->held.tree));
+        h->held.votes = VotesArgs{h->d_vote_block.as<uint32_t>(), h->d_balance.as<uint64_t>(), h->d_flags.as<uint8_t>(),
+                                  h->n_val, h->cfg.filter_slashed, h->d_tpos.as<uint32_t>(), nb, buf,
+                                  reinterpret_cast<VoteTotals*>(buf + nb), expiry_slots_ptr(h), min_vote_slot(h)};
+        h->held.between = [h, words]() -> int { return dist_all_reduce_u64(h, h->d_xchg.p, words, h->stream); };
+        h->held.have_head = true;
+        h->held.active = true;
+        h->held.arena = h->cur;
+        const size_t base = ob.base;
+        const int ai = h->cur;
+        auto complete = [h, ai, base, off, out_root]() -> int {
+            const uint32_t idx = *reinterpret_cast<const uint32_t*>(h->arena[ai].h_pin.as<uint8_t>() + base + off);
+            if (idx >= h->blocks.size()) return fail(h, PE_ERR_NO_DEVICE, "tree kernel returned an invalid head index");
+            memcpy(out_root, h->blocks[idx].root.data(), 32);
+            return PE_OK;
+        };
+        return finish_call(h, st, ob, complete);
+    }
+    if (h->held.active) PE_TRY(held_issue(h));
     {
         ProfScope ps(h, PE_KERNEL_VOTES);
         // no memsets (k_tree zeroes the weights it read; the totals are plain per-workgroup stores), and inside a
@@ -356,7 +381,8 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
         PE_TRY(resident_plan_dev(h, &p));
         plan_dev = p;
     }
-    auto exchange = [h, slots, pin_pk, on_side, plan_dev]() -> int {
+    pe_engine::PipeArena* arena = &h->A();  // the closure may run while a LATER pipeline is the current one (held launches)
+    auto exchange = [h, arena, slots, pin_pk, on_side, plan_dev]() -> int {
         HostLap lap(&h->trace);
         hipStream_t cs = on_side ? h->g1_tail() : h->stream;  // where this aggregate's partials were produced
         hipStream_t xs = cs;
@@ -383,7 +409,7 @@ int pe_aggregate_sharded(pe_engine* h, const pe_attestation* atts, uint32_t n, c
             // exchange completed the arena (and cleared these marks) with the finish not yet enqueued
             h->side_busy = true;
             h->side_ever = true;
-            h->A().side_used = true;
+            arena->side_used = true;
         }
         return PE_OK;
     };

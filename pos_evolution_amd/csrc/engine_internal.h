@@ -312,6 +312,7 @@ struct pe_engine {
         LmdVmArgs lmd{};
         VotesArgs votes{};
         TreeArgs tree{};
+        std::function<int()> between;         // a sharded head: the weights' all-reduce, between the votes and the tree
         std::vector<std::function<int()>> g1;  // the step's G1 launches: behind its k_tree, as without the holding
         bool fence_pending = false;   // pe_pipeline_end_lagged has closed the pipeline: its fence follows these launches
     } held;

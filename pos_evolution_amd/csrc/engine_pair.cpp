@@ -21,11 +21,13 @@ using namespace posevo;
 
 namespace posevo {
 
-// The calls of a streaming pipeline on the engine's own stream, one rank: only there is a next aggregate to wait for.
+// The calls of a streaming pipeline on the engine's own stream: only there is a next aggregate to wait for.  (Sharded steps
+// hold too: every rank makes the same calls, so the collectives the held launches carry -- the weights' all-reduce between
+// votes and tree, the partials' all-gather behind the step's G1 launch -- are issued in the same order on every rank.)
 bool hold_eligible(const pe_engine* h)
 {
-    return h->pairing && h->streaming && h->pipelining && h->stream == h->own_stream && !h->dist_ready() &&
-           h->side_stream != nullptr;
+    return h->pairing && h->streaming && h->pipelining && h->stream == h->own_stream && h->side_stream != nullptr &&
+           !h->dist_wedged;
 }
 
 int fence_arena(pe_engine* h, pe_engine::PipeArena& a)
@@ -62,6 +64,7 @@ int held_issue(pe_engine* h)
     pe_engine::HeldFc L = std::move(h->held);
     h->held = pe_engine::HeldFc{};
     hipStream_t s = h->stream;
+    int rc0 = PE_OK;
     if (L.have_fc) {
         {
             ProfScope ps(h, PE_KERNEL_ATT_VALIDATE);  // timeline mode only
@@ -75,13 +78,14 @@ int held_issue(pe_engine* h)
             ProfScope ps(h, PE_KERNEL_VOTES);
             launch_votes(s, L.votes, /*lean=*/1);
         }
+        if (L.between) rc0 = L.between();
         ProfScope ps(h, PE_KERNEL_TREE);
         launch_tree(s, L.tree, /*lean=*/1);
     }
     const hipError_t e = hipGetLastError();
     const int rc = after_tree(h, L);
     if (e != hipSuccess) return hip_fail(h, e, "launching the held-back fork-choice kernels");
-    return rc;
+    return rc0 ? rc0 : rc;
 }
 
 int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa, const MembersArgs& ma, const UnionArgs& ua)
@@ -100,6 +104,7 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
     }
     pe_engine::HeldFc L = std::move(h->held);
     h->held = pe_engine::HeldFc{};
+    int rc0 = PE_OK;
     // a pair without a common shape goes out as two launches (the two are independent: any order)
     if (L.have_fc) {
         {
@@ -127,6 +132,7 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
                 launch_att_members(s, ma);
             }
         }
+        if (L.between) rc0 = L.between();
         ProfScope ps(h, PE_KERNEL_PAIR_UNION_TREE, s);
         if (!launch_pair_union_tree(s, ua, L.tree)) {
             launch_tree(s, L.tree, /*lean=*/1);
@@ -145,7 +151,7 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
     if (e != hipSuccess) return hip_fail(h, e, "launching the paired kernels");
     if (h->streaming) complete_oldest_if_ready(h);  // as pe_get_head_async did behind its k_tree: the copy-out of the oldest
                                                     // pipeline, if the device is through with it
-    return rc;
+    return rc0 ? rc0 : rc;
 }
 
 }  // namespace posevo

@@ -261,7 +261,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     // Fork-choice launches held back by the PREVIOUS step of a streaming caller go out pairwise with this aggregate's row
     // kernels (engine_pair.cpp).  Anything else that is held -- launches of THIS pipeline (they read the scratch this
     // call rewrites), or an aggregate in a form that is not the plain streaming one -- goes out first, alone and in order.
-    const bool pair_ok = h->held.active && h->held.arena != h->cur && set == 0 && !n_dev && !dev_partials && hold_eligible(h);
+    const bool pair_ok = h->held.active && h->held.arena != h->cur && set == 0 && !n_dev && hold_eligible(h);
     if (h->held.active && !pair_ok) PE_TRY(held_issue(h));
     // an earlier aggregate of THIS pipeline still has to read the arena's resident words / descriptors from its G1 launch
     // (deferred in a streaming pipeline): issue it, then order this call's kernels behind that chain
