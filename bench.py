@@ -492,6 +492,7 @@ def main():
                                                  "runs once per epoch when the workload is built, not in the step; "
                                                  "--with-shuffle puts it on the clock"),
         },
+        "ms_per_step_first_20": float((stamps[min(20, len(stamps) - 1)] - stamps[0]) / min(20, len(stamps) - 1) * 1e3),
         "step_ms_p50": float(np.median(per_step)), "step_ms_min": float(per_step.min()),
         "step_ms_p90": float(np.percentile(per_step, 90)),
         "aggregation_budget": {"seconds": 4.0, "source": "pe:1536 (the last third of a 12 s slot)",

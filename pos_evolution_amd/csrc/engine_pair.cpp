@@ -7,8 +7,8 @@
 // The first chain of step N + 1 needs nothing the other two of step N produce, and each is ~120 us of latency-sized
 // kernels.  So the handlers of step N do not launch when they are called: their argument blocks are kept on the handle
 // (pe_engine::held) and go out when step N + 1's pe_aggregate arrives, each one as a block range of the same grid as a row
-// kernel of that aggregate (pair_kernels.hip).  Everything the step launched BEHIND its k_tree follows the pair that
-// carries the tree: the step's G1 sums (deferred as before) and the fence of its lagged pipeline.
+// kernel of that aggregate (pair_kernels.hip).  The step's G1 sums (deferred as before) go out in front of the pairs -- they
+// depend on the step's row chain only -- and the fence of its lagged pipeline behind the pair that carries its k_tree.
 //
 // Nothing changes for the caller: the per-function ABI, the order of effects on the store (the held kernels run in the
 // same order on the same stream, merely later), the lag contract (a step's outputs are complete when the lag-th next
@@ -39,9 +39,11 @@ int fence_arena(pe_engine* h, pe_engine::PipeArena& a)
     return PE_OK;
 }
 
-// What a step launches behind its k_tree: its G1 sums (on their own streams, ordered behind the engine's stream by the
-// launch closures), then -- if its pipeline has ended meanwhile -- the pipeline's fence.
-static int after_tree(pe_engine* h, pe_engine::HeldFc& L)
+// The step's G1 sums (and what follows them on their streams: a sharded step's all-gather, a signature leg).  They need
+// nothing of the step's fork-choice kernels -- only its row chain, a step old by now -- so they go out FIRST: the accumulation
+// is what paces a streaming run, and queued here it starts the moment its predecessor ends instead of waiting for
+// the pair that carries the step's k_tree (the second step of a run started 110 us late that way).
+static int launch_held_g1(pe_engine* h, pe_engine::HeldFc& L)
 {
     int rc = PE_OK;
     for (auto& f : L.g1) {
@@ -49,6 +51,13 @@ static int after_tree(pe_engine* h, pe_engine::HeldFc& L)
         if (r && !rc) rc = r;
     }
     L.g1.clear();
+    (void)h;
+    return rc;
+}
+// ... and behind the step's last kernel on the engine's stream: the fence of its pipeline, if that has ended meanwhile.
+static int after_tree(pe_engine* h, pe_engine::HeldFc& L)
+{
+    int rc = PE_OK;
     if (L.fence_pending && L.arena >= 0) {
         pe_engine::PipeArena& a = h->arena[L.arena];
         const int r = fence_arena(h, a);
@@ -64,7 +73,7 @@ int held_issue(pe_engine* h)
     pe_engine::HeldFc L = std::move(h->held);
     h->held = pe_engine::HeldFc{};
     hipStream_t s = h->stream;
-    int rc0 = PE_OK;
+    int rc0 = launch_held_g1(h, L);
     if (L.have_fc) {
         {
             ProfScope ps(h, PE_KERNEL_ATT_VALIDATE);  // timeline mode only
@@ -78,7 +87,7 @@ int held_issue(pe_engine* h)
             ProfScope ps(h, PE_KERNEL_VOTES);
             launch_votes(s, L.votes, /*lean=*/1);
         }
-        if (L.between) rc0 = L.between();
+        if (L.between) { const int r = L.between(); if (r && !rc0) rc0 = r; }
         ProfScope ps(h, PE_KERNEL_TREE);
         launch_tree(s, L.tree, /*lean=*/1);
     }
@@ -104,7 +113,7 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
     }
     pe_engine::HeldFc L = std::move(h->held);
     h->held = pe_engine::HeldFc{};
-    int rc0 = PE_OK;
+    int rc0 = launch_held_g1(h, L);
     // a pair without a common shape goes out as two launches (the two are independent: any order)
     if (L.have_fc) {
         {
@@ -132,7 +141,7 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
                 launch_att_members(s, ma);
             }
         }
-        if (L.between) rc0 = L.between();
+        if (L.between) { const int r = L.between(); if (r && !rc0) rc0 = r; }
         ProfScope ps(h, PE_KERNEL_PAIR_UNION_TREE, s);
         if (!launch_pair_union_tree(s, ua, L.tree)) {
             launch_tree(s, L.tree, /*lean=*/1);
