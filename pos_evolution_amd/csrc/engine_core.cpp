@@ -62,7 +62,7 @@ int complete_arena(pe_engine* h, int ai)
             h->aux_busy = false;
         }
         if (h->side_busy) {
-            for (hipStream_t s : {h->side_stream, h->fin_stream, h->norm_stream}) {
+            for (hipStream_t s : {h->side_stream, h->side_stream2, h->fin_stream, h->norm_stream}) {
                 if (!s) continue;
                 hipError_t e2 = bounded_stream_sync(h, s);
                 if (e == hipSuccess) e = e2;
@@ -306,6 +306,12 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
         pe_engine_destroy(h);
         return PE_ERR_NO_DEVICE;
     }
+    // Tune::state_on: the state-transition work on the tree's or the finish's stream instead of its own (the runtime maps
+    // the engine's six streams onto four hardware queues; two streams that share one run in submission order)
+    if (ok_streams && h->tune.side_streams == 2 && mk(&h->side_stream2) != hipSuccess) h->side_stream2 = nullptr;
+    h->aux_owned = h->aux_stream;
+    if (ok_streams && h->tune.state_on == 1) h->aux_stream = h->fin_stream;
+    if (ok_streams && h->tune.state_on == 2) h->aux_stream = h->norm_stream;
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
@@ -319,7 +325,8 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     for (auto& a : h->arena)
         if (hipEventCreateWithFlags(&a.ev_main, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.ev_side, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.ev_rows, hipEventDisableTiming) != hipSuccess) {
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
@@ -340,6 +347,7 @@ void pe_engine_destroy(pe_engine* h)
     (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->side_stream2) (void)hipStreamSynchronize(h->side_stream2);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
@@ -371,6 +379,7 @@ void pe_engine_destroy(pe_engine* h)
         if (a.ev_main) (void)hipEventDestroy(a.ev_main);
         if (a.ev_side) (void)hipEventDestroy(a.ev_side);
         if (a.ev_aux) (void)hipEventDestroy(a.ev_aux);
+        if (a.ev_rows) (void)hipEventDestroy(a.ev_rows);
     }
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
@@ -397,8 +406,9 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
     if (h->ev_xchg) (void)hipEventDestroy(h->ev_xchg);
     if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
-    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->aux_owned) (void)hipStreamDestroy(h->aux_owned);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->side_stream2) (void)hipStreamDestroy(h->side_stream2);
     if (h->fin_stream) (void)hipStreamDestroy(h->fin_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->trace.on && h->g1_tune_calls)
@@ -544,6 +554,7 @@ static void prof_drain(pe_engine* h)
     (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
+    if (h->side_stream2) (void)hipStreamSynchronize(h->side_stream2);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);

@@ -12,7 +12,7 @@ void g1_stream_guard(pe_engine* h, hipStream_t s)
 {
     // ev_join marks the end of the last G1 launch on the side stream (a lagged pipeline may still be running it);
     // waiting on a completed event costs nothing
-    if (h->side_ever && s != h->side_stream && s != h->fin_stream && s != h->norm_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+    if (h->side_ever && s != h->side_stream && s != h->side_stream2 && s != h->fin_stream && s != h->norm_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
 }
 
 // The registry table in the accumulation's field form (k_g1_table_s29), built where the registry is loaded -- on the
@@ -65,6 +65,12 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
         launch_g1_table_s29(s, d_points, h->d_tmp_points29.as<uint32_t>(), n_rows);
         d_points29 = h->d_tmp_points29.as<uint32_t>();
     }
+    // A side-stream chain of a streaming run: the accumulation may be made the only one of its kind on a CU (Tune::exclusive:
+    // the LDS it asks for leaves 78 KB, enough for the fork-choice tree up to 4096 blocks beside it -- an 8192-block tree's
+    // 147 KB workgroup would find no CU while accumulations follow each other, so those stores keep the old signature).
+    const bool chain = fin != s && fin == h->fin_stream;
+    const int exclusive = chain && h->tune.exclusive && h->blocks.size() <= 4096 ? 1 : 0;
+    const bool done_event = chain && h->tune.acc_done_event;
     {
         // Since the paired launches (round 5) the accumulations of a streaming run follow each other on their stream with
         // nothing but queue packets in between, and every packet there is step time: the two event records of a bracket cost
@@ -73,19 +79,19 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
         const bool skip = !h->prof_timeline && s != h->stream && (h->acc_launches++ & 3) != 0;
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s, skip);
         launch_g1_accumulate(s, d_points29, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1);
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1, exclusive,
+                             done_event ? h->ev_acc : nullptr);
     }
-    const bool chain = fin != s && fin == h->fin_stream;  // a side-stream chain
     hipStream_t ts = fin;  // (on the accumulation's own stream the tree measured 0.433 vs 0.338 ms per step, round 3)
     if (ts != s) {
-        HIP_TRY(h, hipEventRecord(h->ev_acc, s));
+        if (!done_event) HIP_TRY(h, hipEventRecord(h->ev_acc, s));
         HIP_TRY(h, hipStreamWaitEvent(ts, h->ev_acc, 0));
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_TREE, ts);
         launch_g1_tree(ts, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
                        /*one_per_cu=*/ts != s ? 1 : 0,   // on its own stream it meets the next step's k_tree: leave it room
-                       plan_dev);
+                       plan_dev, h->tune.tree_rotate, /*solo=*/exclusive);
     }
     hipStream_t ns = fin;
     if (chain && h->norm_stream) {  // the finish gets a stream of its own

@@ -260,6 +260,8 @@ struct pe_engine {
         uint64_t generation = 0;            // ordinal of the pipeline that fills this arena (pe_pipeline_generation)
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
+        hipEvent_t ev_rows = nullptr;  // the end of this arena's row chain on the engine's stream (Tune::rows_event)
+        bool rows_recorded = false;
         bool fenced = false, side_used = false, aux_used = false;
         bool fence_pending = false;  // fenced by pe_pipeline_end_lagged, but ev_main / ev_side are still to be recorded: behind the
                                      // pipeline's held-back fork-choice launches (engine_pair.cpp)
@@ -275,6 +277,12 @@ struct pe_engine {
     bool pipelining = false;
     uint64_t pipes_begun = 0, pipes_completed = 0;  // pe_pipeline_generation / pe_pipeline_completed
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
+    hipStream_t side_stream2 = nullptr; // ... every other one here (Tune::side_streams == 2)
+    unsigned side_turn = 0;
+    hipStream_t side_pick()             // the stream of the next streaming accumulation
+    {
+        return side_stream2 && tune.exclusive && (side_turn++ & 1u) ? side_stream2 : side_stream;
+    }
     hipStream_t fin_stream = nullptr;   // ... its k_g1_tree here, beside the NEXT aggregate's accumulation
     // ... and its k_g1_finish here: on the tree's stream the two latency-bound guests of a step ran one behind the other
     // (tree 250-300 us beside an accumulation + finish 130 us), and that stream, not the accumulation, set the period
@@ -286,6 +294,7 @@ struct pe_engine {
     // follows the head in a step, and on the engine's stream it stood between one step's head and the next step's
     // fork-choice chain (25 + 85 us per 1 M validators beside a running accumulation, profiles/r03_timeline_*.txt).
     hipStream_t aux_stream = nullptr;
+    hipStream_t aux_owned = nullptr;    // the stream created for it (aux_stream may alias another one: Tune::state_on)
     hipStream_t prep_stream = nullptr;  // pe_compute_committees_async: next epochs' shuffles, beside everything else
     DevBuf d_shuffle_scratch;           // ... and their hash tables (the synchronous call uses d_tmp_be)
     hipEvent_t ev_aux_fork = nullptr;
@@ -317,6 +326,28 @@ struct pe_engine {
         bool fence_pending = false;   // pe_pipeline_end_lagged has closed the pipeline: its fence follows these launches
     } held;
     bool pairing = std::getenv("POSEVO_PAIR") == nullptr || std::atoi(std::getenv("POSEVO_PAIR")) != 0;
+    // ---- scheduling knobs of the streaming G1 chain, read once per handle ----
+    struct Tune {
+        static int env(const char* name, int dflt)
+        {
+            const char* e = std::getenv(name);
+            return e && *e ? std::atoi(e) : dflt;
+        }
+        // at most one accumulation workgroup per CU by an LDS request, the tree one per CU by registers (g1_kernels.hip)
+        int exclusive = env("POSEVO_ACC_EXCLUSIVE", 0);
+        // the tree's four-lane levels rotate over the workgroup's waves
+        int tree_rotate = env("POSEVO_TREE_ROTATE", 0);
+        // the accumulation's completion signal is the event its tree waits for (no record packet behind the kernel)
+        int acc_done_event = env("POSEVO_ACC_DONE_EVENT", 0);
+        // the row chain's end is an event of its arena, recorded when the chain is enqueued; the step's accumulation -- launched
+        // one aggregate later -- skips the wait packet when that event has completed by then
+        int rows_event = env("POSEVO_ROWS_EVENT", 0);
+        // which stream carries the state-transition work: 0 = its own (aux), 1 = the tree's (fin), 2 = the finish's (norm)
+        int state_on = env("POSEVO_STATE_ON", 0);
+        // 2: consecutive accumulations of a streaming run alternate between two streams (needs `exclusive`: the successor's
+        // workgroups then take each CU as the predecessor's leave it, instead of the whole launch waiting for the last one)
+        int side_streams = env("POSEVO_SIDE_STREAMS", 1);
+    } tune;
 
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
     // tag: a fold of the group's AttestationData -- a row handed over as resident must BE a row of the resident aggregate,

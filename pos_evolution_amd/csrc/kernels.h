@@ -59,11 +59,14 @@ struct AttPlan;
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
                           uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev = nullptr,
-                          const uint32_t* members1 = nullptr);
+                          const uint32_t* members1 = nullptr, int exclusive = 0, hipEvent_t done = nullptr);
+// exclusive: the launch asks for this much LDS it never touches (more than half a CU's): at most one of its workgroups per CU
+constexpr size_t G1_ACC_EXCLUSIVE_LDS = 82 * 1024;
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
 // (group, workgroup) into wg_partials48.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
-                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0, const AttPlan* plan_dev = nullptr);
+                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0, const AttPlan* plan_dev = nullptr,
+                    int rotate = 0, int solo = 0);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
 // g when first == null), then either write the XYZZ sum (48 u32) or normalise to 96-byte affine.
 void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
