@@ -603,10 +603,13 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     uint8_t* o_sig = ob.host<uint8_t>(off_sig);
     uint32_t* o_bad = ob.host<uint32_t>(off_bad);
     int32_t* o_st = ob.host<int32_t>(off_st);
-    const bool behind_acc = h->last_agg_on_side && out_aggpk96 != nullptr && h->ev_sig != nullptr;
+    const bool behind_acc = h->tune.sig_behind && h->last_agg_on_side && out_aggpk96 != nullptr && h->ev_sig != nullptr;
     auto leg = [h, arena, behind_acc, signatures, sig_bytes, n, sig_on_device, fmt, sig_format_flags, d_sig_in, d_status, d_pts,
                 d_ug, d_member_row, ng_bound, plan_dev, o_sig, o_bad, o_st]() -> int {
-        hipStream_t ss = h->aux_stream && h->stream == h->own_stream ? h->aux_stream : h->stream;
+        // (the leg keeps the stream created for state-transition work even where the flag passes ride the tree's stream --
+        // Tune::state_on: a millisecond of decompression in front of the next k_g1_tree would put the whole G1 chain behind it;
+        // its end is joined into that stream below, so fences and waits on aux_stream cover the leg as before)
+        hipStream_t ss = h->aux_owned && h->stream == h->own_stream ? h->aux_owned : h->stream;
         if (ss != h->stream) {  // behind the grouping (state_stream_begin's fork, on behalf of the leg's own arena)
             HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
             HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
@@ -634,6 +637,10 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
         }
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipMemcpyAsync(o_st, d_status, 4ull * n, hipMemcpyDeviceToHost, ss));
+        if (ss != h->stream && ss != h->aux_stream) {
+            HIP_TRY(h, hipEventRecord(h->ev_leg, ss));
+            HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_leg, 0));
+        }
         return PE_OK;
     };
     // a streaming pipeline holds the aggregate's G1 launch back (behind the step's k_tree): the leg follows it, in the same list

@@ -301,6 +301,7 @@ struct pe_engine {
     bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
     bool state_work_on_main = false;    // state_stream_begin fell back to the engine's stream for a flag pass
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
+    hipEvent_t ev_leg = nullptr;        // the end of a signature leg on aux_owned, joined into aux_stream when that is an alias
     hipEvent_t ev_sig = nullptr;        // pe_aggregate_signed: the decompression of a step's signatures is done -> the next
     bool sig_leg_open = false;          // ... accumulation may start (engine_g1.cpp); set while such an event is outstanding
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -334,7 +335,7 @@ struct pe_engine {
             return e && *e ? std::atoi(e) : dflt;
         }
         // at most one accumulation workgroup per CU by an LDS request, the tree one per CU by registers (g1_kernels.hip)
-        int exclusive = env("POSEVO_ACC_EXCLUSIVE", 0);
+        int exclusive = env("POSEVO_ACC_EXCLUSIVE", 1);
         // the tree's four-lane levels rotate over the workgroup's waves
         int tree_rotate = env("POSEVO_TREE_ROTATE", 0);
         // the accumulation's completion signal is the event its tree waits for (no record packet behind the kernel)
@@ -343,10 +344,13 @@ struct pe_engine {
         // one aggregate later -- skips the wait packet when that event has completed by then
         int rows_event = env("POSEVO_ROWS_EVENT", 0);
         // which stream carries the state-transition work: 0 = its own (aux), 1 = the tree's (fin), 2 = the finish's (norm)
-        int state_on = env("POSEVO_STATE_ON", 0);
+        int state_on = env("POSEVO_STATE_ON", 1);
         // 2: consecutive accumulations of a streaming run alternate between two streams (needs `exclusive`: the successor's
         // workgroups then take each CU as the predecessor's leave it, instead of the whole launch waiting for the last one)
         int side_streams = env("POSEVO_SIDE_STREAMS", 1);
+        // pe_aggregate_signed in pipelined calls: 1 = the signature leg behind its aggregate's accumulation and the next
+        // accumulation behind the leg's decompression (they cost their sum), 0 = the two beside each other (round 4)
+        int sig_behind = env("POSEVO_SIG_BEHIND", 1);
     } tune;
 
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----

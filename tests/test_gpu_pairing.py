@@ -213,3 +213,37 @@ def test_pairing_switched_off_is_the_old_chain(monkeypatch):
     _same_store(e, e2)
     e.close()
     e2.close()
+
+
+KNOB_SETS = [
+    {"POSEVO_ACC_EXCLUSIVE": "0", "POSEVO_STATE_ON": "0"},                       # round 4's signatures and streams
+    {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_STATE_ON": "1"},
+    {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_TREE_ROTATE": "1", "POSEVO_STATE_ON": "2"},
+    {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_SIDE_STREAMS": "2", "POSEVO_ACC_DONE_EVENT": "1", "POSEVO_ROWS_EVENT": "1"},
+    {"POSEVO_ACC_EXCLUSIVE": "0", "POSEVO_TREE_ROTATE": "1", "POSEVO_ACC_DONE_EVENT": "1", "POSEVO_ROWS_EVENT": "1"},
+]
+
+
+@pytest.mark.parametrize("knobs", KNOB_SETS, ids=lambda k: ",".join(f"{a[7:].lower()}={b}" for a, b in k.items()))
+def test_the_scheduling_knobs_change_no_result(knobs, monkeypatch):
+    """The scheduling knobs of the streaming G1 chain (engine_internal.h Tune) decide WHERE and WHEN a step's
+    kernels run -- which stream carries the state-transition work, whether two accumulation workgroups may share a CU, which
+    waves take the tree's upper levels, which event orders the tree behind the accumulation -- never what they compute: every
+    setting against the synchronous twin, step by step, over enough steps for every arena to be reused twice."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)   # read once per handle, when it is created
+    n, lag = 9, 3
+    e = pea.Engine(max_committee_tables=n + 3)
+    w = bench.build_workload(e, _args(65536, 256, 700, n, equivocating_frac=0.01), 0, n)
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(n + lag + 2)
+    got = [_stream_step(e, w, st) for st in w["steps"]]
+    e.drain()
+    for k in list(knobs):
+        monkeypatch.delenv(k)
+    e2 = _twin(w, n)
+    for k, st in enumerate(w["steps"]):
+        _same_step(got[k], _sync_step(e2, w, st), k)
+    _same_store(e, e2)
+    e.close()
+    e2.close()

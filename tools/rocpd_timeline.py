@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Kernel timeline of a few consecutive bench steps from a rocprofv3 rocpd database (kernel-trace):
-start / end of every kernel relative to the first k_bits_union of the window, with overlaps visible.
+start / end of every kernel relative to the first union of the window (k_bits_union, or the paired launch that carries it
+since round 5: k_pair_union_tree), with overlaps visible.
 usage: rocpd_timeline.py results.db [first_step] [n_steps]"""
 import sqlite3
 import sys
@@ -18,7 +19,12 @@ def short(n):
     return n[:28]
 
 
-unions = [i for i, r in enumerate(rows) if "k_bits_union" in r[0]]
+unions = [i for i, r in enumerate(rows) if "k_pair_union_tree" in r[0]]
+if len(unions) < 3:  # unpaired runs (POSEVO_PAIR=0, rounds 1-4)
+    unions = [i for i, r in enumerate(rows) if "k_bits_union" in r[0]]
+if len(unions) < 2:
+    raise SystemExit("no step boundaries (k_pair_union_tree / k_bits_union) in this trace")
+nsteps = min(nsteps, len(unions) - 1)
 if len(unions) <= first + nsteps:
     first = max(0, len(unions) - nsteps - 1)
 lo, hi = unions[first], unions[first + nsteps]
