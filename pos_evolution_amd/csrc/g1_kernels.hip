@@ -761,6 +761,10 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
 // The accumulation has the same problem with ITSELF when it is queued behind its predecessor on the side stream: its
 // workgroups are dispatched as CUs free up and the first CUs to finish take two; hence its launch behind the step's k_tree
 // (engine_internal.h, g1_chain_idle).
+//  * round 5 (`solo`, the default of streaming steps): the padding moved to the ACCUMULATION, which asks for 82 KB it never
+//    touches (launch_g1_accumulate, `exclusive`) -- that rules its doubling-up out whatever arrives when, which the 84 KB here
+//    only made rarer (6 steps of 20 at 340-370 us on one box, profiles/r05_engine_timeline_cold20_paired.txt); this kernel then
+//    keeps its workgroups apart by registers instead (k_g1_tree_solo: 264 + 264 > 512) and asks for the 51 KB it uses.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev, int rotate, int solo)
 {
