@@ -725,7 +725,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
     // dispatcher does double workgroups up on a CU whenever it finds the others busy for a moment (k_g1_tree of the previous
     // step arriving in the same microsecond; the first CUs to retire a predecessor's workgroup): those eight waves then run
     // at half speed for the whole launch, 330-370 us instead of 205-240 in up to six steps of twenty
-    // (profiles/r05_engine_timeline_cold20_paired.txt).  78 KB stay for the guests: k_g1_tree_solo (51 KB), the fork-choice
+    // (profiles/r05_engine_timeline_cold20_before_exclusive.txt).  78 KB stay for the guests: k_g1_tree_solo (51 KB), the fork-choice
     // tree up to 4096 blocks (66 KB), k_att_plan (70 KB), the vote histograms (32 KB each).
     size_t lds_bytes = 0;
     if (exclusive) {
@@ -763,7 +763,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
 // (engine_internal.h, g1_chain_idle).
 //  * round 5 (`solo`, the default of streaming steps): the padding moved to the ACCUMULATION, which asks for 82 KB it never
 //    touches (launch_g1_accumulate, `exclusive`) -- that rules its doubling-up out whatever arrives when, which the 84 KB here
-//    only made rarer (6 steps of 20 at 340-370 us on one box, profiles/r05_engine_timeline_cold20_paired.txt); this kernel then
+//    only made rarer (6 steps of 20 at 340-370 us on one box, profiles/r05_engine_timeline_cold20_before_exclusive.txt); this kernel then
 //    keeps its workgroups apart by registers instead (k_g1_tree_solo: 264 + 264 > 512) and asks for the 51 KB it uses.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev, int rotate, int solo)
