@@ -133,6 +133,13 @@ def main():
         if getattr(args, key) is None:
             setattr(args, key, val)
 
+    # fd 1 carries exactly ONE line, the JSON line of rank 0: libraries print to it too (gloo's "[Gloo] Rank 0 is connected
+    # to ..." at the rendezvous, RCCL's version banner -- through C stdio, i.e. flushed at exit, BEHIND the JSON line).  From
+    # here on everything written to stdout by anyone goes to stderr; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -618,7 +625,7 @@ def main():
         assert out["checked_against_oracle"], f"GPU step differs from the oracle: {chk_out}"
     if _BREAKDOWN is not None:
         out["host_breakdown_ms_per_step"] = {k: v / total * 1e3 for k, v in _BREAKDOWN.items()}
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
