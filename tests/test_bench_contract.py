@@ -66,3 +66,24 @@ def test_the_contract_keys_are_in_the_line():
         assert f'"{key}"' in src, key
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert f'"{key}"' in src or f"{key}=" in src, key
+
+
+def test_stdout_carries_nothing_but_the_line():
+    """The driver reads ONE JSON line from stdout.  bench.py claims descriptor 1 before any library is loaded (gloo and RCCL
+    print banners to it, the latter through C stdio at exit -- behind the line) and writes its line to the saved descriptor.
+    Without a GPU the run ends before the line exists: stdout stays empty, the reason is on stderr, the exit code says so."""
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=240, cwd=ROOT)
+    import torch
+    if torch.cuda.is_available():   # on a GPU box: exactly the line
+        lines = [l for l in p.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and json.loads(lines[0])["steps"] == 2, p.stdout[:400]
+        return
+    assert p.returncode != 0 and p.stdout == "", (p.returncode, p.stdout[:200])
+    assert "needs an MI355X" in p.stderr
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index("os.dup2(2, 1)") < src.index("import torch"), "descriptor 1 is claimed before the first library loads"
+    assert "os.write(json_fd" in src and "print(json.dumps(out))" not in src
