@@ -299,6 +299,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
     const bool ok_streams = mk(&h->side_stream) == hipSuccess && mk(&h->fin_stream) == hipSuccess &&
                             mk(&h->aux_stream) == hipSuccess;
+    h->aux_owned = h->aux_stream;  // what pe_engine_destroy destroys (aux_stream may become an alias below)
     // k_g1_finish has a stream of its own behind k_g1_tree: on one finishing stream the two latency-bound guests of a step
     // ran one behind the other and THAT stream set the step's period (0.43-0.47 -> 0.34 ms, round 3)
     if (hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming) != hipSuccess ||
@@ -309,7 +310,6 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // Tune::state_on: the state-transition work on the tree's or the finish's stream instead of its own (the runtime maps
     // the engine's six streams onto four hardware queues; two streams that share one run in submission order)
     if (ok_streams && h->tune.side_streams == 2 && mk(&h->side_stream2) != hipSuccess) h->side_stream2 = nullptr;
-    h->aux_owned = h->aux_stream;
     if (ok_streams && h->tune.state_on == 1) h->aux_stream = h->fin_stream;
     if (ok_streams && h->tune.state_on == 2) h->aux_stream = h->norm_stream;
     if (!ok_streams ||

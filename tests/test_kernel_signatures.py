@@ -70,3 +70,25 @@ def test_exclusive_lds_request_leaves_room_for_the_guests():
     plan = 71904                                       # k_att_plan / k_pair_plan_lmd (static; att_kernels.resource: see DESIGN 3)
     for name, need in (("k_g1_tree_solo", tree_lds), ("k_tree at 4096 blocks", fc_tree_4096), ("k_att_plan", plan)):
         assert need <= left, f"{name} ({need} B of LDS) finds no room beside an exclusive accumulation ({left} B left)"
+
+
+def test_sweep_knobs_name_switches_the_engine_reads():
+    """tools/sweep.py's variants set environment switches; every POSEVO_* name it sets must be one the handle reads
+    (engine_internal.h, Tune) -- a stale name would make the sweep compare the default with itself."""
+    import ast
+
+    tree = ast.parse(open(os.path.join(ROOT, "tools", "sweep.py")).read())
+    knobs = None
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == "KNOBS":
+            knobs = ast.literal_eval(node.value)
+    assert knobs, "tools/sweep.py: KNOBS"
+    hdr = open(os.path.join(CSRC, "engine_internal.h")).read()
+    read = set(re.findall(r'env\("(POSEVO_[A-Z_]+)"', hdr))
+    for name, (env, _args, _group) in knobs.items():
+        for var in env:
+            if var.startswith("POSEVO_"):
+                assert var in read, f"sweep knob {name} sets {var}, which no handle reads"
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for var in read:
+        assert var in design, f"{var} is read by the engine but missing from DESIGN.md's table of run-time knobs"
