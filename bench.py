@@ -378,6 +378,24 @@ def main():
             e.get_head()
         prof_head = e.profile()
         e.profile_enable(False)
+    # The signed step once more BESIDE this handle, before it goes (how rounds 4 and 5 measured that leg until now): the
+    # difference to the same leg on a handle of its own further down is the runtime's stream -> hardware-queue mapping and
+    # nothing else.
+    signed_beside = None
+    signed_ok = (world == 1 and not emulate and not args.no_signed_steps and not args.no_pipeline and not args.host_rows
+                 and not args.host_arena and not args.no_lag)
+    if signed_ok and dist is None:
+        try:
+            n_signed = min(20, args.steps)
+            signed_beside = signed_steps(pea, w, local_rank, min(3, len(w["steps"]) - n_signed), n_signed, args.lag)
+        except Exception as err:
+            print(f"[bench] with_signatures (beside the main handle) failed: {err!r}", file=sys.stderr)
+    # The main handle is done: release it before the legs below create theirs.  The runtime maps a process's streams onto its
+    # four hardware queues as they are created; with this handle's six still alive a second handle's streams share queues with
+    # their own siblings -- its row kernels queued behind its own finish kernel: the per-slot run read 308 us per slot-step
+    # with every stream strictly behind the other for that reason (profiles/r05_slot_timeline.txt).
+    if dist is None and not emulate:
+        e.close()
 
     if dist is not None:
         t = torch.tensor([dt, float(n_att_local)], dtype=torch.float64, device="cuda" if torch_backend == "nccl" else "cpu")
@@ -599,12 +617,17 @@ def main():
         except Exception as err:   # as above
             print(f"[bench] slot_cadence failed: {err!r}", file=sys.stderr)
             out["slot_cadence"] = {"error": repr(err)}
-    if world == 1 and not emulate and not args.no_signed_steps and not args.no_pipeline and not args.host_rows \
-            and not args.host_arena and not args.no_lag:
+    if signed_ok:
         n_signed = min(20, args.steps)
         try:
             out["with_signatures"] = signed_steps(pea, w, local_rank, min(3, len(w["steps"]) - n_signed), n_signed, args.lag)
             out["ms_per_step_with_signatures"] = out["with_signatures"]["ms_per_step_with_signatures"]
+            if signed_beside is not None:
+                out["with_signatures"]["ms_per_step_beside_another_handle"] = signed_beside["ms_per_step_with_signatures"]
+                out["with_signatures"]["beside_another_handle_detail"] = (
+                    "the same leg run while the headline's handle was still alive (rounds 4-5 measured it so): a second "
+                    "handle's streams land on other hardware queues than a first one's; steps verified "
+                    f"{signed_beside.get('steps_verified')}")
         except Exception as err:   # an extra leg: reported (here and on stderr), never at the cost of the headline line
             print(f"[bench] with_signatures failed: {err!r}", file=sys.stderr)
             out["with_signatures"] = {"error": repr(err)}

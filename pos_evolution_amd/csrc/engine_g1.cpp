@@ -610,24 +610,36 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
         // Tune::state_on: a millisecond of decompression in front of the next k_g1_tree would put the whole G1 chain behind it;
         // its end is joined into that stream below, so fences and waits on aux_stream cover the leg as before)
         hipStream_t ss = h->aux_owned && h->stream == h->own_stream ? h->aux_owned : h->stream;
+        // Tune::sig_on_side (with the leg behind its accumulation): the decompression goes onto the ACCUMULATION's stream, where
+        // "behind this aggregate's accumulation, in front of the next one" is stream order -- no event pair across hardware
+        // queues, and no millisecond-long kernel in the queue the leg's own stream shares with the finish kernel (the runtime
+        // maps the handle's fifth stream onto the fourth's queue: tools/qmap.py).  Only the latency-sized tail (the per-row
+        // sums, the status copy) stays on the leg's stream, behind an event.
+        const bool on_side = behind_acc && ss != h->stream && h->tune.sig_on_side && !h->side_stream2;
+        hipStream_t ds = on_side ? h->side_stream : ss;  // where the signatures are copied in, decompressed and checked
         if (ss != h->stream) {  // behind the grouping (state_stream_begin's fork, on behalf of the leg's own arena)
-            HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
-            HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
+            if (!on_side) {
+                HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
+                HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
+            }   // (on the side stream the aggregate's accumulation, just launched there, is already behind the grouping)
             h->aux_busy = true;
             arena->aux_used = true;
             arena->aux_reads_scratch = true;
-            if (behind_acc) HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_acc, 0));  // the accumulation of this aggregate, just launched
+            if (behind_acc && !on_side) HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_acc, 0));  // the accumulation of this aggregate, just launched
         }
         HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(d_sig_in), signatures, sig_bytes * n,
-                                  sig_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ss));
+                                  sig_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ds));
         if (fmt == PE_SIG_G2_COMPRESSED) {
-            launch_g2_decompress(ss, d_sig_in, n, d_pts, nullptr, d_status);
+            launch_g2_decompress(ds, d_sig_in, n, d_pts, nullptr, d_status);
         } else {
-            HIP_TRY(h, hipMemsetAsync(d_status, 0, 4ull * n, ss));
-            launch_g2_convert(ss, d_sig_in, d_pts, n);
+            HIP_TRY(h, hipMemsetAsync(d_status, 0, 4ull * n, ds));
+            launch_g2_convert(ds, d_sig_in, d_pts, n);
         }
-        if (sig_format_flags & PE_SIG_CHECK_SUBGROUP) launch_g2_subgroup_check(ss, d_pts, n, d_status);
-        if (behind_acc && ss != h->stream) {  // the next accumulation may start: what follows is latency-sized
+        if (sig_format_flags & PE_SIG_CHECK_SUBGROUP) launch_g2_subgroup_check(ds, d_pts, n, d_status);
+        if (on_side) {  // the tail waits for the points; the next accumulation follows on ds by itself
+            HIP_TRY(h, hipEventRecord(h->ev_sig, ds));
+            HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_sig, 0));
+        } else if (behind_acc && ss != h->stream) {  // the next accumulation may start: what follows is latency-sized
             HIP_TRY(h, hipEventRecord(h->ev_sig, ss));
             h->sig_leg_open = true;
         }

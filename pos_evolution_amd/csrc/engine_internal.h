@@ -351,6 +351,9 @@ struct pe_engine {
         // pe_aggregate_signed in pipelined calls: 1 = the signature leg behind its aggregate's accumulation and the next
         // accumulation behind the leg's decompression (they cost their sum), 0 = the two beside each other (round 4)
         int sig_behind = env("POSEVO_SIG_BEHIND", 1);
+        // ... and, behind it, its decompression ON the accumulation's stream (stream order instead of two events across
+        // hardware queues; only the leg's latency-sized tail stays on its own stream)
+        int sig_on_side = env("POSEVO_SIG_ON_SIDE", 0);
     } tune;
 
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
