@@ -168,6 +168,20 @@ hipStream_t state_stream_unordered(pe_engine* h)
     h->A().aux_used = true;
     return h->aux_stream;
 }
+// The stream of the signature legs: the handle's own state-transition stream where it has one, else created at the first leg.
+hipStream_t leg_stream(pe_engine* h)
+{
+    if (!h->aux_owned) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&h->aux_owned, hipStreamNonBlocking, (lo + hi) / 2) != hipSuccess) {
+            (void)hipGetLastError();
+            h->aux_owned = nullptr;
+            return h->aux_stream ? h->aux_stream : h->stream;
+        }
+    }
+    return h->aux_owned;
+}
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch)
 {
     // a caller-owned stream (pe_set_stream) carries everything: the caller orders its own work against it
@@ -297,9 +311,13 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     // k_g1_finish of step N-1/N, each on its own stream.  (CU-masked streams -- a private CU partition for the
     // latency-sized fork-choice kernels -- were measured and dropped: hipExtStreamCreateWithCUMask with 16 / 32 / 48
     // CUs taken out made k_g1_accumulate 1.6x / 1.0x / 5.8x slower, profiles/r02_cu_mask_sweep.txt.)
+    // A handle creates FOUR streams (engine, side, fin, norm): the runtime gives a process's first four streams a hardware
+    // queue each and lets every further one share (tools/qmap.py) -- with a fifth created here, a second handle
+    // in the process shared queues with ITSELF.  The stream of the signature legs (and, with Tune::state_on = 0, of the flag
+    // passes) is created when it is first needed: leg_stream().
     const bool ok_streams = mk(&h->side_stream) == hipSuccess && mk(&h->fin_stream) == hipSuccess &&
-                            mk(&h->aux_stream) == hipSuccess;
-    h->aux_owned = h->aux_stream;  // what pe_engine_destroy destroys (aux_stream may become an alias below)
+                            (h->tune.state_on != 0 || mk(&h->aux_stream) == hipSuccess);
+    h->aux_owned = h->aux_stream;  // what pe_engine_destroy destroys (aux_stream becomes an alias below unless state_on is 0)
     // k_g1_finish has a stream of its own behind k_g1_tree: on one finishing stream the two latency-bound guests of a step
     // ran one behind the other and THAT stream set the step's period (0.43-0.47 -> 0.34 ms, round 3)
     if (hipEventCreateWithFlags(&h->ev_tree, hipEventDisableTiming) != hipSuccess ||

@@ -609,7 +609,7 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
         // (the leg keeps the stream created for state-transition work even where the flag passes ride the tree's stream --
         // Tune::state_on: a millisecond of decompression in front of the next k_g1_tree would put the whole G1 chain behind it;
         // its end is joined into that stream below, so fences and waits on aux_stream cover the leg as before)
-        hipStream_t ss = h->aux_owned && h->stream == h->own_stream ? h->aux_owned : h->stream;
+        hipStream_t ss = h->aux_stream && h->stream == h->own_stream ? leg_stream(h) : h->stream;
         // Tune::sig_on_side (with the leg behind its accumulation): the decompression goes onto the ACCUMULATION's stream, where
         // "behind this aggregate's accumulation, in front of the next one" is stream order -- no event pair across hardware
         // queues, and no millisecond-long kernel in the queue the leg's own stream shares with the finish kernel (the runtime

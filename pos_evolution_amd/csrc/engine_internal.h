@@ -485,6 +485,7 @@ int tree_args(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int 
 VotesArgs votes_args(const pe_engine* h);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
+hipStream_t leg_stream(pe_engine* h);              // where a signature leg runs (created at the first one)
 hipStream_t state_stream_unordered(pe_engine* h);  // the same stream, not ordered behind the engine's
 int aux_join(pe_engine* h, hipStream_t ms);  // ms waits for what this pipeline put on the state-transition stream
 
