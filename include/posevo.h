@@ -479,7 +479,9 @@ int pe_get_store_scalars(const pe_engine* h, uint64_t* time, uint64_t* genesis_t
 /* Everything pe_aggregate does, plus Attestation.signature of every aggregate it forms: the sum in G2 of the member
  * attestations' BLSSignatures, returned in the 96-byte compressed wire form (pe:37, pe:717) -- what a validator client
  * publishes as "a well-packed aggregate attestation" (pe:659).
- *   signatures        n signatures, one per input row, in host or device memory:
+ *   signatures        n signatures, one per input row, in host or device memory (host memory is read before the call
+ *                     returns -- a buffer refilled per step is fine; device memory is read where the leg runs, which in a
+ *                     pipeline may be after the call: it stays unchanged until the pipeline has completed, like device rows):
  *                     PE_SIG_G2_COMPRESSED    96 bytes each (x.c1 | x.c0 big-endian, flag bits in the leading byte): decoded
  *                                             on the device (square root in Fp2, sign and canonicity checks, curve membership);
  *                     PE_SIG_G2_UNCOMPRESSED  192 bytes each (x.c1 | x.c0 | y.c1 | y.c0): converted, trusted to lie on the curve;

@@ -205,8 +205,12 @@ int pe_dist_destroy(pe_engine* h)
             a.pending.clear();
             a.stage_cursor = a.out_cursor = 0;
             a.fenced = a.side_used = a.aux_used = a.aux_reads_scratch = false;
+            a.fence_pending = false;
         }
         h->deferred.clear();
+        // launches held back for the next aggregate (engine_pair.cpp) point into the regions reset above and carry the lost
+        // communicator's collectives: they go with the rest
+        h->held = pe_engine::HeldFc{};
         h->pipelining = h->streaming = false;
         h->side_busy = h->aux_busy = false;
         h->res_valid = false;

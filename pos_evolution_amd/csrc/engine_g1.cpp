@@ -541,6 +541,18 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
         PE_TRY(ensure_quiesced(h, A.d_sig_pts, 192ull * n));
         PE_TRY(ensure_quiesced(h, A.d_sig_status, 4ull * n));
     }
+    bool sig_on_device = false;
+    {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, signatures) == hipSuccess) sig_on_device = pa.type == hipMemoryTypeDevice;
+        else (void)hipGetLastError();
+    }
+    // Signatures in HOST memory are brought in during the call, in front of the grouping on the engine's stream: the leg below
+    // may be deferred past this call's return (a streaming step holds it back until the next aggregate), and a caller is free
+    // to refill a host buffer per step -- as with bits_arena.  Device-resident signatures are read where the leg
+    // runs (include/posevo.h: they stay unchanged until the pipeline completes, like device rows).
+    if (!sig_on_device)
+        HIP_TRY(h, hipMemcpyAsync(h->A().d_sig_in.p, signatures, sig_bytes * n, hipMemcpyHostToDevice, h->stream));
     // host rows: the grouping comes back in group_of (host-derived, complete at return) -- keep one if the caller has none
     auto gof_p = std::make_shared<std::vector<uint32_t>>();
     if (!dev_rows && !group_of) {
@@ -585,12 +597,6 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     const size_t off_st = ob.alloc(4ull * n);
     PE_TRY(ob.ensure());
     memset(ob.host<uint32_t>(off_bad), 0, 4ull * std::max<uint32_t>(ng_bound, 1));
-    bool sig_on_device = false;
-    {
-        hipPointerAttribute_t pa;
-        if (hipPointerGetAttributes(&pa, signatures) == hipSuccess) sig_on_device = pa.type == hipMemoryTypeDevice;
-        else (void)hipGetLastError();
-    }
     // The leg as a launch sequence on the state-transition stream.  Where the aggregate's pubkey sums run on the G1 streams
     // (pipelined calls) the leg goes BEHIND the accumulation (ev_acc) and the NEXT accumulation behind the leg (ev_sig):
     // k_g2_decompress holds an eighth of the chip's SIMDs for ~0.95 ms, and an accumulation that runs beside it ends when the
@@ -627,8 +633,8 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
             arena->aux_reads_scratch = true;
             if (behind_acc && !on_side) HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_acc, 0));  // the accumulation of this aggregate, just launched
         }
-        HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(d_sig_in), signatures, sig_bytes * n,
-                                  sig_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ds));
+        if (sig_on_device)
+            HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(d_sig_in), signatures, sig_bytes * n, hipMemcpyDeviceToDevice, ds));
         if (fmt == PE_SIG_G2_COMPRESSED) {
             launch_g2_decompress(ds, d_sig_in, n, d_pts, nullptr, d_status);
         } else {

@@ -62,7 +62,9 @@ static int after_tree(pe_engine* h, pe_engine::HeldFc& L)
         pe_engine::PipeArena& a = h->arena[L.arena];
         const int r = fence_arena(h, a);
         if (r && !rc) rc = r;
-        if (L.arena != h->cur) h->side_busy = false;  // accounted for by that fence (the current pipeline has launched no G1 yet)
+        // that fence accounts for the old pipeline's G1 launch -- unless the CURRENT pipeline has put work on the side stream
+        // already (held_issue is reachable at any point of a pipeline): then somebody still has to wait for that
+        if (L.arena != h->cur && !h->A().side_used) h->side_busy = false;
     }
     return rc;
 }
@@ -87,9 +89,10 @@ int held_issue(pe_engine* h)
             ProfScope ps(h, PE_KERNEL_VOTES);
             launch_votes(s, L.votes, /*lean=*/1);
         }
-        if (L.between) { const int r = L.between(); if (r && !rc0) rc0 = r; }
+        int rb = PE_OK;
+        if (L.between) { rb = L.between(); if (rb && !rc0) rc0 = rb; }
         ProfScope ps(h, PE_KERNEL_TREE);
-        launch_tree(s, L.tree, /*lean=*/1);
+        if (!rb) launch_tree(s, L.tree, /*lean=*/1);  // no tree over weights whose exchange failed
     }
     const hipError_t e = hipGetLastError();
     const int rc = after_tree(h, L);
@@ -141,9 +144,11 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
                 launch_att_members(s, ma);
             }
         }
-        if (L.between) { const int r = L.between(); if (r && !rc0) rc0 = r; }
+        int rb = PE_OK;
+        if (L.between) { rb = L.between(); if (rb && !rc0) rc0 = rb; }
         ProfScope ps(h, PE_KERNEL_PAIR_UNION_TREE, s);
-        if (!launch_pair_union_tree(s, ua, L.tree)) {
+        if (rb) launch_bits_union(s, ua);  // no tree over weights whose exchange failed
+        else if (!launch_pair_union_tree(s, ua, L.tree)) {
             launch_tree(s, L.tree, /*lean=*/1);
             launch_bits_union(s, ua);
         }
