@@ -169,402 +169,366 @@ void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* ta
 }
 #endif
 
-// ------------------------------------------------------------------ plan: one workgroup
-// 1024 lanes = four waves per SIMD of 64 registers (amdgpu_waves_per_eu(8, 8) caps them; 84 B of scratch per lane): the
-// workgroup must find room on a CU whose SIMDs already hold a wave of the previous step's k_g1_accumulate (232 registers;
-// rounds 2-3: two waves of 168, and 512 lanes of <= 88 here -- a 1024-lane build of 86 registers waits for that kernel to
-// drain: +200 us on every step).  The kernel is a chain of dependent round trips to L2 / HBM beside a kernel that saturates
-// the chip, so its shape is: coalesced chunk loops (lane = consecutive element, independent iterations the compiler can
-// overlap), wave-level prefix sums by shuffles, per-(chunk, wave) totals in an LDS matrix, ONE block scan per matrix; twice
-// the lanes = half the chunks of every phase.
-constexpr int PLAN_WG = 1024;
+// ------------------------------------------------------------------ plan: one lane per input row, many workgroups
+// Rounds 3-5 ran this as ONE workgroup of 1024 lanes with ~70 KB of LDS: 50 us of dependent L2 round trips beside a kernel
+// that saturates the chip, and a paired launch made every LMD block reserve that LDS.  Now every input row has a lane of its
+// own, 256 per workgroup, and what used to be three passes over the groups is one pass over the rows:
+//   * a row is its class's representative iff the grouping table names it (k_att_ingest kept the row of first appearance);
+//   * EVERY row resolves its committee from its own 144 bytes (the loads depend on the row alone, so they travel beside the
+//     table look-up instead of behind it); only representatives count;
+//   * group id, union word / byte offset and member-list start are exclusive prefix sums over the rows in batch order
+//     (non-representatives contribute zero): wave shuffles -> LDS across the workgroup's four waves -> DECOUPLED LOOK-BACK
+//     across workgroups: a workgroup publishes its own sums, adds up its predecessors' (64 per poll by its first wave,
+//     stopping at the nearest one that already knows its inclusive prefix) and publishes its inclusive prefix.  Records are
+//     8-byte words with a "written" bit, stored and loaded with agent-scope atomics (one sc1 store / load each: untorn, no
+//     fence -- MI355X_MICROARCH.md, hand-off granules); a workgroup only ever waits for LOWER block indices, which the
+//     dispatcher has started before it;
+//   * maxima / totals the G1 plan needs go through device-scope atomics, committee row counts likewise;
+//   * every workgroup then drains its memory operations and draws a ticket; the LAST one reads the totals (every atomic and
+//     granule of the others is performed by then), picks k and the block size, turns the row counts of each table into
+//     offsets + fill cursors, writes the AttPlan (device + pinned mirror) and clears the records for the next launch.
+// k_att_members -- which already runs a lane per row -- writes the G1 descriptor and the committee's row-list entry of each
+// group from the lane of its first row (it needs k / the block size: known only after this kernel).
+// LDS: a few hundred bytes.  ~12 us at 8192 rows where the single workgroup took 50.
 constexpr int PLAN_WAVES = PLAN_WG / 64;
-constexpr uint32_t PLAN_SUPER = 32;  // chunks per super-chunk: 32 x 1024 elements per LDS matrix of 512 totals
-constexpr uint32_t PLAN_LDS_NC = 4096;  // committees per table up to which the rows-per-committee lists are built in LDS
-constexpr uint32_t PLAN_LDS_NG = 8192;  // groups up to which their (table, committee) keys are kept in LDS
+constexpr uint32_t PLAN_STALL_LIMIT = 1u << 21;  // polls before a workgroup gives up waiting (seconds: never seen; a lost
+                                                 // predecessor must not hang the device) -> ERR_STALL
+constexpr uint32_t ERR_STALL = 12;
 
 namespace {
-template <typename T>
-__device__ __forceinline__ T block_scan(T v, T* wave_tot /* PLAN_WAVES entries of LDS */, T* total)
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const T o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
-    }
-    __syncthreads();  // wave_tot may still be read by the previous scan
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    T base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < PLAN_WAVES; ++w) {
-        const T t = wave_tot[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    *total = tot;
-    return base + incl - v;
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t wave_excl_u32(uint32_t v, uint32_t* wave_total)
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t word_load(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long plan_wave_incl_u64(unsigned long long v)
 {
     const int lane = threadIdx.x & 63;
-    uint32_t incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
+        const unsigned long long o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
     }
-    *wave_total = __shfl(incl, 63, 64);
-    return incl - v;
+    return v;
 }
-// mat[0 .. cnt) (cnt <= PLAN_SUPER * PLAN_WAVES <= PLAN_WG: one entry per lane) -> exclusive prefix sums + base, in place;
-// returns the total.  All lanes call it.
-static_assert(PLAN_SUPER * PLAN_WAVES <= (uint32_t)PLAN_WG, "scan_matrix scans one matrix entry per lane");
-__device__ __forceinline__ uint32_t scan_matrix(uint32_t* mat, uint32_t cnt, uint32_t base, uint32_t* wt32)
+__device__ __forceinline__ unsigned long long plan_wave_sum_u64(unsigned long long v)
 {
-    __syncthreads();  // the matrix is complete
-    const uint32_t v = threadIdx.x < cnt ? mat[threadIdx.x] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_scan<uint32_t>(v, wt32, &tot);
-    if (threadIdx.x < cnt) mat[threadIdx.x] = base + ex;
-    __syncthreads();
-    return tot;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
-}  // namespace
+__device__ __forceinline__ uint32_t plan_wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, (uint32_t)__shfl_xor(v, off, 64));
+    return v;
+}
+// the three running sums of the scan: A = representatives (low 24 bits after look-back; 16 inside a workgroup) + class sizes,
+// W = union words, B = union bytes
+struct Sum3 { unsigned long long a, w, b; };
 
-// tools/build_variant.sh plantime -DPOSEVO_PLAN_TIMING: wall_clock64() (100 MHz) at the phase boundaries of the last launch,
-// read back through pe_debug_plan_stamps (tools/plan_phases.py)
-#ifdef POSEVO_PLAN_TIMING
-__device__ unsigned long long plan_stamps[16];
-#define PLAN_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) plan_stamps[i] = wall_clock64(); } while (0)
-#else
-#define PLAN_STAMP(i) do { } while (0)
-#endif
-namespace {
-__device__ __forceinline__ void att_plan_body(const AttPlanArgs& a)  // ONE workgroup of PLAN_WG lanes
+__device__ __forceinline__ void att_plan_body(const uint32_t bid, const uint32_t nb, const AttPlanArgs& a)
 {
-    __shared__ uint32_t wt32[PLAN_WAVES];
-    __shared__ unsigned long long wt64[PLAN_WAVES];
-    __shared__ uint32_t matA[PLAN_SUPER * PLAN_WAVES], matB[PLAN_SUPER * PLAN_WAVES], matC[PLAN_SUPER * PLAN_WAVES];
-    __shared__ uint32_t s_max_size, s_not_aligned, s_err, s_rows_t[2];
-    // rows per committee (phase 4 counts, phase 5 offsets and fill cursors) and the groups' (table, committee) keys: in LDS
-    // whenever the tables and the batch fit -- the global-memory form of these phases was 40 of the kernel's 73 us (a chain
-    // of dependent L2 round trips: count with atomics, read back, scan, write, read back, scatter)
-    __shared__ uint32_t s_cnt[2][PLAN_LDS_NC + 1];
-    __shared__ uint32_t s_key[PLAN_LDS_NG];
+    __shared__ unsigned long long s_wave[3][PLAN_WAVES];
+    __shared__ unsigned long long s_base[3];
+    __shared__ uint32_t s_scan[PLAN_WAVES];
+    __shared__ uint32_t s_ticket;
     const uint4* __restrict__ rows = static_cast<const uint4*>(a.rows);
-    const uint32_t* __restrict__ tab = a.tab;
-    const uint32_t* __restrict__ cnt_tab = a.cnt_tab;
-    const uint32_t* __restrict__ slot_of = a.slot_of;
     const uint32_t n = a.n_dev ? min(a.n, *a.n_dev) : a.n;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    if (tid == 0) { s_max_size = 0; s_not_aligned = 0; s_err = a.plan->error; s_rows_t[0] = 0; s_rows_t[1] = 0; }
-    __syncthreads();
-    const bool dead = s_err != 0;  // ingest refused a row: nothing downstream may touch the bits
+    const uint32_t i = bid * PLAN_WG + tid;
+    const bool in = i < n;
+    const bool dead = a.plan->error != 0;  // ingest refused a row: no groups are formed, nothing downstream may touch the bits
 
-    PLAN_STAMP(0);
-    // ---- 1. representatives -> group ids in order of first appearance
-    uint32_t ng = 0;
-    {
-        const uint32_t n_chunks = (n + PLAN_WG - 1) / PLAN_WG;
-        for (uint32_t sc = 0; sc < n_chunks; sc += PLAN_SUPER) {
-            const uint32_t nch = min(PLAN_SUPER, n_chunks - sc);
-            uint32_t mybits = 0;
-            for (uint32_t c0 = 0; c0 < nch; c0 += 4) {  // four chunks' dependent loads (slot -> table) in flight at once
-                uint32_t sl[4], rp[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t i = (sc + c0 + u) * PLAN_WG + tid;
-                    sl[u] = (c0 + u < nch && i < n) ? slot_of[i] : NONE32;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rp[u] = sl[u] != NONE32 ? tab[sl[u]] : NONE32;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t c = c0 + u;
-                    const uint32_t i = (sc + c) * PLAN_WG + tid;
-                    const bool in = sl[u] != NONE32;
-                    if (in) a.rep_of[i] = rp[u];
-                    const bool is_rep = in && rp[u] == i;
-                    const unsigned long long b = __ballot(is_rep);
-                    if (lane == 0 && c < nch) matA[c * PLAN_WAVES + wave] = (uint32_t)__builtin_popcountll(b);
-                    mybits |= (is_rep ? 1u : 0u) << (c & 31);
-                }
-            }
-            const uint32_t tot = scan_matrix(matA, nch * PLAN_WAVES, ng, wt32);
-            for (uint32_t c = 0; c < nch; ++c) {
-                const bool is_rep = (mybits >> c) & 1u;
-                const unsigned long long b = __ballot(is_rep);
-                if (is_rep) {
-                    const uint32_t i = (sc + c) * PLAN_WG + tid;
-                    const uint32_t g = matA[c * PLAN_WAVES + wave] + (uint32_t)__builtin_popcountll(b & lt_mask);
-                    a.gid_of_row[i] = g;
-                    a.rep_row[g] = i;
-                }
-            }
-            ng += tot;
-            __syncthreads();  // matA is rewritten by the next super-chunk
-        }
+    // ---- 1. the row, its class, its committee
+    uint32_t slot = 0;
+    uint4 q0 = make_uint4(0, 0, 0, 0), q5 = q0, q8 = q0;
+    if (in) {
+        slot = a.slot_of[i];
+        const uint4* p = rows + (size_t)9 * i;
+        q0 = p[0]; q5 = p[5]; q8 = p[8];
     }
-    if (dead) ng = 0;
-    __syncthreads();  // rep_row / gid_of_row are re-read below by other lanes (workgroup-scope visibility)
-
-    PLAN_STAMP(1);
-    // ---- 2. per group: committee resolution (get_beacon_committee's index arithmetic, A.6), sizes; wave-level partial
-    //         prefix sums of union words / bytes / member counts, per-(chunk, wave) totals into the matrices
+    uint32_t rep = NONE32, natts = 0;
+    if (in) { rep = a.tab[slot]; natts = a.cnt_tab[slot]; }
     const unsigned long long spe = a.tables.slots_per_epoch;
-    const uint32_t g_chunks = (ng + PLAN_WG - 1) / PLAN_WG;
-    unsigned long long my_members = 0;
-    for (uint32_t c = 0; c < g_chunks; ++c) {
-        const uint32_t g = c * PLAN_WG + tid;
-        uint32_t words = 0, bytes = 0, natts = 0;
-        if (g < ng) {
-            const uint32_t rep = a.rep_row[g];
-            const uint4* p = rows + (size_t)9 * rep;
-            const uint4 q0 = p[0], q5 = p[5], q8 = p[8];
-            natts = cnt_tab[slot_of[rep]];
-            const unsigned long long slot = u64_of(q0.x, q0.y), index = u64_of(q0.z, q0.w), tep = u64_of(q5.z, q5.w);
-            const uint32_t nbits = q8.y;
-            uint32_t size = 0, table = NONE32, pos = 0, mbase = 0, index_over = 0;
-            int32_t st = ST_OK;
-            if (a.tables.t[0].valid && a.tables.t[0].epoch == tep) table = 0;
-            else if (a.tables.t[1].valid && a.tables.t[1].epoch == tep) table = 1;
-            if (table == NONE32) st = ST_NO_TABLE;
-            else {
-                const TableDev& t = a.tables.t[table];
-                const unsigned long long cps = t.n_committees / spe;
-                // compute_committee(index = (slot % SLOTS_PER_EPOCH) * cps + data.index, count = cps * SLOTS_PER_EPOCH):
-                // on_attestation's get_beacon_committee asserts nothing about data.index itself -- only the flat id has
-                // to exist; pe:727 (process_attestation) and pe_aggregate require data.index < cps
-                const unsigned long long flat = index < 0xFFFFFFFFull ? (slot % spe) * cps + index : ~0ull;
-                index_over = index >= cps ? 1u : 0u;
-                if (flat >= t.n_committees) st = ST_INDEX_RANGE;
-                else {
-                    pos = (uint32_t)flat;
-                    mbase = t.offsets[pos];
-                    size = t.offsets[pos + 1] - mbase;
-                    if (nbits != size) st = ST_BITS_LENGTH;  // len(aggregation_bits) == len(committee), pe:730
-                }
-            }
-            if ((st != ST_OK || index_over) && a.want_pk)  // the host path fails the whole aggregate here (engine_attest.cpp)
-                atomicMax(&s_err, st == ST_NO_TABLE ? ERR_NO_COMMITTEES : ERR_INVALID_ARG);
-            if (st == ST_OK) {
-                atomicMax(&s_max_size, size);
-                atomicAdd(&s_rows_t[table], 1u);
-                my_members += size;
-            }
-            words = (nbits + 31) >> 5;
-            bytes = (nbits + 7) >> 3;
-            // word layout == byte layout as long as every union but the last one is a whole number of words
-            if (g + 1 < ng && bytes != 4 * words) atomicOr(&s_not_aligned, 1u);
-            AttGroup& G = a.grp[g];
-            G.rep = rep;
-            G.n_atts = natts;
-            G.cursor = 0;
-            G.n_bits = nbits;
-            G.table = st == ST_NO_TABLE ? NONE32 : table;
-            G.pos = pos;
-            G.size = size;
-            G.member_base = mbase;
-            G.sig_valid = FLAG_SIG_VALID;
-            G.status_agg = (uint32_t)st;
-            G.index_over = index_over;
+    const unsigned long long slot_no = u64_of(q0.x, q0.y), index = u64_of(q0.z, q0.w), tep = u64_of(q5.z, q5.w);
+    const uint32_t nbits = q8.y;
+    uint32_t size = 0, table = NONE32, pos = 0, mbase = 0, index_over = 0;
+    int32_t st = ST_OK;
+    if (a.tables.t[0].valid && a.tables.t[0].epoch == tep) table = 0;
+    else if (a.tables.t[1].valid && a.tables.t[1].epoch == tep) table = 1;
+    if (table == NONE32) st = ST_NO_TABLE;
+    else if (in) {
+        const TableDev& t = a.tables.t[table];
+        const unsigned long long cps = t.n_committees / spe;
+        // compute_committee(index = (slot % SLOTS_PER_EPOCH) * cps + data.index, count = cps * SLOTS_PER_EPOCH):
+        // on_attestation's get_beacon_committee asserts nothing about data.index itself -- only the flat id has
+        // to exist; pe:727 (process_attestation) and pe_aggregate require data.index < cps
+        const unsigned long long flat = index < 0xFFFFFFFFull ? (slot_no % spe) * cps + index : ~0ull;
+        index_over = index >= cps ? 1u : 0u;
+        if (flat >= t.n_committees) st = ST_INDEX_RANGE;
+        else {
+            pos = (uint32_t)flat;
+            mbase = t.offsets[pos];
+            size = t.offsets[pos + 1] - mbase;
+            if (nbits != size) st = ST_BITS_LENGTH;  // len(aggregation_bits) == len(committee), pe:730
         }
-        uint32_t tw, tb, tn;
-        const uint32_t ew = wave_excl_u32(words, &tw), eb = wave_excl_u32(bytes, &tb), en = wave_excl_u32(natts, &tn);
-        if (g < ng) {  // partial (in-wave) offsets; the bases follow in the second pass
-            AttGroup& G = a.grp[g];
-            G.out_word = ew;
-            G.out_byte = eb;
-            G.list_start = en;
-        }
-        const uint32_t m = (c % PLAN_SUPER) * PLAN_WAVES + wave;
-        if (lane == 0) { matA[m] = tw; matB[m] = tb; matC[m] = tn; }
-        // a tree of more than 32 chunks of groups (> 16384 groups) flushes the matrices: handled by the second pass's
-        // running bases -- kept simple: one matrix generation must cover all chunks
     }
-    PLAN_STAMP(2);
-    uint32_t word_total = 0, byte_total = 0, list_total = 0;
-    unsigned long long total_members;
-    (void)block_scan<unsigned long long>(my_members, wt64, &total_members);
-    const uint32_t g_mats = min(g_chunks, PLAN_SUPER) * PLAN_WAVES;
-    word_total = scan_matrix(matA, g_mats, 0, wt32);
-    byte_total = scan_matrix(matB, g_mats, 0, wt32);
-    list_total = scan_matrix(matC, g_mats, 0, wt32);
-    (void)list_total;
+    if (in) a.rep_of[i] = rep;
+    const bool is_rep = in && rep == i && !dead;
+    const bool ok = is_rep && st == ST_OK;
+    const uint32_t words = (nbits + 31) >> 5, bytes = (nbits + 7) >> 3;
 
-    PLAN_STAMP(3);
-    // ---- 3. one block size for every group: k members per lane, blocks of BL = 2^L lanes, group g at slot g * BL.  k
-    // follows from the largest committee so that its tasks fill a block exactly or nearly (sizes that differ by one --
-    // 511 / 512 members -- would otherwise put half of the lanes of every block to sleep)
-    uint32_t k = a.min_k, L = 0;
-    {
-        const uint32_t max_size = s_max_size;
-        const unsigned long long k0 = max((unsigned long long)a.min_k, (total_members + a.target_slots - 1) / a.target_slots);
-        uint32_t tasks = (uint32_t)((max_size + k0 - 1) / k0);
-        if (tasks > (uint32_t)G1_WG) tasks = G1_WG;
-        while ((1u << L) < tasks) ++L;
-        while (L > 0 && ((unsigned long long)ng << L) > a.slot_cap) --L;  // bounded scratch: fewer, longer lanes
-        k = max(a.min_k, (max_size + (1u << L) - 1) >> L);
-        if (k == 0) k = 1;
+    // ---- 2. exclusive prefix sums in batch order: inside the wave, across the workgroup, across the grid
+    Sum3 v;
+    v.a = is_rep ? (1ull | ((unsigned long long)natts << 16)) : 0ull;
+    v.w = is_rep ? (unsigned long long)words : 0ull;
+    v.b = is_rep ? (unsigned long long)bytes : 0ull;
+    Sum3 inc;
+    inc.a = plan_wave_incl_u64(v.a);
+    inc.w = plan_wave_incl_u64(v.w);
+    inc.b = plan_wave_incl_u64(v.b);
+    if (lane == 63) { s_wave[0][wave] = inc.a; s_wave[1][wave] = inc.w; s_wave[2][wave] = inc.b; }
+    __syncthreads();
+    Sum3 wgb{0, 0, 0}, tot{0, 0, 0};  // sums of the waves in front of this one; of the whole workgroup
+#pragma unroll
+    for (int w = 0; w < PLAN_WAVES; ++w) {
+        const unsigned long long ta = s_wave[0][w], tw = s_wave[1][w], tb = s_wave[2][w];
+        if (w < (int)wave) { wgb.a += ta; wgb.w += tw; wgb.b += tb; }
+        tot.a += ta; tot.w += tw; tot.b += tb;
     }
-    PLAN_STAMP(4);
-    // ---- 4. second pass over the groups: final offsets, union + G1 descriptors, committee row counts
-    bool lds_crow = ng <= PLAN_LDS_NG;
-    for (int t = 0; t < 2; ++t)
-        if (a.tables.t[t].valid && a.tables.t[t].n_committees > PLAN_LDS_NC) lds_crow = false;
-    for (int t = 0; t < 2; ++t) {
-        if (!a.tables.t[t].valid) continue;
-        const uint32_t nc = a.tables.t[t].n_committees;
-        if (lds_crow) for (uint32_t c = tid; c <= nc; c += PLAN_WG) s_cnt[t][c] = 0;
-        else for (uint32_t c = tid; c <= nc; c += PLAN_WG) a.crow_cursor[t][c] = 0;
+    // own sums in the grid's form: representatives in 24 bits, class sizes above
+    const unsigned long long tot_a24 = (tot.a & 0xFFFFull) | ((tot.a >> 16) << 24);
+    PlanRec* __restrict__ rec = a.rec;
+    if (wave == 0) {
+        Sum3 base{0, 0, 0};
+        if (bid == 0) {
+            if (lane == 0) {
+                granule_store(&rec[0].incl[0], (tot_a24 << 1) | 1ull);
+                granule_store(&rec[0].incl[1], (tot.w << 1) | 1ull);
+                granule_store(&rec[0].incl[2], (tot.b << 1) | 1ull);
+            }
+        } else {
+            if (lane == 0) {
+                granule_store(&rec[bid].agg[0], (tot_a24 << 1) | 1ull);
+                granule_store(&rec[bid].agg[1], (tot.w << 1) | 1ull);
+                granule_store(&rec[bid].agg[2], (tot.b << 1) | 1ull);
+            }
+            int hi = (int)bid - 1;
+            uint32_t polls = 0;
+            bool stalled = false;
+            for (;;) {  // one window of 64 predecessors per turn, nearest first (lane 0 = block hi)
+                const int j = hi - (int)lane;
+                const bool valid = j >= 0;
+                unsigned long long x0 = 0, x1 = 0, x2 = 0;
+                bool have_incl = false;
+                for (;;) {
+                    bool ready = true;
+                    if (valid) {
+                        const unsigned long long i0 = granule_load(&rec[j].incl[0]), i1 = granule_load(&rec[j].incl[1]),
+                                                 i2 = granule_load(&rec[j].incl[2]);
+                        if (i0 & i1 & i2 & 1ull) { x0 = i0; x1 = i1; x2 = i2; have_incl = true; }
+                        else {
+                            const unsigned long long a0 = granule_load(&rec[j].agg[0]), a1 = granule_load(&rec[j].agg[1]),
+                                                     a2 = granule_load(&rec[j].agg[2]);
+                            if (a0 & a1 & a2 & 1ull) { x0 = a0; x1 = a1; x2 = a2; }
+                            else ready = false;
+                        }
+                    }
+                    if (__all(ready)) break;
+                    if (++polls > PLAN_STALL_LIMIT) { stalled = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (stalled) break;
+                const unsigned long long mi = __ballot(valid && have_incl);
+                const int first = mi ? __builtin_ctzll(mi) : 64;  // nearest predecessor that knows its inclusive prefix
+                const bool take = valid && (int)lane <= first;
+                base.a += plan_wave_sum_u64(take ? x0 >> 1 : 0ull);
+                base.w += plan_wave_sum_u64(take ? x1 >> 1 : 0ull);
+                base.b += plan_wave_sum_u64(take ? x2 >> 1 : 0ull);
+                if (mi) break;
+                hi -= 64;
+                if (hi < 0) break;
+            }
+            if (stalled && lane == 0) atomicMax(&a.sync->err, ERR_STALL);
+            if (lane == 0) {
+                granule_store(&rec[bid].incl[0], ((base.a + tot_a24) << 1) | 1ull);
+                granule_store(&rec[bid].incl[1], ((base.w + tot.w) << 1) | 1ull);
+                granule_store(&rec[bid].incl[2], ((base.b + tot.b) << 1) | 1ull);
+            }
+        }
+        if (lane == 0) { s_base[0] = base.a; s_base[1] = base.w; s_base[2] = base.b; }
     }
     __syncthreads();
-    for (uint32_t c = 0; c < g_chunks; ++c) {
-        const uint32_t g = c * PLAN_WG + tid;
-        if (g >= ng) continue;
-        const uint32_t m = (c % PLAN_SUPER) * PLAN_WAVES + wave;
-        AttGroup& G = a.grp[g];
-        const uint32_t out_word = G.out_word + matA[m], out_byte = G.out_byte + matB[m], ls = G.list_start + matC[m];
+
+    // ---- 3. the group's records, from the lane of its first row
+    uint32_t g = 0;
+    if (is_rep) {
+        const unsigned long long ex_a = wgb.a + inc.a - v.a;  // in-workgroup form: count | sizes << 16
+        g = (uint32_t)(s_base[0] & 0xFFFFFFull) + (uint32_t)(ex_a & 0xFFFFull);
+        const uint32_t list_start = (uint32_t)((s_base[0] >> 24) + (ex_a >> 16));
+        const uint32_t out_word = (uint32_t)(s_base[1] + wgb.w + inc.w - v.w);
+        const uint32_t out_byte = (uint32_t)(s_base[2] + wgb.b + inc.b - v.b);
+        AttGroup G;
+        G.rep = i;
+        G.n_atts = natts;
+        G.list_start = list_start;
+        G.cursor = 0;
+        G.n_bits = nbits;
         G.out_word = out_word;
         G.out_byte = out_byte;
-        G.list_start = ls;
+        G.table = st == ST_NO_TABLE ? NONE32 : table;
+        G.pos = pos;
+        G.size = size;
+        G.member_base = mbase;
+        G.sig_valid = FLAG_SIG_VALID;
+        G.status_agg = (uint32_t)st;
+        G.index_over = index_over;
+        G.pad[0] = G.pad[1] = 0;
+        a.grp[g] = G;
         UnionGroup u;
-        u.list_start = ls;
-        u.n_atts = G.n_atts;
-        u.n_bits = G.n_bits;
+        u.list_start = list_start;
+        u.n_atts = natts;
+        u.n_bits = nbits;
         u.out_word = out_word;
         a.ug[g] = u;
-        const bool ok = G.status_agg == ST_OK;
-        G1Group d;
-        d.member_start = G.member_base;
-        d.n_members = ok ? G.size : 0u;
-        d.bits_word = out_word;
-        d.slot_base = g << L;
-        d.n_tasks = ok ? (G.size + k - 1) / k : 0u;
-        d.k = k | (G.table == 1 ? 0x80000000u : 0u);
-        d.log2_block = L;
-        d.out_base = g;
-        a.g1[g] = d;
-        if (lds_crow) {
-            s_key[g] = ok ? ((G.table << 31) | G.pos) : NONE32;
-            if (ok) atomicAdd(&s_cnt[G.table][G.pos], 1u);
-        } else if (ok) {
-            atomicAdd(&a.crow_cursor[G.table][G.pos], 1u);
-        }
+        a.gid_of_row[i] = g;
+        if (ok) atomicAdd(&a.crow_cnt[table][pos], 1u);  // rows per committee of each candidate table
     }
-    __syncthreads();
-
-    PLAN_STAMP(5);
-    // ---- 5. rows per committee of each candidate table (unordered lists; consumers order by group id).  A table without a
-    // row is skipped: its consumers (k_lmd_vm_tables, k_participation_tables) return on plan->n_rows_table[t] == 0.
-    if (lds_crow) {
-        for (int t = 0; t < 2; ++t) {
-            if (!a.tables.t[t].valid || s_rows_t[t] == 0) continue;
-            const uint32_t nc = a.tables.t[t].n_committees;
-            const uint32_t per = (nc + 1 + PLAN_WG - 1) / PLAN_WG;  // consecutive entries per lane (entry nc: the end mark)
-            const uint32_t b0 = min(tid * per, nc + 1), b1 = min(b0 + per, nc + 1);
-            uint32_t sum = 0;
-            for (uint32_t i = b0; i < b1; ++i) sum += i < nc ? s_cnt[t][i] : 0u;
-            uint32_t tot;
-            uint32_t run = block_scan<uint32_t>(sum, wt32, &tot);
-            for (uint32_t i = b0; i < b1; ++i) {
-                const uint32_t v = i < nc ? s_cnt[t][i] : 0u;
-                s_cnt[t][i] = run;  // becomes the fill cursor
-                a.crow_start[t][i] = run;
-                run += v;
-            }
+    // sums / maxima over all groups: one atomic per wave and value that has something to say
+    {
+        // the host path fails the whole aggregate on a group without a committee when pubkeys are wanted (engine_attest.cpp)
+        const uint32_t e = (is_rep && (st != ST_OK || index_over) && a.want_pk) ? (st == ST_NO_TABLE ? ERR_NO_COMMITTEES : ERR_INVALID_ARG) : 0u;
+        const uint32_t w_err = plan_wave_max_u32(e);
+        const uint32_t w_size = plan_wave_max_u32(ok ? size : 0u);
+        // word layout == byte layout as long as every union but the LAST one is a whole number of words: remember the first
+        // group that is not (the last workgroup knows which group is the last)
+        const uint32_t w_mis = plan_wave_max_u32((is_rep && bytes != 4 * words) ? ~g : 0u);
+        const uint32_t w_r0 = (uint32_t)__builtin_popcountll(__ballot(ok && table == 0));
+        const uint32_t w_r1 = (uint32_t)__builtin_popcountll(__ballot(ok && table == 1));
+        const unsigned long long w_mem = plan_wave_sum_u64(ok ? (unsigned long long)size : 0ull);
+        if (lane == 0) {
+            PlanSync* S = a.sync;
+            if (w_err) atomicMax(&S->err, w_err);
+            if (w_size) atomicMax(&S->max_size, w_size);
+            if (w_mis) atomicMax(&S->mis_key, w_mis);
+            if (w_r0) atomicAdd(&S->rows_t[0], w_r0);
+            if (w_r1) atomicAdd(&S->rows_t[1], w_r1);
+            if (w_mem) atomicAdd(&S->total_members, w_mem);
         }
-        __syncthreads();
-        for (uint32_t g = tid; g < ng; g += PLAN_WG) {
-            const uint32_t key = s_key[g];
-            if (key != NONE32) a.crow_list[key >> 31][atomicAdd(&s_cnt[key >> 31][key & 0x7FFFFFFFu], 1u)] = g;
-        }
-    } else {
-    for (int t = 0; t < 2; ++t) {
-        if (!a.tables.t[t].valid || s_rows_t[t] == 0) continue;
-        const uint32_t nc = a.tables.t[t].n_committees;
-        const uint32_t c_chunks = (nc + 1 + PLAN_WG - 1) / PLAN_WG;
-        uint32_t base = 0;
-        for (uint32_t sc = 0; sc < c_chunks; sc += PLAN_SUPER) {
-            const uint32_t nch = min(PLAN_SUPER, c_chunks - sc);
-            for (uint32_t c = 0; c < nch; ++c) {
-                const uint32_t idx = (sc + c) * PLAN_WG + tid;
-                const uint32_t v = idx < nc ? a.crow_cursor[t][idx] : 0u;
-                uint32_t tv;
-                const uint32_t ev = wave_excl_u32(v, &tv);
-                if (idx <= nc) a.crow_start[t][idx] = ev;
-                if (lane == 0) matA[c * PLAN_WAVES + wave] = tv;
-            }
-            const uint32_t tot = scan_matrix(matA, nch * PLAN_WAVES, base, wt32);
-            for (uint32_t c = 0; c < nch; ++c) {
-                const uint32_t idx = (sc + c) * PLAN_WG + tid;
-                if (idx <= nc) {
-                    const uint32_t st0 = a.crow_start[t][idx] + matA[c * PLAN_WAVES + wave];
-                    a.crow_start[t][idx] = st0;
-                    if (idx < nc) a.crow_cursor[t][idx] = st0;  // becomes the fill cursor
-                }
-            }
-            base += tot;
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    for (uint32_t g = tid; g < ng; g += PLAN_WG) {
-        const AttGroup& G = a.grp[g];
-        if (G.status_agg == ST_OK) a.crow_list[G.table][atomicAdd(&a.crow_cursor[G.table][G.pos], 1u)] = g;
-    }
     }
 
-    PLAN_STAMP(6);
-    // ---- 6. the plan, for the kernels that follow and (pinned mirror) for the host's completion
+    // ---- 4. arrive; the last workgroup writes the plan
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics and granules are performed
+    __syncthreads();
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(&a.sync->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != nb - 1) return;
+
+    PlanSync* S = a.sync;
+    const uint32_t rows_t0 = word_load(&S->rows_t[0]), rows_t1 = word_load(&S->rows_t[1]);
     if (tid == 0) {
-        uint32_t err = s_err;
-        if (!err && g_chunks > PLAN_SUPER) err = ERR_CAPACITY;        // more than PLAN_SUPER x PLAN_WG (32768) groups in one call
-        if (!err && byte_total > a.out_arena_cap) err = ERR_CAPACITY;  // "output bit arena too small"
+        const unsigned long long la = granule_load(&rec[nb - 1].incl[0]) >> 1, lw = granule_load(&rec[nb - 1].incl[1]) >> 1,
+                                 lb = granule_load(&rec[nb - 1].incl[2]) >> 1;
+        const uint32_t ng = (uint32_t)(la & 0xFFFFFFull);
+        const uint32_t max_size = word_load(&S->max_size), mis_key = word_load(&S->mis_key);
+        const unsigned long long total_members = granule_load(&S->total_members);
+        uint32_t err = max(a.plan->error, word_load(&S->err));
+        if (!err && (lb > a.out_arena_cap || lw > 0xFFFFFFFFull)) err = ERR_CAPACITY;  // "output bit arena too small"
+        // one block size for every group: k members per lane, blocks of BL = 2^L lanes, group g at slot g * BL.  k
+        // follows from the largest committee so that its tasks fill a block exactly or nearly (sizes that differ by one --
+        // 511 / 512 members -- would otherwise put half of the lanes of every block to sleep)
+        uint32_t k = a.min_k, L = 0;
+        {
+            const unsigned long long k0 = max((unsigned long long)a.min_k, (total_members + a.target_slots - 1) / a.target_slots);
+            uint32_t tasks = (uint32_t)((max_size + k0 - 1) / k0);
+            if (tasks > (uint32_t)G1_WG) tasks = G1_WG;
+            while ((1u << L) < tasks) ++L;
+            while (L > 0 && ((unsigned long long)ng << L) > a.slot_cap) --L;  // bounded scratch: fewer, longer lanes
+            k = max(a.min_k, (max_size + (1u << L) - 1) >> L);
+            if (k == 0) k = 1;
+        }
         AttPlan p;
         p.n_groups = err ? 0u : ng;  // a failing aggregate forms no groups: the handlers behind it apply nothing
         p.n_slots = p.n_groups << L;
         p.k = k;
         p.log2_block = L;
-        p.out_words = word_total;
-        p.out_bytes = byte_total;
+        p.out_words = (uint32_t)lw;
+        p.out_bytes = (uint32_t)min(lb, 0xFFFFFFFFull);
         p.error = err;
-        p.packed_same = s_not_aligned ? 0u : 1u;
-        p.n_rows_table[0] = s_rows_t[0];
-        p.n_rows_table[1] = s_rows_t[1];
+        p.packed_same = (mis_key != 0 && (~mis_key) + 1 < ng) ? 0u : 1u;
+        p.n_rows_table[0] = rows_t0;
+        p.n_rows_table[1] = rows_t1;
         p.n_rows_in = n;
         p.last_error = err;
         p.total_members = total_members;
         *a.plan = p;
         *a.plan_host = p;
     }
+    // rows per committee of each candidate table: counts -> offsets + fill cursors (the lists themselves are filled by
+    // k_att_members; unordered, consumers order by group id).  A table without a row is skipped: its consumers
+    // (k_lmd_vm_tables, k_participation_tables) return on plan->n_rows_table[t] == 0.
+    for (int t = 0; t < 2; ++t) {
+        if (!a.tables.t[t].valid || (t ? rows_t1 : rows_t0) == 0) continue;
+        const uint32_t nc = a.tables.t[t].n_committees;
+        const uint32_t per = (nc + 1 + PLAN_WG - 1) / PLAN_WG;  // consecutive entries per lane (entry nc: the end mark)
+        const uint32_t b0 = min(tid * per, nc + 1), b1 = min(b0 + per, nc + 1);
+        uint32_t sum = 0;
+        for (uint32_t c = b0; c < b1; ++c) sum += c < nc ? word_load(&a.crow_cnt[t][c]) : 0u;
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if ((int)lane >= off) incl += o;
+        }
+        __syncthreads();  // s_scan may still be read by the previous table's scan
+        if (lane == 63) s_scan[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < wave; ++w) run += s_scan[w];
+        for (uint32_t c = b0; c < b1; ++c) {
+            const uint32_t cnt = c < nc ? word_load(&a.crow_cnt[t][c]) : 0u;
+            a.crow_start[t][c] = run;
+            a.crow_cursor[t][c] = run;
+            if (c < nc && cnt) __hip_atomic_store(&a.crow_cnt[t][c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the next launch
+            run += cnt;
+        }
+    }
+    // the records, clean for the next launch
+    __syncthreads();
+    // (stored the way they are read -- agent-scope, past the XCD's L2 -- so that no stale line of zeros waits there for the
+    // next launch's polls)
+    for (uint32_t j = tid; j < nb; j += PLAN_WG)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { granule_store(&rec[j].agg[q], 0ull); granule_store(&rec[j].incl[q], 0ull); }
+    if (tid == 0) {
+        unsigned long long* z = reinterpret_cast<unsigned long long*>(S);
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(PlanSync) / 8); ++q) granule_store(z + q, 0ull);
+    }
 }
+inline unsigned att_plan_blocks(const AttPlanArgs& a) { return std::max(1u, (a.n + PLAN_WG - 1) / PLAN_WG); }
 }  // namespace
 
 #ifndef POSEVO_BODIES_ONLY
-__global__ void __launch_bounds__(PLAN_WG) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: see PLAN_WG
+__global__ void __launch_bounds__(PLAN_WG) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_att_plan(const AttPlanArgs a)
 {
     __builtin_amdgcn_s_setprio(3);
-    att_plan_body(a);
+    att_plan_body(blockIdx.x, gridDim.x, a);
 }
 
 void launch_att_plan(hipStream_t s, const AttPlanArgs& a)
 {
-    hipLaunchKernelGGL(k_att_plan, dim3(1), dim3(PLAN_WG), 0, s, a);
+    hipLaunchKernelGGL(k_att_plan, dim3(att_plan_blocks(a)), dim3(PLAN_WG), 0, s, a);
 }
-#endif
-#if defined(POSEVO_PLAN_TIMING) && !defined(POSEVO_BODIES_ONLY)
-}  // namespace posevo
-extern "C" int pe_debug_plan_stamps(unsigned long long* out16)
-{
-    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(posevo::plan_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-namespace posevo {
 #endif
 
 // ------------------------------------------------------------------ members
@@ -598,11 +562,28 @@ __device__ __forceinline__ void att_members_body(const uint32_t i /* input row o
         ubytes[p] = q8.x;       // byte offset of the member's bits in the arena (copied whole, offset 0)
         member_row[p] = i;
         if (!(q8.z & FLAG_SIG_VALID)) atomicAnd(&G.sig_valid, 0u);
-        if (rep == i && host_out_rows) {  // the group's output row: its data, bits_offset into the packed output arena
-            uint4* o = host_out_rows + (size_t)9 * g;
+        if (rep == i) {
+            // the lane of the group's first row: the group's summation descriptor (k and the block size are the plan's: known
+            // since k_att_plan's last workgroup) and its entry in its committee's row list
+            const uint32_t k = plan->k, L = plan->log2_block;
+            const bool ok = G.status_agg == (uint32_t)ST_OK;
+            G1Group d;
+            d.member_start = G.member_base;
+            d.n_members = ok ? G.size : 0u;
+            d.bits_word = G.out_word;
+            d.slot_base = g << L;
+            d.n_tasks = ok ? (G.size + k - 1) / k : 0u;
+            d.k = k | (G.table == 1 ? 0x80000000u : 0u);
+            d.log2_block = L;
+            d.out_base = g;
+            a.g1[g] = d;
+            if (ok) a.crow_list[G.table][atomicAdd(&a.crow_cursor[G.table][G.pos], 1u)] = g;
+            if (host_out_rows) {  // the group's output row: its data, bits_offset into the packed output arena
+                uint4* o = host_out_rows + (size_t)9 * g;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = rows[(size_t)9 * i + k];
-            o[8] = make_uint4(G.out_byte, q8.y, q8.z, 0u);  // flags: the host folds in the verdicts at completion
+                for (int k8 = 0; k8 < 8; ++k8) o[k8] = rows[(size_t)9 * i + k8];
+                o[8] = make_uint4(G.out_byte, q8.y, q8.z, 0u);  // flags: the host folds in the verdicts at completion
+            }
         }
     }
     tab[slot] = ATT_EMPTY;  // every row of a class clears the class's slot: the table is empty again for the next call
@@ -623,14 +604,6 @@ void launch_att_members(hipStream_t s, const MembersArgs& a)
 {
     if (a.n == 0) return;
     hipLaunchKernelGGL(k_att_members, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
-}
-void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
-                        const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
-                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows,
-                        const uint32_t* n_dev)
-{
-    launch_att_members(s, MembersArgs{rows, n, tab, cnt_tab, slot_of, rep_of, gid_of_row, grp, plan, ubytes, member_row,
-                                      host_group_of, host_out_rows, n_dev});
 }
 #endif
 

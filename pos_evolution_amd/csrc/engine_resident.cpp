@@ -23,13 +23,15 @@ namespace {
 
 struct RrLayout {  // typed views into PipeArena::d_rr
     AttPlan* plan;
-    uint32_t *slot_of, *rep_of, *gid_of_row, *rep_row, *ubytes, *member_row;
+    uint32_t *slot_of, *rep_of, *gid_of_row, *ubytes, *member_row;
+    PlanSync* sync;
+    PlanRec* rec;
     AttGroup* grp;
     UnionGroup* ug;
     G1Group* g1;
     AttRow *rows_fc, *rows_st;
     int32_t *status_fc, *status_st;
-    uint32_t *crow_start[2], *crow_cursor[2], *crow_list[2];
+    uint32_t *crow_start[2], *crow_cursor[2], *crow_cnt[2], *crow_list[2];
     size_t bytes;
 };
 
@@ -46,7 +48,8 @@ RrLayout rr_layout(uint8_t* base, uint32_t cap_n, uint32_t cap_c)
     L.slot_of = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
     L.rep_of = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
     L.gid_of_row = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
-    L.rep_row = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
+    L.sync = reinterpret_cast<PlanSync*>(take(sizeof(PlanSync)));
+    L.rec = reinterpret_cast<PlanRec*>(take(sizeof(PlanRec) * ((size_t)cap_n / PLAN_WG + 1)));
     L.ubytes = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
     L.member_row = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
     L.grp = reinterpret_cast<AttGroup*>(take(sizeof(AttGroup) * (size_t)cap_n));
@@ -59,6 +62,7 @@ RrLayout rr_layout(uint8_t* base, uint32_t cap_n, uint32_t cap_c)
     for (int t = 0; t < 2; ++t) {
         L.crow_start[t] = reinterpret_cast<uint32_t*>(take(4ull * (cap_c + 1)));
         L.crow_cursor[t] = reinterpret_cast<uint32_t*>(take(4ull * (cap_c + 1)));
+        L.crow_cnt[t] = reinterpret_cast<uint32_t*>(take(4ull * (cap_c + 1)));
         L.crow_list[t] = reinterpret_cast<uint32_t*>(take(4ull * cap_n));
     }
     L.bytes = off;
@@ -167,6 +171,7 @@ int plan_error_to_status(pe_engine* h, uint32_t err, const char* who)
         case 0: return PE_OK;
         case 10: return fail(h, PE_ERR_CAPACITY, std::string(who) + ": output capacity too small for the groups formed");
         case 11: return fail(h, PE_ERR_NO_COMMITTEES, std::string(who) + ": no committee table for a group's target epoch");
+        case 12: return fail(h, PE_ERR_NO_DEVICE, std::string(who) + ": a workgroup of k_att_plan gave up waiting for its predecessors' records");
         default:
             return fail(h, PE_ERR_INVALID_ARG, std::string(who) + ": a row was refused on the device (bits exceed the arena, "
                         "target epoch beyond 32 bits, committee index out of range or len(aggregation_bits) != len(committee))");
@@ -206,6 +211,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     if (!h->initialised) return fail(h, PE_ERR_STATE, "rows in device memory: the store's clock picks the committee tables; call pe_store_init first");
     if ((uintptr_t)d_rows & 15) return fail(h, PE_ERR_INVALID_ARG, "rows in device memory must be 16-byte aligned");
     if (arena_len >= 0xFFFFFFF0ull) return fail(h, PE_ERR_CAPACITY, "bit arena exceeds 4 GiB");
+    if (n >= PLAN_MAX_ROWS) return fail(h, PE_ERR_CAPACITY, "rows in device memory: at most 2^24 - 1 rows per aggregate");
     const bool want_pk = out_aggpk96 != nullptr || dev_partials != nullptr;
     if (want_pk && !h->have_points) return fail(h, PE_ERR_STATE, "aggregate pubkeys requested but no pubkeys loaded");
     HostLap lap(&h->trace);
@@ -304,15 +310,15 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     pa.slot_of = L.slot_of;
     pa.rep_of = L.rep_of;
     pa.gid_of_row = L.gid_of_row;
-    pa.rep_row = L.rep_row;
     pa.grp = L.grp;
     pa.ug = L.ug;
-    pa.g1 = L.g1;
     for (int t = 0; t < 2; ++t) {
         pa.crow_start[t] = L.crow_start[t];
         pa.crow_cursor[t] = L.crow_cursor[t];
-        pa.crow_list[t] = L.crow_list[t];
+        pa.crow_cnt[t] = L.crow_cnt[t];
     }
+    pa.sync = L.sync;
+    pa.rec = L.rec;
     pa.plan = L.plan;
     pa.plan_host = plan_host;
     pa.out_arena_cap = out_arena_cap;
@@ -322,7 +328,8 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     pa.want_pk = want_pk ? 1u : 0u;
     pa.tables = tables;
     const MembersArgs ma{d_rows, n, RS.tab.as<uint32_t>(), cnt_tab, L.slot_of, L.rep_of, L.gid_of_row, L.grp, L.plan, L.ubytes,
-                         L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev};
+                         L.member_row, group_of ? ob.host<uint32_t>(off_gof) : nullptr, ob.host<uint8_t>(off_rows), n_dev,
+                         L.g1, {L.crow_cursor[0], L.crow_cursor[1]}, {L.crow_list[0], L.crow_list[1]}};
     const UnionArgs ua{L.ug, n, L.ubytes, st.dev<uint8_t>(off_arena), RS.bits.as<uint32_t>(), RS.info.as<uint32_t>(),
                        ob.host<uint32_t>(off_obits), ob.host<uint32_t>(off_oinfo), L.plan};
     // ingest -> plan -> members -> union, each one beside the held-back fork-choice kernel of the previous step if there is one

@@ -165,7 +165,7 @@ struct TablesDev {
     TableDev t[2];
     uint64_t slots_per_epoch;
 };
-struct AttPlan {                  // one per resident-rows aggregate: written by k_att_plan (device copy + pinned mirror)
+struct AttPlan {                  // one per resident-rows aggregate: written by k_att_plan's last workgroup (device copy + pinned mirror)
     uint32_t n_groups;
     uint32_t n_slots;             // G1 plan: uniform blocks of 1 << log2_block lane slots, group g at slot g << log2_block
     uint32_t k, log2_block;
@@ -217,21 +217,35 @@ void launch_att_ingest(hipStream_t s, const void* rows, uint32_t n, uint32_t* ta
                        const uint32_t* n_dev = nullptr,  // n_dev: the row count lives on the device, n bounds it
                        const void* arena_src = nullptr, void* arena_dst = nullptr);  // arena_src (device memory, 16-byte
                                                           // aligned): the launch copies arena_len bytes to arena_dst itself
+// k_att_plan runs one lane per input row over as many 256-lane workgroups as the batch needs.  What its workgroups tell each
+// other travels through two small records in device memory, both all-zero between launches (the last workgroup to finish
+// clears them):
+struct PlanSync {                 // sums / maxima over all groups (device-scope atomics) + the arrival ticket
+    uint32_t ticket;              // workgroups that have finished their part; the one that draws the last ticket writes the plan
+    uint32_t max_size;            // largest committee among the resolved groups
+    uint32_t rows_t[2];           // groups resolved against each candidate table
+    uint32_t mis_key;             // max of ~g over groups whose union is not a whole number of words (0 = none)
+    uint32_t err;                 // max of the groups' error words
+    uint32_t pad[2];
+    unsigned long long total_members, pad2[3];
+};
+struct PlanRec {                  // one per workgroup: its own sums (agg) and the sums up to and including it (incl), each value
+    unsigned long long agg[3], incl[3], pad[2];  // an 8-byte word with bit 0 = "written" (decoupled look-back, att_kernels.hip)
+};
+constexpr uint32_t PLAN_WG = 256;
+constexpr uint32_t PLAN_MAX_ROWS = 1u << 24;  // rows per resident aggregate (the look-back words hold 24-bit row counts)
 struct AttPlanArgs {
     const void* rows; uint32_t n; const uint32_t* n_dev;
     const uint32_t* tab; const uint32_t* cnt_tab; const uint32_t* slot_of;
-    uint32_t* rep_of; uint32_t* gid_of_row; uint32_t* rep_row;
-    AttGroup* grp; UnionGroup* ug; G1Group* g1;
-    uint32_t* crow_start[2]; uint32_t* crow_cursor[2]; uint32_t* crow_list[2];
+    uint32_t* rep_of; uint32_t* gid_of_row;
+    AttGroup* grp; UnionGroup* ug;
+    uint32_t* crow_start[2]; uint32_t* crow_cursor[2]; uint32_t* crow_cnt[2];
+    PlanSync* sync; PlanRec* rec;
     AttPlan* plan; AttPlan* plan_host;
     uint64_t out_arena_cap; uint32_t target_slots, slot_cap, min_k, want_pk;
     TablesDev tables;
 };
 void launch_att_plan(hipStream_t s, const AttPlanArgs& a);
-void launch_att_members(hipStream_t s, const void* rows, uint32_t n, uint32_t* tab, uint32_t* cnt_tab, const uint32_t* slot_of,
-                        const uint32_t* rep_of, const uint32_t* gid_of_row, AttGroup* grp, AttPlan* plan,
-                        uint32_t* ubytes, uint32_t* member_row, uint32_t* host_group_of, void* host_out_rows,
-                        const uint32_t* n_dev = nullptr);
 // committee-sharded exchange (pe_aggregate_exchange): the groups of the resident aggregate packed into fixed slots
 // ([4 words header | slots x (36 words row, count, reserved, wps words of OR-ed bits)]), and `world` such buffers unpacked
 // into one dense batch of rows (36 words each) + bits (wps words per row); *n_dev = rows unpacked
@@ -286,6 +300,7 @@ struct MembersArgs {
     const void* rows; uint32_t n; uint32_t* tab; uint32_t* cnt_tab; const uint32_t* slot_of; const uint32_t* rep_of;
     const uint32_t* gid_of_row; AttGroup* grp; AttPlan* plan; uint32_t* ubytes; uint32_t* member_row;
     uint32_t* host_group_of; void* host_out_rows; const uint32_t* n_dev;
+    G1Group* g1; uint32_t* crow_cursor[2]; uint32_t* crow_list[2];  // written per group by the lane of its first row
 };
 struct VotesArgs {
     const uint32_t* vote_block; const uint64_t* eff_balance; const uint8_t* flags; uint64_t n_val;

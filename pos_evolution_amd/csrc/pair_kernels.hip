@@ -10,8 +10,7 @@
 // on the CUs with no second queue: the chain becomes the sum of the pairwise maxima.
 //
 //   k_pair_ingest_validate   k_att_ingest(N+1)   |  k_att_validate_fc(N)      256-lane blocks
-//   k_pair_plan_lmd          k_att_plan(N+1)     |  k_lmd_vm_tables(N)        block 0 = the plan's one workgroup (1024 lanes,
-//                                                                            <= 64 VGPRs), the rest 1024 validators each
+//   k_pair_plan_lmd          k_att_plan(N+1)     |  k_lmd_vm_tables(N)        256-lane blocks: the plan's first, then 256 validators each
 //   k_pair_members_votes     k_att_members(N+1)  |  k_votes<lean>(N)          the votes' fat workgroups first, 512 lanes
 //   k_pair_union_tree        k_bits_union(N+1)   |  k_tree<lean>(N)           block 0 = the tree's one workgroup
 //
@@ -43,22 +42,22 @@ bool launch_pair_ingest_validate(hipStream_t s, const IngestArgs& ia, const Vali
 }
 
 // ------------------------------------------------------------------ plan(N+1) | LMD(N)
-// The plan's shape rules: 1024 lanes, <= 64 registers (it must start on a CU whose SIMDs hold a wave of the accumulation,
-// att_kernels.hip), ~70 KB of static LDS -- which every LMD block of this grid then reserves too: two blocks of 1024
-// validators per CU, i.e. the 8 waves per SIMD the register cap allows anyway.
+// 256-lane blocks both: the plan's workgroups first (a workgroup of the plan waits for the records of LOWER block indices
+// only, att_kernels.hip), then one lane per validator.  No LDS to speak of: the LMD blocks queue for nothing (round 5's
+// one-workgroup plan made each of them reserve its 70 KB).
 __global__ void __launch_bounds__(PLAN_WG) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_pair_plan_lmd(const AttPlanArgs pa, const LmdVmArgs la)
+k_pair_plan_lmd(const AttPlanArgs pa, const LmdVmArgs la, const uint32_t nb_plan)
 {
     __builtin_amdgcn_s_setprio(3);
-    if (blockIdx.x == 0) att_plan_body(pa);
-    else lmd_vm_tables_body((unsigned long long)(blockIdx.x - 1) * PLAN_WG + threadIdx.x, la);
+    if (blockIdx.x < nb_plan) att_plan_body(blockIdx.x, nb_plan, pa);
+    else lmd_vm_tables_body((unsigned long long)(blockIdx.x - nb_plan) * PLAN_WG + threadIdx.x, la);
 }
 
 bool launch_pair_plan_lmd(hipStream_t s, const AttPlanArgs& pa, const LmdVmArgs& la)
 {
     if (la.n_val == 0) return false;
-    const unsigned nb_lmd = (unsigned)((la.n_val + PLAN_WG - 1) / PLAN_WG);
-    hipLaunchKernelGGL(k_pair_plan_lmd, dim3(1 + nb_lmd), dim3(PLAN_WG), 0, s, pa, la);
+    const unsigned nb_plan = att_plan_blocks(pa), nb_lmd = (unsigned)((la.n_val + PLAN_WG - 1) / PLAN_WG);
+    hipLaunchKernelGGL(k_pair_plan_lmd, dim3(nb_plan + nb_lmd), dim3(PLAN_WG), 0, s, pa, la, (uint32_t)nb_plan);
     return true;
 }
 

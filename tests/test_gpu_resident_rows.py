@@ -121,6 +121,30 @@ def test_rows_in_shuffled_order_keep_first_appearance_order(engine_factory):
     _assert_same_state(wa["e"], wb["e"])
 
 
+@pytest.mark.parametrize("n_val,n_comm,parts,shuffle", [(200000, 2048, 40, True),     # 81 920 rows = 320 workgroups: five look-back windows
+                                                         (150000, 36864, 1, False),    # more groups than round 5's plan could number (32 768)
+                                                         (9000, 64, 37, True)])        # 2368 rows: a ragged last workgroup
+def test_the_plan_over_many_workgroups_equals_the_host_grouping(engine_factory, n_val, n_comm, parts, shuffle):
+    """k_att_plan runs one lane per row over ceil(n / 256) workgroups that hand their running sums to each other through
+    look-back records (att_kernels.hip): group ids, union offsets, member lists, committee row lists and the G1 plan of a
+    batch that spans many workgroups -- rows of a group far apart -- must be what the host path derives; twice on the same
+    engine (the records have to come back clean)."""
+    wa = _world(engine_factory, n_val, n_comm, seed=21, density=0.7, parts=parts)
+    wb = _world(engine_factory, n_val, n_comm, seed=21, density=0.7, parts=parts)
+    atts = wa["atts"]
+    if shuffle:
+        atts = np.ascontiguousarray(atts[np.random.Generator(np.random.PCG64(7)).permutation(len(atts))])
+    host = _host_step(wa["e"], atts, wa["arena"], wa["ctx"])
+    res = _resident_step(wb["e"], atts, wb["arena"], wb["ctx"], mode="pipelined", dev_arena=True)
+    _assert_same(host, res)
+    assert host[0]["n_groups"] == n_comm
+    assert set(np.unique(host[1]).tolist()) <= {0, 11}, "only empty unions (committees of a few members) may be refused"
+    _assert_same_state(wa["e"], wb["e"])
+    again = _resident_step(wb["e"], atts, wb["arena"], wb["ctx"], mode="sync", want_pk=False)
+    assert again[0]["n_groups"] == n_comm and np.array_equal(again[0]["atts"], host[0]["atts"])
+    assert np.array_equal(again[0]["out_arena"], host[0]["out_arena"]) and np.array_equal(again[0]["group_of"], host[0]["group_of"])
+
+
 def _violations(w, e_list):
     """One row per assert of validate_on_attestation (A.4) / process_attestation (pe:724-730) / A.7, each on a committee
     of its own, plus untouched rows.  Needs a block inside the attested epoch and a store clock 10 slots into the next
