@@ -41,7 +41,10 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
     sigs = synth.signature_points(e, n_rows, a, b)            # row i signs with (a + i * b) * G2
     sig_t = torch.from_numpy(sigs.reshape(-1).copy()).cuda()
     sig_dev = DeviceArena(sig_t.data_ptr(), sig_t.numel(), keep=sig_t)
-    e.set_pipeline_lag(lag)
+    # the legs of POSEVO_SIG_BATCH (4) steps share one decompression launch of ~0.95 ms: a lag depth of batch + the ~3-4 steps that
+    # launch lasts keeps the host from waiting for it (include/posevo.h: pe_pipeline_set_lag; 7 is the deepest)
+    sig_lag = max(lag, 7)
+    e.set_pipeline_lag(sig_lag)
     e.reuse_outputs(len(steps) + 2)
     got = [run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev) for st in steps[:n_warm]]
     e.drain()
@@ -82,11 +85,12 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
         "ms_per_step_with_signatures": dt / n_timed * 1e3,
         "attestations_per_s": n_att / dt,
         "signatures_per_step": n_rows,
-        "steps": n_timed, "warmup": n_warm,
+        "steps": n_timed, "warmup": n_warm, "lag": sig_lag, "steps_per_decompression": int(os.environ.get("POSEVO_SIG_BATCH", "4")),
         "detail": ("pe_aggregate_signed in pe_aggregate's place: one compressed BLSSignature (96 B, resident in HBM) per partial "
-                   "aggregate -> k_g2_decompress (an Fp2 square root each) -> per-group G2 sums -> compressed aggregate "
-                   "signatures, on the state-transition stream beside the aggregate pubkeys and the fork choice; the rest of "
-                   "the step as the headline's; streaming pipelines, drain included"),
+                   "aggregate -> k_g2_decompress (an Fp2 square root each; ONE launch for the legs of `steps_per_decompression` "
+                   "consecutive steps) -> per-group G2 sums -> compressed aggregate signatures, on the signature legs' stream beside "
+                   "the aggregate pubkeys and the fork choice; the rest of the step as the headline's; streaming pipelines, drain "
+                   "included"),
         "steps_verified": int(sum(same[n_warm:])),
         "aggregate_signatures_checked_against_oracle": len(sample),
     }

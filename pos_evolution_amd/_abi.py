@@ -29,10 +29,11 @@ PE_DIST_ID_BYTES = 256
 (PE_KERNEL_G1_ACCUMULATE, PE_KERNEL_G1_NORMALISE, PE_KERNEL_VOTES, PE_KERNEL_TREE, PE_KERNEL_LMD,
  PE_KERNEL_PARTICIPATION, PE_KERNEL_BITS_UNION, PE_KERNEL_G2_ACCUMULATE, PE_KERNEL_G2_NORMALISE,
  PE_KERNEL_G1_TREE, PE_KERNEL_ATT_GROUP, PE_KERNEL_ATT_VALIDATE, PE_KERNEL_PAIR_INGEST_VALIDATE,
- PE_KERNEL_PAIR_PLAN_LMD, PE_KERNEL_PAIR_MEMBERS_VOTES, PE_KERNEL_PAIR_UNION_TREE, PE_KERNEL_COUNT) = range(17)
+ PE_KERNEL_PAIR_PLAN_LMD, PE_KERNEL_PAIR_MEMBERS_VOTES, PE_KERNEL_PAIR_UNION_TREE, PE_KERNEL_G2_DECOMPRESS,
+ PE_KERNEL_COUNT) = range(18)
 KERNEL_NAMES = ["g1_accumulate", "g1_normalise", "votes", "tree", "lmd", "participation", "bits_union",
                 "g2_accumulate", "g2_normalise", "g1_tree", "att_group", "att_validate", "pair_ingest_validate",
-                "pair_plan_lmd", "pair_members_votes", "pair_union_tree"]
+                "pair_plan_lmd", "pair_members_votes", "pair_union_tree", "g2_decompress"]
 
 ATT_STATUS_NAMES = {
     0: "ok", 1: "target epoch not current or previous", 2: "target epoch != epoch(slot)",

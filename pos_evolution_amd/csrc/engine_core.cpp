@@ -42,6 +42,7 @@ int complete_arena(pe_engine* h, int ai)
     // work that has not been launched
     if (h->held.active && h->held.arena == ai) PE_TRY(held_issue(h));
     if (ai == h->cur) PE_TRY(run_deferred(h));  // deferred launches belong to the arena the calls are going into
+    if (sig_batch_holds(h, ai)) PE_TRY(sig_batch_flush(h));  // a signature leg still collected for a later launch: now
     if (a.fence_pending) PE_TRY(fence_arena(h, a));  // (cannot happen behind held_issue; kept as the invariant's last line)
     hipError_t e = hipSuccess;
     if (a.fenced) {  // a lagged pipeline: its end was marked on every stream it used
@@ -62,7 +63,7 @@ int complete_arena(pe_engine* h, int ai)
             h->aux_busy = false;
         }
         if (h->side_busy) {
-            for (hipStream_t s : {h->side_stream, h->side_stream2, h->fin_stream, h->norm_stream}) {
+            for (hipStream_t s : {h->side_stream, h->fin_stream, h->norm_stream}) {
                 if (!s) continue;
                 hipError_t e2 = bounded_stream_sync(h, s);
                 if (e == hipSuccess) e = e2;
@@ -96,7 +97,7 @@ void complete_oldest_if_ready(pe_engine* h)
 {
     const int ai = (h->cur + 1) % h->n_arenas;
     pe_engine::PipeArena& a = h->arena[ai];
-    if (!a.fenced || a.fence_pending || a.pending.empty()) return;
+    if (!a.fenced || a.fence_pending || a.pending.empty() || sig_batch_holds(h, ai)) return;
     if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess) ||
         (a.aux_used && hipEventQuery(a.ev_aux) != hipSuccess)) {
         (void)hipGetLastError();  // hipErrorNotReady is not an error here
@@ -327,13 +328,10 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     }
     // Tune::state_on: the state-transition work on the tree's or the finish's stream instead of its own (the runtime maps
     // the engine's six streams onto four hardware queues; two streams that share one run in submission order)
-    if (ok_streams && h->tune.side_streams == 2 && mk(&h->side_stream2) != hipSuccess) h->side_stream2 = nullptr;
     if (ok_streams && h->tune.state_on == 1) h->aux_stream = h->fin_stream;
-    if (ok_streams && h->tune.state_on == 2) h->aux_stream = h->norm_stream;
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_sig, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_leg, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -344,8 +342,7 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     for (auto& a : h->arena)
         if (hipEventCreateWithFlags(&a.ev_main, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.ev_side, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.ev_rows, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess) {
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
@@ -366,7 +363,6 @@ void pe_engine_destroy(pe_engine* h)
     (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
-    if (h->side_stream2) (void)hipStreamSynchronize(h->side_stream2);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
@@ -398,7 +394,6 @@ void pe_engine_destroy(pe_engine* h)
         if (a.ev_main) (void)hipEventDestroy(a.ev_main);
         if (a.ev_side) (void)hipEventDestroy(a.ev_side);
         if (a.ev_aux) (void)hipEventDestroy(a.ev_aux);
-        if (a.ev_rows) (void)hipEventDestroy(a.ev_rows);
     }
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
                       &h->d_part_cur, &h->d_part_prev, &h->d_tsize, &h->d_tparent, &h->d_trank, &h->d_tleaf,
@@ -420,7 +415,6 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
-    if (h->ev_sig) (void)hipEventDestroy(h->ev_sig);
     if (h->ev_leg) (void)hipEventDestroy(h->ev_leg);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
@@ -428,7 +422,6 @@ void pe_engine_destroy(pe_engine* h)
     if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);
     if (h->aux_owned) (void)hipStreamDestroy(h->aux_owned);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-    if (h->side_stream2) (void)hipStreamDestroy(h->side_stream2);
     if (h->fin_stream) (void)hipStreamDestroy(h->fin_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->trace.on && h->g1_tune_calls)
@@ -574,7 +567,6 @@ static void prof_drain(pe_engine* h)
     (void)flush_pending(h);
     (void)hipStreamSynchronize(h->stream);
     if (h->side_stream) (void)hipStreamSynchronize(h->side_stream);
-    if (h->side_stream2) (void)hipStreamSynchronize(h->side_stream2);
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);

@@ -211,6 +211,7 @@ int pe_dist_destroy(pe_engine* h)
         // launches held back for the next aggregate (engine_pair.cpp) point into the regions reset above and carry the lost
         // communicator's collectives: they go with the rest
         h->held = pe_engine::HeldFc{};
+        h->sig_batch.clear();
         h->pipelining = h->streaming = false;
         h->side_busy = h->aux_busy = false;
         h->res_valid = false;

@@ -12,7 +12,7 @@ void g1_stream_guard(pe_engine* h, hipStream_t s)
 {
     // ev_join marks the end of the last G1 launch on the side stream (a lagged pipeline may still be running it);
     // waiting on a completed event costs nothing
-    if (h->side_ever && s != h->side_stream && s != h->side_stream2 && s != h->fin_stream && s != h->norm_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
+    if (h->side_ever && s != h->side_stream && s != h->fin_stream && s != h->norm_stream) (void)hipStreamWaitEvent(s, h->ev_join, 0);
 }
 
 // The registry table in the accumulation's field form (k_g1_table_s29), built where the registry is loaded -- on the
@@ -70,7 +70,6 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     // 147 KB workgroup would find no CU while accumulations follow each other, so those stores keep the old signature).
     const bool chain = fin != s && fin == h->fin_stream;
     const int exclusive = chain && h->tune.exclusive && h->blocks.size() <= 4096 ? 1 : 0;
-    const bool done_event = chain && h->tune.acc_done_event;
     {
         // Since the paired launches (round 5) the accumulations of a streaming run follow each other on their stream with
         // nothing but queue packets in between, and every packet there is step time: the two event records of a bracket cost
@@ -79,19 +78,18 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
         const bool skip = !h->prof_timeline && s != h->stream && (h->acc_launches++ & 3) != 0;
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s, skip);
         launch_g1_accumulate(s, d_points29, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1, exclusive,
-                             done_event ? h->ev_acc : nullptr);
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1, exclusive);
     }
     hipStream_t ts = fin;  // (on the accumulation's own stream the tree measured 0.433 vs 0.338 ms per step, round 3)
     if (ts != s) {
-        if (!done_event) HIP_TRY(h, hipEventRecord(h->ev_acc, s));
+        HIP_TRY(h, hipEventRecord(h->ev_acc, s));
         HIP_TRY(h, hipStreamWaitEvent(ts, h->ev_acc, 0));
     }
     {
         ProfScope ps(h, PE_KERNEL_G1_TREE, ts);
         launch_g1_tree(ts, lane_partials->as<uint32_t>(), d_groups, plan.n_groups, plan.n_slots, partials->as<uint32_t>(),
                        /*one_per_cu=*/ts != s ? 1 : 0,   // on its own stream it meets the next step's k_tree: leave it room
-                       plan_dev, h->tune.tree_rotate, /*solo=*/exclusive);
+                       plan_dev, /*solo=*/exclusive);
     }
     hipStream_t ns = fin;
     if (chain && h->norm_stream) {  // the finish gets a stream of its own
@@ -108,6 +106,69 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     }
     HIP_TRY(h, hipGetLastError());
     return PE_OK;
+}
+
+// The collected signature legs (pe_aggregate_signed), launched: one decompression over all of them, then per leg the subgroup
+// check it asked for, the per-group sums and the status copy into ITS arena's pinned block.  Arenas whose pipelines have been
+// fenced meanwhile get their state-transition mark re-recorded behind the leg: whoever completes them waits for it.
+int sig_batch_flush(pe_engine* h)
+{
+    if (h->sig_batch.empty()) return PE_OK;
+    std::vector<pe_engine::SigSeg> segs;
+    segs.swap(h->sig_batch);
+    const bool own = h->aux_stream && h->stream == h->own_stream;
+    hipStream_t ss = own ? leg_stream(h) : h->stream;
+    if (ss != h->stream) {  // behind the groupings (and the host signatures' copies) enqueued on the engine's stream so far
+        HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
+    }
+    G2DecompressBatch b{};
+    for (auto& sg : segs) {
+        if (sg.copy_from) HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(sg.d_in), sg.copy_from, sg.bytes, hipMemcpyDeviceToDevice, ss));
+        if (sg.compressed) {
+            b.in96[b.count] = sg.d_in;
+            b.out_mont48[b.count] = sg.d_pts;
+            b.status[b.count] = sg.d_status;
+            b.n[b.count] = sg.n;
+            ++b.count;
+        } else {
+            HIP_TRY(h, hipMemsetAsync(sg.d_status, 0, 4ull * sg.n, ss));
+            launch_g2_convert(ss, sg.d_in, sg.d_pts, sg.n);
+        }
+    }
+    if (b.count) {
+        ProfScope ps(h, PE_KERNEL_G2_DECOMPRESS, ss);
+        launch_g2_decompress_batch(ss, b);
+    }
+    for (auto& sg : segs) {
+        if (sg.check_subgroup) launch_g2_subgroup_check(ss, sg.d_pts, sg.n, sg.d_status);
+        {
+            ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
+            launch_g2_aggregate_rows(ss, sg.d_pts, sg.d_status, sg.d_ug, sg.d_member_row, sg.ng_bound, sg.plan_dev, sg.o_sig, sg.o_bad);
+        }
+        HIP_TRY(h, hipMemcpyAsync(sg.o_st, sg.d_status, 4ull * sg.n, hipMemcpyDeviceToHost, ss));
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (ss != h->stream) {
+        if (ss != h->aux_stream) {  // the legs' end, joined into the stream fences and waits look at
+            HIP_TRY(h, hipEventRecord(h->ev_leg, ss));
+            HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_leg, 0));
+        }
+        h->aux_busy = true;
+        for (auto& sg : segs) {
+            pe_engine::PipeArena& a = h->arena[sg.arena];
+            a.aux_used = true;
+            a.aux_reads_scratch = true;
+            if (a.fenced && !a.fence_pending) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));
+        }
+    }
+    return PE_OK;
+}
+bool sig_batch_holds(const pe_engine* h, int arena)
+{
+    for (const auto& sg : h->sig_batch)
+        if (sg.arena == arena) return true;
+    return false;
 }
 
 }  // namespace posevo
@@ -597,73 +658,38 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     const size_t off_st = ob.alloc(4ull * n);
     PE_TRY(ob.ensure());
     memset(ob.host<uint32_t>(off_bad), 0, 4ull * std::max<uint32_t>(ng_bound, 1));
-    // The leg as a launch sequence on the state-transition stream.  Where the aggregate's pubkey sums run on the G1 streams
-    // (pipelined calls) the leg goes BEHIND the accumulation (ev_acc) and the NEXT accumulation behind the leg (ev_sig):
-    // k_g2_decompress holds an eighth of the chip's SIMDs for ~0.95 ms, and an accumulation that runs beside it ends when the
-    // decompression ends (0.84 ms instead of 0.2: the SIMDs' arbiters serve the older wave first) -- one behind the other the
-    // two cost their sum, 1.15 ms per signed step instead of 1.56 (profiles/r04_signed_timeline.txt).
-    pe_engine::PipeArena* arena = &A;
-    const uint8_t* d_sig_in = A.d_sig_in.as<uint8_t>();
-    int32_t* d_status = A.d_sig_status.as<int32_t>();
-    uint32_t* d_pts = A.d_sig_pts.as<uint32_t>();
-    uint8_t* o_sig = ob.host<uint8_t>(off_sig);
-    uint32_t* o_bad = ob.host<uint32_t>(off_bad);
-    int32_t* o_st = ob.host<int32_t>(off_st);
-    const bool behind_acc = h->tune.sig_behind && h->last_agg_on_side && out_aggpk96 != nullptr && h->ev_sig != nullptr;
-    auto leg = [h, arena, behind_acc, signatures, sig_bytes, n, sig_on_device, fmt, sig_format_flags, d_sig_in, d_status, d_pts,
-                d_ug, d_member_row, ng_bound, plan_dev, o_sig, o_bad, o_st]() -> int {
-        // (the leg keeps the stream created for state-transition work even where the flag passes ride the tree's stream --
-        // Tune::state_on: a millisecond of decompression in front of the next k_g1_tree would put the whole G1 chain behind it;
-        // its end is joined into that stream below, so fences and waits on aux_stream cover the leg as before)
-        hipStream_t ss = h->aux_stream && h->stream == h->own_stream ? leg_stream(h) : h->stream;
-        // Tune::sig_on_side (with the leg behind its accumulation): the decompression goes onto the ACCUMULATION's stream, where
-        // "behind this aggregate's accumulation, in front of the next one" is stream order -- no event pair across hardware
-        // queues, and no millisecond-long kernel in the queue the leg's own stream shares with the finish kernel (the runtime
-        // maps the handle's fifth stream onto the fourth's queue: tools/qmap.py).  Only the latency-sized tail (the per-row
-        // sums, the status copy) stays on the leg's stream, behind an event.
-        const bool on_side = behind_acc && ss != h->stream && h->tune.sig_on_side && !h->side_stream2;
-        hipStream_t ds = on_side ? h->side_stream : ss;  // where the signatures are copied in, decompressed and checked
-        if (ss != h->stream) {  // behind the grouping (state_stream_begin's fork, on behalf of the leg's own arena)
-            if (!on_side) {
-                HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
-                HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
-            }   // (on the side stream the aggregate's accumulation, just launched there, is already behind the grouping)
-            h->aux_busy = true;
-            arena->aux_used = true;
-            arena->aux_reads_scratch = true;
-            if (behind_acc && !on_side) HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_acc, 0));  // the accumulation of this aggregate, just launched
-        }
-        if (sig_on_device)
-            HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(d_sig_in), signatures, sig_bytes * n, hipMemcpyDeviceToDevice, ds));
-        if (fmt == PE_SIG_G2_COMPRESSED) {
-            launch_g2_decompress(ds, d_sig_in, n, d_pts, nullptr, d_status);
-        } else {
-            HIP_TRY(h, hipMemsetAsync(d_status, 0, 4ull * n, ds));
-            launch_g2_convert(ds, d_sig_in, d_pts, n);
-        }
-        if (sig_format_flags & PE_SIG_CHECK_SUBGROUP) launch_g2_subgroup_check(ds, d_pts, n, d_status);
-        if (on_side) {  // the tail waits for the points; the next accumulation follows on ds by itself
-            HIP_TRY(h, hipEventRecord(h->ev_sig, ds));
-            HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_sig, 0));
-        } else if (behind_acc && ss != h->stream) {  // the next accumulation may start: what follows is latency-sized
-            HIP_TRY(h, hipEventRecord(h->ev_sig, ss));
-            h->sig_leg_open = true;
-        }
-        {
-            ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
-            launch_g2_aggregate_rows(ss, d_pts, d_status, d_ug, d_member_row, ng_bound, plan_dev, o_sig, o_bad);
-        }
-        HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipMemcpyAsync(o_st, d_status, 4ull * n, hipMemcpyDeviceToHost, ss));
-        if (ss != h->stream && ss != h->aux_stream) {
-            HIP_TRY(h, hipEventRecord(h->ev_leg, ss));
-            HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_leg, 0));
-        }
-        return PE_OK;
-    };
-    // a streaming pipeline holds the aggregate's G1 launch back (behind the step's k_tree): the leg follows it, in the same list
-    if (behind_acc && !h->deferred.empty()) h->deferred.push_back(leg);
-    else PE_TRY(leg());
+    // The leg: decode the signatures, sum them per group, compress the sums -- on the signature legs' stream, beside the
+    // aggregate's pubkey sums and the fork-choice kernels.  k_g2_decompress is ONE chain of ~970 dependent Fp products per lane:
+    // 8192 signatures are 128 waves that hold an eighth of the chip for ~0.95 ms, and so are 65 536.  A streaming caller's legs
+    // are therefore COLLECTED (pe_engine::sig_batch) and decoded by one launch per Tune::sig_batch steps (sig_batch_flush); the
+    // per-step sums follow it.  A step's signature outputs stay inside the lag contract as long as the lag depth exceeds the
+    // batch by the ~4 steps a decompression lasts (bench.py runs the signed leg at lag 7); a pipeline that completes earlier
+    // (a drain, a synchronous call) flushes what has been collected (complete_arena).
+    pe_engine::SigSeg seg;
+    seg.arena = h->cur;
+    seg.n = n;
+    seg.compressed = fmt == PE_SIG_G2_COMPRESSED;
+    seg.check_subgroup = (sig_format_flags & PE_SIG_CHECK_SUBGROUP) != 0;
+    seg.d_in = A.d_sig_in.as<uint8_t>();
+    seg.copy_from = nullptr;
+    if (sig_on_device) {  // in place where the kernel's 16-byte loads allow it, else through the arena's scratch (copied by the leg)
+        if ((reinterpret_cast<uintptr_t>(signatures) & 15) == 0) seg.d_in = signatures;
+        else seg.copy_from = signatures;
+    }
+    seg.bytes = sig_bytes * n;
+    seg.d_pts = A.d_sig_pts.as<uint32_t>();
+    seg.d_status = A.d_sig_status.as<int32_t>();
+    seg.d_ug = d_ug;
+    seg.d_member_row = d_member_row;
+    seg.ng_bound = ng_bound;
+    seg.plan_dev = plan_dev;
+    seg.o_sig = ob.host<uint8_t>(off_sig);
+    seg.o_bad = ob.host<uint32_t>(off_bad);
+    seg.o_st = ob.host<int32_t>(off_st);
+    const bool collect = seg.compressed && h->streaming && h->pipelining && h->stream == h->own_stream && h->aux_stream != nullptr;
+    h->sig_batch.push_back(seg);
+    if (!collect || h->sig_batch.size() >= (size_t)std::min<int>(std::max(h->tune.sig_batch, 1), (int)G2_BATCH_MAX))
+        PE_TRY(sig_batch_flush(h));
     const size_t base = ob.base;
     const int ai = h->cur;
     auto complete = [h, ai, base, off_sig, off_bad, off_st, n, ng_bound, dev_rows, out_n_groups, out_atts, out_signatures96,

@@ -260,8 +260,6 @@ struct pe_engine {
         uint64_t generation = 0;            // ordinal of the pipeline that fills this arena (pe_pipeline_generation)
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
-        hipEvent_t ev_rows = nullptr;  // the end of this arena's row chain on the engine's stream (Tune::rows_event)
-        bool rows_recorded = false;
         bool fenced = false, side_used = false, aux_used = false;
         bool fence_pending = false;  // fenced by pe_pipeline_end_lagged, but ev_main / ev_side are still to be recorded: behind the
                                      // pipeline's held-back fork-choice launches (engine_pair.cpp)
@@ -277,12 +275,6 @@ struct pe_engine {
     bool pipelining = false;
     uint64_t pipes_begun = 0, pipes_completed = 0;  // pe_pipeline_generation / pe_pipeline_completed
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
-    hipStream_t side_stream2 = nullptr; // ... every other one here (Tune::side_streams == 2)
-    unsigned side_turn = 0;
-    hipStream_t side_pick()             // the stream of the next streaming accumulation
-    {
-        return side_stream2 && tune.exclusive && (side_turn++ & 1u) ? side_stream2 : side_stream;
-    }
     hipStream_t fin_stream = nullptr;   // ... its k_g1_tree here, beside the NEXT aggregate's accumulation
     // ... and its k_g1_finish here: on the tree's stream the two latency-bound guests of a step ran one behind the other
     // (tree 250-300 us beside an accumulation + finish 130 us), and that stream, not the accumulation, set the period
@@ -302,8 +294,20 @@ struct pe_engine {
     bool state_work_on_main = false;    // state_stream_begin fell back to the engine's stream for a flag pass
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
     hipEvent_t ev_leg = nullptr;        // the end of a signature leg on aux_owned, joined into aux_stream when that is an alias
-    hipEvent_t ev_sig = nullptr;        // pe_aggregate_signed: the decompression of a step's signatures is done -> the next
-    bool sig_leg_open = false;          // ... accumulation may start (engine_g1.cpp); set while such an event is outstanding
+    // pe_aggregate_signed: the signature legs of a streaming caller's steps, collected until Tune::sig_batch of them go out
+    // behind ONE decompression launch (engine_g1.cpp: sig_batch_flush)
+    struct SigSeg {
+        int arena;                      // the arena (pipeline) whose pinned block takes the leg's outputs
+        uint32_t n;
+        bool compressed, check_subgroup;
+        const uint8_t* d_in;            // wire bytes on the device (the caller's, or the arena's scratch)
+        const uint8_t* copy_from;       // device-resident signatures at an address the kernel cannot read in place: copied first
+        size_t bytes;
+        uint32_t* d_pts; int32_t* d_status;
+        const UnionGroup* d_ug; const uint32_t* d_member_row; uint32_t ng_bound; const AttPlan* plan_dev;
+        uint8_t* o_sig; uint32_t* o_bad; int32_t* o_st;
+    };
+    std::vector<SigSeg> sig_batch;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_busy = false;             // the side stream holds work of the current arena nobody has waited for yet
     bool side_ever = false;             // ev_join has been recorded at least once
@@ -336,24 +340,11 @@ struct pe_engine {
         }
         // at most one accumulation workgroup per CU by an LDS request, the tree one per CU by registers (g1_kernels.hip)
         int exclusive = env("POSEVO_ACC_EXCLUSIVE", 1);
-        // the tree's four-lane levels rotate over the workgroup's waves
-        int tree_rotate = env("POSEVO_TREE_ROTATE", 0);
-        // the accumulation's completion signal is the event its tree waits for (no record packet behind the kernel)
-        int acc_done_event = env("POSEVO_ACC_DONE_EVENT", 0);
-        // the row chain's end is an event of its arena, recorded when the chain is enqueued; the step's accumulation -- launched
-        // one aggregate later -- skips the wait packet when that event has completed by then
-        int rows_event = env("POSEVO_ROWS_EVENT", 0);
-        // which stream carries the state-transition work: 0 = its own (aux), 1 = the tree's (fin), 2 = the finish's (norm)
+        // which stream carries the state-transition work: 0 = its own (aux), 1 = the tree's (fin)
         int state_on = env("POSEVO_STATE_ON", 1);
-        // 2: consecutive accumulations of a streaming run alternate between two streams (needs `exclusive`: the successor's
-        // workgroups then take each CU as the predecessor's leave it, instead of the whole launch waiting for the last one)
-        int side_streams = env("POSEVO_SIDE_STREAMS", 1);
-        // pe_aggregate_signed in pipelined calls: 1 = the signature leg behind its aggregate's accumulation and the next
-        // accumulation behind the leg's decompression (they cost their sum), 0 = the two beside each other (round 4)
-        int sig_behind = env("POSEVO_SIG_BEHIND", 1);
-        // ... and, behind it, its decompression ON the accumulation's stream (stream order instead of two events across
-        // hardware queues; only the leg's latency-sized tail stays on its own stream)
-        int sig_on_side = env("POSEVO_SIG_ON_SIDE", 0);
+        // pe_aggregate_signed in streaming steps: how many steps' signature legs share one decompression launch (1 = a launch
+        // per step, round 5's shape; at most G2_BATCH_MAX)
+        int sig_batch = env("POSEVO_SIG_BATCH", 4);
     } tune;
 
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
@@ -486,6 +477,8 @@ VotesArgs votes_args(const pe_engine* h);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
 hipStream_t leg_stream(pe_engine* h);              // where a signature leg runs (created at the first one)
+int sig_batch_flush(pe_engine* h);                 // launch the signature legs collected so far (engine_g1.cpp)
+bool sig_batch_holds(const pe_engine* h, int arena);  // ... one of which writes into this arena's output block
 hipStream_t state_stream_unordered(pe_engine* h);  // the same stream, not ordered behind the engine's
 int aux_join(pe_engine* h, hipStream_t ms);  // ms waits for what this pipeline put on the state-transition stream
 

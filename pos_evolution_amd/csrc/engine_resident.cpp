@@ -275,6 +275,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     if (set == 0) {
         if (!h->deferred.empty()) PE_TRY(run_deferred(h));
         if (A.side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
+        if (sig_batch_holds(h, h->cur)) PE_TRY(sig_batch_flush(h));  // a collected signature leg of this pipeline reads them too
         PE_TRY(aux_join(h, ms));  // ... or from a process_attestation / signature leg on the state-transition stream
     }
     h->res_valid = false;
@@ -349,31 +350,14 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
         bound.n_partials = n;
         const G1Group* d_groups = L.g1;
         const AttPlan* d_plan = L.plan;
-        bool rows_marked = false;
-        if (on_side && h->tune.rows_event && h->streaming) {
-            HIP_TRY(h, hipEventRecord(arena->ev_rows, h->stream));
-            rows_marked = true;
-        }
-        auto launch_g1 = [h, arena, d_points, tables, d_union, d_groups, bound, out_pk, on_side, d_plan, dev_partials,
-                          rows_marked]() -> int {
-            hipStream_t gs = on_side ? (h->streaming ? h->side_pick() : h->side_stream) : h->stream;
-            if (on_side && rows_marked) {
-                // behind this aggregate's row chain, whose end was recorded when it was enqueued.  A held launch goes out one
-                // aggregate later: the chain has long ended by then and the side stream is spared the wait packet
-                if (hipEventQuery(arena->ev_rows) != hipSuccess) {
-                    (void)hipGetLastError();  // hipErrorNotReady is not an error of this call
-                    HIP_TRY(h, hipStreamWaitEvent(gs, arena->ev_rows, 0));
-                }
-            } else if (on_side) {  // behind everything enqueued on the engine's stream so far (see aggregate_impl)
+        auto launch_g1 = [h, arena, d_points, tables, d_union, d_groups, bound, out_pk, on_side, d_plan, dev_partials]() -> int {
+            hipStream_t gs = on_side ? h->side_stream : h->stream;
+            if (on_side) {  // behind everything enqueued on the engine's stream so far (see aggregate_impl)
                 HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
                 HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_fork, 0));
             }
             if (on_side) {
                 if (arena->side_used) HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_join, 0));
-                if (h->sig_leg_open) {  // the previous step's signature decompression first (pe_aggregate_signed)
-                    HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_sig, 0));
-                    h->sig_leg_open = false;
-                }
             } else {
                 g1_stream_guard(h, gs);
             }

@@ -337,14 +337,10 @@ __device__ __forceinline__ void g1_slot_block(const G1Group* __restrict__ groups
 //   k_g1_tree_solo  the same code + eight accumulation registers nobody reads (264 in all): two of ITS workgroups never share
 //                   a SIMD whatever the LDS says, while one still fits beside an accumulation wave (232 + 264 <= 512).  That
 //                   frees the LDS for the accumulation's own exclusion (launch_g1_accumulate, `exclusive`).
-// rotate: the four-lane levels take their lanes from a different wave each (128 pairs' lanes -> waves 2 and 3, 64 -> wave 1,
-// the rest -> wave 0) instead of always from lane 0 up: every wave of the workgroup then issues about the same number of
-// products (L1 + L2 + one more level) where wave 0 issued all eight levels and waves 2 / 3 only two -- the accumulation wave
-// that shares wave 0's SIMD was the last of its launch to end.  Same pairs, same sums.
 template <bool SOLO>
 __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups,
                                              uint32_t n_groups, uint32_t n_slots, uint32_t* __restrict__ wg_partials,
-                                             const AttPlan* __restrict__ plan_dev, const int rotate)
+                                             const AttPlan* __restrict__ plan_dev)
 {
     if (SOLO) asm volatile("" ::: "a7");
     if (plan_dev) {
@@ -376,10 +372,8 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
 #endif
     for (int n = G1_WG / 2; n >= 1; n >>= 1) {  // n = number of pairs at this level
         if (n <= G1_WG / 4) {  // four lanes per pair from the second level on (g1x_add_quad: depth 4 instead of 7)
-            // lanes [base, base + 4 n): base is a multiple of the wave size, so a pair's four lanes stay in one wave
-            const int base = !rotate ? 0 : n == G1_WG / 8 ? G1_WG / 2 : n == G1_WG / 16 ? G1_WG / 4 : 0;
-            const int w = (tid - base) >> 2, q = tid & 3;
-            const bool active = tid >= base && w < n;
+            const int w = tid >> 2, q = tid & 3;
+            const bool active = w < n;
             fp out_a, out_b;
             uint32_t out = NONE32, sz = 0;
             bool store_lds = false;
@@ -503,15 +497,15 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
 
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g1_tree(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups, uint32_t n_groups,
-          uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev, int rotate)
+          uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev)
 {
-    g1_tree_body<false>(lane_partials, groups, n_groups, n_slots, wg_partials, plan_dev, rotate);
+    g1_tree_body<false>(lane_partials, groups, n_groups, n_slots, wg_partials, plan_dev);
 }
 __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(1, 1), amdgpu_num_vgpr(256)))
 k_g1_tree_solo(const uint32_t* __restrict__ lane_partials, const G1Group* __restrict__ groups, uint32_t n_groups,
-               uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev, int rotate)
+               uint32_t n_slots, uint32_t* __restrict__ wg_partials, const AttPlan* __restrict__ plan_dev)
 {
-    g1_tree_body<true>(lane_partials, groups, n_groups, n_slots, wg_partials, plan_dev, rotate);
+    g1_tree_body<true>(lane_partials, groups, n_groups, n_slots, wg_partials, plan_dev);
 }
 
 // ---------------------------------------------------------------- the accumulation (S29 field form)
@@ -716,7 +710,7 @@ void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t*
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
                               const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
                               uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
-                              const uint32_t* members1, int exclusive, hipEvent_t done)
+                              const uint32_t* members1, int exclusive)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
@@ -726,20 +720,13 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
     // step arriving in the same microsecond; the first CUs to retire a predecessor's workgroup): those eight waves then run
     // at half speed for the whole launch, 330-370 us instead of 205-240 in up to six steps of twenty
     // (profiles/r05_engine_timeline_cold20_before_exclusive.txt).  78 KB stay for the guests: k_g1_tree_solo (51 KB), the fork-choice
-    // tree up to 4096 blocks (66 KB), k_att_plan (70 KB), the vote histograms (32 KB each).
+    // tree up to 4096 blocks (66 KB), the vote histograms (32 KB each).
     size_t lds_bytes = 0;
     if (exclusive) {
         lds_bytes = G1_ACC_EXCLUSIVE_LDS;
         if (first_use_on_this_device<82>())
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_accumulate), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)G1_ACC_EXCLUSIVE_LDS);
-    }
-    if (done) {
-        // the launch's own completion signal as the event the tree's stream waits for: one packet less between two
-        // consecutive accumulations on their stream than a record behind the kernel (every packet there is step time)
-        hipExtLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), lds_bytes, s, nullptr, done, 0, points_s29, members,
-                              bit_arena, groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
-        return;
     }
     hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), lds_bytes, s, points_s29, members, bit_arena,
                        groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
@@ -766,7 +753,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
 //    only made rarer (6 steps of 20 at 340-370 us on one box, profiles/r05_engine_timeline_cold20_before_exclusive.txt); this kernel then
 //    keeps its workgroups apart by registers instead (k_g1_tree_solo: 264 + 264 > 512) and asks for the 51 KB it uses.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
-                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev, int rotate, int solo)
+                    uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev, int solo)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
@@ -775,7 +762,7 @@ void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group*
         // beside an accumulation that asks for G1_ACC_EXCLUSIVE_LDS: one workgroup per CU by registers (264), the LDS request
         // is what the kernel uses (51 KB)
         hipLaunchKernelGGL(k_g1_tree_solo, dim3(blocks), dim3(G1_WG), lds_bytes, s, lane_partials, groups, n_groups, n_slots,
-                           wg_partials48, plan_dev, rotate);
+                           wg_partials48, plan_dev);
         return;
     }
     if (one_per_cu) {
@@ -786,7 +773,7 @@ void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group*
         lds_bytes = padded;
     }
     hipLaunchKernelGGL(k_g1_tree, dim3(blocks), dim3(G1_WG), lds_bytes, s, lane_partials, groups, n_groups, n_slots,
-                       wg_partials48, plan_dev, rotate);
+                       wg_partials48, plan_dev);
 }
 
 // ---------------------------------------------------------------- finish

@@ -56,12 +56,9 @@ void launch_g2_convert(hipStream_t s, const uint8_t* be192, uint32_t* mont48, ui
 // One lane per point.  y = sqrt(x^3 + 4(1+u)) in Fp2 by the "complex method" (p = 3 mod 4): s = sqrt(norm) in Fp,
 // d = (a0 + s)/2, w = d^((p-3)/4): y = d w + (a1 w / 2) u if d is a residue, -(a1 w / 2) + (d w) u otherwise -- two windowed
 // Fp exponentiations (fp_sqrt.h), no inversion, no second attempt: ~1000 Montgomery products per point.  status: 0 ok, 1 malformed encoding, 2 not on the curve.
-__global__ void __launch_bounds__(64)
-k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restrict__ out_mont48,
-                uint8_t* __restrict__ out_be192, int32_t* __restrict__ status)
+__device__ __forceinline__ void g2_decompress_one(const uint64_t i, const uint8_t* __restrict__ in96, uint32_t* __restrict__ out_mont48,
+                                                  uint8_t* __restrict__ out_be192, int32_t* __restrict__ status)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const uint8_t* src = in96 + 96 * i;
     const uint32_t lead = src[0];
     const bool c_flag = lead & 0x80, inf_flag = lead & 0x40, sign_flag = lead & 0x20;
@@ -179,12 +176,43 @@ k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restri
     }
 }
 
+__global__ void __launch_bounds__(64)
+k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restrict__ out_mont48,
+                uint8_t* __restrict__ out_be192, int32_t* __restrict__ status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g2_decompress_one(i, in96, out_mont48, out_be192, status);
+}
+// Several arrays of signatures in ONE launch (the signature legs of consecutive streaming steps, engine_g1.cpp): a launch is as
+// long as one lane's chain of ~970 dependent products whatever its size, so the legs of B steps cost what one cost.
+__global__ void __launch_bounds__(64)
+k_g2_decompress_batch(const G2DecompressBatch b)
+{
+    uint32_t k = 0;
+    while (k + 1 < b.count && blockIdx.x >= b.first_block[k + 1]) ++k;
+    const uint64_t i = (uint64_t)(blockIdx.x - b.first_block[k]) * 64 + threadIdx.x;
+    if (i >= b.n[k]) return;
+    g2_decompress_one(i, b.in96[k], b.out_mont48[k], nullptr, b.status[k]);
+}
+
 void launch_g2_decompress(hipStream_t s, const uint8_t* in96, uint64_t n, uint32_t* out_mont48, uint8_t* out_be192,
                           int32_t* status)
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_g2_decompress, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in96, n, out_mont48, out_be192,
                        status);
+}
+void launch_g2_decompress_batch(hipStream_t s, G2DecompressBatch& b)
+{
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < b.count; ++k) {
+        b.first_block[k] = blocks;
+        blocks += (b.n[k] + 63) / 64;
+    }
+    b.first_block[b.count] = blocks;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_g2_decompress_batch, dim3(blocks), dim3(64), 0, s, b);
 }
 
 // ---------------------------------------------------------------- accumulate

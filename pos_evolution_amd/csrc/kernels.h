@@ -59,14 +59,14 @@ struct AttPlan;
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
                           uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev = nullptr,
-                          const uint32_t* members1 = nullptr, int exclusive = 0, hipEvent_t done = nullptr);
+                          const uint32_t* members1 = nullptr, int exclusive = 0);
 // exclusive: the launch asks for this much LDS it never touches (more than half a CU's): at most one of its workgroups per CU
 constexpr size_t G1_ACC_EXCLUSIVE_LDS = 82 * 1024;
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per
 // (group, workgroup) into wg_partials48.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu = 0, const AttPlan* plan_dev = nullptr,
-                    int rotate = 0, int solo = 0);
+                    int solo = 0);
 // Per group: add its n_parts partials (stride = part_stride partials apart, starting at first[g] or
 // g when first == null), then either write the XYZZ sum (48 u32) or normalise to 96-byte affine.
 void launch_g1_finish(hipStream_t s, const uint32_t* partials48, const G1Group* groups, uint32_t n_groups,
@@ -349,6 +349,13 @@ void launch_g2_accumulate(hipStream_t s, const uint32_t* points_mont48, const ui
                           const G1Group* groups, uint32_t n_groups, uint32_t n_slots, uint32_t* wg_partials96);
 void launch_g2_decompress(hipStream_t s, const uint8_t* in96, uint64_t n, uint32_t* out_mont48, uint8_t* out_be192,
                           int32_t* status);
+// up to G2_BATCH_MAX arrays of compressed signatures decoded by one launch (first_block is filled by the launcher)
+constexpr uint32_t G2_BATCH_MAX = 8;
+struct G2DecompressBatch {
+    const uint8_t* in96[G2_BATCH_MAX]; uint32_t* out_mont48[G2_BATCH_MAX]; int32_t* status[G2_BATCH_MAX];
+    uint32_t n[G2_BATCH_MAX]; uint32_t first_block[G2_BATCH_MAX + 1]; uint32_t count;
+};
+void launch_g2_decompress_batch(hipStream_t s, G2DecompressBatch& b);
 void launch_g2_finish(hipStream_t s, const uint32_t* partials96, const G1Group* groups, uint32_t n_groups,
                       uint8_t* out_be192);
 // r * P == infinity per decoded point: status 0 -> 3 where it fails (non-zero entries are left alone)

@@ -15,4 +15,32 @@ call_b() {
   bash tools/gpu.sh r06b label:all tests
 }
 
+# call c: (1) what inflates the accumulation in situ -- a diagnostic build (libposevo_dbg.so: POSEVO_DBG_SKIP=1 launches no
+# k_g1_finish, =2 neither tree nor finish; results are garbage, nothing is verified) against the same build with both;
+# (2) the unaggregated-signature leg under the profiler: kernel stats, two SQ counter passes, FETCH / WRITE
+call_c() {
+  O=gpurun_out/r06c; mkdir -p $O
+  timeout 600 python -m pytest tests/test_gpu_resident_rows.py -x -q -k "many_workgroups" > $O/pytest_plan.log 2>&1; echo "[r06c] plan tests rc $?"; tail -4 $O/pytest_plan.log
+  export POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_dbg.so BENCH_ARGS="--no-verify-steps --no-oracle-check --no-shuffle-variant"
+  for k in 0 1 2 0; do POSEVO_DBG_SKIP=$k bash tools/gpu.sh r06c label:skip$k quick; done
+  unset POSEVO_LIB_PATH BENCH_ARGS
+  cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+  timeout 300 python tools/sig_epoch.py --calls 3 > $O/sig_epoch_plain.txt 2>&1; cat $O/sig_epoch_plain.txt
+  rm -rf $O/prof; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o sig -- python tools/sig_epoch.py --calls 3 > $O/sig_epoch_rocprof.txt 2>&1
+  timeout 120 python tools/rocpd_stats.py $O/prof/sig_results.db $O/sig_kernel_stats.txt > /dev/null 2>&1; cut -c1-150 $O/sig_kernel_stats.txt | head -14; rm -rf $O/prof
+  i=0
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" \
+             "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1)); rm -rf $O/pmc; timeout 600 rocprofv3 --kernel-trace --pmc $set -d $O/pmc -o p -- python tools/sig_epoch.py --calls 2 > $O/sig_pmc_$i.log 2>&1
+    for c in $set; do echo "== $c"; timeout 60 python tools/rocpd_pmc.py $O/pmc/p_results.db $c 2>/dev/null | python -c "
+import json,sys
+d=json.load(sys.stdin)
+for k,v in d.items():
+    if 'g2' in k: print('  ',k[:40],v)
+"; done > $O/sig_pmc_$i.txt 2>&1
+    cat $O/sig_pmc_$i.txt; rm -rf $O/pmc
+  done
+}
+
 "call_$1"

@@ -23,13 +23,8 @@ KNOBS = {
     "hwq6": ({"GPU_MAX_HW_QUEUES": "6"}, [], "hwq"),
     "hwq8": ({"GPU_MAX_HW_QUEUES": "8"}, [], "hwq"),
     "state_on_aux": ({"POSEVO_STATE_ON": "0"}, [], "state"),
-    "state_on_norm": ({"POSEVO_STATE_ON": "2"}, [], "state"),
-    "tree_rotate": ({"POSEVO_TREE_ROTATE": "1"}, [], None),
     "not_exclusive": ({"POSEVO_ACC_EXCLUSIVE": "0"}, [], "excl"),
-    "done_event": ({"POSEVO_ACC_DONE_EVENT": "1"}, [], None),
-    "rows_event": ({"POSEVO_ROWS_EVENT": "1"}, [], None),
-    "two_side": ({"POSEVO_SIDE_STREAMS": "2"}, [], "excl"),
-    "sig_beside": ({"POSEVO_SIG_BEHIND": "0"}, [], None),
+    "unpaired": ({"POSEVO_PAIR": "0"}, [], None),
 }
 
 
