@@ -42,6 +42,12 @@ int pe_profile_get(pe_engine* h, int kernel, uint64_t* launches, double* total_m
  * inside a kind): kernel id, start and duration in ms.  At most cap entries are written; *out_n = how many exist. */
 int pe_profile_timeline(pe_engine* h, int32_t* kernel, double* start_ms, double* duration_ms, uint32_t cap, uint32_t* out_n);
 
+/* Which of the handle's four hot streams (engine, accumulation, tree, finish) share a hardware queue, asked of the device
+ * again (a spin kernel on one stream, clock stamps on the others; everything enqueued completes first):
+ * out_class[i] = the lowest i' whose stream shares stream i's queue -- {0, 1, 2, 3} when every stream has a queue of its own,
+ * which is what pe_engine_create arranges whatever the process created before the handle (POSEVO_QUEUE_PROBE=0 skips it). */
+int pe_profile_queue_classes(pe_engine* h, int32_t out_class[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,7 @@ SIGNATURES = {
     "pe_profile_reset": (C.c_int, [_H]),
     "pe_profile_get": (C.c_int, [_H, C.c_int, _u64p, _P(C.c_double)]),
     "pe_profile_timeline": (C.c_int, [_H, _i32p, C.c_void_p, C.c_void_p, C.c_uint32, _P(C.c_uint32)]),
+    "pe_profile_queue_classes": (C.c_int, [_H, _i32p]),
 }
 
 PE_ROWS_RESIDENT = 1  # include/posevo.h: "every group of the last pe_aggregate over rows in device memory"

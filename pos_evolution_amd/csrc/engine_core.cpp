@@ -71,6 +71,12 @@ int complete_arena(pe_engine* h, int ai)
             h->side_busy = false;
         }
     }
+    if (a.leg_used) {  // the arena's signature leg runs on a stream of its own: joined into no other (a ~1 ms decompression in
+                       // front of the tree's stream would put every G1 chain behind it)
+        hipError_t e2 = bounded_event_sync(h, a.ev_leg);
+        if (e == hipSuccess) e = e2;
+        a.leg_used = false;
+    }
     std::vector<std::function<int()>> todo;
     todo.swap(a.pending);
     // arenas complete oldest first; the CURRENT arena completed in the middle of its own pipeline (a block that had to grow)
@@ -99,7 +105,7 @@ void complete_oldest_if_ready(pe_engine* h)
     pe_engine::PipeArena& a = h->arena[ai];
     if (!a.fenced || a.fence_pending || a.pending.empty() || sig_batch_holds(h, ai)) return;
     if (hipEventQuery(a.ev_main) != hipSuccess || (a.side_used && hipEventQuery(a.ev_side) != hipSuccess) ||
-        (a.aux_used && hipEventQuery(a.ev_aux) != hipSuccess)) {
+        (a.aux_used && hipEventQuery(a.ev_aux) != hipSuccess) || (a.leg_used && hipEventQuery(a.ev_leg) != hipSuccess)) {
         (void)hipGetLastError();  // hipErrorNotReady is not an error here
         return;
     }
@@ -224,6 +230,57 @@ int need_init(pe_engine* h, bool flush, bool keep_held)
     return rc ? rc : rc2;
 }
 
+// ---- which streams share a hardware queue ------------------------------------------------------------------------------
+// The runtime maps a process's streams onto GPU_MAX_HW_QUEUES (four) hardware queues per priority and a queue runs its
+// packets in submission order: two of the handle's hot streams on one queue run strictly behind each other (round 5: a handle
+// created beside another one, or after the host had created streams of its own, ran its finish kernel in its row chain's
+// queue -- 308 us per slot-step instead of 120).  HIP does not say which queue a stream got, so the handle ASKS the device:
+// a kernel that spins for ~60 us on one stream, a kernel that stamps the clock on each of the others -- a stamp taken after
+// the spin ended sat in the spinner's queue.  pe_engine_create keeps creating streams until four of them lie on four different
+// queues (at most ten; the rest are destroyed), ~0.3 ms once per handle; POSEVO_QUEUE_PROBE=0 skips it.
+namespace {
+__global__ void k_probe_spin(unsigned long long* out, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    out[0] = wall_clock64();
+}
+__global__ void k_probe_mark(unsigned long long* out) { out[0] = wall_clock64(); }
+}  // namespace
+
+// cls[i] = the lowest index among the streams that share stream i's queue.  false: the probe itself failed (nothing is known).
+bool probe_queue_classes(const std::vector<hipStream_t>& c, std::vector<int>& cls)
+{
+    const size_t n = c.size();
+    cls.assign(n, -1);
+    unsigned long long* out = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&out), 8 * (n + 1), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    bool ok = true;
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, c[0], out + n, 1ull);   // code objects in, clocks up
+    hipLaunchKernelGGL(k_probe_mark, dim3(1), dim3(1), 0, c[0], out);
+    ok = hipStreamSynchronize(c[0]) == hipSuccess;
+    for (size_t i = 0; i < n && ok; ++i) {
+        if (cls[i] != -1) continue;
+        cls[i] = (int)i;
+        bool any = false;
+        for (size_t j = i + 1; j < n; ++j) any = any || cls[j] == -1;
+        if (!any) break;
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, c[i], out + n, 6000ull);  // 60 us
+        for (size_t j = i + 1; j < n; ++j)
+            if (cls[j] == -1) hipLaunchKernelGGL(k_probe_mark, dim3(1), dim3(1), 0, c[j], out + j);
+        for (size_t j = i; j < n; ++j)
+            if (j == i || cls[j] == -1) ok = ok && hipStreamSynchronize(c[j]) == hipSuccess;
+        for (size_t j = i + 1; j < n && ok; ++j)
+            if (cls[j] == -1 && out[j] >= out[n]) cls[j] = (int)i;  // stamped after the spin had ended: behind it in its queue
+    }
+    if (hipGetLastError() != hipSuccess) ok = false;
+    (void)hipHostFree(out);
+    return ok;
+}
+
 }  // namespace posevo
 
 extern "C" {
@@ -326,13 +383,41 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
         pe_engine_destroy(h);
         return PE_ERR_NO_DEVICE;
     }
-    // Tune::state_on: the state-transition work on the tree's or the finish's stream instead of its own (the runtime maps
-    // the engine's six streams onto four hardware queues; two streams that share one run in submission order)
+    // The four hot streams on four different hardware queues, whatever the process created before this handle
+    if (ok_streams && h->tune.queue_probe) {
+        std::vector<hipStream_t> cand = {h->own_stream, h->side_stream, h->fin_stream, h->norm_stream};
+        std::vector<int> cls;
+        for (;;) {
+            if (!probe_queue_classes(cand, cls)) break;
+            std::vector<size_t> reps;
+            for (size_t i = 0; i < cand.size(); ++i)
+                if (cls[i] == (int)i) reps.push_back(i);
+            if (reps.size() >= 4 || cand.size() >= 10) {
+                if (reps.size() >= 4) {  // the first four queue representatives serve; what shares a queue with one of them goes
+                    hipStream_t pick[4] = {cand[reps[0]], cand[reps[1]], cand[reps[2]], cand[reps[3]]};
+                    for (hipStream_t st : cand)
+                        if (st != pick[0] && st != pick[1] && st != pick[2] && st != pick[3]) (void)hipStreamDestroy(st);
+                    h->own_stream = h->stream = pick[0];
+                    h->side_stream = pick[1];
+                    h->fin_stream = pick[2];
+                    h->norm_stream = pick[3];
+                    h->queues_distinct = true;
+                } else {                 // fewer than four queues to be had (GPU_MAX_HW_QUEUES < 4?): the first four streams stay
+                    for (size_t i = 4; i < cand.size(); ++i) (void)hipStreamDestroy(cand[i]);
+                }
+                break;
+            }
+            hipStream_t extra = nullptr;
+            if (mk(&extra) != hipSuccess) { (void)hipGetLastError(); for (size_t i = 4; i < cand.size(); ++i) (void)hipStreamDestroy(cand[i]); break; }
+            cand.push_back(extra);
+        }
+    }
+    // Tune::state_on: the state-transition work on the tree's stream instead of its own (the runtime maps the engine's
+    // streams onto four hardware queues; two streams that share one run in submission order)
     if (ok_streams && h->tune.state_on == 1) h->aux_stream = h->fin_stream;
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_leg, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         false) {
@@ -342,7 +427,8 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     for (auto& a : h->arena)
         if (hipEventCreateWithFlags(&a.ev_main, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&a.ev_side, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&a.ev_aux, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.ev_leg, hipEventDisableTiming) != hipSuccess) {
             pe_engine_destroy(h);
             return PE_ERR_NO_DEVICE;
         }
@@ -366,6 +452,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (h->aux_owned) (void)hipStreamSynchronize(h->aux_owned);
     if (h->prep_stream) { (void)hipStreamSynchronize(h->prep_stream); (void)hipStreamDestroy(h->prep_stream); }
     if (h->prof_base) (void)hipEventDestroy(h->prof_base);
     h->d_shuffle_scratch.release();
@@ -393,6 +480,7 @@ void pe_engine_destroy(pe_engine* h)
         a.h_pin.release();
         if (a.ev_main) (void)hipEventDestroy(a.ev_main);
         if (a.ev_side) (void)hipEventDestroy(a.ev_side);
+        if (a.ev_leg) (void)hipEventDestroy(a.ev_leg);
         if (a.ev_aux) (void)hipEventDestroy(a.ev_aux);
     }
     for (DevBuf* b : {&h->d_points, &h->d_balance, &h->d_flags, &h->d_incr, &h->d_sbalance, &h->d_sflags, &h->d_vote_key, &h->d_vote_block, &h->d_vote_slot,
@@ -415,7 +503,6 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
-    if (h->ev_leg) (void)hipEventDestroy(h->ev_leg);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
     if (h->ev_xchg) (void)hipEventDestroy(h->ev_xchg);
@@ -545,6 +632,18 @@ int pe_pipeline_end_lagged(pe_engine* h)
 }
 
 // ---------------------------------------------------------------- profiling
+int pe_profile_queue_classes(pe_engine* h, int32_t out_class[4])
+{
+    if (!h || !out_class) return PE_ERR_INVALID_ARG;
+    PE_TRY(enter(h));
+    if (!h->side_stream || !h->fin_stream || !h->norm_stream) return fail(h, PE_ERR_STATE, "the handle has no stream set of its own");
+    for (hipStream_t s : {h->own_stream, h->side_stream, h->fin_stream, h->norm_stream}) HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<int> cls;
+    if (!probe_queue_classes({h->own_stream, h->side_stream, h->fin_stream, h->norm_stream}, cls))
+        return fail(h, PE_ERR_NO_DEVICE, "the queue probe failed");
+    for (int i = 0; i < 4; ++i) out_class[i] = cls[i];
+    return PE_OK;
+}
 int pe_profile_enable(pe_engine* h, int on)
 {
     if (!h) return PE_ERR_INVALID_ARG;
@@ -570,6 +669,7 @@ static void prof_drain(pe_engine* h)
     if (h->fin_stream) (void)hipStreamSynchronize(h->fin_stream);
     if (h->norm_stream) (void)hipStreamSynchronize(h->norm_stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (h->aux_owned) (void)hipStreamSynchronize(h->aux_owned);
     for (int k = 0; k < PE_KERNEL_COUNT; ++k) {
         auto& p = h->prof[k];
         for (auto& ev : p.pending) {

@@ -205,7 +205,7 @@ int pe_dist_destroy(pe_engine* h)
             a.pending.clear();
             a.stage_cursor = a.out_cursor = 0;
             a.fenced = a.side_used = a.aux_used = a.aux_reads_scratch = false;
-            a.fence_pending = false;
+            a.fence_pending = a.leg_used = false;
         }
         h->deferred.clear();
         // launches held back for the next aggregate (engine_pair.cpp) point into the regions reset above and carry the lost

@@ -109,8 +109,9 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
 }
 
 // The collected signature legs (pe_aggregate_signed), launched: one decompression over all of them, then per leg the subgroup
-// check it asked for, the per-group sums and the status copy into ITS arena's pinned block.  Arenas whose pipelines have been
-// fenced meanwhile get their state-transition mark re-recorded behind the leg: whoever completes them waits for it.
+// check it asked for, the per-group sums and the status copy into ITS arena's pinned block, marked by the arena's ev_leg.  The
+// legs' stream is joined into no other stream: round 5 joined it into the state-transition stream -- which is the tree's
+// (Tune::state_on) -- and every G1 chain then stood behind the decompression.
 int sig_batch_flush(pe_engine* h)
 {
     if (h->sig_batch.empty()) return PE_OK;
@@ -147,21 +148,13 @@ int sig_batch_flush(pe_engine* h)
             launch_g2_aggregate_rows(ss, sg.d_pts, sg.d_status, sg.d_ug, sg.d_member_row, sg.ng_bound, sg.plan_dev, sg.o_sig, sg.o_bad);
         }
         HIP_TRY(h, hipMemcpyAsync(sg.o_st, sg.d_status, 4ull * sg.n, hipMemcpyDeviceToHost, ss));
+        if (ss != h->stream) {  // the leg's own mark: whoever completes its arena (or rewrites the arena's scratch) waits for it
+            pe_engine::PipeArena& a = h->arena[sg.arena];
+            HIP_TRY(h, hipEventRecord(a.ev_leg, ss));
+            a.leg_used = true;
+        }
     }
     HIP_TRY(h, hipGetLastError());
-    if (ss != h->stream) {
-        if (ss != h->aux_stream) {  // the legs' end, joined into the stream fences and waits look at
-            HIP_TRY(h, hipEventRecord(h->ev_leg, ss));
-            HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_leg, 0));
-        }
-        h->aux_busy = true;
-        for (auto& sg : segs) {
-            pe_engine::PipeArena& a = h->arena[sg.arena];
-            a.aux_used = true;
-            a.aux_reads_scratch = true;
-            if (a.fenced && !a.fence_pending) HIP_TRY(h, hipEventRecord(a.ev_aux, h->aux_stream));
-        }
-    }
     return PE_OK;
 }
 bool sig_batch_holds(const pe_engine* h, int arena)

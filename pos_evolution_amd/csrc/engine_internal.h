@@ -260,6 +260,8 @@ struct pe_engine {
         uint64_t generation = 0;            // ordinal of the pipeline that fills this arena (pe_pipeline_generation)
         std::vector<std::function<int()>> pending;
         hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_aux = nullptr;  // recorded by pe_pipeline_end_lagged
+        hipEvent_t ev_leg = nullptr;   // the end of this arena's signature leg on the legs' stream (sig_batch_flush)
+        bool leg_used = false;         // ... recorded and not yet waited for
         bool fenced = false, side_used = false, aux_used = false;
         bool fence_pending = false;  // fenced by pe_pipeline_end_lagged, but ev_main / ev_side are still to be recorded: behind the
                                      // pipeline's held-back fork-choice launches (engine_pair.cpp)
@@ -275,6 +277,7 @@ struct pe_engine {
     bool pipelining = false;
     uint64_t pipes_begun = 0, pipes_completed = 0;  // pe_pipeline_generation / pe_pipeline_completed
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
+    bool queues_distinct = false;       // the probe at creation found engine / side / fin / norm on four different hardware queues
     hipStream_t fin_stream = nullptr;   // ... its k_g1_tree here, beside the NEXT aggregate's accumulation
     // ... and its k_g1_finish here: on the tree's stream the two latency-bound guests of a step ran one behind the other
     // (tree 250-300 us beside an accumulation + finish 130 us), and that stream, not the accumulation, set the period
@@ -293,7 +296,6 @@ struct pe_engine {
     bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
     bool state_work_on_main = false;    // state_stream_begin fell back to the engine's stream for a flag pass
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
-    hipEvent_t ev_leg = nullptr;        // the end of a signature leg on aux_owned, joined into aux_stream when that is an alias
     // pe_aggregate_signed: the signature legs of a streaming caller's steps, collected until Tune::sig_batch of them go out
     // behind ONE decompression launch (engine_g1.cpp: sig_batch_flush)
     struct SigSeg {
@@ -345,6 +347,8 @@ struct pe_engine {
         // pe_aggregate_signed in streaming steps: how many steps' signature legs share one decompression launch (1 = a launch
         // per step, round 5's shape; at most G2_BATCH_MAX)
         int sig_batch = env("POSEVO_SIG_BATCH", 4);
+        // pe_engine_create asks the device which of its streams share a hardware queue and keeps four that do not (engine_core.cpp)
+        int queue_probe = env("POSEVO_QUEUE_PROBE", 1);
     } tune;
 
     // ---- device-resident hand-over of the last pe_aggregate (PE_BITS_RESIDENT) ----
@@ -477,6 +481,7 @@ VotesArgs votes_args(const pe_engine* h);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
 hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
 hipStream_t leg_stream(pe_engine* h);              // where a signature leg runs (created at the first one)
+bool probe_queue_classes(const std::vector<hipStream_t>& streams, std::vector<int>& cls);  // which share a hardware queue
 int sig_batch_flush(pe_engine* h);                 // launch the signature legs collected so far (engine_g1.cpp)
 bool sig_batch_holds(const pe_engine* h, int arena);  // ... one of which writes into this arena's output block
 hipStream_t state_stream_unordered(pe_engine* h);  // the same stream, not ordered behind the engine's

@@ -276,6 +276,7 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
         if (!h->deferred.empty()) PE_TRY(run_deferred(h));
         if (A.side_used) HIP_TRY(h, hipStreamWaitEvent(ms, h->ev_join, 0));
         if (sig_batch_holds(h, h->cur)) PE_TRY(sig_batch_flush(h));  // a collected signature leg of this pipeline reads them too
+        if (A.leg_used) HIP_TRY(h, hipStreamWaitEvent(ms, A.ev_leg, 0));
         PE_TRY(aux_join(h, ms));  // ... or from a process_attestation / signature leg on the state-transition stream
     }
     h->res_valid = false;

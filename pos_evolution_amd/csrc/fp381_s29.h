@@ -296,26 +296,47 @@ PE_HD void fq_to_mont32(uint32_t* w, const fq& a)
 }
 
 // ---- a^((p-3)/4): the exponentiation under every square root of the decompression kernels (fp_sqrt.h) ----
-// One lane per point there, a few thousand points a call: a single wave per SIMD and nothing beside it to hide the carry chains
-// of the 12 x 32 product (~2 us per dependent product).  This form's column sums are independent multiply-adds: the same
+// One lane per point there: a chain of ~460 dependent products.  This form's column sums are independent multiply-adds: the
 // chain runs at the multiplier's issue rate (301 / 392 multiply-adds per squaring / product).
-// Fixed 4-bit windows over the 379-bit exponent (wave-uniform branches and table index; the table a^1 .. a^15 is indexed at
-// run time, i.e. lives in scratch: 14 dwords read per window): 14 + 376 + at most 94 products.
-PE_HD_CONST uint32_t FQ_PM3D4_EXP[12] = {0xffffeaaau, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
-                                         0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};  // (p-3)/4
+// The exponent is a constant, so the schedule is too (tools/gen_fp29_consts.py: sliding windows of at most four bits over the
+// ODD powers a, a^3 .. a^15): 375 squarings + 78 products + 8 for the table.  The table is EIGHT values held in registers and
+// picked by a wave-uniform selector -- rounds 4-5 indexed a 16-entry table at run time, i.e. kept it in scratch: 1120 bytes per
+// lane, 147 MB for a chip full of waves, which the runtime hands out per dispatch (profiles/r06_sig_*: the kernel measured
+// 15 ms, the call around it 35-50).  No scratch now.
+PE_HD void fq_pick_odd(fq& r, uint32_t v, const fq& t1, const fq& t3, const fq& t5, const fq& t7, const fq& t9, const fq& t11,
+                       const fq& t13, const fq& t15)
+{
+#pragma unroll
+    for (int i = 0; i < FQ_N; ++i)
+        r.l[i] = v == 1 ? t1.l[i] : v == 3 ? t3.l[i] : v == 5 ? t5.l[i] : v == 7 ? t7.l[i] : v == 9 ? t9.l[i]
+               : v == 11 ? t11.l[i] : v == 13 ? t13.l[i] : t15.l[i];
+}
 PE_HD void fq_pow_pm3d4(fq& w, const fq& a)  // a: limbs as the products accept them (|limb| <= 2^29 + 16), any residue
 {
-    fq tab[16];
-    fq_norm(tab[1], a);  // balanced digits: signed x signed multiplies below
+    fq t1, t3, t5, t7, t9, t11, t13, t15, a2;
+    fq_norm(t1, a);  // balanced digits: signed x signed multiplies below
+    fq_sqr(a2, t1);
+    fq_mul(t3, t1, a2);
+    fq_mul(t5, t3, a2);
+    fq_mul(t7, t5, a2);
+    fq_mul(t9, t7, a2);
+    fq_mul(t11, t9, a2);
+    fq_mul(t13, t11, a2);
+    fq_mul(t15, t13, a2);
+    fq acc;
+    fq_pick_odd(acc, FQ_PM3D4_FIRST, t1, t3, t5, t7, t9, t11, t13, t15);
+    constexpr int n_sched = (int)(sizeof(FQ_PM3D4_SW) / sizeof(FQ_PM3D4_SW[0]));
 #pragma nounroll
-    for (int k = 2; k < 16; ++k) fq_mul(tab[k], tab[k - 1], tab[1]);
-    fq acc = tab[(FQ_PM3D4_EXP[11] >> 24) & 15u];  // bits 376..378: the top (non-zero) window
+    for (int i = 0; i < n_sched; ++i) {
+        const uint32_t e = FQ_PM3D4_SW[i];
+        const uint32_t n_sq = e & 0xFFu, v = e >> 8;
 #pragma nounroll
-    for (int i = 93; i >= 0; --i) {
-#pragma nounroll
-        for (int k = 0; k < 4; ++k) fq_sqr(acc, acc);
-        const uint32_t nb = (FQ_PM3D4_EXP[i >> 3] >> ((i & 7) * 4)) & 15u;
-        if (nb) fq_mul(acc, acc, tab[nb]);
+        for (uint32_t k = 0; k < n_sq; ++k) fq_sqr(acc, acc);
+        if (v) {
+            fq m;
+            fq_pick_odd(m, v, t1, t3, t5, t7, t9, t11, t13, t15);
+            fq_mul(acc, acc, m);
+        }
     }
     w = acc;
 }

@@ -176,7 +176,7 @@ __device__ __forceinline__ void g2_decompress_one(const uint64_t i, const uint8_
     }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restrict__ out_mont48,
                 uint8_t* __restrict__ out_be192, int32_t* __restrict__ status)
 {
@@ -186,7 +186,7 @@ k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restri
 }
 // Several arrays of signatures in ONE launch (the signature legs of consecutive streaming steps, engine_g1.cpp): a launch is as
 // long as one lane's chain of ~970 dependent products whatever its size, so the legs of B steps cost what one cost.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_g2_decompress_batch(const G2DecompressBatch b)
 {
     uint32_t k = 0;

@@ -1051,6 +1051,13 @@ class Engine:
         rows = [(_abi.KERNEL_NAMES[int(k[i])], float(t0[i]), float(dt[i])) for i in range(min(n.value, k.size))]
         return sorted(rows, key=lambda r: r[1])
 
+    def profile_queue_classes(self):
+        """pe_profile_queue_classes: for the engine / accumulation / tree / finish streams, the lowest of them that shares
+        its hardware queue -- [0, 1, 2, 3] when each has a queue of its own."""
+        out = np.zeros(4, dtype=np.int32)
+        self._check(self._lib.pe_profile_queue_classes(self._h, _ptr(out, C.c_int32)))
+        return [int(x) for x in out]
+
     def profile_reset(self):
         self._check(self._lib.pe_profile_reset(self._h))
 

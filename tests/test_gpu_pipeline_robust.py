@@ -246,3 +246,25 @@ def test_two_aggregates_with_process_attestation_between(engine_factory, dev_row
             assert np.array_equal(gp[:ng], rp[:ng]) and np.array_equal(gn[:ng], rn[:ng]), rep
         assert np.array_equal(e.participation_get(0), ref_part[0]), rep
         assert np.array_equal(e.participation_get(1), ref_part[1]), rep
+
+
+def test_a_handles_hot_streams_get_a_hardware_queue_each_whatever_was_created_before():
+    """The runtime maps streams onto four hardware queues in creation order and a queue runs its packets in order: a handle
+    created after other streams -- torch's, another handle's -- used to share queues with ITSELF (round 5: its finish kernel in
+    its row chain's queue, 308 us per slot-step instead of 120).  pe_engine_create now asks the device which of its streams
+    share a queue and keeps four that do not (engine_core.cpp: probe_queue_classes); pe_profile_queue_classes asks again."""
+    import torch
+
+    torch.zeros(8, device="cuda").add_(1)             # work on torch's null stream
+    side = [torch.cuda.Stream() for _ in range(3)]    # ... and three more streams of the host's own
+    for s in side:
+        with torch.cuda.stream(s):
+            torch.zeros(8, device="cuda").add_(1)
+    torch.cuda.synchronize()
+    first = pea.Engine()
+    second = pea.Engine()                             # beside another handle AND the host's streams
+    for e in (first, second):
+        assert e.profile_queue_classes() == [0, 1, 2, 3], "two of the handle's hot streams share a hardware queue"
+    first.close()
+    second.close()
+    del side

@@ -124,11 +124,13 @@ def test_config5_shape_aggregate_2048_committees_of_2048_over_4m_registry(engine
         assert agg["aggpk96"][g].tobytes() == synth.registry_closed_form(mem[agg["bits"][g]]), g
 
 
-@pytest.mark.parametrize("shape,lag,n_epochs,boost", [("configs1", 2, 3, False), ("configs1", 4, 5, False), ("configs1", 4, 5, True),
-                                                      ("configs2", 2, 3, False), ("configs2", 4, 3, True),
-                                                      ("configs3", 2, 3, False), ("configs3", 4, 3, False),
-                                                      ("configs4", 4, 2, False)])
-def test_the_timed_path_against_the_oracle(shape, lag, n_epochs, boost):
+@pytest.mark.parametrize("shape,lag,n_epochs,boost,tree_kind", [
+    ("configs1", 2, 3, False, None), ("configs1", 4, 5, False, None), ("configs1", 4, 5, True, None),
+    ("configs2", 2, 3, False, None), ("configs2", 4, 3, True, None),
+    ("configs2", 4, 3, False, "chain"), ("configs2", 2, 3, True, "chain"),   # SURVEY 8(d) c3's worst case: ONE chain, 4096 deep
+    ("configs3", 2, 3, False, None), ("configs3", 4, 3, False, None), ("configs3", 4, 3, True, None),
+    ("configs4", 4, 2, False, None)])
+def test_the_timed_path_against_the_oracle(shape, lag, n_epochs, boost, tree_kind):
     """The path bench.py TIMES -- attestation rows and bits resident in HBM (PE_ROWS_RESIDENT: grouped, resolved and validated
     on the device), streaming pipelines whose outputs complete `lag` steps later, pe_get_head_async -- held against the C
     oracle DIRECTLY, on bench.build_workload's own workload at the BASELINE configs[1..4] shapes (configs[2] with its
@@ -138,16 +140,19 @@ def test_the_timed_path_against_the_oracle(shape, lag, n_epochs, boost):
     the oracle; the -m gpu tests held it against the host-row path.)  Round 5: configs[1] on SURVEY 8(d)'s 2048-block
     branchy chain, configs[4] with its 1 % equivocating validators (pe:1438 and A.1's mask inside the timed path), and
     `boost`: proposer_boost_root set on a leaf behind every step's on_tick (pe:1020-1024; the oracle's head and weights
-    carry the same boost)."""
+    carry the same boost).  Round 6: configs[2] also on the 4096-deep single chain SURVEY 8(d) names as c3's worst case (the
+    paired lean tree k_pair_union_tree<512, 8, true> walks it in the streaming steps), and the boost at configs[3]."""
     import types
 
     cfg = bench.SHAPES[shape]
     args = types.SimpleNamespace(validators_local=cfg["validators"], blocks=cfg["blocks"], committees=cfg["committees"], parts=4,
                                  mixed_balances=cfg["mixed_balances"], host_arena=False, host_rows=False, with_shuffle=False,
-                                 by_committee=False, world=1, shuffle_variant_from=n_epochs, tree_kind=cfg["tree_kind"],
-                                 equivocating_frac=cfg["equivocating_frac"], boost=boost)
+                                 by_committee=False, world=1, shuffle_variant_from=n_epochs,
+                                 tree_kind=tree_kind or cfg["tree_kind"], equivocating_frac=cfg["equivocating_frac"], boost=boost)
     e = pea.Engine(max_committee_tables=n_epochs + 3)
     w = bench.build_workload(e, args, 0, n_epochs)
+    if tree_kind == "chain":
+        assert int((w["tree"].parent[1:] == np.arange(cfg["blocks"] - 1)).sum()) == cfg["blocks"] - 1, "one chain, every block on it"
     assert all("rows_in" in st and "arena_in" in st for st in w["steps"])
     assert (w["equivocating"] is not None and len(w["equivocating"]) == cfg["validators"] // 100) == (shape == "configs4")
     assert all(("boost_idx" in st) == boost for st in w["steps"])

@@ -43,4 +43,58 @@ for k,v in d.items():
   done
 }
 
+# call d: collected signature legs -- their tests, the signed step at 1 / 4 / 8 steps per decompression on one box; the bench's
+# unaggregated-signature leg under the profiler (why 45 ms there when the kernel takes 15 alone); the skip diagnostic of call c
+# again, this time under the kernel trace (real durations, not the engine's events)
+call_d() {
+  O=gpurun_out/r06d; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pairing.py tests/test_gpu_g2.py -x -q > $O/pytest_sig.log 2>&1; echo "[r06d] pairing + g2 tests rc $?"; tail -6 $O/pytest_sig.log
+  for b in 4 1 8; do
+    POSEVO_SIG_BATCH=$b timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant > $O/bench_sig$b.json 2> $O/bench_sig$b.err
+    echo "[r06d] sig batch $b: rc $? $(python - <<PY
+import json
+d=json.loads(open("$O/bench_sig$b.json").read().strip().splitlines()[-1])
+s=d.get("with_signatures",{}); u=d.get("with_unaggregated_signatures",{})
+print("ms/step", round(d["ms_per_step"],4), "signed", d.get("ms_per_step_with_signatures"), "verified", s.get("steps_verified"), "| unagg ms/epoch", u.get("ms_per_epoch"), u.get("error"))
+PY
+)"
+  done
+  cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+  rm -rf $O/prof; timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o b -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant --no-verify-steps --no-oracle-check > $O/bench_rocprof.json 2> $O/bench_rocprof.err
+  timeout 120 python tools/rocpd_stats.py $O/prof/b_results.db $O/bench_kernel_stats.txt > /dev/null 2>&1; cut -c1-150 $O/bench_kernel_stats.txt | head -30; rm -rf $O/prof
+  export POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_dbg.so
+  for k in 0 1 2; do
+    rm -rf $O/prof; POSEVO_DBG_SKIP=$k timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o s -- python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant --no-signed-steps --no-verify-steps --no-oracle-check > $O/bench_skip$k.json 2> $O/bench_skip$k.err
+    timeout 120 python tools/rocpd_stats.py $O/prof/s_results.db $O/skip${k}_kernel_stats.txt > /dev/null 2>&1; echo "== skip $k"; cut -c1-150 $O/skip${k}_kernel_stats.txt | head -12; rm -rf $O/prof
+  done
+  unset POSEVO_LIB_PATH
+}
+
+# call e: the legs' stream no longer joined into the tree's; fq_pow_pm3d4 with its table in registers (no scratch); the timed
+# path on the 4096-deep chain and with the boost at configs[3]; the skip diagnostic with no-op kernels in place of tree / finish
+# (every event and dependency as in the real run)
+call_e() {
+  O=gpurun_out/r06e; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pairing.py tests/test_gpu_g2.py tests/test_gpu_keyvalidate.py -x -q > $O/pytest_sig.log 2>&1; echo "[r06e] pairing + g2 tests rc $?"; tail -6 $O/pytest_sig.log
+  timeout 1200 python -m pytest tests/test_gpu_shapes.py -x -q -k "timed_path or signed_steps" > $O/pytest_shapes.log 2>&1; echo "[r06e] shapes tests rc $?"; tail -6 $O/pytest_shapes.log
+  timeout 300 python tools/sig_epoch.py --calls 3 > $O/sig_epoch_plain.txt 2>&1; cat $O/sig_epoch_plain.txt
+  for b in 4 1 8; do
+    POSEVO_SIG_BATCH=$b timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant > $O/bench_sig$b.json 2> $O/bench_sig$b.err
+    echo "[r06e] sig batch $b: rc $? $(python - <<PY
+import json
+d=json.loads(open("$O/bench_sig$b.json").read().strip().splitlines()[-1])
+s=d.get("with_signatures",{}); u=d.get("with_unaggregated_signatures",{})
+print("ms/step", round(d["ms_per_step"],4), "signed", d.get("ms_per_step_with_signatures"), "verified", s.get("steps_verified"), "| unagg ms/epoch", u.get("ms_per_epoch"), u.get("roofline_valu",{}).get("frac"), u.get("error"))
+PY
+)"
+  done
+  cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+  export POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_dbg.so
+  for k in 0 1 2 3; do
+    rm -rf $O/prof; POSEVO_DBG_SKIP=$k timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o s -- python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant --no-signed-steps --no-verify-steps --no-oracle-check > $O/bench_skip$k.json 2> $O/bench_skip$k.err
+    timeout 120 python tools/rocpd_stats.py $O/prof/s_results.db $O/skip${k}_kernel_stats.txt > /dev/null 2>&1; echo "== skip $k: $(timeout 20 python tools/benchline.py < $O/bench_skip$k.json | cut -c1-60)"; grep -E "k_g1_accumulate|k_g1_finish|k_g1_tree|k_dbg|k_pair" $O/skip${k}_kernel_stats.txt | cut -c1-150; rm -rf $O/prof
+  done
+  unset POSEVO_LIB_PATH
+}
+
 "call_$1"
