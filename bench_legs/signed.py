@@ -45,7 +45,7 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
     # launch lasts keeps the host from waiting for it (include/posevo.h: pe_pipeline_set_lag; 7 is the deepest)
     sig_lag = max(lag, 7)
     e.set_pipeline_lag(sig_lag)
-    e.reuse_outputs(len(steps) + 2)
+    e.reuse_outputs(max(len(steps), sig_lag) + 2)
     got = [run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev) for st in steps[:n_warm]]
     e.drain()
     e.fill_ring()

@@ -175,13 +175,16 @@ hipStream_t state_stream_unordered(pe_engine* h)
     h->A().aux_used = true;
     return h->aux_stream;
 }
-// The stream of the signature legs: the handle's own state-transition stream where it has one, else created at the first leg.
+// The stream of the signature legs: the handle's own state-transition stream where it has one, else created at the first leg --
+// at the LEAST priority: the runtime keeps a set of hardware queues per priority level, so the legs' ~1 ms decompressions get a
+// queue that none of the engine's four hot streams shares (as a fifth normal-priority stream it landed in the tree's queue, and
+// every G1 tree, flag pass and finish of four steps stood behind each decompression: profiles/r06_engine_timeline_signed_before.txt).
 hipStream_t leg_stream(pe_engine* h)
 {
     if (!h->aux_owned) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&h->aux_owned, hipStreamNonBlocking, (lo + hi) / 2) != hipSuccess) {
+        if (hipStreamCreateWithPriority(&h->aux_owned, hipStreamNonBlocking, lo) != hipSuccess) {
             (void)hipGetLastError();
             h->aux_owned = nullptr;
             return h->aux_stream ? h->aux_stream : h->stream;

@@ -141,12 +141,24 @@ int sig_batch_flush(pe_engine* h)
         ProfScope ps(h, PE_KERNEL_G2_DECOMPRESS, ss);
         launch_g2_decompress_batch(ss, b);
     }
+    G2AggregateRowsBatch r{};
     for (auto& sg : segs) {
         if (sg.check_subgroup) launch_g2_subgroup_check(ss, sg.d_pts, sg.n, sg.d_status);
-        {
-            ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
-            launch_g2_aggregate_rows(ss, sg.d_pts, sg.d_status, sg.d_ug, sg.d_member_row, sg.ng_bound, sg.plan_dev, sg.o_sig, sg.o_bad);
-        }
+        r.pts[r.count] = sg.d_pts;
+        r.status[r.count] = sg.d_status;
+        r.ug[r.count] = sg.d_ug;
+        r.member_row[r.count] = sg.d_member_row;
+        r.plan_dev[r.count] = sg.plan_dev;
+        r.out96[r.count] = sg.o_sig;
+        r.out_bad[r.count] = sg.o_bad;
+        r.n_groups[r.count] = sg.ng_bound;
+        ++r.count;
+    }
+    {
+        ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
+        launch_g2_aggregate_rows(ss, r);
+    }
+    for (auto& sg : segs) {
         HIP_TRY(h, hipMemcpyAsync(sg.o_st, sg.d_status, 4ull * sg.n, hipMemcpyDeviceToHost, ss));
         if (ss != h->stream) {  // the leg's own mark: whoever completes its arena (or rewrites the arena's scratch) waits for it
             pe_engine::PipeArena& a = h->arena[sg.arena];

@@ -5,6 +5,9 @@
 
 namespace posevo {
 
+#ifndef POSEVO_POW_INLINE
+#define POSEVO_POW_INLINE __noinline__
+#endif
 static __device__ const uint32_t FP_HALF[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
                                                 0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};     // (p-1)/2
 
@@ -48,7 +51,7 @@ __device__ __forceinline__ void fp_half(fp& r, const fp& a)
 // residue, (a w)^2 = -a and (a w) w = -1.
 // The chain itself runs in the 29-bit form (fp381_s29.h, fq_pow_pm3d4: why, and the windows); Montgomery words in, canonical
 // Montgomery words out, one product each way.
-__device__ __noinline__ void fp_pow_pm3d4(fp& w, const fp& a)
+__device__ POSEVO_POW_INLINE void fp_pow_pm3d4(fp& w, const fp& a)
 {
     fq x, r;
     fq_from_mont32(x, a.l);

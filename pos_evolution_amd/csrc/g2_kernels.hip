@@ -13,6 +13,12 @@
 // (Round 4 measured this file's kernels with their Fp products as CALLS, like g1_kernels.hip's -- DESIGN.md 3.8: k_g2_accumulate
 // 1.222 ms against 1.218 ms inlined, 2048 x 512 points (gpurun_out/r04g2): its five LDS tree levels of 26 dependent products
 // are what it waits for, not instruction fetch.  The inlined form stays: no scratch.)
+// The square roots' exponentiation inlined into this file's kernels: as a call it cost the decompression 208-448 bytes of scratch
+// per lane (what lives across the call), i.e. 110-235 MB for a chip full of waves, which the runtime hands out per dispatch when
+// it exceeds its 140 MiB bound (the kernel took 15 ms, the call around it 35-50: profiles/r06_sig_*).  Inlined: no scratch.
+#ifndef POSEVO_POW_INLINE
+#define POSEVO_POW_INLINE __forceinline__
+#endif
 #include "g2.h"
 #include "fp_sqrt.h"
 #include "kernels.h"
@@ -176,7 +182,7 @@ __device__ __forceinline__ void g2_decompress_one(const uint64_t i, const uint8_
     }
 }
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restrict__ out_mont48,
                 uint8_t* __restrict__ out_be192, int32_t* __restrict__ status)
 {
@@ -186,7 +192,7 @@ k_g2_decompress(const uint8_t* __restrict__ in96, uint64_t n, uint32_t* __restri
 }
 // Several arrays of signatures in ONE launch (the signature legs of consecutive streaming steps, engine_g1.cpp): a launch is as
 // long as one lane's chain of ~970 dependent products whatever its size, so the legs of B steps cost what one cost.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_g2_decompress_batch(const G2DecompressBatch b)
 {
     uint32_t k = 0;
@@ -546,13 +552,13 @@ void launch_g2_mask_bad(hipStream_t s, uint32_t* points_mont48, uint64_t n, cons
 // 96-byte COMPRESSED BLSSignature (x.c1 | x.c0, flag bits: 0x80 compressed, 0x40 infinity, 0x20 y is the larger root)
 // and bad[g] = number of members whose signature did not decode (status != 0; they are left out of the sum -- the caller
 // clears PE_ATT_FLAG_SIGNATURE_VALID on the row).
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_g2_aggregate_rows(const uint32_t* __restrict__ pts, const int32_t* __restrict__ status,
-                    const UnionGroup* __restrict__ ug, const uint32_t* __restrict__ member_row, uint32_t n_groups,
-                    const AttPlan* __restrict__ plan_dev, uint8_t* __restrict__ out96, uint32_t* __restrict__ out_bad)
+__device__ __forceinline__ void g2_aggregate_rows_body(const uint32_t lane, const uint32_t* __restrict__ pts,
+                                                       const int32_t* __restrict__ status, const UnionGroup* __restrict__ ug,
+                                                       const uint32_t* __restrict__ member_row, uint32_t n_groups,
+                                                       const AttPlan* __restrict__ plan_dev, uint8_t* __restrict__ out96,
+                                                       uint32_t* __restrict__ out_bad)
 {
-    if (plan_dev) n_groups = plan_dev->n_groups;
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (plan_dev) n_groups = min(n_groups, plan_dev->n_groups);
     const uint32_t g = lane >> 1;
     const bool role = lane & 1;
     if (g >= n_groups) return;
@@ -594,14 +600,27 @@ k_g2_aggregate_rows(const uint32_t* __restrict__ pts, const int32_t* __restrict_
     fp_store_be48(ox, x);
     if (role) o[0] |= (uint8_t)(0x80 | (sign ? 0x20 : 0));
 }
-
-void launch_g2_aggregate_rows(hipStream_t s, const uint32_t* points_mont48, const int32_t* status, const UnionGroup* ug,
-                              const uint32_t* member_row, uint32_t n_groups, const AttPlan* plan_dev, uint8_t* out96,
-                              uint32_t* out_bad)
+// the legs of up to G2_BATCH_MAX steps in one launch (first_block is filled by the launcher): the kernel is one chain of a few
+// additions and one normalisation deep -- ~180 us whether it serves one step's groups or eight steps'
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_g2_aggregate_rows(const G2AggregateRowsBatch b)
 {
-    if (n_groups == 0) return;
-    hipLaunchKernelGGL(k_g2_aggregate_rows, dim3((2 * n_groups + 63) / 64), dim3(64), 0, s, points_mont48, status, ug,
-                       member_row, n_groups, plan_dev, out96, out_bad);
+    uint32_t k = 0;
+    while (k + 1 < b.count && blockIdx.x >= b.first_block[k + 1]) ++k;
+    g2_aggregate_rows_body((blockIdx.x - b.first_block[k]) * 64 + threadIdx.x, b.pts[k], b.status[k], b.ug[k], b.member_row[k],
+                           b.n_groups[k], b.plan_dev[k], b.out96[k], b.out_bad[k]);
+}
+
+void launch_g2_aggregate_rows(hipStream_t s, G2AggregateRowsBatch& b)
+{
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < b.count; ++k) {
+        b.first_block[k] = blocks;
+        blocks += (2 * b.n_groups[k] + 63) / 64;
+    }
+    b.first_block[b.count] = blocks;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_g2_aggregate_rows, dim3(blocks), dim3(64), 0, s, b);
 }
 
 }  // namespace posevo

@@ -364,11 +364,15 @@ void launch_g2_subgroup_check(hipStream_t s, const uint32_t* points_mont48, uint
 void launch_g2_mask_bad(hipStream_t s, uint32_t* points_mont48, uint64_t n, const int32_t* status);
 // the signature leg of pe_aggregate: per group the sum of its members' signature points (rows member_row[list_start ..
 // + n_atts) of `ug`), compressed to the 96-byte BLSSignature wire form; out_bad[g] = members that did not decode
+// (for the legs of up to G2_BATCH_MAX steps in one launch; n_groups bounds plan_dev's count; first_block is filled by the launcher)
 struct UnionGroup;
 struct AttPlan;
-void launch_g2_aggregate_rows(hipStream_t s, const uint32_t* points_mont48, const int32_t* status, const UnionGroup* ug,
-                              const uint32_t* member_row, uint32_t n_groups, const AttPlan* plan_dev, uint8_t* out96,
-                              uint32_t* out_bad);
+struct G2AggregateRowsBatch {
+    const uint32_t* pts[G2_BATCH_MAX]; const int32_t* status[G2_BATCH_MAX]; const UnionGroup* ug[G2_BATCH_MAX];
+    const uint32_t* member_row[G2_BATCH_MAX]; const AttPlan* plan_dev[G2_BATCH_MAX]; uint8_t* out96[G2_BATCH_MAX];
+    uint32_t* out_bad[G2_BATCH_MAX]; uint32_t n_groups[G2_BATCH_MAX]; uint32_t first_block[G2_BATCH_MAX + 1]; uint32_t count;
+};
+void launch_g2_aggregate_rows(hipStream_t s, G2AggregateRowsBatch& b);
 
 // get_indexed_attestation: sorted attesting indices per row, written at out_offsets[row] (committees <= 8192 members)
 void launch_indexed_attestations(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,

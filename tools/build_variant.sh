@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/pos_evolution_amd/csrc
 OUT=$ROOT/build/variants; mkdir -p "$OUT/$NAME"
 make -C "$SRC" -j8 > /dev/null
-for k in att_kernels g1_kernels g2_kernels fc_kernels shuffle_kernels; do
+for k in att_kernels g1_kernels g2_kernels fc_kernels shuffle_kernels pair_kernels; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$SRC/$k.hip" -o "$OUT/$NAME/$k.o" &
 done
 wait

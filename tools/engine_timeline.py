@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--cold", type=int, default=0,
                     help="K > 0: the picture of a K-step run that starts from a drained engine and ends with its drain (what a\n"
                          "short timed region pays for ramp and drain): every accumulation's start / end and the last kernel's end")
+    ap.add_argument("--signed", action="store_true",
+                    help="pe_aggregate_signed in pe_aggregate's place (one compressed signature per row, resident in HBM)")
     a = ap.parse_args()
 
     import torch
@@ -48,16 +50,24 @@ def main():
     w = bench.build_workload(e, args, 0, a.steps)
     e.set_pipeline_lag(a.lag)
     e.reuse_outputs(a.lag + 2)
+    sigs = None
+    if a.signed:
+        import pos_evolution_amd.synth as synth
+        from pos_evolution_amd import DeviceArena
+
+        sg = synth.signature_points(e, len(w["steps"][0]["atts"]))
+        sig_t = torch.from_numpy(sg.reshape(-1).copy()).cuda()
+        sigs = DeviceArena(sig_t.data_ptr(), sig_t.numel(), keep=sig_t)
     warm = max(a.lag + 2, a.steps - a.show - a.lag - 2)
     if a.cold:
         warm = a.steps - a.cold
     for s in range(warm):
-        bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False)
+        bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False, sigs=sigs)
     e.drain()
     e.profile_enable(2)
     e.profile_reset()              # time zero
     for s in range(warm, a.steps):
-        bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False)
+        bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False, sigs=sigs)
     e.drain()
     tl = e.profile_timeline()
     e.profile_enable(0)

@@ -97,4 +97,52 @@ PY
   unset POSEVO_LIB_PATH
 }
 
+# call f: the queue probe's test; the signed step's own timeline (what holds it at 1 ms); the cold 20-step picture of the
+# headline; the skip diagnostic once more, skipping only inside the streaming chain (the registry's points come from k_g1_finish too)
+call_f() {
+  O=gpurun_out/r06f; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pipeline_robust.py tests/test_gpu_pairing.py -x -q > $O/pytest_a.log 2>&1; echo "[r06f] robust + pairing tests rc $?"; tail -6 $O/pytest_a.log
+  timeout 600 python -m pytest tests/test_gpu_shapes.py -x -q -k "signed_steps" > $O/pytest_b.log 2>&1; echo "[r06f] signed bench test rc $?"; tail -4 $O/pytest_b.log
+  timeout 300 python tools/engine_timeline.py --signed --lag 7 --steps 30 --show 8 > $O/engine_timeline_signed.txt 2>&1; tail -130 $O/engine_timeline_signed.txt | cut -c1-60
+  timeout 300 python tools/engine_timeline.py --cold 20 --steps 26 > $O/engine_timeline_cold20.txt 2>&1; head -30 $O/engine_timeline_cold20.txt
+  bash tools/gpu.sh r06f label:probe driver quick
+  POSEVO_QUEUE_PROBE=0 bash tools/gpu.sh r06f label:noprobe driver
+  cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+  export POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_dbg.so
+  for k in 0 1 3 2; do
+    rm -rf $O/prof; POSEVO_DBG_SKIP=$k timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o s -- python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant --no-signed-steps --no-verify-steps --no-oracle-check > $O/bench_skip$k.json 2> $O/bench_skip$k.err
+    timeout 120 python tools/rocpd_stats.py $O/prof/s_results.db $O/skip${k}_kernel_stats.txt > /dev/null 2>&1; echo "== skip $k: $(timeout 20 python tools/benchline.py < $O/bench_skip$k.json | cut -c1-60)"; grep -E "k_g1_accumulate|k_g1_finish|k_g1_tree|k_dbg" $O/skip${k}_kernel_stats.txt | cut -c1-150; rm -rf $O/prof
+  done
+  unset POSEVO_LIB_PATH
+}
+
+# call g: the legs' stream at the least priority (a hardware queue of the low-priority set, shared with none of the hot
+# streams), one k_g2_aggregate_rows launch per batch; the square roots' exponentiation inlined (no scratch) against the called
+# form (build/variants/libposevo_pownoinline.so) in the unaggregated-signature leg
+call_g() {
+  O=gpurun_out/r06g; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pairing.py tests/test_gpu_g2.py tests/test_gpu_keyvalidate.py -x -q > $O/pytest_sig.log 2>&1; echo "[r06g] pairing + g2 tests rc $?"; tail -6 $O/pytest_sig.log
+  timeout 300 python tools/engine_timeline.py --signed --lag 7 --steps 30 --show 8 > $O/engine_timeline_signed.txt 2>&1; tail -24 $O/engine_timeline_signed.txt | cut -c1-70; grep -c g2_decompress $O/engine_timeline_signed.txt
+  for b in 4 8; do
+    POSEVO_SIG_BATCH=$b timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant > $O/bench_sig$b.json 2> $O/bench_sig$b.err
+    echo "[r06g] sig batch $b: rc $? $(python - <<PY
+import json
+d=json.loads(open("$O/bench_sig$b.json").read().strip().splitlines()[-1])
+s=d.get("with_signatures",{}); u=d.get("with_unaggregated_signatures",{})
+print("ms/step", round(d["ms_per_step"],4), "signed", d.get("ms_per_step_with_signatures"), "beside", s.get("ms_per_step_beside_another_handle"), "verified", s.get("steps_verified"), "| unagg ms/epoch", u.get("ms_per_epoch"), u.get("roofline_valu",{}).get("frac"), u.get("error"))
+PY
+)"
+  done
+  POSEVO_LIB_PATH=$PWD/build/variants/libposevo_pownoinline.so timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant > $O/bench_pownoinline.json 2> $O/bench_pownoinline.err
+  python - <<PY
+import json
+d=json.loads(open("$O/bench_pownoinline.json").read().strip().splitlines()[-1])
+u=d.get("with_unaggregated_signatures",{})
+print("[r06g] called pow (208 B of scratch): signed", d.get("ms_per_step_with_signatures"), "unagg ms/epoch", u.get("ms_per_epoch"), u.get("roofline_valu",{}).get("frac"))
+PY
+  timeout 300 python tools/sig_epoch.py --calls 3 2>&1 | grep call
+  POSEVO_LIB_PATH=$PWD/build/variants/libposevo_pownoinline.so timeout 300 python tools/sig_epoch.py --calls 3 2>&1 | grep call
+  bash tools/gpu.sh r06g label:all tests
+}
+
 "call_$1"
