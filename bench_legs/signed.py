@@ -41,9 +41,9 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
     sigs = synth.signature_points(e, n_rows, a, b)            # row i signs with (a + i * b) * G2
     sig_t = torch.from_numpy(sigs.reshape(-1).copy()).cuda()
     sig_dev = DeviceArena(sig_t.data_ptr(), sig_t.numel(), keep=sig_t)
-    # the legs of POSEVO_SIG_BATCH (4) steps share one decompression launch of ~0.95 ms: a lag depth of batch + the ~3-4 steps that
-    # launch lasts keeps the host from waiting for it (include/posevo.h: pe_pipeline_set_lag; 7 is the deepest)
-    sig_lag = max(lag, 7)
+    # the legs of POSEVO_SIG_BATCH (8) steps share one decompression launch of ~0.95 ms: a lag depth of batch + the ~4-5 steps that
+    # launch and the sums behind it last keeps the host from waiting for it (include/posevo.h: pe_pipeline_set_lag; 15 is the deepest)
+    sig_lag = max(lag, 15)
     e.set_pipeline_lag(sig_lag)
     e.reuse_outputs(max(len(steps), sig_lag) + 2)
     got = [run_step_single(e, w, st, lagged=True, sync_head=False, sigs=sig_dev) for st in steps[:n_warm]]
@@ -85,7 +85,7 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
         "ms_per_step_with_signatures": dt / n_timed * 1e3,
         "attestations_per_s": n_att / dt,
         "signatures_per_step": n_rows,
-        "steps": n_timed, "warmup": n_warm, "lag": sig_lag, "steps_per_decompression": int(os.environ.get("POSEVO_SIG_BATCH", "4")),
+        "steps": n_timed, "warmup": n_warm, "lag": sig_lag, "steps_per_decompression": int(os.environ.get("POSEVO_SIG_BATCH", "8")),
         "detail": ("pe_aggregate_signed in pe_aggregate's place: one compressed BLSSignature (96 B, resident in HBM) per partial "
                    "aggregate -> k_g2_decompress (an Fp2 square root each; ONE launch for the legs of `steps_per_decompression` "
                    "consecutive steps) -> per-group G2 sums -> compressed aggregate signatures, on the signature legs' stream beside "
@@ -139,8 +139,11 @@ def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32
         got.append(e.aggregate_signatures(sig_dev, p["offsets"], index=p["index"]))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_call = []
     for p in prepared[n_warm:]:
+        t1 = time.perf_counter()
         got.append(e.aggregate_signatures(sig_dev, p["offsets"], index=p["index"]))
+        per_call.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_sig = int(sum(p["n"] for p in prepared[n_warm:]))
@@ -160,6 +163,7 @@ def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32
     ceiling = 68.6e9    # dependent S29 products per second, chip-wide (tools/fpbench29, profiles/r04_fpbench29.txt)
     return {
         "ms_per_epoch": dt / n_timed * 1e3,
+        "ms_per_call": [round(x, 2) for x in per_call],
         "signatures_per_s": n_sig / dt,
         "signatures_per_epoch": n_sig // n_timed,
         "committees": len(prepared[0]["lists"]),

@@ -10,6 +10,11 @@ Rccl& rccl()
     static Rccl r = [] {
         Rccl x;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // POSEVO_RCCL_PATH: the library to load instead (a deployment's own build; tests/native/stub_rccl.cpp, with which two
+        // processes sharing one GPU drive this file's RCCL path -- real RCCL refuses two ranks on one device)
+        if (const char* p = getenv("POSEVO_RCCL_PATH"))
+            if (*p) x.lib = dlopen(p, RTLD_NOW | RTLD_LOCAL);
+        if (!x.lib)
         for (const char* n : names)
             if ((x.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // one already in the process (torch's)
         if (!x.lib)

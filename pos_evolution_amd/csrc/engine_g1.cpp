@@ -119,13 +119,23 @@ int sig_batch_flush(pe_engine* h)
     segs.swap(h->sig_batch);
     const bool own = h->aux_stream && h->stream == h->own_stream;
     hipStream_t ss = own ? leg_stream(h) : h->stream;
+    // Where the decompression runs.  Beside an accumulation it starves it: both want the multiplier, the SIMDs' arbiters serve
+    // the older wave, and an accumulation that meets a decompression ends when that ends (0.8-1.2 ms instead of 0.2; round 4
+    // measured it, round 6 again with whole batches: profiles/r06_engine_timeline_signed_beside.txt).  A streaming caller's
+    // batch therefore goes onto the ACCUMULATIONS' stream, between two of them by stream order -- no event, no overlap: one
+    // ~1 ms launch per batch of steps is what the signatures cost the G1 chain; the latency-sized rest (sums, status copies)
+    // follows on the legs' own stream.
+    bool between = own && h->side_stream != nullptr;
+    for (auto& sg : segs) between = between && sg.streaming;
+    hipStream_t ds = between ? h->side_stream : ss;
     if (ss != h->stream) {  // behind the groupings (and the host signatures' copies) enqueued on the engine's stream so far
         HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
+        if (ds != ss) HIP_TRY(h, hipStreamWaitEvent(ds, h->ev_aux_fork, 0));
     }
     G2DecompressBatch b{};
     for (auto& sg : segs) {
-        if (sg.copy_from) HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(sg.d_in), sg.copy_from, sg.bytes, hipMemcpyDeviceToDevice, ss));
+        if (sg.copy_from) HIP_TRY(h, hipMemcpyAsync(const_cast<uint8_t*>(sg.d_in), sg.copy_from, sg.bytes, hipMemcpyDeviceToDevice, ds));
         if (sg.compressed) {
             b.in96[b.count] = sg.d_in;
             b.out_mont48[b.count] = sg.d_pts;
@@ -133,13 +143,17 @@ int sig_batch_flush(pe_engine* h)
             b.n[b.count] = sg.n;
             ++b.count;
         } else {
-            HIP_TRY(h, hipMemsetAsync(sg.d_status, 0, 4ull * sg.n, ss));
-            launch_g2_convert(ss, sg.d_in, sg.d_pts, sg.n);
+            HIP_TRY(h, hipMemsetAsync(sg.d_status, 0, 4ull * sg.n, ds));
+            launch_g2_convert(ds, sg.d_in, sg.d_pts, sg.n);
         }
     }
     if (b.count) {
-        ProfScope ps(h, PE_KERNEL_G2_DECOMPRESS, ss);
-        launch_g2_decompress_batch(ss, b);
+        ProfScope ps(h, PE_KERNEL_G2_DECOMPRESS, ds);
+        launch_g2_decompress_batch(ds, b);
+    }
+    if (ds != ss) {
+        HIP_TRY(h, hipEventRecord(h->ev_sig, ds));
+        HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_sig, 0));
     }
     G2AggregateRowsBatch r{};
     for (auto& sg : segs) {
@@ -482,6 +496,7 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
     PE_TRY(enter(h));
     if (n_groups == 0) return PE_OK;
     if (n >= 0xFFFFFFFFull / 48) return fail(h, PE_ERR_CAPACITY, "too many signatures");
+    HostLap lap(&h->trace);
     const uint32_t total = offsets[n_groups];
     for (uint32_t g = 0; g < n_groups; ++g)
         if (offsets[g + 1] < offsets[g]) return fail(h, PE_ERR_INVALID_ARG, "offsets not monotone");
@@ -510,7 +525,9 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
     HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(192, 192ull * n + 4ull * n + 4ull * n_groups + 64)));
     uint32_t* d_pts = h->d_tmp_points.as<uint32_t>();
     int32_t* d_status = reinterpret_cast<int32_t*>(h->d_tmp_points.as<uint8_t>() + 192ull * n);
+    lap.mark("usig.1_checks_scratch");
     launch_g2_decompress(s, d_in, n, d_pts, nullptr, d_status);  // a signature that does not decode becomes the (0, 0) row: infinity
+    lap.mark("usig.2_decompress_launch");
     if (sig_flags & PE_SIG_CHECK_SUBGROUP) {
         launch_g2_subgroup_check(s, d_pts, n, d_status);
         launch_g2_mask_bad(s, d_pts, n, d_status);  // a decoded point outside G2 is left out of its sum like an undecodable one
@@ -554,14 +571,18 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
         if (total) HIP_TRY(h, hipMemcpyAsync(index_local.data(), index, 4ull * total, hipMemcpyDeviceToHost, s));
         index_host = index_local.data();
     }
+    lap.mark("usig.3_plan_launch_copies");
     HIP_TRY(h, hipStreamSynchronize(s));
+    lap.mark("usig.4_wait");
     PE_TRY(pe_g2_compress(ob.host<uint8_t>(off_o), n_groups, out_signatures96));
+    lap.mark("usig.5_compress");
     if (out_bad)
         for (uint32_t g = 0; g < n_groups; ++g) {
             uint32_t bad = 0;
             for (uint32_t j = offsets[g]; j < offsets[g + 1]; ++j) bad += status_host[index_host ? index_host[j] : j] != 0;
             out_bad[g] = bad;
         }
+    lap.mark("usig.6_bad_counts");
     return PE_OK;
 }
 
@@ -600,6 +621,7 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
                                     out_bits_arena, out_arena_cap, nullptr, out_aggpk96, out_count);
     const bool dev_rows = rows_on_device(atts);
     const size_t sig_bytes = fmt == PE_SIG_G2_COMPRESSED ? 96 : 192;
+    HostLap lap(&h->trace);
     {   // the arena's signature scratch, sized while nothing of this call is in flight
         if (!h->pipelining) PE_TRY(flush_pending(h));
         pe_engine::PipeArena& A = h->A();
@@ -625,9 +647,11 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
         gof_p->resize(n);
         group_of = gof_p->data();
     }
+    lap.mark("sagg.1_prepare");
     const int rc = pe_aggregate(h, atts, n, bits_arena, arena_len, nullptr, out_atts, out_n_groups, group_of, out_bits_arena,
                                 out_arena_cap, nullptr, out_aggpk96, out_count);
     if (rc) return rc;
+    lap.mark("sagg.2_aggregate");
     pe_engine::PipeArena& A = h->A();
     const UnionGroup* d_ug = nullptr;
     const uint32_t* d_member_row = nullptr;
@@ -692,9 +716,13 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     seg.o_bad = ob.host<uint32_t>(off_bad);
     seg.o_st = ob.host<int32_t>(off_st);
     const bool collect = seg.compressed && h->streaming && h->pipelining && h->stream == h->own_stream && h->aux_stream != nullptr;
+    seg.streaming = collect && h->last_agg_on_side && h->side_stream != nullptr;
     h->sig_batch.push_back(seg);
-    if (!collect || h->sig_batch.size() >= (size_t)std::min<int>(std::max(h->tune.sig_batch, 1), (int)G2_BATCH_MAX))
+    lap.mark("sagg.3_leg_collect");
+    if (!collect || h->sig_batch.size() >= (size_t)std::min<int>(std::max(h->tune.sig_batch, 1), (int)G2_BATCH_MAX)) {
         PE_TRY(sig_batch_flush(h));
+        lap.mark("sagg.4_leg_flush");
+    }
     const size_t base = ob.base;
     const int ai = h->cur;
     auto complete = [h, ai, base, off_sig, off_bad, off_st, n, ng_bound, dev_rows, out_n_groups, out_atts, out_signatures96,

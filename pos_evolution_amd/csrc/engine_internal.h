@@ -269,7 +269,7 @@ struct pe_engine {
     };
     // lag depth L (pe_pipeline_set_lag, default 2) = L + 1 arenas in rotation: a lagged end waits for the pipeline L
     // back, never for the finish kernel of the one that has only just been fenced.  Arenas allocate on first use.
-    static constexpr int MAX_ARENAS = 8;
+    static constexpr int MAX_ARENAS = 16;
     int n_arenas = 3;
     PipeArena arena[MAX_ARENAS];
     int cur = 0;
@@ -302,6 +302,7 @@ struct pe_engine {
         int arena;                      // the arena (pipeline) whose pinned block takes the leg's outputs
         uint32_t n;
         bool compressed, check_subgroup;
+        bool streaming;                 // collected in a streaming step whose accumulations run on the side stream
         const uint8_t* d_in;            // wire bytes on the device (the caller's, or the arena's scratch)
         const uint8_t* copy_from;       // device-resident signatures at an address the kernel cannot read in place: copied first
         size_t bytes;
@@ -310,6 +311,7 @@ struct pe_engine {
         uint8_t* o_sig; uint32_t* o_bad; int32_t* o_st;
     };
     std::vector<SigSeg> sig_batch;
+    hipEvent_t ev_sig = nullptr;        // a batch's decompression is done (on the accumulations' stream) -> its sums may start
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool side_busy = false;             // the side stream holds work of the current arena nobody has waited for yet
     bool side_ever = false;             // ev_join has been recorded at least once
@@ -346,7 +348,7 @@ struct pe_engine {
         int state_on = env("POSEVO_STATE_ON", 1);
         // pe_aggregate_signed in streaming steps: how many steps' signature legs share one decompression launch (1 = a launch
         // per step, round 5's shape; at most G2_BATCH_MAX)
-        int sig_batch = env("POSEVO_SIG_BATCH", 4);
+        int sig_batch = env("POSEVO_SIG_BATCH", 8);
         // pe_engine_create asks the device which of its streams share a hardware queue and keeps four that do not (engine_core.cpp)
         int queue_probe = env("POSEVO_QUEUE_PROBE", 1);
     } tune;

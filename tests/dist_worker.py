@@ -51,6 +51,8 @@ def main():
     shard.set_proposer_boost(boost)   # the boost needs the GLOBAL active balance: carried by the all-reduce
 
     coll = HostStagedCollectives()
+    if len(sys.argv) > 3 and sys.argv[3].startswith("stubrccl"):
+        return stub_rccl_sharded(shard, whole, rank, world, sys.argv[3], dict(V=V, C=C, spe=spe, steps=steps + 2, tree=tree, lo=lo, hi=hi))
     if rows_mode == "committee":
         return committee_sharded(shard, whole, coll, rank, world, pipe_mode, dict(V=V, C=C, spe=spe, steps=steps, tree=tree,
                                                                                 bal=bal, flags=flags, pts=pts))
@@ -138,6 +140,83 @@ def main():
     digest = hashlib.sha256(ref_head).hexdigest()[:12]
     sys.stdout.write(f"DIST_WORKER_OK rank {rank} rows={rows_mode} pipe={pipe_mode} steps={steps} head={digest} "
                      f"collectives={coll.calls}\n")
+    sys.stdout.flush()
+    dist.destroy_process_group()
+
+
+def stub_rccl_sharded(shard, whole, rank, world, mode, W):
+    """The engine's OWN RCCL path (pe_dist_unique_id / pe_dist_init_ex: two communicators, or one with "stubrccl1") over
+    tests/native/libstub_rccl.so (POSEVO_RCCL_PATH), streaming lagged steps over device rows with held / paired launches.
+    The ranks run SKEWED: rank 1 drains after every step (its held launches and their collectives go out at once, alone),
+    rank 0 keeps its pipelines in flight (its collectives go out with the next aggregate, between paired launches) -- the order
+    of the collectives per communicator must be the same on both, or the synchronous stub dead-locks and times out.  Every
+    step of every rank against the unsharded twin; the ranks' call logs must agree line by line."""
+    import torch
+    import torch.distributed as dist
+
+    import pos_evolution_amd.synth as synth
+    from pos_evolution_amd import RESIDENT, ROWS_RESIDENT, DeviceArena, DeviceRows
+    from pos_evolution_amd._abi import pe_state_ctx
+    from tests.test_gpu_sharded import _local_attestations, _local_committees
+
+    V, C, spe, steps, tree, lo, hi = W["V"], W["C"], W["spe"], W["steps"], W["tree"], W["lo"], W["hi"]
+    ids = [shard.dist_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    shard.dist_init_ex(ids[0], rank, world, single_comm=mode.endswith("1"))
+    shard.dist_set_max_groups(C)
+    ep0 = int(tree.slot.max()) // spe + 1
+    keep, done = [], []
+    for s in range(steps):
+        ep = ep0 + s
+        comm = synth.random_committees(V, C, 100 + s)
+        lc = _local_committees(comm, lo, hi)
+        whole.set_committees(ep, comm.offsets, comm.members)
+        shard.set_committees(ep, lc.offsets, lc.members)
+        atts, arena, bit_rows = synth.epoch_attestations(comm, tree, ep, spe, seed=s, density=0.9, parts=2,
+                                                         source=(0, tree.roots[0].tobytes()), vote_recent=32)
+        la, larena = _local_attestations(atts, bit_rows, comm, lo, hi)
+        ctx = pe_state_ctx()
+        ctx.slot = (ep + 1) * spe
+        ctx.chain_tip_root[:] = tree.roots[tree.roots.shape[0] - 1].tobytes()
+        ctx.current_justified_root[:] = tree.roots[0].tobytes()
+        ctx.previous_justified_root[:] = tree.roots[0].tobytes()
+        ctx.base_reward_per_increment = 777
+        for e in (whole, shard):
+            e.on_tick((ep + 1) * spe * 12)
+            e.participation_rotate()
+        ref = whole.aggregate(packed=(atts, arena), want_aggregate_pubkeys=True)
+        st, _, cnt = whole.on_attestation_batch(packed=(ref["atts"], ref["out_arena"]))
+        ref_head, ref_w = whole.get_head(), whole.get_weights()
+        whole.process_attestation_batch(ctx, packed=(ref["atts"], ref["out_arena"]))
+        r = torch.from_numpy(la.view(np.uint8).reshape(-1)).cuda()
+        b = torch.from_numpy(larena).cuda()
+        keep.append((r, b))
+        with shard.pipeline(lagged=True):
+            agg = shard.aggregate_sharded(packed=(DeviceRows(r.data_ptr(), len(la), keep=r), DeviceArena(b.data_ptr(), b.numel(), keep=b)))
+            lst, _, lcnt = shard.on_attestation_batch(packed=(ROWS_RESIDENT, RESIDENT), cap=C)
+            head = shard.get_head_sharded_async()
+            lpst, _ = shard.process_attestation_batch(ctx, packed=(ROWS_RESIDENT, RESIDENT), cap=C)
+        done.append(dict(s=s, agg=agg, head=head, lst=lst, lpst=lpst, ref=ref, ref_head=ref_head, st=st))
+        if rank == 1 or s == steps - 1:
+            shard.drain()
+            assert np.array_equal(shard.last_weights(), ref_w), f"step {s}: reduced weights differ from the unsharded ones"
+            assert np.array_equal(shard.latest_messages()[1], whole.latest_messages()[1][lo:hi]), f"step {s}: latest messages"
+    for d in done:
+        g = d["ref"]["n_groups"]
+        assert d["agg"]["n_groups"] == g and bytes(d["head"]) == d["ref_head"], f"step {d['s']}: groups / head"
+        assert np.array_equal(np.asarray(d["agg"]["aggpk96"])[:g], d["ref"]["aggpk96"]), f"step {d['s']}: aggregate pubkeys"
+        assert (np.asarray(d["lst"])[:g] == 0).all() and (np.asarray(d["lpst"])[:g] == 0).all() and (d["st"] == 0).all()
+    shard.dist_destroy()
+    dist.barrier()
+    logs = [None] * world
+    mine = open(os.environ["STUB_RCCL_LOG"] + f".{rank}").read().split("\n")
+    dist.all_gather_object(logs, mine)
+    # communicator ordinals are per process (this process also created none before): the logs must agree line by line
+    assert all(lg == logs[0] for lg in logs), "the ranks issued their collectives in different order:\n" + "\n---\n".join("\n".join(x) for x in logs)
+    n_ar = sum(1 for x in mine if " allreduce " in x)
+    n_ag = sum(1 for x in mine if " allgather " in x)
+    assert n_ar >= steps and n_ag == steps, (n_ar, n_ag)
+    sys.stdout.write(f"DIST_WORKER_OK rank {rank} rows=device pipe=lagged coll={mode} steps={steps} all_reduce={n_ar} all_gather={n_ag}\n")
     sys.stdout.flush()
     dist.destroy_process_group()
 

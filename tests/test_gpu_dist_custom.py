@@ -22,3 +22,23 @@ def test_engine_owned_sharded_step_two_ranks_one_gpu(rows_mode, pipe_mode):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.count("DIST_WORKER_OK") == 2, out.stdout[-3000:] + "\n" + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("mode", ["stubrccl", "stubrccl1"])
+def test_the_engines_own_rccl_path_two_skewed_ranks_over_a_stub_librccl(mode, tmp_path):
+    """pe_dist_unique_id / pe_dist_init_ex (two communicators; "stubrccl1": PE_DIST_SINGLE_COMM), the collectives the engine
+    issues between its held and paired launches, pe_dist_destroy -- with TWO ranks, which real RCCL cannot give on one GPU
+    (it refuses two ranks per device): tests/native/stub_rccl.cpp stands in (POSEVO_RCCL_PATH), synchronous and therefore
+    stricter than RCCL about the order of collectives.  Rank 1 drains after every step, rank 0 only at the end
+    (tests/dist_worker.py: stub_rccl_sharded)."""
+    native = os.path.join(ROOT, "tests", "native")
+    lib, src = os.path.join(native, "libstub_rccl.so"), os.path.join(native, "stub_rccl.cpp")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-o", lib, src])
+    port = 29870 + (1 if mode.endswith("1") else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), "device", "lagged", mode]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", POSEVO_RCCL_PATH=lib, STUB_RCCL_LOG=str(tmp_path / "calls"),
+               STUB_RCCL_TIMEOUT_MS="20000", POSEVO_DIST_TIMEOUT_MS="30000")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("DIST_WORKER_OK") == 2, out.stdout[-3000:] + "\n" + out.stderr[-3000:]

@@ -145,4 +145,40 @@ PY
   bash tools/gpu.sh r06g label:all tests
 }
 
+# call h: where the host of the signed step waits (POSEVO_HOST_TRACE), the engine's RCCL path over the stub library with two
+# skewed ranks, the unaggregated leg call by call, the full default bench line (slot cadence included)
+call_h() {
+  O=gpurun_out/r06h; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_dist_custom.py -x -q -k "stub" > $O/pytest_stub.log 2>&1; echo "[r06h] stub rccl tests rc $?"; tail -25 $O/pytest_stub.log | cut -c1-220
+  POSEVO_HOST_TRACE=1 timeout 300 python tools/engine_timeline.py --signed --lag 7 --steps 30 --show 8 > $O/engine_timeline_signed.txt 2> $O/host_trace_signed.txt; grep "posevo host" $O/host_trace_signed.txt | cut -c1-120
+  bash tools/gpu.sh r06h label:full bench
+  python - <<PY
+import json
+d=json.loads(open("$O/bench_full_full.json").read().strip().splitlines()[-1])
+print("slot", d.get("slot_cadence")); print("unagg", {k:v for k,v in d.get("with_unaggregated_signatures",{}).items() if k!="detail"})
+print("signed", d.get("ms_per_step_with_signatures"), "shuffle", d.get("ms_per_step_with_shuffle"))
+PY
+}
+
+# call i: a batch's decompression on the accumulations' stream (between two of them), arena ring of up to 16 (lag 15), 8 steps
+# per decompression; the unaggregated leg's host phases in the bench and in tools/sig_epoch.py; the slot cadence's timeline
+call_i() {
+  O=gpurun_out/r06i; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pairing.py tests/test_gpu_g2.py tests/test_gpu_pipeline.py tests/test_gpu_pipeline_robust.py -x -q > $O/pytest_sig.log 2>&1; echo "[r06i] pairing + g2 + pipeline tests rc $?"; tail -6 $O/pytest_sig.log
+  timeout 300 python tools/engine_timeline.py --signed --lag 15 --steps 44 --show 12 > $O/engine_timeline_signed.txt 2>&1; tail -22 $O/engine_timeline_signed.txt | cut -c1-70
+  for b in 8 4; do
+    POSEVO_SIG_BATCH=$b POSEVO_HOST_TRACE=1 POSEVO_SLOT_TIMELINE=$O/slot_timeline_$b.txt timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-shuffle-variant > $O/bench_sig$b.json 2> $O/bench_sig$b.err
+    echo "[r06i] sig batch $b: rc $? $(python - <<PY
+import json
+d=json.loads(open("$O/bench_sig$b.json").read().strip().splitlines()[-1])
+s=d.get("with_signatures",{}); u=d.get("with_unaggregated_signatures",{})
+print("ms/step", round(d["ms_per_step"],4), "signed", d.get("ms_per_step_with_signatures"), "beside", s.get("ms_per_step_beside_another_handle"), "verified", s.get("steps_verified"), "| unagg", u.get("ms_per_call"), "| slot p50", d.get("slot_cadence",{}).get("slot_step_us_p50"))
+PY
+)"
+  done
+  grep "usig\." $O/bench_sig8.err | cut -c1-120
+  POSEVO_HOST_TRACE=1 timeout 300 python tools/sig_epoch.py --calls 4 2>&1 | grep "call\|usig" | cut -c1-120
+  sed -n 1,4p $O/slot_timeline_8.txt; awk 'NR>300 && NR<360' $O/slot_timeline_8.txt
+}
+
 "call_$1"
