@@ -97,7 +97,7 @@ def signed_steps(pea, w, device, n_warm, n_timed, lag):
 
 
 
-def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32):
+def unaggregated_signatures(pea, w, device, n_warm=3, n_timed=4, check_groups=32):
     """The epoch's UNAGGREGATED signatures (pe:717: every attester signs; pe:474 / pe:659 / pe:1536: aggregated per committee):
     one compressed 96-byte BLSSignature per validator resident in HBM (V x 96 bytes), the attesters of every committee as an
     index list resident in HBM -> pe_aggregate_signatures: k_g2_decompress over the whole chip (an Fp2 square root per
@@ -110,7 +110,10 @@ def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32
     import pos_evolution_amd.synth as synth
     from .cpu import cpu_step_inputs
 
-    steps = w["steps"][:n_warm + n_timed]
+    # n_warm = 3: the leg starts after seconds of host-side checking with the device idle; the first calls run at 2-3 x the
+    # steady time (allocations of the engine's scratch and pinned blocks, clocks coming back up): `ms_per_call` lists the timed
+    # calls one by one, `warmup_ms_per_call` the warm-up ones
+    steps = [w["steps"][k % len(w["steps"])] for k in range(n_warm + n_timed)]
     V = w["bal"].size
     e = pea.Engine(device=device)
     a, b, period = 0xABCDEF12345, 0x1357, 16384
@@ -134,9 +137,11 @@ def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32
         prepared.append(dict(lists=lists, offsets=offsets, index=DeviceArena(idx_t.data_ptr(), idx_t.numel() * 4, keep=idx_t),
                              n=int(index.size)))
     torch.cuda.synchronize()
-    got = []
+    got, warm_calls = [], []
     for p in prepared[:n_warm]:
+        t1 = time.perf_counter()
         got.append(e.aggregate_signatures(sig_dev, p["offsets"], index=p["index"]))
+        warm_calls.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     per_call = []
@@ -164,6 +169,7 @@ def unaggregated_signatures(pea, w, device, n_warm=1, n_timed=4, check_groups=32
     return {
         "ms_per_epoch": dt / n_timed * 1e3,
         "ms_per_call": [round(x, 2) for x in per_call],
+        "warmup_ms_per_call": [round(x, 2) for x in warm_calls],
         "signatures_per_s": n_sig / dt,
         "signatures_per_epoch": n_sig // n_timed,
         "committees": len(prepared[0]["lists"]),

@@ -150,6 +150,39 @@ int ensure_quiesced(pe_engine* h, DevBuf& b, size_t bytes)
     return PE_OK;
 }
 
+// The same for a buffer every arena of the rotation holds: when the current arena's copy has to grow, everything enqueued is
+// waited for once -- and then EVERY arena's copy grows, so that the steps of a stream look alike: an arena that grew at ITS
+// first use drained the pipeline once per arena (a lag depth of 15 means sixteen such steps; the signed leg of round 6 ran at
+// 1.5 ms per step until its three buffers grew together).
+int ensure_quiesced_arenas(pe_engine* h, DevBuf pe_engine::PipeArena::*m, size_t bytes)
+{
+    if (bytes <= (h->A().*m).cap) return PE_OK;
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    for (int i = 0; i < h->n_arenas; ++i) HIP_TRY(h, (h->arena[i].*m).ensure(bytes));
+    return PE_OK;
+}
+// ... and for the staging / output blocks, which grow without a device-wide wait: the arenas nothing is in flight on grow with
+// the current one (at the start of a stream that is all of them).
+void grow_idle_arenas(pe_engine* h, size_t stage_bytes, size_t out_bytes)
+{
+    for (int i = 0; i < h->n_arenas; ++i) {
+        pe_engine::PipeArena& o = h->arena[i];
+        if (i == h->cur || !o.pending.empty() || o.fenced || o.fence_pending || o.stage_cursor || o.out_cursor) continue;
+        if (h->held.active && h->held.arena == i) continue;
+        if (stage_bytes && (o.h_stage.cap < stage_bytes || o.d_stage.cap < stage_bytes)) {
+            (void)o.h_stage.ensure(stage_bytes);
+            (void)o.d_stage.ensure(stage_bytes);
+        }
+        if (out_bytes && (o.d_outblk.cap < out_bytes || o.h_pin.cap < out_bytes)) {
+            (void)o.d_outblk.ensure(out_bytes);
+            (void)o.h_pin.ensure(out_bytes);
+        }
+    }
+    (void)hipGetLastError();
+}
+
 // Entry of a call that is not part of the pipelined hot path: complete whatever the batch calls left enqueued.
 static int aux_quiesce(pe_engine* h)
 {

@@ -542,8 +542,15 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
     for (uint32_t g = 0; g < n_groups; ++g) gr[g].member_start = offsets[g];
     if (index && !idx_dev) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
     const uint32_t* d_index = !index ? nullptr : idx_dev ? index : st.dev<uint32_t>(off_i);
+    // statuses and (for the bad-member counts) a device-resident index come back through the PINNED output block: a copy
+    // into the caller's pageable memory is staged and pinned by the runtime page by page -- 2 x 4 MB cost the call 30 ms of
+    // its 50 in bench.py's process (profiles/r06_sig_host_phases.txt)
+    const bool want_status = sig_status != nullptr || out_bad != nullptr;
+    const bool want_index_back = out_bad != nullptr && idx_dev;
     OutBlock ob(h);
     const size_t off_o = ob.alloc(192ull * n_groups);
+    const size_t off_st = want_status ? ob.alloc(4ull * n) : 0;
+    const size_t off_ix = want_index_back ? ob.alloc(4ull * total) : 0;
     PE_TRY(ob.ensure());
     HIP_TRY(h, st.upload());
     HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(384, 384ull * plan.n_partials)));
@@ -556,25 +563,19 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
         launch_g2_finish(s, h->d_partials.as<uint32_t>(), st.dev<G1Group>(off_g), plan.n_groups, ob.dev<uint8_t>(off_o));
     }
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, ob.download());
-    std::vector<int32_t> status_local;
-    int32_t* status_host = sig_status;
-    if (!status_host && out_bad) {
-        status_local.resize(n);
-        status_host = status_local.data();
-    }
-    if (status_host && n) HIP_TRY(h, hipMemcpyAsync(status_host, d_status, 4ull * n, hipMemcpyDeviceToHost, s));
-    std::vector<uint32_t> index_local;
+    HIP_TRY(h, ob.download(off_o, 192ull * n_groups));
+    const int32_t* status_host = want_status ? ob.host<int32_t>(off_st) : nullptr;
+    if (want_status && n) HIP_TRY(h, hipMemcpyAsync(ob.host<int32_t>(off_st), d_status, 4ull * n, hipMemcpyDeviceToHost, s));
     const uint32_t* index_host = index;
-    if (out_bad && idx_dev) {  // the caller's index lives on the device: the bad-member counts need it here
-        index_local.resize(total);
-        if (total) HIP_TRY(h, hipMemcpyAsync(index_local.data(), index, 4ull * total, hipMemcpyDeviceToHost, s));
-        index_host = index_local.data();
+    if (want_index_back) {  // the caller's index lives on the device: the bad-member counts need it here
+        if (total) HIP_TRY(h, hipMemcpyAsync(ob.host<uint32_t>(off_ix), index, 4ull * total, hipMemcpyDeviceToHost, s));
+        index_host = ob.host<uint32_t>(off_ix);
     }
     lap.mark("usig.3_plan_launch_copies");
     HIP_TRY(h, hipStreamSynchronize(s));
     lap.mark("usig.4_wait");
     PE_TRY(pe_g2_compress(ob.host<uint8_t>(off_o), n_groups, out_signatures96));
+    if (sig_status && n) memcpy(sig_status, status_host, 4ull * n);
     lap.mark("usig.5_compress");
     if (out_bad)
         for (uint32_t g = 0; g < n_groups; ++g) {
@@ -625,9 +626,10 @@ int pe_aggregate_signed(pe_engine* h, const pe_attestation* atts, uint32_t n, co
     {   // the arena's signature scratch, sized while nothing of this call is in flight
         if (!h->pipelining) PE_TRY(flush_pending(h));
         pe_engine::PipeArena& A = h->A();
-        PE_TRY(ensure_quiesced(h, A.d_sig_in, sig_bytes * n));
-        PE_TRY(ensure_quiesced(h, A.d_sig_pts, 192ull * n));
-        PE_TRY(ensure_quiesced(h, A.d_sig_status, 4ull * n));
+        (void)A;
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_sig_in, sig_bytes * n));
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_sig_pts, 192ull * n));
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_sig_status, 4ull * n));
     }
     bool sig_on_device = false;
     {

@@ -547,6 +547,7 @@ uint32_t pack_bits(const uint8_t* src, uint32_t n_use, uint32_t* dst_words);
 // consecutive regions (nothing an enqueued copy or kernel still needs is overwritten); outside one the cursor is 0.
 // Growing a block re-allocates it, so a call reserves BEFORE it takes pointers, and a reservation that has to grow a
 // block with enqueued work behind it first waits for that work (flush_pending).
+void grow_idle_arenas(pe_engine* h, size_t stage_bytes, size_t out_bytes);  // engine_core.cpp
 struct Stage {
     pe_engine* h;
     size_t base, used = 0;
@@ -564,6 +565,7 @@ struct Stage {
             hipError_t e = h->A().h_stage.ensure(want);
             if (e == hipSuccess) e = h->A().d_stage.ensure(want);
             if (e != hipSuccess) return hip_fail(h, e, "staging block");
+            grow_idle_arenas(h, want, 0);
         }
         return PE_OK;
     }
@@ -605,6 +607,7 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
             hipError_t e = h->A().d_outblk.ensure(want);
             if (e == hipSuccess) e = h->A().h_pin.ensure(want);
             if (e != hipSuccess) return hip_fail(h, e, "output block");
+            grow_idle_arenas(h, 0, want);
         }
         return PE_OK;
     }
@@ -646,6 +649,8 @@ inline bool g1_chain_idle(const pe_engine* h)
 int finish_call(pe_engine* h, const Stage& st, const OutBlock& ob, std::function<int()> complete, bool force_sync = false);
 // A device buffer other enqueued work may still read: wait for that work before re-allocating it.
 int ensure_quiesced(pe_engine* h, DevBuf& b, size_t bytes);
+int ensure_quiesced_arenas(pe_engine* h, DevBuf pe_engine::PipeArena::*m, size_t bytes);  // ... of every arena of the rotation
+void grow_idle_arenas(pe_engine* h, size_t stage_bytes, size_t out_bytes);
 
 // ------------------------------------------------------------------ G1 plan
 constexpr uint32_t G1_TARGET_LANES = 131072;  // 2 waves per SIMD on 256 CUs

@@ -231,8 +231,13 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     PE_TRY(st.reserve((size_t)arena_len + 256));
     const size_t pad_at = ((size_t)arena_len + 15) & ~size_t(15);  // 32 zero bytes behind the bits, written by k_att_ingest
     const size_t off_arena = st.alloc(pad_at + 32);
-    PE_TRY(ensure_quiesced(h, RS.bits, words_cap * 4 + 64));
-    PE_TRY(ensure_quiesced(h, RS.info, 8ull * n + 64));
+    if (set == 0) {
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_res_bits, words_cap * 4 + 64));
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_res_info, 8ull * n + 64));
+    } else {
+        PE_TRY(ensure_quiesced(h, RS.bits, words_cap * 4 + 64));
+        PE_TRY(ensure_quiesced(h, RS.info, 8ull * n + 64));
+    }
     OutBlock ob(h);
     const size_t off_plan = ob.alloc(sizeof(AttPlan));
     const size_t off_rows = ob.alloc(sizeof(pe_attestation) * (size_t)n);
@@ -242,8 +247,8 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     const size_t off_opk = out_aggpk96 ? ob.alloc(96ull * n) : 0;
     PE_TRY(ob.ensure());
     if (want_pk) {  // scratch of the G1 chain, sized by the bounds before anything is in flight
-        PE_TRY(ensure_quiesced(h, A.d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
-        PE_TRY(ensure_quiesced(h, A.d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
         PE_TRY(ensure_quiesced(h, h->d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
         PE_TRY(ensure_quiesced(h, h->d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
     }

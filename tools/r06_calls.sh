@@ -181,4 +181,22 @@ PY
   sed -n 1,4p $O/slot_timeline_8.txt; awk 'NR>300 && NR<360' $O/slot_timeline_8.txt
 }
 
+# call j: arenas grow together (no per-arena first-use drain), statuses / index back through the pinned block
+call_j() {
+  O=gpurun_out/r06j; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pairing.py tests/test_gpu_g2.py tests/test_gpu_pipeline.py tests/test_gpu_pipeline_robust.py -x -q > $O/pytest_sig.log 2>&1; echo "[r06j] pairing + g2 + pipeline tests rc $?"; tail -6 $O/pytest_sig.log
+  timeout 300 python tools/engine_timeline.py --signed --lag 15 --steps 44 --show 12 > $O/engine_timeline_signed.txt 2>&1; tail -22 $O/engine_timeline_signed.txt | cut -c1-70
+  for b in 8 4 1; do
+    POSEVO_SIG_BATCH=$b POSEVO_HOST_TRACE=1 timeout 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-shuffle-variant --no-slot-cadence > $O/bench_sig$b.json 2> $O/bench_sig$b.err
+    echo "[r06j] sig batch $b: rc $? $(python - <<PY
+import json
+d=json.loads(open("$O/bench_sig$b.json").read().strip().splitlines()[-1])
+s=d.get("with_signatures",{}); u=d.get("with_unaggregated_signatures",{})
+print("ms/step", round(d["ms_per_step"],4), "signed", d.get("ms_per_step_with_signatures"), "beside", s.get("ms_per_step_beside_another_handle"), "verified", s.get("steps_verified"), "| unagg", u.get("ms_per_call"), u.get("roofline_valu",{}).get("frac"))
+PY
+)"
+  done
+  grep "usig\.\|sagg\." $O/bench_sig8.err | cut -c1-120
+}
+
 "call_$1"
