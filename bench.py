@@ -165,6 +165,10 @@ def main():
     if world > 1 or os.environ.get("POSEVO_FORCE_DIST"):
         import torch.distributed as dist
 
+        if world == 1:  # POSEVO_FORCE_DIST without a launcher: a one-rank rendezvous of its own
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29571")):
+                os.environ.setdefault(k, v)
+
         if torch_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -295,7 +299,13 @@ def main():
         if args.warmup < 2:
             quiet_the_host()
         e.drain()
-        e.profile_reset()   # the warm-up launches are not part of the per-kernel averages
+        # Inside the timed region only the roofline's kernel is bracketed (k_g1_accumulate, one launch in four): every bracket
+        # is two event packets on a stream of latency-sized kernels plus host time, and twelve more of them per step were
+        # charged to the engine (round 6: profiles/NOTES_r06.md).  The other kernels' averages are those of the warm-up steps.
+        prof_warm = e.profile() if args.warmup >= 3 else None
+        if prof_warm is not None:
+            e.profile_enable(3)
+        e.profile_reset()   # the warm-up launches are not part of the timed region's averages
         barrier()
         t0 = time.perf_counter()
         inflight = []
@@ -321,6 +331,8 @@ def main():
         gc.enable()
         prof = e.profile()
         e.profile_enable(False)
+        if prof_warm is not None:
+            prof = {k: (v if k == "g1_accumulate" or v["launches"] else prof_warm[k]) for k, v in prof.items()}
         assert n_rejected == 0, "synthetic attestations were rejected"
         dt_var = None
         if n_var:  # the same steps with the next epoch's shuffle enqueued inside each of them
@@ -562,6 +574,9 @@ def main():
                          if votes is not prof["votes"] else "the timed steps' own launches"),
         },
         "kernel_avg_ms": kernel_ms,
+        "kernel_avg_ms_detail": ("g1_accumulate: HIP events inside the timed region (one launch in four); every other kernel: the "
+                                 "warm-up steps' launches (nothing but the roofline's kernel is bracketed while the clock runs)"
+                                 if args.warmup >= 3 else "HIP events inside the timed region"),
         "kernel_launches": {k: v["launches"] for k, v in prof.items()},
     }
     if emulate:

@@ -31,7 +31,8 @@ extern "C" {
 #define PE_KERNEL_PAIR_UNION_TREE      15
 #define PE_KERNEL_G2_DECOMPRESS 16  /* the signature legs' decompression: one launch per POSEVO_SIG_BATCH streaming steps (round 6) */
 #define PE_KERNEL_COUNT         17
-/* on = 0 off, 1 per-kernel totals, 2 totals + a timeline: every bracketed launch's start (relative to the last
+/* on = 0 off, 1 per-kernel totals, 3 totals of PE_KERNEL_G1_ACCUMULATE only (what a timed region can afford: every bracket is
+ * two event packets on its stream), 2 totals + a timeline: every bracketed launch's start (relative to the last
  * pe_profile_reset, which marks time zero on the engine's stream) and duration, read with pe_profile_timeline.  The
  * events are the engine's own, on the streams the kernels run on: an in-situ picture of a streaming step without a
  * profiler's serialisation (rocprofv3 stretches the 0.28 ms step to 0.4). */

@@ -687,6 +687,7 @@ int pe_profile_enable(pe_engine* h, int on)
     if (!h) return PE_ERR_INVALID_ARG;
     h->profiling = on != 0;
     h->prof_timeline = on == 2;
+    h->prof_dominant_only = on == 3;
     if (h->prof_timeline && !h->prof_base && hipEventCreate(&h->prof_base) != hipSuccess) {
         h->prof_base = nullptr;
         h->prof_timeline = false;

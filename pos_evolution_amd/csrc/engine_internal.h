@@ -411,6 +411,8 @@ struct pe_engine {
     KernelProfile prof[PE_KERNEL_COUNT];
     // pe_profile_enable(h, 2): also a timeline of the bracketed launches (start relative to prof_base, duration)
     bool prof_timeline = false;
+    bool prof_dominant_only = false;  // pe_profile_enable(h, 3): bracket k_g1_accumulate only (every bracket is two event
+                                        // packets on a stream of latency-sized kernels, and host time)
     hipEvent_t prof_base = nullptr;
     struct TimelineEntry { int32_t kernel; float start_ms, dur_ms; };
     std::vector<TimelineEntry> prof_tl;
@@ -448,6 +450,7 @@ struct ProfScope {
     ProfScope(pe_engine* h_, int k_, hipStream_t s_ = nullptr, bool sampled_out = false) : h(h_), k(k_), s(s_ ? s_ : h_->stream)
     {
         if (!h->profiling || sampled_out) return;
+        if (h->prof_dominant_only && k != PE_KERNEL_G1_ACCUMULATE) return;  // mode 3: the roofline's kernel alone
         if ((k == PE_KERNEL_ATT_GROUP || k == PE_KERNEL_ATT_VALIDATE) && !h->prof_timeline) return;  // timeline-only brackets
         a = take(h);
         b = take(h);

@@ -1035,7 +1035,8 @@ class Engine:
 
     # -- profiling --------------------------------------------------------
     def profile_enable(self, on=True):
-        """0 / False off, 1 / True per-kernel totals, 2 totals + the timeline of profile_timeline()."""
+        """0 / False off, 1 / True per-kernel totals, 3 totals of the accumulation only, 2 totals + the timeline of
+        profile_timeline()."""
         self._check(self._lib.pe_profile_enable(self._h, int(on)))
 
     def profile_timeline(self):

@@ -199,4 +199,23 @@ PY
   grep "usig\.\|sagg\." $O/bench_sig8.err | cut -c1-120
 }
 
+# call k: the whole -m gpu suite at HEAD; the full default bench line; the per-rank load of an 8-way range shard (one rank over
+# the engine's RCCL communicators, POSEVO_FORCE_DIST=1) at configs[3] / configs[4]; the driver's command
+call_k() {
+  O=gpurun_out/r06k; mkdir -p $O
+  bash tools/gpu.sh r06k label:all tests
+  bash tools/gpu.sh r06k label:full bench
+  python - <<PY
+import json
+d=json.loads(open("$O/bench_full_full.json").read().strip().splitlines()[-1])
+sc=d.get("slot_cadence",{}); u=d.get("with_unaggregated_signatures",{})
+print("slot p50", sc.get("slot_step_us_p50"), "tick->head", sc.get("tick_to_head_us_p50"), "| signed", d.get("ms_per_step_with_signatures"), "shuffle", d.get("ms_per_step_with_shuffle"))
+print("unagg", u.get("ms_per_epoch"), u.get("ms_per_call"), u.get("warmup_ms_per_call"), u.get("roofline_valu",{}).get("frac"))
+PY
+  for shape in "configs3 131072" "configs4 524288"; do set -- $shape
+    POSEVO_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --shape $1 --validators $2 --steps 100 --warmup 6 --no-cpu-baseline --no-signed-steps --no-slot-cadence --no-shuffle-variant > $O/rank_$1.json 2> $O/rank_$1.err
+    echo "[r06k] per-rank step of an 8-way range shard, $1: rc $? $(timeout 20 python tools/benchline.py < $O/rank_$1.json 2>/dev/null | cut -c1-200)"; done
+  bash tools/gpu.sh r06k label:final driver
+}
+
 "call_$1"
