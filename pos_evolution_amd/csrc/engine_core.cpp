@@ -160,7 +160,9 @@ int ensure_quiesced_arenas(pe_engine* h, DevBuf pe_engine::PipeArena::*m, size_t
     int rc = flush_pending(h);
     if (rc) return rc;
     HIP_TRY(h, hipDeviceSynchronize());
-    for (int i = 0; i < h->n_arenas; ++i) HIP_TRY(h, (h->arena[i].*m).ensure(bytes));
+    HIP_TRY(h, (h->A().*m).ensure(bytes));
+    const size_t cap = (h->A().*m).cap;  // with its head-room: the others get exactly that
+    for (int i = 0; i < h->n_arenas; ++i) HIP_TRY(h, (h->arena[i].*m).ensure(cap, false, nullptr, true));
     return PE_OK;
 }
 // ... and for the staging / output blocks, which grow without a device-wide wait: the arenas nothing is in flight on grow with
@@ -171,13 +173,13 @@ void grow_idle_arenas(pe_engine* h, size_t stage_bytes, size_t out_bytes)
         pe_engine::PipeArena& o = h->arena[i];
         if (i == h->cur || !o.pending.empty() || o.fenced || o.fence_pending || o.stage_cursor || o.out_cursor) continue;
         if (h->held.active && h->held.arena == i) continue;
-        if (stage_bytes && (o.h_stage.cap < stage_bytes || o.d_stage.cap < stage_bytes)) {
-            (void)o.h_stage.ensure(stage_bytes);
-            (void)o.d_stage.ensure(stage_bytes);
+        if (stage_bytes) {  // exactly the current arena's capacities
+            (void)o.h_stage.ensure(h->A().h_stage.cap, true);
+            (void)o.d_stage.ensure(h->A().d_stage.cap, false, nullptr, true);
         }
-        if (out_bytes && (o.d_outblk.cap < out_bytes || o.h_pin.cap < out_bytes)) {
-            (void)o.d_outblk.ensure(out_bytes);
-            (void)o.h_pin.ensure(out_bytes);
+        if (out_bytes) {
+            (void)o.d_outblk.ensure(h->A().d_outblk.cap, false, nullptr, true);
+            (void)o.h_pin.ensure(h->A().h_pin.cap, true);
         }
     }
     (void)hipGetLastError();
@@ -577,7 +579,9 @@ int pe_pipeline_begin(pe_engine* h)
 {
     if (!h) return PE_ERR_INVALID_ARG;
     (void)hipSetDevice(h->device);
+    HostLap lap(&h->trace);
     PE_TRY(complete_arena(h, h->cur));  // a lagged pipeline in the other arena stays in flight
+    lap.mark("pipe.begin_1_complete_current");
     // Steps of a stream look alike: size this (idle) arena like the largest one now, instead of growing it call by call
     // inside the pipeline -- a growth there waits for everything enqueued and re-allocates pinned memory (milliseconds).
     {
@@ -591,13 +595,15 @@ int pe_pipeline_begin(pe_engine* h)
             part = std::max(part, o.d_partials.cap);
             lane = std::max(lane, o.d_lane_partials.cap);
         }
-        if (stage) { HIP_TRY(h, a.d_stage.ensure(stage)); HIP_TRY(h, a.h_stage.ensure(stage)); }
-        if (out) { HIP_TRY(h, a.d_outblk.ensure(out)); HIP_TRY(h, a.h_pin.ensure(out)); }
-        if (bits) HIP_TRY(h, a.d_res_bits.ensure(bits));
-        if (info) HIP_TRY(h, a.d_res_info.ensure(info));
-        if (part) HIP_TRY(h, a.d_partials.ensure(part));
-        if (lane) HIP_TRY(h, a.d_lane_partials.ensure(lane));
+        // exact sizes: head-room here would make every arena overshoot the one it copies (see DevBuf::ensure)
+        if (stage) { HIP_TRY(h, a.d_stage.ensure(stage, false, nullptr, true)); HIP_TRY(h, a.h_stage.ensure(stage, true)); }
+        if (out) { HIP_TRY(h, a.d_outblk.ensure(out, false, nullptr, true)); HIP_TRY(h, a.h_pin.ensure(out, true)); }
+        if (bits) HIP_TRY(h, a.d_res_bits.ensure(bits, false, nullptr, true));
+        if (info) HIP_TRY(h, a.d_res_info.ensure(info, false, nullptr, true));
+        if (part) HIP_TRY(h, a.d_partials.ensure(part, false, nullptr, true));
+        if (lane) HIP_TRY(h, a.d_lane_partials.ensure(lane, false, nullptr, true));
     }
+    lap.mark("pipe.begin_2_size_arena");
     h->A().table_stamp_at_begin = h->table_stamp;
     h->A().generation = ++h->pipes_begun;
     h->pipelining = true;
@@ -629,6 +635,27 @@ int pe_pipeline_set_lag(pe_engine* h, uint32_t depth)
     PE_TRY(enter(h));  // nothing is in flight afterwards: the rotation may change
     h->n_arenas = (int)depth + 1;
     h->cur = 0;
+    // The arenas that join the rotation get what the others have grown to (a registry load pushes 100 MB through the staging
+    // and output blocks before any caller sets its lag): sized HERE, not at each one's first pipeline inside a stream of steps
+    // (7 ms of pinned allocations per arena: a 20-step run at lag 8 read 1.5 ms per step).
+    {
+        using A = pe_engine::PipeArena;
+        DevBuf A::*dev[] = {&A::d_stage, &A::d_outblk, &A::d_res_bits, &A::d_res_info, &A::d_partials, &A::d_lane_partials,
+                            &A::d_sig_in, &A::d_sig_pts, &A::d_sig_status};
+        for (auto m : dev) {
+            size_t cap = 0;
+            for (auto& o : h->arena) cap = std::max(cap, (o.*m).cap);
+            if (cap)
+                for (int i = 0; i < h->n_arenas; ++i) HIP_TRY(h, (h->arena[i].*m).ensure(cap, false, nullptr, true));
+        }
+        PinBuf A::*pin[] = {&A::h_stage, &A::h_pin};
+        for (auto m : pin) {
+            size_t cap = 0;
+            for (auto& o : h->arena) cap = std::max(cap, (o.*m).cap);
+            if (cap)
+                for (int i = 0; i < h->n_arenas; ++i) HIP_TRY(h, (h->arena[i].*m).ensure(cap, true));
+        }
+    }
     return PE_OK;
 }
 uint32_t pe_pipeline_get_lag(const pe_engine* h) { return h ? (uint32_t)h->n_arenas - 1 : 0; }

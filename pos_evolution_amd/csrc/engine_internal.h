@@ -73,10 +73,12 @@ struct Block {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr)
+    // exact: no head-room -- for buffers sized to MATCH others (the arenas of a rotation): with head-room each arena that
+    // catches up overshoots the one it copies, and the next one catches up with that (a free + malloc per arena and turn)
+    hipError_t ensure(size_t bytes, bool keep = false, hipStream_t s = nullptr, bool exact = false)
     {
         if (bytes <= cap) return hipSuccess;
-        size_t ncap = std::max(bytes, cap + cap / 2);
+        size_t ncap = exact ? bytes : std::max(bytes, cap + cap / 2);
         ncap = (ncap + 255) & ~size_t(255);
         void* np = nullptr;
         hipError_t e = hipMalloc(&np, ncap);
@@ -102,10 +104,10 @@ struct DevBuf {
 struct PinBuf {
     void* p = nullptr;
     size_t cap = 0;
-    hipError_t ensure(size_t bytes)
+    hipError_t ensure(size_t bytes, bool exact = false)
     {
         if (bytes <= cap) return hipSuccess;
-        size_t ncap = (std::max(bytes, cap * 2) + 4095) & ~size_t(4095);
+        size_t ncap = ((exact ? bytes : std::max(bytes, cap * 2)) + 4095) & ~size_t(4095);
         void* np = nullptr;
         hipError_t e = hipHostMalloc(&np, ncap, hipHostMallocDefault);
         if (e != hipSuccess) return e;

@@ -218,4 +218,28 @@ PY
   bash tools/gpu.sh r06k label:final driver
 }
 
+# call l: the driver's command three times (brackets of the roofline's kernel only inside the timed region), 200 steps, the
+# per-rank load of an 8-way range shard, the bench tests
+call_l() {
+  O=gpurun_out/r06l; mkdir -p $O
+  for i in 1 2 3; do bash tools/gpu.sh r06l label:d$i driver; done
+  bash tools/gpu.sh r06l label:q quick
+  for shape in "configs3 131072" "configs4 524288"; do set -- $shape
+    POSEVO_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --shape $1 --validators $2 --steps 100 --warmup 6 --no-cpu-baseline --no-signed-steps --no-slot-cadence --no-shuffle-variant > $O/rank_$1.json 2> $O/rank_$1.err
+    echo "[r06l] per-rank step of an 8-way range shard, $1: rc $? $(timeout 20 python tools/benchline.py < $O/rank_$1.json 2>/dev/null | cut -c1-200)"; done
+  timeout 900 python -m pytest tests/test_gpu_shapes.py tests/test_gpu_pairing.py -x -q -k "signed or bench or knobs" > $O/pytest.log 2>&1; echo "[r06l] tests rc $?"; tail -4 $O/pytest.log
+}
+
+# call m: lag depth of the headline (an arena's first use no longer lands inside the timed region): the driver's command and
+# 200 steps at lag 4 / 6 / 8 / 12
+call_m() {
+  O=gpurun_out/r06m; mkdir -p $O
+  for lag in 4 6 8 12 4 8; do
+    BENCH_ARGS="--lag $lag --no-signed-steps --no-slot-cadence --no-shuffle-variant --no-cpu-baseline" bash tools/gpu.sh r06m label:lag${lag} driver
+  done
+  for lag in 4 8; do
+    BENCH_ARGS="--lag $lag" bash tools/gpu.sh r06m label:lag${lag} quick
+  done
+}
+
 "call_$1"
