@@ -48,6 +48,10 @@ int pe_profile_timeline(pe_engine* h, int32_t* kernel, double* start_ms, double*
  * out_class[i] = the lowest i' whose stream shares stream i's queue -- {0, 1, 2, 3} when every stream has a queue of its own,
  * which is what pe_engine_create arranges whatever the process created before the handle (POSEVO_QUEUE_PROBE=0 skips it). */
 int pe_profile_queue_classes(pe_engine* h, int32_t out_class[4]);
+/* How often the handle has (re)allocated a buffer of its arenas (staging / output blocks, resident words, G1 and signature scratch)
+ * since it was created.  Every such growth inside a stream of steps is milliseconds of allocation or a drained pipeline; after the
+ * first step of a stream of like steps the count must stand still, whatever the lag depth. */
+int pe_profile_arena_growths(const pe_engine* h, uint64_t* out);
 
 #ifdef __cplusplus
 }

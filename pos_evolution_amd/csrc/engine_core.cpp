@@ -160,6 +160,7 @@ int ensure_quiesced_arenas(pe_engine* h, DevBuf pe_engine::PipeArena::*m, size_t
     int rc = flush_pending(h);
     if (rc) return rc;
     HIP_TRY(h, hipDeviceSynchronize());
+    ++h->arena_growths;
     HIP_TRY(h, (h->A().*m).ensure(bytes));
     const size_t cap = (h->A().*m).cap;  // with its head-room: the others get exactly that
     for (int i = 0; i < h->n_arenas; ++i) HIP_TRY(h, (h->arena[i].*m).ensure(cap, false, nullptr, true));
@@ -595,6 +596,9 @@ int pe_pipeline_begin(pe_engine* h)
             part = std::max(part, o.d_partials.cap);
             lane = std::max(lane, o.d_lane_partials.cap);
         }
+        if (a.d_stage.cap < stage || a.h_stage.cap < stage || a.d_outblk.cap < out || a.h_pin.cap < out || a.d_res_bits.cap < bits ||
+            a.d_res_info.cap < info || a.d_partials.cap < part || a.d_lane_partials.cap < lane)
+            ++h->arena_growths;
         // exact sizes: head-room here would make every arena overshoot the one it copies (see DevBuf::ensure)
         if (stage) { HIP_TRY(h, a.d_stage.ensure(stage, false, nullptr, true)); HIP_TRY(h, a.h_stage.ensure(stage, true)); }
         if (out) { HIP_TRY(h, a.d_outblk.ensure(out, false, nullptr, true)); HIP_TRY(h, a.h_pin.ensure(out, true)); }
@@ -697,6 +701,12 @@ int pe_pipeline_end_lagged(pe_engine* h)
 }
 
 // ---------------------------------------------------------------- profiling
+int pe_profile_arena_growths(const pe_engine* h, uint64_t* out)
+{
+    if (!h || !out) return PE_ERR_INVALID_ARG;
+    *out = h->arena_growths;
+    return PE_OK;
+}
 int pe_profile_queue_classes(pe_engine* h, int32_t out_class[4])
 {
     if (!h || !out_class) return PE_ERR_INVALID_ARG;

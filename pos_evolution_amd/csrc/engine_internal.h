@@ -279,6 +279,8 @@ struct pe_engine {
     bool pipelining = false;
     uint64_t pipes_begun = 0, pipes_completed = 0;  // pe_pipeline_generation / pe_pipeline_completed
     hipStream_t side_stream = nullptr;  // k_g1_accumulate of a pipelined pe_aggregate runs here, beside the fork-choice kernels
+    uint64_t arena_growths = 0;         // (re)allocations of arena buffers since the handle was created (pe_profile_arena_growths):
+                                        // a stream of like steps must not make any after its first one
     bool queues_distinct = false;       // the probe at creation found engine / side / fin / norm on four different hardware queues
     hipStream_t fin_stream = nullptr;   // ... its k_g1_tree here, beside the NEXT aggregate's accumulation
     // ... and its k_g1_finish here: on the tree's stream the two latency-bound guests of a step ran one behind the other
@@ -570,6 +572,7 @@ struct Stage {
             hipError_t e = h->A().h_stage.ensure(want);
             if (e == hipSuccess) e = h->A().d_stage.ensure(want);
             if (e != hipSuccess) return hip_fail(h, e, "staging block");
+            ++h->arena_growths;
             grow_idle_arenas(h, want, 0);
         }
         return PE_OK;
@@ -612,6 +615,7 @@ struct OutBlock {  // device output block + pinned landing zone with the same la
             hipError_t e = h->A().d_outblk.ensure(want);
             if (e == hipSuccess) e = h->A().h_pin.ensure(want);
             if (e != hipSuccess) return hip_fail(h, e, "output block");
+            ++h->arena_growths;
             grow_idle_arenas(h, 0, want);
         }
         return PE_OK;

@@ -1059,6 +1059,12 @@ class Engine:
         self._check(self._lib.pe_profile_queue_classes(self._h, _ptr(out, C.c_int32)))
         return [int(x) for x in out]
 
+    def profile_arena_growths(self) -> int:
+        """pe_profile_arena_growths: (re)allocations of arena buffers since the handle was created."""
+        n = C.c_uint64(0)
+        self._check(self._lib.pe_profile_arena_growths(self._h, C.byref(n)))
+        return int(n.value)
+
     def profile_reset(self):
         self._check(self._lib.pe_profile_reset(self._h))
 

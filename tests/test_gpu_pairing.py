@@ -315,3 +315,31 @@ def test_collected_signature_legs_equal_the_synchronous_calls(batch, n, lag, whe
     _same_store(e, e2)
     e.close()
     e2.close()
+
+
+@pytest.mark.parametrize("lag", [2, 6, 12])
+def test_a_stream_of_like_steps_allocates_nothing_after_its_first_step(lag):
+    """Every arena of the rotation is sized before the stream runs: an arena that sized itself at ITS first pipeline cost 7 ms of
+    pinned allocations inside the stream (round 6: the driver's command read 1.5 ms per step at lag 8, the signed step 1.5 ms at
+    lag 15) -- also the arenas that JOIN the rotation when the caller sets its lag after the registry load has grown the first
+    three.  pe_profile_arena_growths counts every (re)allocation of an arena buffer; signed steps included (their scratch too)."""
+    import torch
+    import pos_evolution_amd.synth as synth
+    from pos_evolution_amd import DeviceArena
+
+    n = lag + 5
+    e = pea.Engine(max_committee_tables=n + 3)
+    w = bench.build_workload(e, _args(32768, 128, 300, n), 0, n)      # loads the registry: the default rotation's blocks grow
+    sg = synth.signature_points(e, len(w["steps"][0]["atts"]))
+    t = torch.from_numpy(sg.reshape(-1).copy()).cuda()
+    sigs = DeviceArena(t.data_ptr(), t.numel(), keep=t)
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(n + lag + 2)
+    got = [_signed_stream_step(e, w, w["steps"][0], sigs)]
+    e.drain()
+    before = e.profile_arena_growths()
+    got += [_signed_stream_step(e, w, st, sigs) for st in w["steps"][1:]]
+    e.drain()
+    assert e.profile_arena_growths() == before, "an arena buffer was (re)allocated inside the stream"
+    assert all(int(r["agg"]["n_groups"]) == 128 and not np.asarray(r["status"])[:128].any() for r in got)
+    e.close()
