@@ -522,9 +522,10 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
         if (n) HIP_TRY(h, hipMemcpyAsync(h->d_tmp_be.p, signatures96, 96ull * n, sig_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
         d_in = h->d_tmp_be.as<uint8_t>();
     }
-    HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(192, 192ull * n + 4ull * n + 4ull * n_groups + 64)));
+    HIP_TRY(h, h->d_tmp_points.ensure(std::max<size_t>(192, 192ull * n + 4ull * n + (idx_dev ? 4ull * total : 0) + 64)));
     uint32_t* d_pts = h->d_tmp_points.as<uint32_t>();
     int32_t* d_status = reinterpret_cast<int32_t*>(h->d_tmp_points.as<uint8_t>() + 192ull * n);
+    uint32_t* d_index_checked = reinterpret_cast<uint32_t*>(h->d_tmp_points.as<uint8_t>() + 196ull * n);  // a device index, range-checked
     lap.mark("usig.1_checks_scratch");
     launch_g2_decompress(s, d_in, n, d_pts, nullptr, d_status);  // a signature that does not decode becomes the (0, 0) row: infinity
     lap.mark("usig.2_decompress_launch");
@@ -541,18 +542,25 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
     plan_g1(n_groups, [&](uint32_t g) { return offsets[g + 1] - offsets[g]; }, gr, &plan, G2_WG_SLOTS, G1_TARGET_LANES / 2);
     for (uint32_t g = 0; g < n_groups; ++g) gr[g].member_start = offsets[g];
     if (index && !idx_dev) memcpy(st.host<uint32_t>(off_i), index, 4ull * total);
-    const uint32_t* d_index = !index ? nullptr : idx_dev ? index : st.dev<uint32_t>(off_i);
-    // statuses and (for the bad-member counts) a device-resident index come back through the PINNED output block: a copy
-    // into the caller's pageable memory is staged and pinned by the runtime page by page -- 2 x 4 MB cost the call 30 ms of
-    // its 50 in bench.py's process (profiles/r06_sig_host_phases.txt)
-    const bool want_status = sig_status != nullptr || out_bad != nullptr;
-    const bool want_index_back = out_bad != nullptr && idx_dev;
+    const uint32_t* d_index = !index ? nullptr : idx_dev ? d_index_checked : st.dev<uint32_t>(off_i);
+    // Statuses come back through the PINNED output block (a copy into the caller's pageable memory is staged and pinned by the
+    // runtime page by page: 2 x 4 MB cost the call 30 ms of its 50 in bench.py's process, profiles/r06_sig_host_phases.txt); the
+    // bad-member counts are taken on the device (k_g2_count_bad), so neither statuses nor index travel for them; a device-resident
+    // index is range-checked there too (k_g2_index_check: the host cannot read it).
+    const bool want_status = sig_status != nullptr;
     OutBlock ob(h);
     const size_t off_o = ob.alloc(192ull * n_groups);
     const size_t off_st = want_status ? ob.alloc(4ull * n) : 0;
-    const size_t off_ix = want_index_back ? ob.alloc(4ull * total) : 0;
+    const size_t off_bad = ob.alloc(4ull * n_groups);
+    const size_t off_err = ob.alloc(4);
     PE_TRY(ob.ensure());
+    *ob.host<uint32_t>(off_err) = 0;
     HIP_TRY(h, st.upload());
+    if (idx_dev) {
+        HIP_TRY(h, hipMemsetAsync(ob.dev<uint32_t>(off_err), 0, 4, s));
+        launch_g2_index_check(s, index, total, (uint32_t)n, d_index_checked, ob.dev<uint32_t>(off_err));
+        HIP_TRY(h, ob.download(off_err, 4));
+    }
     HIP_TRY(h, h->d_partials.ensure(std::max<size_t>(384, 384ull * plan.n_partials)));
     {
         ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE);
@@ -562,28 +570,19 @@ int pe_aggregate_signatures(pe_engine* h, const uint8_t* signatures96, uint64_t 
         ProfScope ps(h, PE_KERNEL_G2_NORMALISE);
         launch_g2_finish(s, h->d_partials.as<uint32_t>(), st.dev<G1Group>(off_g), plan.n_groups, ob.dev<uint8_t>(off_o));
     }
+    if (out_bad) launch_g2_count_bad(s, d_status, d_index, st.dev<G1Group>(off_g), n_groups, ob.dev<uint32_t>(off_bad));
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, ob.download(off_o, 192ull * n_groups));
-    const int32_t* status_host = want_status ? ob.host<int32_t>(off_st) : nullptr;
+    if (out_bad) HIP_TRY(h, ob.download(off_bad, 4ull * n_groups));
     if (want_status && n) HIP_TRY(h, hipMemcpyAsync(ob.host<int32_t>(off_st), d_status, 4ull * n, hipMemcpyDeviceToHost, s));
-    const uint32_t* index_host = index;
-    if (want_index_back) {  // the caller's index lives on the device: the bad-member counts need it here
-        if (total) HIP_TRY(h, hipMemcpyAsync(ob.host<uint32_t>(off_ix), index, 4ull * total, hipMemcpyDeviceToHost, s));
-        index_host = ob.host<uint32_t>(off_ix);
-    }
     lap.mark("usig.3_plan_launch_copies");
     HIP_TRY(h, hipStreamSynchronize(s));
     lap.mark("usig.4_wait");
+    if (*ob.host<uint32_t>(off_err)) return fail(h, PE_ERR_INVALID_ARG, "signature index out of range (device-resident index)");
     PE_TRY(pe_g2_compress(ob.host<uint8_t>(off_o), n_groups, out_signatures96));
-    if (sig_status && n) memcpy(sig_status, status_host, 4ull * n);
-    lap.mark("usig.5_compress");
-    if (out_bad)
-        for (uint32_t g = 0; g < n_groups; ++g) {
-            uint32_t bad = 0;
-            for (uint32_t j = offsets[g]; j < offsets[g + 1]; ++j) bad += status_host[index_host ? index_host[j] : j] != 0;
-            out_bad[g] = bad;
-        }
-    lap.mark("usig.6_bad_counts");
+    if (sig_status && n) memcpy(sig_status, ob.host<int32_t>(off_st), 4ull * n);
+    if (out_bad) memcpy(out_bad, ob.host<uint32_t>(off_bad), 4ull * n_groups);
+    lap.mark("usig.5_outputs");
     return PE_OK;
 }
 

@@ -623,4 +623,44 @@ void launch_g2_aggregate_rows(hipStream_t s, G2AggregateRowsBatch& b)
     hipLaunchKernelGGL(k_g2_aggregate_rows, dim3(blocks), dim3(64), 0, s, b);
 }
 
+// ---------------------------------------------------------------- pe_aggregate_signatures: the index list, on the device
+// A caller's DEVICE-resident index list cannot be range-checked by the host: this pass copies it into the engine's scratch with
+// every entry >= n replaced by 0 and an error word set (the sums then read defined memory and the call fails);
+// k_g2_count_bad counts, per group, the members whose signature did not decode -- one wave per group -- so that neither the
+// statuses nor the index have to travel to the host for it.
+__global__ void __launch_bounds__(256)
+k_g2_index_check(const uint32_t* __restrict__ index, uint32_t total, uint32_t n, uint32_t* __restrict__ out_index,
+                 uint32_t* __restrict__ err)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= total) return;
+    uint32_t v = index[j];
+    if (v >= n) { atomicOr(err, 1u); v = 0; }
+    out_index[j] = v;
+}
+__global__ void __launch_bounds__(256)
+k_g2_count_bad(const int32_t* __restrict__ status, const uint32_t* __restrict__ index, const G1Group* __restrict__ groups,
+               uint32_t n_groups, uint32_t* __restrict__ out_bad)
+{
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_groups) return;
+    const uint32_t lane = threadIdx.x & 63, first = groups[g].member_start, cnt = groups[g].n_members;
+    uint32_t bad = 0;
+    for (uint32_t j = lane; j < cnt; j += 64) bad += status[index ? index[first + j] : first + j] != 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) bad += __shfl_xor(bad, off, 64);
+    if (lane == 0) out_bad[g] = bad;
+}
+void launch_g2_index_check(hipStream_t s, const uint32_t* index, uint32_t total, uint32_t n, uint32_t* out_index, uint32_t* err)
+{
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_g2_index_check, dim3((total + 255) / 256), dim3(256), 0, s, index, total, n, out_index, err);
+}
+void launch_g2_count_bad(hipStream_t s, const int32_t* status, const uint32_t* index, const G1Group* groups, uint32_t n_groups,
+                         uint32_t* out_bad)
+{
+    if (n_groups == 0) return;
+    hipLaunchKernelGGL(k_g2_count_bad, dim3((n_groups + 3) / 4), dim3(256), 0, s, status, index, groups, n_groups, out_bad);
+}
+
 }  // namespace posevo

@@ -373,6 +373,11 @@ struct G2AggregateRowsBatch {
     uint32_t* out_bad[G2_BATCH_MAX]; uint32_t n_groups[G2_BATCH_MAX]; uint32_t first_block[G2_BATCH_MAX + 1]; uint32_t count;
 };
 void launch_g2_aggregate_rows(hipStream_t s, G2AggregateRowsBatch& b);
+// pe_aggregate_signatures: a device-resident index list copied with entries >= n replaced by 0 (*err |= 1 then); members per
+// group whose status is non-zero (groups: member_start / n_members)
+void launch_g2_index_check(hipStream_t s, const uint32_t* index, uint32_t total, uint32_t n, uint32_t* out_index, uint32_t* err);
+void launch_g2_count_bad(hipStream_t s, const int32_t* status, const uint32_t* index, const G1Group* groups, uint32_t n_groups,
+                         uint32_t* out_bad);
 
 // get_indexed_attestation: sorted attesting indices per row, written at out_offsets[row] (committees <= 8192 members)
 void launch_indexed_attestations(hipStream_t s, const AttRow* rows, uint32_t n_rows, const uint32_t* members,

@@ -298,6 +298,14 @@ def test_aggregate_signatures_vs_oracle(engine_factory, where):
     assert bytes(agg[0]) == g2.compress(None)
     with pytest.raises(AssertionError):
         e.aggregate_signatures(sig, [0, 10], index=np.array([n] * 10, dtype=np.uint32))
+    if where == "device":   # the host cannot read a device-resident index: it is range-checked on the device
+        bad_idx = index.copy()
+        bad_idx[17] = n + 5
+        bt = torch.from_numpy(bad_idx).cuda()
+        with pytest.raises(AssertionError):
+            e.aggregate_signatures(sig_in, offsets, index=pea.DeviceArena(bt.data_ptr(), bt.numel() * 4, keep=bt))
+        agg2, status2, bad2 = e.aggregate_signatures(sig_in, offsets, index=idx_in)   # the handle is fine afterwards
+        assert np.array_equal(agg2, e.aggregate_signatures(sig, offsets, index=index)[0]) and int(bad2.sum()) == 2
 
 
 def test_aggregate_signatures_of_a_whole_epoch(engine_factory):

@@ -1,5 +1,5 @@
-"""CPU: profiles/README.md is the index the docs point into -- every round-5 file it names exists, every round-5 file that
-exists is named, the round's call script parses, and the bench line kept as the round's record carries the contract's keys."""
+"""CPU: profiles/README.md is the index the docs point into -- every round-5 / round-6 file it names exists, every such file
+that exists is named, the rounds' call scripts parse, and the bench line kept as the round's record carries the contract's keys."""
 import json
 import os
 import re
@@ -20,35 +20,43 @@ def _expand(name):
     return out
 
 
-def test_round5_index_and_files_agree():
+import pytest
+
+
+@pytest.mark.parametrize("rnd,least", [("r05", 30), ("r06", 25)])
+def test_round_index_and_files_agree(rnd, least):
     text = open(os.path.join(PROF, "README.md")).read()
-    section = text[text.index("## Round 5"):]
+    start = text.index("## Round " + rnd[-1])
+    nxt = text.find("\n## Round ", start + 1)
+    section = text[start:nxt if nxt > 0 else len(text)]
     named = set()
     for tok in re.findall(r"`([^`]+)`", section):
         tok = tok.strip()
         if "/" in tok and not tok.startswith("profiles/"):
             continue                                  # a tool or test path
         tok = tok[len("profiles/"):] if tok.startswith("profiles/") else tok
-        if re.fullmatch(r"(r05_[\w{},.+-]+|hbm_traffic\.json|NOTES_r05\.md)", tok) and tok.endswith((".json", ".txt", ".md")):
+        if re.fullmatch(r"(%s_[\w{},.+-]+|hbm_traffic\.json|NOTES_%s\.md)" % (rnd, rnd), tok) and tok.endswith((".json", ".txt", ".md")):
             named.update(_expand(tok))
-    assert len(named) > 30, sorted(named)
+    assert len(named) > least, sorted(named)
     missing = sorted(n for n in named if not os.path.exists(os.path.join(PROF, n)))
     assert not missing, f"profiles/README.md names files that are not there: {missing}"
-    present = {f for f in os.listdir(PROF) if f.startswith("r05_")}
+    present = {f for f in os.listdir(PROF) if f.startswith(rnd + "_")}
     unnamed = sorted(present - named)
-    assert not unnamed, f"round-5 files without a line in profiles/README.md: {unnamed}"
+    assert not unnamed, f"{rnd} files without a line in profiles/README.md: {unnamed}"
 
 
-def test_round5_call_script_parses():
-    path = os.path.join(ROOT, "tools", "r05_calls.sh")
+@pytest.mark.parametrize("script,letters", [("r05_calls.sh", "efghijkl"), ("r06_calls.sh", "bcdefghijklmp")])
+def test_round_call_script_parses(script, letters):
+    path = os.path.join(ROOT, "tools", script)
     assert subprocess.run(["bash", "-n", path]).returncode == 0
     src = open(path).read()
-    for letter in "efghijkl":
+    for letter in letters:
         assert f"call_{letter}()" in src
 
 
-def test_the_rounds_bench_record_has_the_contract_keys():
-    d = json.load(open(os.path.join(PROF, "r05_bench_full.json")))
+@pytest.mark.parametrize("record", ["r05_bench_full.json", "r06_bench_full.json"])
+def test_the_rounds_bench_record_has_the_contract_keys(record):
+    d = json.load(open(os.path.join(PROF, record)))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key

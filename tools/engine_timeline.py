@@ -64,6 +64,11 @@ def main():
     for s in range(warm):
         bench.run_step_single(e, w, w["steps"][s], pipelined=True, lagged=True, sync_head=False, sigs=sigs)
     e.drain()
+    import gc
+
+    gc.collect()
+    gc.disable()                   # as bench.py does over its timed steps: with torch loaded a full collection is tens of ms
+                                   # (a 35-40 ms hole in two of this tool's pictures in round 6)
     e.profile_enable(2)
     e.profile_reset()              # time zero
     for s in range(warm, a.steps):

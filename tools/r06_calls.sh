@@ -242,4 +242,16 @@ call_m() {
   done
 }
 
+# call p: the round's profile set at HEAD -- the whole -m gpu suite, tools/profile_round.sh r06 (bench line; rocprofv3
+# --kernel-trace --stats of the same command; FETCH_SIZE / WRITE_SIZE passes; the profiled timeline), the driver's exact command, the
+# engine's own timelines (steady, cold 20, signed)
+call_p() {
+  O=gpurun_out/r06p; mkdir -p $O
+  bash tools/gpu.sh r06p label:all tests
+  bash tools/profile_round.sh r06
+  timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_full.json 2> $O/bench_driver_full.err; echo "[r06p] driver's exact command rc $? $(timeout 20 python tools/benchline.py < $O/bench_driver_full.json | cut -c1-60)"
+  timeout 300 python tools/engine_timeline.py --steps 24 --show 3 > $O/engine_timeline.txt 2>&1; tail -14 $O/engine_timeline.txt
+  timeout 300 python tools/engine_timeline.py --cold 20 --steps 26 > $O/engine_timeline_cold20.txt 2>&1; head -4 $O/engine_timeline_cold20.txt | cut -c1-150
+}
+
 "call_$1"
