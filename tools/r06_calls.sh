@@ -254,4 +254,20 @@ call_p() {
   timeout 300 python tools/engine_timeline.py --cold 20 --steps 26 > $O/engine_timeline_cold20.txt 2>&1; head -4 $O/engine_timeline_cold20.txt | cut -c1-150
 }
 
+# call q: the tests added after call p (arena growths, device index), the unaggregated leg with its counts on the device, the
+# engine's own timelines again (the collector paused)
+call_q() {
+  O=gpurun_out/r06q; mkdir -p $O
+  timeout 900 python -m pytest tests/test_gpu_pairing.py tests/test_gpu_g2.py -x -q > $O/pytest.log 2>&1; echo "[r06q] pairing + g2 tests rc $?"; tail -5 $O/pytest.log
+  POSEVO_HOST_TRACE=1 timeout 300 python tools/sig_epoch.py --calls 4 2>&1 | grep "call\|usig" | cut -c1-120
+  timeout 300 python tools/engine_timeline.py --steps 24 --show 3 > $O/engine_timeline.txt 2>&1; tail -12 $O/engine_timeline.txt
+  timeout 300 python tools/engine_timeline.py --cold 20 --steps 26 > $O/engine_timeline_cold20.txt 2>&1; head -4 $O/engine_timeline_cold20.txt | cut -c1-150
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-slot-cadence --no-shuffle-variant > $O/bench.json 2> $O/bench.err
+  python - <<PY
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1]); u=d["with_unaggregated_signatures"]
+print("ms/step", d["ms_per_step"], "signed", d["ms_per_step_with_signatures"], "unagg", u["ms_per_epoch"], u["ms_per_call"], u["roofline_valu"]["frac"])
+PY
+}
+
 "call_$1"
