@@ -757,7 +757,7 @@ int aggregate_impl(pe_engine* h, const pe_attestation* atts, uint32_t n, const u
             PE_TRY(ensure_quiesced(h, arena->d_partials,
                                    std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan_pk.n_partials)));
             PE_TRY(ensure_quiesced(h, arena->d_lane_partials,
-                                   (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
+                                   (size_t)G1_LANE_PARTIAL_BYTES * G1_WG * ((plan_pk.n_slots + G1_WG - 1) / G1_WG)));
             h->deferred.push_back(launch_g1);
         } else {
             int rc = launch_g1();

@@ -45,7 +45,7 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
     if (!lane_partials) lane_partials = &h->d_lane_partials;
     PE_TRY(ensure_quiesced(h, *partials,
                            std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * plan.n_partials)));
-    const size_t lane_bytes = (size_t)PE_G1_PARTIAL_BYTES * G1_WG * ((plan.n_slots + G1_WG - 1) / G1_WG);
+    const size_t lane_bytes = (size_t)G1_LANE_PARTIAL_BYTES * G1_WG * ((plan.n_slots + G1_WG - 1) / G1_WG);
     PE_TRY(ensure_quiesced(h, *lane_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, lane_bytes)));
     // the table in the accumulation's field form (S29): the registry's is built at the first use after the registry
     // changed; caller-supplied points (pe_g1_sum, the G1-flavoured signature leg: d_tmp_points) are converted per call

@@ -248,9 +248,9 @@ int aggregate_resident(pe_engine* h, const pe_attestation* d_rows, uint32_t n, c
     PE_TRY(ob.ensure());
     if (want_pk) {  // scratch of the G1 chain, sized by the bounds before anything is in flight
         PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
-        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
+        PE_TRY(ensure_quiesced_arenas(h, &pe_engine::PipeArena::d_lane_partials, (size_t)G1_LANE_PARTIAL_BYTES * slot_cap));
         PE_TRY(ensure_quiesced(h, h->d_partials, std::max<size_t>(PE_G1_PARTIAL_BYTES, (size_t)PE_G1_PARTIAL_BYTES * n)));
-        PE_TRY(ensure_quiesced(h, h->d_lane_partials, (size_t)PE_G1_PARTIAL_BYTES * slot_cap));
+        PE_TRY(ensure_quiesced(h, h->d_lane_partials, (size_t)G1_LANE_PARTIAL_BYTES * slot_cap));
     }
     lap.mark("ragg.1_reserve");
     *out_n_groups = 0;  // known when the call completes

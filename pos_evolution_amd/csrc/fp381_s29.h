@@ -13,7 +13,7 @@
 // Round 4 measured (tools/fpbench29, tools/icbench, tools/accbench): 14 % more dependent products per second,
 // 25 % more mixed adds (the squaring is 301 multiply-adds), and the accumulation kernel 158 us against 183 for a million
 // points -- a mixed add of 3 738 multiply-adds runs at the multiplier's issue rate, the simple instructions around them are
-// free and carries are not.  It is the accumulation's form; tree, finish and the wire formats stay in fp381.h.
+// free and carries are not.  It is the accumulation's form and, since round 6, the tree's; finish and the wire formats stay in fp381.h.
 //
 // Lazy, signed values.  R' / p > 2^25, so a product of operands of magnitude < 2^386 (32 p) comes out in (-eps, p + eps)
 // with no final subtraction; a - b is a plain limb-wise subtraction (limbs of both signs are fine in the next product as

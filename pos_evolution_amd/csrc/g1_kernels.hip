@@ -294,6 +294,221 @@ __device__ unsigned long long g1_wave_info[3 * 4 * 4096];  // per wave: HW_ID | 
 #define G1_STAMP(i) do { } while (0)
 #endif
 
+// ONE copy of the product and of the squaring for everything that is not the loop body (the hand-over of a finished
+// accumulator, the complete add of the rare path): called, arguments and result in registers.
+__device__ __noinline__ fq fq_mul_nc(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6,
+                                     int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13,
+                                     int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6,
+                                     int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13)
+{
+    const fq a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+    const fq b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}};
+    fq r;
+    fq_mul(r, a, b);
+    return r;
+}
+__device__ __noinline__ fq fq_sqr_nc(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6,
+                                     int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13)
+{
+    const fq a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
+    fq r;
+    fq_sqr(r, a);
+    return r;
+}
+struct FqCalled {
+    __device__ __forceinline__ static void mul(fq& r, const fq& a, const fq& b)
+    {
+        r = fq_mul_nc(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
+                      a.l[12], a.l[13], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9],
+                      b.l[10], b.l[11], b.l[12], b.l[13]);
+    }
+    __device__ __forceinline__ static void sqr(fq& r, const fq& a)
+    {
+        r = fq_sqr_nc(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
+                      a.l[12], a.l[13]);
+    }
+};
+
+
+// ---------------------------------------------------------------- the tree's S29 helpers (round 6)
+// The lanes' partials reach the tree in the accumulation's own field form: X | Y | ZZ | ZZZ as 14 limbs each (56 words, X and
+// Y carry-passed, ZZ and ZZZ products; all limbs zero = infinity).  Round 4-5 converted every lane's accumulator to the 12 x 32
+// form first (four products + four exact reductions per LANE, inside the kernel that paces the step); now the tree adds in
+// S29 and converts once per GROUP, at the block's last level.  Same formulas as g1.h's two- and four-lane cooperative adds;
+// what differs is the lazy form's bookkeeping: a difference of two balanced values goes into the next product as it is,
+// X3 = RR - PPP - 2 Q (three terms) and Y3 (stored) take one carry pass each.
+constexpr int G1S_WORDS = 4 * FQ_N;
+__device__ __forceinline__ void fq_select(fq& r, bool c, const fq& a, const fq& b)  // r = c ? a : b
+{
+#pragma unroll
+    for (int j = 0; j < FQ_N; ++j) r.l[j] = c ? a.l[j] : b.l[j];
+}
+__device__ __forceinline__ void fq_xchg(fq& r, const fq& a)  // r = a of the partner lane (lane ^ 1)
+{
+#pragma unroll
+    for (int j = 0; j < FQ_N; ++j) r.l[j] = __shfl_xor(a.l[j], 1, 64);
+}
+__device__ __forceinline__ void fq_from_lane(fq& r, const fq& a, int src_lane)
+{
+#pragma unroll
+    for (int j = 0; j < FQ_N; ++j) r.l[j] = __shfl(a.l[j], src_lane, 64);
+}
+__device__ __forceinline__ void lds_store_fq(uint32_t* lds, int coord, int slot, const fq& v)
+{
+#pragma unroll
+    for (int k = 0; k < FQ_N; ++k) lds[(FQ_N * coord + k) * G1_WG + slot] = (uint32_t)v.l[k];
+}
+__device__ __forceinline__ void lds_load_fq(fq& v, const uint32_t* lds, int coord, int slot)
+{
+#pragma unroll
+    for (int k = 0; k < FQ_N; ++k) v.l[k] = (int32_t)lds[(FQ_N * coord + k) * G1_WG + slot];
+}
+__device__ __forceinline__ void lds_load_q(g1q& p, const uint32_t* lds, int slot)
+{
+    lds_load_fq(p.x, lds, 0, slot);
+    lds_load_fq(p.y, lds, 1, slot);
+    lds_load_fq(p.zz, lds, 2, slot);
+    lds_load_fq(p.zzz, lds, 3, slot);
+    p.inf = fq_limbs_zero(p.zz);
+    p.affine = false;
+}
+// one coordinate -> its 12 canonical Montgomery words of the 12 x 32 form (what k_g1_finish and the exchange read); zero limbs
+// (infinity) give zero words
+__device__ __forceinline__ void global_store_fq_as_mont32(uint32_t* __restrict__ dst, const fq& v)
+{
+    uint32_t w[12];
+    fq_to_mont32_via<FqCalled>(w, v);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    d[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    d[2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
+// p += q, both XYZZ in S29, every case of the group law: the rare path of the cooperative adds (an infinity operand, P1 = +-P2)
+__device__ __noinline__ void g1q_add_full(g1q& p, const g1q& q)
+{
+    if (q.inf) return;
+    if (p.inf) { p = q; return; }
+    fq U1, U2, S1, S2, P, R;
+    FqCalled::mul(U1, p.x, q.zz);
+    FqCalled::mul(U2, q.x, p.zz);
+    FqCalled::mul(S1, p.y, q.zzz);
+    FqCalled::mul(S2, q.y, p.zzz);
+    fq_sub(P, U2, U1);
+    fq_sub(R, S2, S1);
+    if (fq_is_zero_modp(P)) {
+        if (fq_is_zero_modp(R)) g1q_double<FqCalled>(p);
+        else g1q_set_inf(p);
+        return;
+    }
+    fq PP, PPP, Q, X3, t;
+    FqCalled::sqr(PP, P);
+    FqCalled::mul(PPP, P, PP);
+    FqCalled::mul(Q, U1, PP);
+    FqCalled::sqr(X3, R);
+    fq_sub_sub2_norm(X3, X3, PPP, Q);
+    fq_sub(t, Q, X3);
+    FqCalled::mul(t, R, t);
+    FqCalled::mul(S1, S1, PPP);
+    fq_sub_norm(p.y, t, S1);
+    FqCalled::mul(t, p.zz, q.zz);
+    FqCalled::mul(p.zz, t, PP);
+    FqCalled::mul(t, p.zzz, q.zzz);
+    FqCalled::mul(p.zzz, t, PPP);
+    p.x = X3;
+}
+// two lanes per pair (g1.h: g1x_add_pair).  role 0 owns P1, role 1 owns P2; neither is infinity (caller).  false: P1 = +-P2.
+// Outputs: role 0: out_a = X3, out_b = Y3;  role 1: out_a = ZZ3, out_b = ZZZ3.
+__device__ __forceinline__ bool g1s_add_pair(fq& out_a, fq& out_b, bool role, const fq& x_own, const fq& y_own,
+                                             const fq& zz_own, const fq& zzz_own, const fq& zz_oth, const fq& zzz_oth)
+{
+    fq m1, m2, o1, o2;
+    FqCalled::mul(m1, x_own, zz_oth);   // U1 | U2
+    FqCalled::mul(m2, y_own, zzz_oth);  // S1 | S2
+    fq_xchg(o1, m1);
+    fq_xchg(o2, m2);
+    fq U1, S1, P, R;
+    {
+        fq U2, S2;
+        fq_select(U1, role, o1, m1);
+        fq_select(U2, role, m1, o1);
+        fq_select(S1, role, o2, m2);
+        fq_select(S2, role, m2, o2);
+        fq_sub(P, U2, U1);
+        fq_sub(R, S2, S1);
+    }
+    if (fq_is_zero_modp(P)) return false;  // identical in both lanes of the pair
+    fq a, b, m3, x3, m4, x4, m5;
+    fq_select(a, role, R, P);
+    FqCalled::sqr(m3, a);    // PP | RR
+    fq_xchg(x3, m3);         // role 0 receives RR, role 1 receives PP
+    fq_select(a, role, zz_own, P);
+    fq_select(b, role, zz_oth, m3);
+    FqCalled::mul(m4, a, b);  // PPP | ZZ1*ZZ2
+    fq_xchg(x4, m4);          // role 1 receives PPP
+    fq_select(a, role, zzz_own, U1);
+    fq_select(b, role, zzz_oth, m3);
+    FqCalled::mul(m5, a, b);  // Q | ZZZ1*ZZZ2
+    fq X3, T, t;
+    fq_sub_sub2_norm(X3, x3, m4, m5);  // role 0: RR - PPP - 2 Q   (role 1 computes don't-cares of the same magnitudes)
+    fq_sub(T, m5, X3);
+    fq m6, m7;
+    fq_select(a, role, m4, R);   // ZZ1*ZZ2   | R
+    fq_select(b, role, x3, T);   // PP        | Q - X3
+    FqCalled::mul(m6, a, b);     // role 0: R*(Q-X3), role 1: ZZ3
+    fq_select(a, role, m5, S1);  // ZZZ1*ZZZ2 | S1
+    fq_select(b, role, x4, m4);  // PPP (received) | PPP (own)
+    FqCalled::mul(m7, a, b);     // role 0: S1*PPP, role 1: ZZZ3
+    fq_sub_norm(t, m6, m7);      // role 0: Y3
+    fq_select(out_a, role, m6, X3);
+    fq_select(out_b, role, m7, t);
+    return true;
+}
+// four lanes per pair (g1.h: g1x_add_quad).  Inputs per lane: a, b = (X1, ZZ2) | (X2, ZZ1) | (Y1, ZZZ2) | (Y2, ZZZ1).
+// Outputs: q2: out_a = X3, out_b = Y3;  q1: out_a = ZZ3;  q3: out_a = ZZZ3.  false: P1 = +-P2.
+__device__ __forceinline__ bool g1s_add_quad(fq& out_a, fq& out_b, int q, const fq& a, const fq& b)
+{
+    const int base = (int)(threadIdx.x & 63) & ~3;
+    const bool even = (q & 1) == 0;
+    fq m1, t, d, send;
+    FqCalled::mul(m1, a, b);          // U1 | U2 | S1 | S2
+    fq_select(send, even, b, m1);     // q0: ZZ2, q1: U2, q2: ZZZ2, q3: S2
+    fq_xchg(t, send);                 // q0: U2,  q1: ZZ2, q2: S2,  q3: ZZZ2
+    fq_sub(d, t, m1);                 // q0: P,   q2: R   (odd lanes: unused)
+    const int p_zero = __shfl((int)fq_is_zero_modp(d), base, 64);
+    if (p_zero) return false;         // identical in the four lanes
+    fq x, y, m2;
+    fq_select(x, even, d, b);
+    fq_select(y, even, d, t);
+    FqCalled::mul(m2, x, y);          // PP | A | RR | B
+    fq pp, u1;
+    fq_from_lane(pp, m2, base);       // PP to everyone
+    fq_from_lane(u1, m1, base);       // U1 to everyone (q3 needs it)
+    fq m3, sel;
+    fq_select(sel, q == 1, m2, u1);
+    fq_select(x, q == 0, d, sel);     // q0: P, q1: A, q2 and q3: U1
+    fq_select(y, q == 0, m2, pp);     // q0: PP, others: PP
+    FqCalled::mul(m3, x, y);          // q0: PPP, q1: ZZ3, q2 and q3: Q = U1 PP
+    fq ppp, s1;
+    fq_from_lane(ppp, m3, base);      // PPP to everyone
+    fq_from_lane(s1, m1, base + 2);   // S1 to everyone (q0 needs it)
+    fq X3, T, tmp;
+    fq_sub_sub2_norm(X3, m2, ppp, m3);  // q2: X3 = RR - PPP - 2 Q
+    fq_sub(T, m3, X3);                  // q2: Q - X3
+    fq m4;
+    fq_select(sel, q == 2, d, m2);
+    fq_select(x, q == 0, s1, sel);    // q0: S1, q2: R, q3: B (q1: A, unused)
+    fq_select(sel, q == 2, T, ppp);
+    fq_select(y, q == 0, m3, sel);    // q0: PPP, q2: Q - X3, q3: PPP
+    FqCalled::mul(m4, x, y);          // q0: T2, q2: T1, q3: ZZZ3
+    fq t2;
+    fq_from_lane(t2, m4, base);
+    fq_sub_norm(tmp, m4, t2);         // q2: Y3
+    fq_select(sel, q == 1, m3, m4);
+    fq_select(out_a, q == 2, X3, sel);
+    out_b = tmp;
+    return true;
+}
+
 // The sum of one launch runs in THREE kernels since round 2:
 //   k_g1_accumulate  per-lane XYZZ accumulation of k gathered points (mixed adds, S29 form since round 4): throughput-
 //                    bound, at the multiplier's issue floor; writes one partial per lane slot, limb-major per workgroup
@@ -326,11 +541,11 @@ __device__ __forceinline__ void g1_slot_block(const G1Group* __restrict__ groups
     }
 }
 
-// lane partials in HBM: word k of lane `tid` of workgroup `wg` at ((wg * 48 + k) * 256 + tid): a wave's 64 lanes write
-// 256 contiguous bytes per word (k_g1_accumulate's hand-over loop writes them, k_g1_tree reads them into LDS)
+// lane partials in HBM: word k of lane `tid` of workgroup `wg` at ((wg * 56 + k) * 256 + tid): a wave's 64 lanes write
+// 256 contiguous bytes per word (k_g1_accumulate's hand-over writes them -- S29 limbs, round 6 --, k_g1_tree reads them into LDS)
 
-// Two waves per SIMD (256 VGPRs with the called product, 32 B of scratch): the shape that fits beside ONE wave of the
-// next aggregate's k_g1_accumulate (<= 256 VGPRs) on every SIMD, which is how streaming steps run it (round 4).
+// Two waves per SIMD: the shape that fits beside ONE wave of the next aggregate's k_g1_accumulate (<= 256 VGPRs) on every SIMD,
+// which is how streaming steps run it (round 4).
 //
 // The body is shared by two kernels that differ in their resource signature only (launch_g1_tree):
 //   k_g1_tree       <= 256 registers: two of its workgroups fit a CU's register file; the 84 KB LDS request keeps them apart;
@@ -347,8 +562,8 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
         n_groups = plan_dev->n_groups;
         n_slots = plan_dev->n_slots;
     }
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 48*256 partial words + 2*256 block info
-    uint32_t* lds_out = lds + G1X_WORDS * G1_WG;  // output slot of the block a partial belongs to
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // 56*256 partial words + 2*256 block info
+    uint32_t* lds_out = lds + G1S_WORDS * G1_WG;  // output slot of the block a partial belongs to
     uint32_t* lds_sz = lds_out + G1_WG;           // current block size (0 = empty / retired)
     const int tid = threadIdx.x;
     // a workgroup takes slabs wg, wg + gridDim.x, ... (launch_g1_tree starts one workgroup per slab)
@@ -359,9 +574,9 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
     g1_slot_block(groups, n_groups, n_slots, slot, my_out, my_size, d, t);
     if (my_size == 1) my_size = 0;  // written by k_g1_accumulate
     {
-        const uint32_t* b = lane_partials + (size_t)wg * G1X_WORDS * G1_WG + tid;
+        const uint32_t* b = lane_partials + (size_t)wg * G1S_WORDS * G1_WG + tid;
 #pragma unroll
-        for (int k = 0; k < G1X_WORDS; ++k) lds[k * G1_WG + tid] = b[k * G1_WG];
+        for (int k = 0; k < G1S_WORDS; ++k) lds[k * G1_WG + tid] = b[k * G1_WG];
     }
     lds_out[tid] = my_out;
     lds_sz[tid] = my_size;
@@ -371,39 +586,40 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
     int g1_level = 0;
 #endif
     for (int n = G1_WG / 2; n >= 1; n >>= 1) {  // n = number of pairs at this level
-        if (n <= G1_WG / 4) {  // four lanes per pair from the second level on (g1x_add_quad: depth 4 instead of 7)
+        if (n <= G1_WG / 4) {  // four lanes per pair from the second level on (g1s_add_quad: depth 4 instead of 7)
             const int w = tid >> 2, q = tid & 3;
             const bool active = w < n;
-            fp out_a, out_b;
+            fq out_a, out_b;
             uint32_t out = NONE32, sz = 0;
             bool store_lds = false;
             if (active) {
                 sz = lds_sz[2 * w];
                 out = lds_out[2 * w];
                 if (sz >= 2) {
-                    fp a, b;
-                    lds_load_fp(a, lds, q >> 1, 2 * w + (q & 1));             // X1 | X2 | Y1 | Y2
-                    lds_load_fp(b, lds, 2 + (q >> 1), 2 * w + ((q & 1) ^ 1));  // ZZ2 | ZZ1 | ZZZ2 | ZZZ1
-                    // ZZZ == 0 <=> ZZ == 0, so every lane sees "its" partner point's infinity in b
-                    const unsigned long long inf_lanes = __ballot(fp_is_zero(b));
+                    fq a, b;
+                    lds_load_fq(a, lds, q >> 1, 2 * w + (q & 1));             // X1 | X2 | Y1 | Y2
+                    lds_load_fq(b, lds, 2 + (q >> 1), 2 * w + ((q & 1) ^ 1));  // ZZ2 | ZZ1 | ZZZ2 | ZZZ1
+                    // all limbs zero <=> infinity (ZZZ with ZZ), so every lane sees "its" partner point's infinity in b
+                    const unsigned long long inf_lanes = __ballot(fq_limbs_zero(b));
                     bool fast = ((inf_lanes >> ((tid & 63) & ~3)) & 0xFull) == 0;
-                    if (fast) fast = g1x_add_quad(out_a, out_b, q, a, b);
+                    if (fast) fast = g1s_add_quad(out_a, out_b, q, a, b);
                     if (!fast) {  // an infinity operand or P1 = +-P2: rare; the four lanes run the complete add
-                        g1x p1, p2;
-                        lds_load_x(p1, lds, 2 * w);
-                        lds_load_x(p2, lds, 2 * w + 1);
-                        g1x_add(p1, p2);
-                        fp sel;
-                        fp_select(sel, q == 1, p1.zz, p1.zzz);
-                        fp_select(out_a, q == 2, p1.x, sel);
+                        g1q p1, p2;
+                        lds_load_q(p1, lds, 2 * w);
+                        lds_load_q(p2, lds, 2 * w + 1);
+                        g1q_add_full(p1, p2);
+                        if (p1.inf) g1q_set_inf(p1);  // all limbs zero
+                        fq sel;
+                        fq_select(sel, q == 1, p1.zz, p1.zzz);
+                        fq_select(out_a, q == 2, p1.x, sel);
                         out_b = p1.y;
                     }
                     sz >>= 1;
-                    if (sz == 1) {  // block finished: q2 writes X|Y, q1 ZZ, q3 ZZZ of the 192-byte partial
+                    if (sz == 1) {  // block finished: q2 writes X|Y, q1 ZZ, q3 ZZZ of the 192-byte partial (12 x 32 words)
                         uint32_t* dst = wg_partials + (size_t)G1X_WORDS * out;
-                        if (q == 2) { global_store_fp(dst, out_a); global_store_fp(dst + 12, out_b); }
-                        else if (q == 1) global_store_fp(dst + 24, out_a);
-                        else if (q == 3) global_store_fp(dst + 36, out_a);
+                        if (q == 2) { global_store_fq_as_mont32(dst, out_a); global_store_fq_as_mont32(dst + 12, out_b); }
+                        else if (q == 1) global_store_fq_as_mont32(dst + 24, out_a);
+                        else if (q == 3) global_store_fq_as_mont32(dst + 36, out_a);
                         sz = 0;
                     } else {
                         store_lds = true;
@@ -415,9 +631,9 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
             __syncthreads();
             if (active) {
                 if (store_lds) {
-                    if (q == 2) { lds_store_fp(lds, 0, w, out_a); lds_store_fp(lds, 1, w, out_b); }
-                    else if (q == 1) lds_store_fp(lds, 2, w, out_a);
-                    else if (q == 3) lds_store_fp(lds, 3, w, out_a);
+                    if (q == 2) { lds_store_fq(lds, 0, w, out_a); lds_store_fq(lds, 1, w, out_b); }
+                    else if (q == 1) lds_store_fq(lds, 2, w, out_a);
+                    else if (q == 3) lds_store_fq(lds, 3, w, out_a);
                 }
                 if (q == 0) {
                     lds_out[w] = out;
@@ -434,7 +650,7 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
         const int w = tid >> 1;
         const bool role = tid & 1;
         const bool active = w < n;
-        fp out_a, out_b;
+        fq out_a, out_b;
         uint32_t out = NONE32, sz = 0;
         bool store_lds = false;
         if (active) {
@@ -442,31 +658,32 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
             out = lds_out[2 * w];
             if (sz >= 2) {
                 const int own = 2 * w + (role ? 1 : 0), oth = 2 * w + (role ? 0 : 1);
-                fp x_own, y_own, zz_own, zzz_own, zz_oth, zzz_oth;
-                lds_load_fp(zz_own, lds, 2, own);
-                lds_load_fp(zz_oth, lds, 2, oth);
-                const bool own_inf = fp_is_zero(zz_own), oth_inf = fp_is_zero(zz_oth);
+                fq x_own, y_own, zz_own, zzz_own, zz_oth, zzz_oth;
+                lds_load_fq(zz_own, lds, 2, own);
+                lds_load_fq(zz_oth, lds, 2, oth);
+                const bool own_inf = fq_limbs_zero(zz_own), oth_inf = fq_limbs_zero(zz_oth);
                 bool fast = !own_inf && !oth_inf;  // identical in both lanes of the pair
                 if (fast) {
-                    lds_load_fp(x_own, lds, 0, own);
-                    lds_load_fp(y_own, lds, 1, own);
-                    lds_load_fp(zzz_own, lds, 3, own);
-                    lds_load_fp(zzz_oth, lds, 3, oth);
-                    fast = g1x_add_pair(out_a, out_b, role, x_own, y_own, zz_own, zzz_own, zz_oth, zzz_oth);
+                    lds_load_fq(x_own, lds, 0, own);
+                    lds_load_fq(y_own, lds, 1, own);
+                    lds_load_fq(zzz_own, lds, 3, own);
+                    lds_load_fq(zzz_oth, lds, 3, oth);
+                    fast = g1s_add_pair(out_a, out_b, role, x_own, y_own, zz_own, zzz_own, zz_oth, zzz_oth);
                 }
                 if (!fast) {  // an infinity operand or P1 = +-P2: rare; both lanes run the complete single-lane add
-                    g1x p1, p2;
-                    lds_load_x(p1, lds, 2 * w);
-                    lds_load_x(p2, lds, 2 * w + 1);
-                    g1x_add(p1, p2);
-                    fp_select(out_a, role, p1.zz, p1.x);
-                    fp_select(out_b, role, p1.zzz, p1.y);
+                    g1q p1, p2;
+                    lds_load_q(p1, lds, 2 * w);
+                    lds_load_q(p2, lds, 2 * w + 1);
+                    g1q_add_full(p1, p2);
+                    if (p1.inf) g1q_set_inf(p1);
+                    fq_select(out_a, role, p1.zz, p1.x);
+                    fq_select(out_b, role, p1.zzz, p1.y);
                 }
                 sz >>= 1;
                 if (sz == 1) {  // block finished: role 0 writes X|Y, role 1 writes ZZ|ZZZ of the 192-byte partial
                     uint32_t* dst = wg_partials + (size_t)G1X_WORDS * out + (role ? 24 : 0);
-                    global_store_fp(dst, out_a);
-                    global_store_fp(dst + 12, out_b);
+                    global_store_fq_as_mont32(dst, out_a);
+                    global_store_fq_as_mont32(dst + 12, out_b);
                     sz = 0;
                 } else {
                     store_lds = true;
@@ -478,8 +695,8 @@ __device__ __forceinline__ void g1_tree_body(const uint32_t* __restrict__ lane_p
         __syncthreads();
         if (active) {
             if (store_lds) {
-                lds_store_fp(lds, role ? 2 : 0, w, out_a);
-                lds_store_fp(lds, role ? 3 : 1, w, out_b);
+                lds_store_fq(lds, role ? 2 : 0, w, out_a);
+                lds_store_fq(lds, role ? 3 : 1, w, out_b);
             }
             if (!role) {
                 lds_out[w] = out;
@@ -554,41 +771,6 @@ __device__ __forceinline__ bool load_point_s29(fq& x, fq& y, const uint32_t* __r
     y.l[10] = v6.x; y.l[11] = v6.y; y.l[12] = v6.z; y.l[13] = v6.w;
     return v7.x != 0;  // the row holds a point
 }
-
-// ONE copy of the product and of the squaring for everything that is not the loop body (the hand-over of a finished
-// accumulator, the complete add of the rare path): called, arguments and result in registers.
-__device__ __noinline__ fq fq_mul_nc(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6,
-                                     int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13,
-                                     int32_t b0, int32_t b1, int32_t b2, int32_t b3, int32_t b4, int32_t b5, int32_t b6,
-                                     int32_t b7, int32_t b8, int32_t b9, int32_t b10, int32_t b11, int32_t b12, int32_t b13)
-{
-    const fq a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
-    const fq b = {{b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13}};
-    fq r;
-    fq_mul(r, a, b);
-    return r;
-}
-__device__ __noinline__ fq fq_sqr_nc(int32_t a0, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t a5, int32_t a6,
-                                     int32_t a7, int32_t a8, int32_t a9, int32_t a10, int32_t a11, int32_t a12, int32_t a13)
-{
-    const fq a = {{a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13}};
-    fq r;
-    fq_sqr(r, a);
-    return r;
-}
-struct FqCalled {
-    __device__ __forceinline__ static void mul(fq& r, const fq& a, const fq& b)
-    {
-        r = fq_mul_nc(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
-                      a.l[12], a.l[13], b.l[0], b.l[1], b.l[2], b.l[3], b.l[4], b.l[5], b.l[6], b.l[7], b.l[8], b.l[9],
-                      b.l[10], b.l[11], b.l[12], b.l[13]);
-    }
-    __device__ __forceinline__ static void sqr(fq& r, const fq& a)
-    {
-        r = fq_sqr_nc(a.l[0], a.l[1], a.l[2], a.l[3], a.l[4], a.l[5], a.l[6], a.l[7], a.l[8], a.l[9], a.l[10], a.l[11],
-                      a.l[12], a.l[13]);
-    }
-};
 
 // The accumulation.  What shapes it (round 4, tools/icbench.hip): the instruction cache.  A lane's loop holds ONE
 // straight-line body -- the general mixed add, g1q_madd_fast: eight products + two squarings, ~38 KB -- and nothing else:
@@ -681,24 +863,30 @@ k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__
             if (fetch(j, qx, qy)) g1q_add_affine<FqCalled>(acc, qx, qy, false);
         }
     }
-    // hand-over: coordinate c of the accumulator -> words 12 c .. 12 c + 11 (12 x 32-bit Montgomery form, canonical); zero
-    // words for infinity.  Rolled on purpose (see above): the coordinates rotate through acc.x.
-    uint32_t* b = lane_partials + (size_t)blockIdx.x * G1X_WORDS * G1_WG + tid;
-    uint32_t* dst = my_size == 1 ? wg_partials + (size_t)G1X_WORDS * my_out : nullptr;  // single-task group: done
+    // hand-over: the accumulator as it is -- X | Y | ZZ | ZZZ, 14 limbs each, limb-major per workgroup; all limbs zero for
+    // infinity.  (Rounds 4-5 converted every lane's accumulator to the 12 x 32 words here: four products and four exact
+    // reductions per lane inside the kernel that paces the step; k_g1_tree adds in S29 now and converts once per group.)
+    uint32_t* b = lane_partials + (size_t)blockIdx.x * G1S_WORDS * G1_WG + tid;
     const bool inf = acc.inf;
-#pragma nounroll
-    for (int c = 0; c < 4; ++c) {
-        uint32_t w[12];
-        fq_to_mont32_via<FqCalled>(w, acc.x);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            const uint32_t v = inf ? 0u : w[k];
-            b[(12 * c + k) * G1_WG] = v;
-            if (dst) dst[12 * c + k] = v;
+    for (int k = 0; k < FQ_N; ++k) {
+        b[k * G1_WG] = inf ? 0u : (uint32_t)acc.x.l[k];
+        b[(FQ_N + k) * G1_WG] = inf ? 0u : (uint32_t)acc.y.l[k];
+        b[(2 * FQ_N + k) * G1_WG] = inf ? 0u : (uint32_t)acc.zz.l[k];
+        b[(3 * FQ_N + k) * G1_WG] = inf ? 0u : (uint32_t)acc.zzz.l[k];
+    }
+    if (my_size == 1) {  // a group of one task: done here, in the words k_g1_finish reads (rare: committees of <= k members)
+        uint32_t* dst = wg_partials + (size_t)G1X_WORDS * my_out;
+#pragma nounroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t w[12];
+            fq_to_mont32_via<FqCalled>(w, acc.x);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) dst[12 * c + k] = inf ? 0u : w[k];
+            acc.x = acc.y;
+            acc.y = acc.zz;
+            acc.zz = acc.zzz;
         }
-        acc.x = acc.y;
-        acc.y = acc.zz;
-        acc.zz = acc.zzz;
     }
 }
 
@@ -719,7 +907,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
     // dispatcher does double workgroups up on a CU whenever it finds the others busy for a moment (k_g1_tree of the previous
     // step arriving in the same microsecond; the first CUs to retire a predecessor's workgroup): those eight waves then run
     // at half speed for the whole launch, 330-370 us instead of 205-240 in up to six steps of twenty
-    // (profiles/r05_engine_timeline_cold20_before_exclusive.txt).  78 KB stay for the guests: k_g1_tree_solo (51 KB), the fork-choice
+    // (profiles/r05_engine_timeline_cold20_before_exclusive.txt).  78 KB stay for the guests: k_g1_tree_solo (58 KB), the fork-choice
     // tree up to 4096 blocks (66 KB), the vote histograms (32 KB each).
     size_t lds_bytes = 0;
     if (exclusive) {
@@ -732,7 +920,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
                        groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
 }
 
-// one_per_cu (the tree of a streaming step, on its own stream): ask for 84 KB of LDS instead of the 50 KB the kernel uses,
+// one_per_cu (the tree of a streaming step, on its own stream): ask for 84 KB of LDS instead of the 58 KB the kernel uses,
 // so that a CU (160 KB) never holds two of its workgroups.  Two reasons, one per round:
 //  * round 2: the tree of step N runs when the accumulation of step N retires -- which is when the fork-choice kernels of step
 //    N+1 arrive, and k_tree's single workgroup (82 KB of LDS at 4096 blocks) found no CU with room until this kernel had
@@ -751,16 +939,16 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
 //  * round 5 (`solo`, the default of streaming steps): the padding moved to the ACCUMULATION, which asks for 82 KB it never
 //    touches (launch_g1_accumulate, `exclusive`) -- that rules its doubling-up out whatever arrives when, which the 84 KB here
 //    only made rarer (6 steps of 20 at 340-370 us on one box, profiles/r05_engine_timeline_cold20_before_exclusive.txt); this kernel then
-//    keeps its workgroups apart by registers instead (k_g1_tree_solo: 264 + 264 > 512) and asks for the 51 KB it uses.
+//    keeps its workgroups apart by registers instead (k_g1_tree_solo: 264 + 264 > 512) and asks for the 58 KB it uses.
 void launch_g1_tree(hipStream_t s, const uint32_t* lane_partials, const G1Group* groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* wg_partials48, int one_per_cu, const AttPlan* plan_dev, int solo)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
-    size_t lds_bytes = (G1X_WORDS + 2) * G1_WG * sizeof(uint32_t);
+    size_t lds_bytes = (G1S_WORDS + 2) * G1_WG * sizeof(uint32_t);
     if (solo) {
         // beside an accumulation that asks for G1_ACC_EXCLUSIVE_LDS: one workgroup per CU by registers (264), the LDS request
-        // is what the kernel uses (51 KB)
+        // is what the kernel uses (58 KB)
         hipLaunchKernelGGL(k_g1_tree_solo, dim3(blocks), dim3(G1_WG), lds_bytes, s, lane_partials, groups, n_groups, n_slots,
                            wg_partials48, plan_dev);
         return;

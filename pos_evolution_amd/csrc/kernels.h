@@ -28,6 +28,7 @@ constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr int G1_ROW_WORDS = 32;
 constexpr int G2_WG_SLOTS = 128;        // point slots per 256-lane workgroup of the G2 kernels (a lane pair per point)
 constexpr int G1_WG = 256;             // lanes (task slots) per workgroup of the accumulate kernel
+constexpr int G1_LANE_PARTIAL_BYTES = 224;  // a lane's partial on its way to the tree: X | Y | ZZ | ZZZ as 14 limbs of 29 bits each
 constexpr int TREE_MAX_BLOCKS = 8192;  // LDS-resident block tree capacity (K_tree)
 constexpr int VOTES_MAX_WG = 256;      // workgroups of K_votes = slots of per-workgroup partial totals
 
@@ -52,7 +53,7 @@ void launch_g1_convert(hipStream_t s, const uint8_t* be96, uint32_t* mont24, uin
 // holds a point), built from the 24-word Montgomery table.
 void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n);
 // Per-lane XYZZ accumulation of k gathered points over that table: one partial per lane slot into lane_partials (limb-major
-// per workgroup: ceil(n_slots / 256) * 256 * 192 bytes, 12 x 32-bit Montgomery words); single-task groups are written
+// per workgroup: ceil(n_slots / 256) * 256 * G1_LANE_PARTIAL_BYTES, the accumulation's own 14 x 29-bit limbs); single-task groups are written
 // straight to wg_partials48.  plan_dev (nullable): n_groups / n_slots are read from this device-resident AttPlan instead (the
 // arguments are then upper bounds that size the grid); members1: the member array of groups whose G1Group::k has bit 31 set.
 struct AttPlan;

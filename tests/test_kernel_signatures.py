@@ -65,7 +65,7 @@ def test_exclusive_lds_request_leaves_room_for_the_guests():
     cu = 160 * 1024
     assert 2 * req > cu, "two accumulation workgroups would fit one CU"
     left = cu - req
-    tree_lds = (48 + 2) * 256 * 4                      # k_g1_tree(_solo): 48 words per partial + 2 of block info, 256 lanes
+    tree_lds = (56 + 2) * 256 * 4                      # k_g1_tree(_solo): 56 words per S29 partial + 2 of block info, 256 lanes
     fc_tree_4096 = 8 * (4096 + 18) + 4 * (2 * 4096 + 16)  # fc_kernels.hip tree_lds_bytes(4096): the paired union | tree launch
     for name, need in (("k_g1_tree_solo", tree_lds), ("k_tree at 4096 blocks", fc_tree_4096)):
         assert need <= left, f"{name} ({need} B of LDS) finds no room beside an exclusive accumulation ({left} B left)"

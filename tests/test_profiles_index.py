@@ -45,7 +45,7 @@ def test_round_index_and_files_agree(rnd, least):
     assert not unnamed, f"{rnd} files without a line in profiles/README.md: {unnamed}"
 
 
-@pytest.mark.parametrize("script,letters", [("r05_calls.sh", "efghijkl"), ("r06_calls.sh", "bcdefghijklmp")])
+@pytest.mark.parametrize("script,letters", [("r05_calls.sh", "efghijkl"), ("r06_calls.sh", "bcdefghijklmpqr")])
 def test_round_call_script_parses(script, letters):
     path = os.path.join(ROOT, "tools", script)
     assert subprocess.run(["bash", "-n", path]).returncode == 0

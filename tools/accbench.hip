@@ -45,7 +45,7 @@ int main(int argc, char** argv)
     CHECK(hipMemcpy(d_mem, members.data(), members.size() * 4, hipMemcpyHostToDevice));
     launch_g1_table_s29(0, d_pts, d_pts29, NV);
     CHECK(hipDeviceSynchronize());
-    const size_t lane_words = (size_t)G1X_WORDS * 131072 * 2;
+    const size_t lane_words = (size_t)(G1_LANE_PARTIAL_BYTES / 4) * 131072 * 2;
     CHECK(hipMalloc(&d_lane, lane_words * 4));
     CHECK(hipMalloc(&d_lane2, lane_words * 4));
     CHECK(hipMalloc(&d_wg, (size_t)G1X_WORDS * NG * 4 * 4));

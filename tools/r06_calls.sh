@@ -270,4 +270,22 @@ print("ms/step", d["ms_per_step"], "signed", d["ms_per_step_with_signatures"], "
 PY
 }
 
+# call r: the tree in S29 form (lane partials as 56 limbs, one conversion per group) -- the G1 parity tests, then A/B against the
+# previous commit's library (pos_evolution_amd/libposevo_base.so) on this box, alternating; the engine's timeline for the tree
+call_r() {
+  O=gpurun_out/r06r; mkdir -p $O
+  timeout 1200 python -m pytest tests/test_gpu_g1_accumulate.py tests/test_gpu_edge_cases.py tests/test_gpu_shapes.py tests/test_gpu_pairing.py tests/test_gpu_resident_rows.py -x -q > $O/pytest_g1.log 2>&1; echo "[r06r] g1 tests rc $?"; tail -8 $O/pytest_g1.log
+  export BENCH_ARGS="--no-shuffle-variant"
+  for i in 1 2; do
+    bash tools/gpu.sh r06r label:new$i quick
+    POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_base.so bash tools/gpu.sh r06r label:base$i quick
+  done
+  BENCH_ARGS="--no-cpu-baseline --no-slot-cadence --no-signed-steps --no-shuffle-variant" bash tools/gpu.sh r06r label:new driver
+  BENCH_ARGS="--no-cpu-baseline --no-slot-cadence --no-signed-steps --no-shuffle-variant" POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_base.so bash tools/gpu.sh r06r label:base driver
+  timeout 300 python tools/engine_timeline.py --steps 24 --show 2 > $O/engine_timeline_new.txt 2>&1; tail -30 $O/engine_timeline_new.txt
+  POSEVO_LIB_PATH=$PWD/pos_evolution_amd/libposevo_base.so timeout 300 python tools/engine_timeline.py --steps 24 --show 2 > $O/engine_timeline_base.txt 2>&1; tail -30 $O/engine_timeline_base.txt
+  unset BENCH_ARGS
+  bash tools/gpu.sh r06r label:all tests
+}
+
 "call_$1"
