@@ -329,6 +329,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
+        acc_mhz = e.profile_accumulate_mhz()   # the clock every timed step's dominant kernel ran at
         prof = e.profile()
         e.profile_enable(False)
         if prof_warm is not None:
@@ -349,7 +350,7 @@ def main():
             if verify:
                 kept.extend(more)
         return dict(dt=dt, stamps=stamps, n_att_local=n_att_local, last=last, prof=prof, kept=kept, verify=verify,
-                    sharded_chk=sharded_chk, dt_var=dt_var)
+                    sharded_chk=sharded_chk, dt_var=dt_var, acc_mhz=acc_mhz)
 
     e, w, ex, engine_rccl, exchange_how = setup(single_comm=False)
     dist_fallback = None
@@ -454,15 +455,20 @@ def main():
     k_run = max(4, -(-VL // 65536))
     lane_runs = C * -(-(VL // C) // k_run)
     mixed_adds = max(att_per_launch - lane_runs, 0.0)
-    macs = mixed_adds * MACS_ADD + lane_runs * 4 * MACS_MUL
+    macs = mixed_adds * MACS_ADD   # (until round 6 + 4 products per lane: the hand-over's conversion, now the tree's, per group)
     # the multiplier's issue rate (tools/ubench_valu, profiles/r01_ubench_valu_fpmul.log: v_mad_u64_u32 every 2.496 ns per SIMD
     # at two waves, 2.454 at four; v_mad_i64_i32 is the same unit): 1024 SIMDs x 64 lanes
     MAC_PEAK = 1024 * 64 / 2.496e-9
     valu_peak = MAC_PEAK / MACS_ADD              # mixed adds per second if the SIMDs issued nothing but multiply-adds
     valu_ach = mixed_adds / (acc_ms * 1e-3) if acc_ms else 0.0
-    # the tree over the lanes' partials (12 x 32-bit form, 288 multiply-adds + 288 carry adds per product, 14 products per
-    # add): one add per lane but one per committee; it runs on the same SIMDs beside the NEXT accumulation
-    tree_macs = 14.0 * 288 * max(lane_runs - C, 0)
+    # the tree over the lanes' partials (S29 form since round 6: 12 products + 2 squarings per full add, one add per lane but one
+    # per committee, + 4 products per committee for the hand-over to k_g1_finish's words); beside the NEXT accumulation
+    tree_macs = (12.0 * MACS_MUL + 2.0 * MACS_SQR) * max(lane_runs - C, 0) + 4.0 * MACS_MUL * C
+    # the clock the timed steps' accumulations ran at (pe_profile_accumulate_mhz); the multiplier's rate above is one multiply-add
+    # per SIX shader cycles and SIMD, which is 2.496 ns at 2.404 GHz -- the sustained clock; a run of a few milliseconds from an
+    # idle device sees ~2.05 GHz (tools/clockramp.hip)
+    acc_mhz = [float(x) for x in R["acc_mhz"] if x > 0]
+    mhz_mean = sum(acc_mhz) / len(acc_mhz) if acc_mhz else None
     votes = prof_head["votes"] if prof_head is not None and prof_head["votes"]["launches"] else prof["votes"]
     votes_ms = votes["total_ms"] / max(votes["launches"], 1)
     votes_bytes = 13.0 * VL + 32.0 * args.blocks
@@ -499,8 +505,8 @@ def main():
         "scaling": scaling,
         "vs_baseline": None,
         "dtype": "int32",
-        "dtype_detail": ("381-bit Fp, exact integer arithmetic: the accumulation (dominant kernel) in 14 signed 29-bit limbs "
-                         "held in int32 with int64 column sums (fp381_s29.h); tree / finish in 12 x u32 Montgomery limbs; "
+        "dtype_detail": ("381-bit Fp, exact integer arithmetic: accumulation (dominant kernel) and tree in 14 signed 29-bit "
+                         "limbs held in int32 with int64 column sums (fp381_s29.h); finish in 12 x u32 Montgomery limbs; "
                          "u64 Gwei weights"),
         "data": "synthetic",
         "config": {
@@ -545,6 +551,15 @@ def main():
             "note": "integer-VALU bound (3738 multiply-adds per 100 B gathered), not HBM bound: "
                     "see roofline_valu and DESIGN.md; the votes kernel below is the HBM-streaming one",
         },
+        "shader_mhz": ({"k_g1_accumulate_first_timed_launch": round(acc_mhz[0], 1), "last_timed_launch": round(acc_mhz[-1], 1),
+                        "mean": round(mhz_mean, 1), "min": round(min(acc_mhz), 1), "max": round(max(acc_mhz), 1),
+                        "launches": len(acc_mhz),
+                        "how": "workgroup 0 of every timed k_g1_accumulate launch counts shader cycles against the fixed 100 MHz "
+                               "counter (pe_profile_accumulate_mhz)",
+                        "why": "the step is bound by the integer multiplier, so it follows the power management's clock one to "
+                               "one: ~2.05 GHz for the first milliseconds of heavy load after an idle moment, ~2.4 GHz after ~35 ms "
+                               "of it (tools/clockramp.hip, profiles/r06_clockramp.txt) -- most of the distance between "
+                               "--steps 20 and --steps 200"} if acc_mhz else None),
         "roofline_valu": {
             "kernel": "k_g1_accumulate", "bound": "integer VALU: v_mad_i64_i32 / v_mad_u64_u32 issue (S29 field form)",
             "achieved": valu_ach / 1e9, "peak": valu_peak / 1e9, "unit": "G mixed adds/s", "frac": valu_ach / valu_peak,
@@ -554,6 +569,11 @@ def main():
                            "profiles/r01_ubench_valu_fpmul.log) x 1024 SIMDs x 64 lanes / 3738 multiply-adds per mixed add = "
                            "7.0 G/s; the same adds in a loop without loads reach 6.96 G/s (tools/icbench, "
                            "profiles/r04_icbench.txt), the kernel alone 5.8 G/s (tools/accbench, profiles/r04_accbench.txt)",
+            "at_measured_clock": ({"mean_shader_mhz": round(mhz_mean, 1), "peak": 1024 * 64 * mhz_mean * 1e6 / 6.0 / MACS_ADD / 1e9,
+                                   "frac": valu_ach / (1024 * 64 * mhz_mean * 1e6 / 6.0 / MACS_ADD),
+                                   "note": "the same ceiling at the clock the timed launches ran at (six cycles per multiply-add "
+                                           "and SIMD): what the kernel makes of the cycles it was given"}
+                                  if mhz_mean else None),
             "step_view": {
                 "tree_multiply_adds_per_step": tree_macs,
                 "multiply_adds_per_step": macs + tree_macs,

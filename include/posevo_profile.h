@@ -52,6 +52,12 @@ int pe_profile_queue_classes(pe_engine* h, int32_t out_class[4]);
  * since it was created.  Every such growth inside a stream of steps is milliseconds of allocation or a drained pipeline; after the
  * first step of a stream of like steps the count must stand still, whatever the lag depth. */
 int pe_profile_arena_growths(const pe_engine* h, uint64_t* out);
+/* The shader clock each k_g1_accumulate launch ran at, in MHz, for the launches since pe_profile_reset made while profiling was
+ * on (the last 4096 of them), in launch order: workgroup 0 of every launch counts shader cycles against the fixed 100 MHz counter.
+ * out_n = how many there are; at most cap are written.  The clock is the power management's and a multiplier-bound kernel follows
+ * it one to one: ~2.05 GHz for the first milliseconds of heavy load after an idle moment, ~2.4 GHz after ~35 ms of it
+ * (tools/clockramp.hip, profiles/r06_clockramp.txt) -- which is most of the distance between a 20-step and a 200-step run. */
+int pe_profile_accumulate_mhz(pe_engine* h, double* out_mhz, uint32_t cap, uint32_t* out_n);
 
 #ifdef __cplusplus
 }

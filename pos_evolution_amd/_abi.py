@@ -189,6 +189,7 @@ SIGNATURES = {
     "pe_profile_timeline": (C.c_int, [_H, _i32p, C.c_void_p, C.c_void_p, C.c_uint32, _P(C.c_uint32)]),
     "pe_profile_queue_classes": (C.c_int, [_H, _i32p]),
     "pe_profile_arena_growths": (C.c_int, [_H, _P(C.c_uint64)]),
+    "pe_profile_accumulate_mhz": (C.c_int, [_H, C.c_void_p, C.c_uint32, _P(C.c_uint32)]),
 }
 
 PE_ROWS_RESIDENT = 1  # include/posevo.h: "every group of the last pe_aggregate over rows in device memory"

@@ -543,6 +543,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->ev_acc) (void)hipEventDestroy(h->ev_acc);
+    if (h->acc_clock) (void)hipHostFree(h->acc_clock);
     if (h->ev_sig) (void)hipEventDestroy(h->ev_sig);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
@@ -773,8 +774,22 @@ int pe_profile_reset(pe_engine* h)
     prof_drain(h);
     for (auto& p : h->prof) { p.launches = 0; p.total_ms = 0; }
     h->acc_launches = 0;  // the first accumulation behind a reset is bracketed (one in four is, engine_g1.cpp)
+    h->acc_clock_n = 0;
     h->prof_tl.clear();
     if (h->prof_timeline && h->prof_base) HIP_TRY(h, hipEventRecord(h->prof_base, h->stream));  // time zero
+    return PE_OK;
+}
+int pe_profile_accumulate_mhz(pe_engine* h, double* out_mhz, uint32_t cap, uint32_t* out_n)
+{
+    if (!h || !out_n || (cap && !out_mhz)) return PE_ERR_INVALID_ARG;
+    prof_drain(h);
+    const uint64_t n = std::min<uint64_t>(h->acc_clock_n, pe_engine::ACC_CLOCK_RING);
+    const uint64_t first = h->acc_clock_n - n;  // the ring keeps the last ACC_CLOCK_RING launches
+    *out_n = (uint32_t)n;
+    for (uint64_t i = 0; i < n && i < cap; ++i) {
+        const unsigned long long* r = h->acc_clock + 2 * ((first + i) % pe_engine::ACC_CLOCK_RING);
+        out_mhz[i] = r[0] ? 100.0 * (double)r[1] / (double)r[0] : 0.0;  // 0: the launch had no workgroup 0 to report (empty plan)
+    }
     return PE_OK;
 }
 int pe_profile_timeline(pe_engine* h, int32_t* kernel, double* start_ms, double* duration_ms, uint32_t cap, uint32_t* out_n)

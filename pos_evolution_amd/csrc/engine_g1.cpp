@@ -77,8 +77,20 @@ int launch_g1_planned(pe_engine* h, const uint32_t* d_points, const uint32_t* d_
         // pe_profile_get's launch count says how many were measured); timeline mode brackets all.
         const bool skip = !h->prof_timeline && s != h->stream && (h->acc_launches++ & 3) != 0;
         ProfScope ps(h, PE_KERNEL_G1_ACCUMULATE, s, skip);
+        unsigned long long* clock_rec = nullptr;
+        if (h->profiling) {
+            if (!h->acc_clock && hipHostMalloc(reinterpret_cast<void**>(&h->acc_clock), 16ull * pe_engine::ACC_CLOCK_RING,
+                                               hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                h->acc_clock = nullptr;
+            }
+            if (h->acc_clock) {
+                clock_rec = h->acc_clock + 2 * (h->acc_clock_n++ % pe_engine::ACC_CLOCK_RING);
+                clock_rec[0] = clock_rec[1] = 0;
+            }
+        }
         launch_g1_accumulate(s, d_points29, d_members, d_bits, d_groups, plan.n_groups, plan.n_slots,
-                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1, exclusive);
+                             lane_partials->as<uint32_t>(), partials->as<uint32_t>(), plan_dev, d_members1, exclusive, clock_rec);
     }
     hipStream_t ts = fin;  // (on the accumulation's own stream the tree measured 0.433 vs 0.338 ms per step, round 3)
     if (ts != s) {

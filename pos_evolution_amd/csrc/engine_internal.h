@@ -412,6 +412,11 @@ struct pe_engine {
     // ---- profiling ----
     bool profiling = false;
     uint64_t acc_launches = 0;  // k_g1_accumulate launches: totals mode brackets every 4th one (launch_g1_planned)
+    // the shader clock of the accumulations launched while profiling is on (pe_profile_accumulate_mhz): a ring of
+    // {100 MHz ticks, shader cycles} pairs in host memory, written by workgroup 0 of each launch
+    static constexpr uint32_t ACC_CLOCK_RING = 4096;
+    unsigned long long* acc_clock = nullptr;
+    uint64_t acc_clock_n = 0;
     KernelProfile prof[PE_KERNEL_COUNT];
     // pe_profile_enable(h, 2): also a timeline of the bracketed launches (start relative to prof_base, duration)
     bool prof_timeline = false;

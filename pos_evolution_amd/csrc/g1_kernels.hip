@@ -789,13 +789,20 @@ __global__ void __launch_bounds__(G1_WG) __attribute__((amdgpu_waves_per_eu(2, 2
 k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__ members,
                     const uint32_t* __restrict__ bit_arena, const G1Group* __restrict__ groups, uint32_t n_groups,
                     uint32_t n_slots, uint32_t* __restrict__ lane_partials, uint32_t* __restrict__ wg_partials,
-                    const AttPlan* __restrict__ plan_dev, const uint32_t* __restrict__ members1)
+                    const AttPlan* __restrict__ plan_dev, const uint32_t* __restrict__ members1,
+                    unsigned long long* __restrict__ clock_rec)
 {
     const int tid = threadIdx.x;
     if (plan_dev) {
         n_groups = plan_dev->n_groups;
         n_slots = plan_dev->n_slots;
         if (blockIdx.x * G1_WG >= n_slots) return;
+    }
+    // the clock this launch ran at (pe_profile_accumulate_mhz): workgroup 0 counts shader cycles against the fixed 100 MHz counter
+    unsigned long long rec_w0 = 0, rec_c0 = 0;
+    if (clock_rec && blockIdx.x == 0) {
+        rec_w0 = wall_clock64();
+        rec_c0 = clock64();
     }
     const uint32_t slot = blockIdx.x * G1_WG + tid;
     G1_STAMP(0);
@@ -888,6 +895,10 @@ k_g1_accumulate(const uint32_t* __restrict__ pts29, const uint32_t* __restrict__
             acc.zz = acc.zzz;
         }
     }
+    if (clock_rec && blockIdx.x == 0 && tid == 0) {
+        clock_rec[0] = wall_clock64() - rec_w0;
+        clock_rec[1] = clock64() - rec_c0;
+    }
 }
 
 void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t* points_s29, uint64_t n)
@@ -898,7 +909,7 @@ void launch_g1_table_s29(hipStream_t s, const uint32_t* points_mont24, uint32_t*
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
                               const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
                               uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev,
-                              const uint32_t* members1, int exclusive)
+                              const uint32_t* members1, int exclusive, unsigned long long* clock_rec)
 {
     if (n_groups == 0 || n_slots == 0) return;
     const unsigned blocks = (n_slots + G1_WG - 1) / G1_WG;
@@ -917,7 +928,7 @@ void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint3
                                       (int)G1_ACC_EXCLUSIVE_LDS);
     }
     hipLaunchKernelGGL(k_g1_accumulate, dim3(blocks), dim3(G1_WG), lds_bytes, s, points_s29, members, bit_arena,
-                       groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1);
+                       groups, n_groups, n_slots, lane_partials, wg_partials48, plan_dev, members1, clock_rec);
 }
 
 // one_per_cu (the tree of a streaming step, on its own stream): ask for 84 KB of LDS instead of the 58 KB the kernel uses,

@@ -60,7 +60,7 @@ struct AttPlan;
 void launch_g1_accumulate(hipStream_t s, const uint32_t* points_s29, const uint32_t* members,
                           const uint32_t* bit_arena, const G1Group* groups, uint32_t n_groups, uint32_t n_slots,
                           uint32_t* lane_partials, uint32_t* wg_partials48, const AttPlan* plan_dev = nullptr,
-                          const uint32_t* members1 = nullptr, int exclusive = 0);
+                          const uint32_t* members1 = nullptr, int exclusive = 0, unsigned long long* clock_rec = nullptr);
 // exclusive: the launch asks for this much LDS it never touches (more than half a CU's): at most one of its workgroups per CU
 constexpr size_t G1_ACC_EXCLUSIVE_LDS = 82 * 1024;
 // The compacting LDS tree over each workgroup's 256 lane partials: one 48-u32 XYZZ partial (192 bytes) per

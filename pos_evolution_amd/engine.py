@@ -1065,6 +1065,14 @@ class Engine:
         self._check(self._lib.pe_profile_arena_growths(self._h, C.byref(n)))
         return int(n.value)
 
+    def profile_accumulate_mhz(self):
+        """pe_profile_accumulate_mhz: the shader clock (MHz) of each k_g1_accumulate launch since profile_reset(), in launch
+        order (launches made while profiling was on; the last 4096)."""
+        out = np.zeros(4096, dtype=np.float64)
+        n = C.c_uint32(0)
+        self._check(self._lib.pe_profile_accumulate_mhz(self._h, out.ctypes.data_as(C.c_void_p), 4096, C.byref(n)))
+        return out[:min(int(n.value), 4096)].copy()
+
     def profile_reset(self):
         self._check(self._lib.pe_profile_reset(self._h))
 

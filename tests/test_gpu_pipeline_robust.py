@@ -268,3 +268,23 @@ def test_a_handles_hot_streams_get_a_hardware_queue_each_whatever_was_created_be
     first.close()
     second.close()
     del side
+
+
+def test_every_profiled_accumulation_reports_the_clock_it_ran_at(engine_factory):
+    """pe_profile_accumulate_mhz: workgroup 0 of each k_g1_accumulate launch made while profiling is on counts shader cycles
+    against the fixed 100 MHz counter; one reading per launch since profile_reset, in launch order, in the range of the
+    device's clock (power management moves it between ~2.0 and ~2.45 GHz: profiles/r06_clockramp.txt)."""
+    w = _world(engine_factory, n_val=1 << 14, n_comm=32, seed=11)
+    e = w["e"]
+    assert e.profile_accumulate_mhz().size == 0
+    e.profile_enable(True)
+    e.profile_reset()
+    for _ in range(3):
+        _step_streaming(w)
+    e.drain()
+    mhz = e.profile_accumulate_mhz()
+    e.profile_enable(False)
+    assert mhz.size == 3, mhz
+    assert ((mhz > 800.0) & (mhz < 3200.0)).all(), mhz
+    e.profile_reset()
+    assert e.profile_accumulate_mhz().size == 0
