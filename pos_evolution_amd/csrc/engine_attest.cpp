@@ -1039,7 +1039,7 @@ int pe_process_attestation_batch(pe_engine* h, const pe_state_ctx* st, const pe_
     const uint32_t* d_gates = resident ? h->arena[h->res_arena].d_res_info.as<uint32_t>() : nullptr;
     HIP_TRY(h, stg.upload());
     memset(ob.host<uint8_t>(off_num), 0, 8ull * n);  // the kernel writes the numerators straight into the pinned block
-    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true);  // behind the upload and the unions; beside whatever follows on the engine's stream
+    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true, (uint32_t)std::min<size_t>(n, UINT32_MAX));  // behind the upload and the unions; beside whatever follows on the engine's stream
     for (size_t k = 0; k < ord.size();) {
         size_t e = k + 1;
         while (e < ord.size() && round_of[ord[e]] == round_of[ord[k]] && acc[ord[e]].table == acc[ord[k]].table) ++e;

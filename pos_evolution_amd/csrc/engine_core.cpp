@@ -228,10 +228,25 @@ hipStream_t leg_stream(pe_engine* h)
     }
     return h->aux_owned;
 }
-hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch)
+hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch, uint32_t rows_hint)
 {
     // a caller-owned stream (pe_set_stream) carries everything: the caller orders its own work against it
     if (h->stream != h->own_stream || !h->aux_stream) return h->stream;
+    // Tune::state_on = 2: WHICH of the G1 chain's streams carries the flag passes follows the size of the step.  They ride the
+    // shorter of the two kernels that own a stream: the tree's (~75 us of latency whatever the size) beside an epoch-sized
+    // accumulation (~210 us), the accumulation's beside a slot-sized one (~40 us: four adds per lane) -- there the tree's
+    // stream with the flag passes on it (75 + 35 us) set the per-slot step's period (profiles/NOTES_r06.md 9).  Consecutive flag
+    // passes are ordered (participation flags decide the reward numerators of the next): a change of stream goes through an event.
+    if (h->tune.state_on == 2 && rows_hint && h->side_stream && h->fin_stream && h->ev_aux_switch) {
+        hipStream_t want = rows_hint <= pe_engine::STATE_ON_SIDE_MAX_ROWS ? h->side_stream : h->fin_stream;
+        if (want != h->aux_stream) {
+            if (hipEventRecord(h->ev_aux_switch, h->aux_stream) == hipSuccess &&
+                hipStreamWaitEvent(want, h->ev_aux_switch, 0) == hipSuccess)
+                h->aux_stream = want;   // what the old stream held is now in front of everything that follows on the new one
+            else
+                (void)hipGetLastError();
+        }
+    }
     if (hipEventRecord(h->ev_aux_fork, h->stream) != hipSuccess ||
         hipStreamWaitEvent(h->aux_stream, h->ev_aux_fork, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -453,9 +468,10 @@ int pe_engine_create(const pe_config* cfg, pe_engine** out)
     }
     // Tune::state_on: the state-transition work on the tree's stream instead of its own (the runtime maps the engine's
     // streams onto four hardware queues; two streams that share one run in submission order)
-    if (ok_streams && h->tune.state_on == 1) h->aux_stream = h->fin_stream;
+    if (ok_streams && h->tune.state_on != 0) h->aux_stream = h->fin_stream;  // (2: state_stream_begin moves it by the step's size)
     if (!ok_streams ||
         hipEventCreateWithFlags(&h->ev_aux_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_aux_switch, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_acc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_sig, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -546,6 +562,7 @@ void pe_engine_destroy(pe_engine* h)
     if (h->acc_clock) (void)hipHostFree(h->acc_clock);
     if (h->ev_sig) (void)hipEventDestroy(h->ev_sig);
     if (h->ev_aux_fork) (void)hipEventDestroy(h->ev_aux_fork);
+    if (h->ev_aux_switch) (void)hipEventDestroy(h->ev_aux_switch);
     if (h->ev_tree) (void)hipEventDestroy(h->ev_tree);
     if (h->ev_xchg) (void)hipEventDestroy(h->ev_xchg);
     if (h->norm_stream) (void)hipStreamDestroy(h->norm_stream);

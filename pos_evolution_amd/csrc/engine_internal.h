@@ -297,6 +297,8 @@ struct pe_engine {
     hipStream_t prep_stream = nullptr;  // pe_compute_committees_async: next epochs' shuffles, beside everything else
     DevBuf d_shuffle_scratch;           // ... and their hash tables (the synchronous call uses d_tmp_be)
     hipEvent_t ev_aux_fork = nullptr;
+    hipEvent_t ev_aux_switch = nullptr;  // state_stream_begin: the state-transition work changes its stream (Tune::state_on = 2)
+    static constexpr uint32_t STATE_ON_SIDE_MAX_ROWS = 1024;  // steps over at most this many rows: flag passes on the accumulation's stream
     bool aux_busy = false;              // the aux stream holds work nobody has waited for yet
     bool state_work_on_main = false;    // state_stream_begin fell back to the engine's stream for a flag pass
     hipEvent_t ev_acc = nullptr;        // accumulate done -> finish may start
@@ -348,8 +350,9 @@ struct pe_engine {
         }
         // at most one accumulation workgroup per CU by an LDS request, the tree one per CU by registers (g1_kernels.hip)
         int exclusive = env("POSEVO_ACC_EXCLUSIVE", 1);
-        // which stream carries the state-transition work: 0 = its own (aux), 1 = the tree's (fin)
-        int state_on = env("POSEVO_STATE_ON", 1);
+        // which stream carries the state-transition work: 0 = its own (aux), 1 = the tree's (fin), 2 = the tree's for steps over
+        // more than 1024 rows and the accumulation's for smaller ones (state_stream_begin)
+        int state_on = env("POSEVO_STATE_ON", 2);
         // pe_aggregate_signed in streaming steps: how many steps' signature legs share one decompression launch (1 = a launch
         // per step, round 5's shape; at most G2_BATCH_MAX)
         int sig_batch = env("POSEVO_SIG_BATCH", 8);
@@ -493,7 +496,7 @@ int fence_arena(pe_engine* h, pe_engine::PipeArena& a);  // ev_main / ev_side of
 int tree_args(pe_engine* h, uint64_t* d_direct, const VoteTotals* d_totals, int clear_direct, uint32_t* head_word, TreeArgs* out);
 VotesArgs votes_args(const pe_engine* h);
 // The stream state-transition work goes to, ordered behind everything enqueued on the engine's stream so far.
-hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false);
+hipStream_t state_stream_begin(pe_engine* h, bool reads_scratch = false, uint32_t rows_hint = 0);
 hipStream_t leg_stream(pe_engine* h);              // where a signature leg runs (created at the first one)
 bool probe_queue_classes(const std::vector<hipStream_t>& streams, std::vector<int>& cls);  // which share a hardware queue
 int sig_batch_flush(pe_engine* h);                 // launch the signature legs collected so far (engine_g1.cpp)

@@ -592,7 +592,7 @@ int process_attestation_resident(pe_engine* h, const pe_state_ctx* sc, uint32_t 
     memset(ob.host<int32_t>(off_status), 0, 4ull * cap);
     memset(ob.host<uint64_t>(off_num), 0, 8ull * cap);  // k_participation_tables writes the rows it runs
     const uint32_t n_launch = std::max<uint32_t>(h->rr.n_in, 1);
-    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true);  // behind the unions and the plan; beside the next step's fork-choice chain
+    hipStream_t ss = state_stream_begin(h, /*reads_scratch=*/true, n_launch);  // behind the unions and the plan; beside the next step's fork-choice chain
     {
         ProfScope ps(h, PE_KERNEL_ATT_VALIDATE, ss);  // timeline mode only
         launch_att_validate_state(ss, h->rr.rows, L.grp, L.plan, n_launch, cap, block_table_dev(h), S,

@@ -217,7 +217,8 @@ def test_pairing_switched_off_is_the_old_chain(monkeypatch):
 
 KNOB_SETS = [
     {"POSEVO_ACC_EXCLUSIVE": "0", "POSEVO_STATE_ON": "0"},                       # round 4's signatures and streams
-    {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_STATE_ON": "1"},                       # the defaults, spelled out
+    {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_STATE_ON": "2"},                       # the defaults, spelled out
+    {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_STATE_ON": "1"},                       # the flag passes always on the tree's stream
     {"POSEVO_ACC_EXCLUSIVE": "1", "POSEVO_STATE_ON": "0"},
 ]
 
@@ -241,6 +242,37 @@ def test_the_scheduling_knobs_change_no_result(knobs, monkeypatch):
         monkeypatch.delenv(k)
     e2 = _twin(w, n)
     for k, st in enumerate(w["steps"]):
+        _same_step(got[k], _sync_step(e2, w, st), k)
+    _same_store(e, e2)
+    e.close()
+    e2.close()
+
+
+def test_steps_of_changing_size_move_the_flag_passes_between_streams_and_change_no_result():
+    """Tune::state_on = 2 (the default): the flag passes of process_attestation ride the tree's stream in steps over more than
+    1024 rows and the accumulation's in smaller ones (engine_core.cpp: state_stream_begin).  The numerators of a step depend on
+    the flags its predecessors set (pe:744-750), so a change of stream must keep their order: steps of 1536 and 700 rows in
+    every succession -- large, small, small, large, small, large, large -- against the synchronous twin, step by step."""
+    from pos_evolution_amd import DeviceRows
+
+    n, lag = 7, 3
+    small = (False, True, True, False, True, False, False)
+    e = pea.Engine(max_committee_tables=n + 3)
+    w = bench.build_workload(e, _args(65536, 512, 600, n), 0, n)
+    assert w["steps"][0]["atts"].shape[0] == 1536
+    steps = []
+    for st, sm in zip(w["steps"], small):
+        if sm:  # the first 700 rows of the step, on the device and on the host
+            st = dict(st)
+            st["rows_in"] = DeviceRows(st["rows_in"].ptr, 700, keep=st["rows_in"].keep)
+            st["atts"] = np.ascontiguousarray(st["atts"][:700])
+        steps.append(st)
+    e.set_pipeline_lag(lag)
+    e.reuse_outputs(n + lag + 2)
+    got = [_stream_step(e, w, st) for st in steps]
+    e.drain()
+    e2 = _twin(w, n)
+    for k, st in enumerate(steps):
         _same_step(got[k], _sync_step(e2, w, st), k)
     _same_store(e, e2)
     e.close()
