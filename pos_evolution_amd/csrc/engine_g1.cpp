@@ -140,6 +140,10 @@ int sig_batch_flush(pe_engine* h)
     bool between = own && h->side_stream != nullptr;
     for (auto& sg : segs) between = between && sg.streaming;
     hipStream_t ds = between ? h->side_stream : ss;
+    // ... and so do the sums since round 6: on the legs' low-priority stream they ran beside the accumulations after all (a fifth
+    // active queue, and one accumulation in eight at 360 us instead of 200): 0.62 / 0.55 ms per signed step against 0.53 / 0.52
+    // with the whole leg between two accumulations (profiles/NOTES_r06.md 10)
+    if (between) ss = ds;
     if (ss != h->stream) {  // behind the groupings (and the host signatures' copies) enqueued on the engine's stream so far
         HIP_TRY(h, hipEventRecord(h->ev_aux_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(ss, h->ev_aux_fork, 0));
@@ -184,8 +188,15 @@ int sig_batch_flush(pe_engine* h)
         ProfScope ps(h, PE_KERNEL_G2_ACCUMULATE, ss);
         launch_g2_aggregate_rows(ss, r);
     }
+    G2StatusOutBatch so{};
     for (auto& sg : segs) {
-        HIP_TRY(h, hipMemcpyAsync(sg.o_st, sg.d_status, 4ull * sg.n, hipMemcpyDeviceToHost, ss));
+        so.src[so.count] = sg.d_status;
+        so.dst_host[so.count] = sg.o_st;
+        so.n[so.count] = sg.n;
+        ++so.count;
+    }
+    launch_g2_status_out(ss, so);  // (one copy command per leg: ~15 us each on a stream the accumulations wait behind)
+    for (auto& sg : segs) {
         if (ss != h->stream) {  // the leg's own mark: whoever completes its arena (or rewrites the arena's scratch) waits for it
             pe_engine::PipeArena& a = h->arena[sg.arena];
             HIP_TRY(h, hipEventRecord(a.ev_leg, ss));

@@ -651,6 +651,19 @@ k_g2_count_bad(const int32_t* __restrict__ status, const uint32_t* __restrict__ 
     for (int off = 32; off >= 1; off >>= 1) bad += __shfl_xor(bad, off, 64);
     if (lane == 0) out_bad[g] = bad;
 }
+__global__ void __launch_bounds__(256)
+k_g2_status_out(const G2StatusOutBatch b)
+{
+    const uint32_t seg = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < b.n[seg]) b.dst_host[seg][i] = b.src[seg][i];
+}
+void launch_g2_status_out(hipStream_t s, const G2StatusOutBatch& b)
+{
+    uint32_t most = 0;
+    for (uint32_t k = 0; k < b.count; ++k) most = std::max(most, b.n[k]);
+    if (b.count == 0 || most == 0) return;
+    hipLaunchKernelGGL(k_g2_status_out, dim3((most + 255) / 256, b.count), dim3(256), 0, s, b);
+}
 void launch_g2_index_check(hipStream_t s, const uint32_t* index, uint32_t total, uint32_t n, uint32_t* out_index, uint32_t* err)
 {
     if (total == 0) return;

@@ -374,6 +374,10 @@ struct G2AggregateRowsBatch {
     uint32_t* out_bad[G2_BATCH_MAX]; uint32_t n_groups[G2_BATCH_MAX]; uint32_t first_block[G2_BATCH_MAX + 1]; uint32_t count;
 };
 void launch_g2_aggregate_rows(hipStream_t s, G2AggregateRowsBatch& b);
+// the per-signature statuses of up to G2_BATCH_MAX legs into their pinned output blocks, one launch (a copy command per leg cost
+// the stream ~15 us each)
+struct G2StatusOutBatch { const int32_t* src[G2_BATCH_MAX]; int32_t* dst_host[G2_BATCH_MAX]; uint32_t n[G2_BATCH_MAX]; uint32_t count; };
+void launch_g2_status_out(hipStream_t s, const G2StatusOutBatch& b);
 // pe_aggregate_signatures: a device-resident index list copied with entries >= n replaced by 0 (*err |= 1 then); members per
 // group whose status is non-zero (groups: member_start / n_members)
 void launch_g2_index_check(hipStream_t s, const uint32_t* index, uint32_t total, uint32_t n, uint32_t* out_index, uint32_t* err);
