@@ -383,39 +383,9 @@ __device__ __forceinline__ void global_store_fq_as_mont32(uint32_t* __restrict__
     d[1] = make_uint4(w[4], w[5], w[6], w[7]);
     d[2] = make_uint4(w[8], w[9], w[10], w[11]);
 }
-// p += q, both XYZZ in S29, every case of the group law: the rare path of the cooperative adds (an infinity operand, P1 = +-P2)
-__device__ __noinline__ void g1q_add_full(g1q& p, const g1q& q)
-{
-    if (q.inf) return;
-    if (p.inf) { p = q; return; }
-    fq U1, U2, S1, S2, P, R;
-    FqCalled::mul(U1, p.x, q.zz);
-    FqCalled::mul(U2, q.x, p.zz);
-    FqCalled::mul(S1, p.y, q.zzz);
-    FqCalled::mul(S2, q.y, p.zzz);
-    fq_sub(P, U2, U1);
-    fq_sub(R, S2, S1);
-    if (fq_is_zero_modp(P)) {
-        if (fq_is_zero_modp(R)) g1q_double<FqCalled>(p);
-        else g1q_set_inf(p);
-        return;
-    }
-    fq PP, PPP, Q, X3, t;
-    FqCalled::sqr(PP, P);
-    FqCalled::mul(PPP, P, PP);
-    FqCalled::mul(Q, U1, PP);
-    FqCalled::sqr(X3, R);
-    fq_sub_sub2_norm(X3, X3, PPP, Q);
-    fq_sub(t, Q, X3);
-    FqCalled::mul(t, R, t);
-    FqCalled::mul(S1, S1, PPP);
-    fq_sub_norm(p.y, t, S1);
-    FqCalled::mul(t, p.zz, q.zz);
-    FqCalled::mul(p.zz, t, PP);
-    FqCalled::mul(t, p.zzz, q.zzz);
-    FqCalled::mul(p.zzz, t, PPP);
-    p.x = X3;
-}
+// p += q, both XYZZ in S29, every case of the group law (g1_s29.h: g1q_add) over the called products: the rare path of the
+// cooperative adds (an infinity operand, P1 = +-P2)
+__device__ __noinline__ void g1q_add_full(g1q& p, const g1q& q) { g1q_add<FqCalled>(p, q); }
 // two lanes per pair (g1.h: g1x_add_pair).  role 0 owns P1, role 1 owns P2; neither is infinity (caller).  false: P1 = +-P2.
 // Outputs: role 0: out_a = X3, out_b = Y3;  role 1: out_a = ZZ3, out_b = ZZZ3.
 __device__ __forceinline__ bool g1s_add_pair(fq& out_a, fq& out_b, bool role, const fq& x_own, const fq& y_own,

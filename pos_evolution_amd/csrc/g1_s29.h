@@ -197,6 +197,44 @@ template <class MP = FqInline> PE_HD void fq_to_mont32_via(uint32_t* w, const fq
     fq_canonical_near(c, t);
     fq_to_words32(w, c);
 }
+// p += q, both in XYZZ form with lazy coordinates -- X and Y carry-passed values (or a table row's canonical limbs), ZZ and ZZZ
+// products (or the constant one) --, every case of the group law (add-2008-s: 12 products + 2 squarings).  What k_g1_tree adds
+// the lanes' accumulators with (round 6); the cooperative two- and four-lane versions in g1_kernels.hip are this formula spread
+// over lanes, and fall back to it for an infinity operand or P1 = +-P2.
+template <class MP = FqInline> PE_HD void g1q_add(g1q& p, const g1q& q)
+{
+    if (q.inf) return;
+    if (p.inf) { p = q; return; }
+    fq U1, U2, S1, S2, P, R;
+    MP::mul(U1, p.x, q.zz);
+    MP::mul(U2, q.x, p.zz);
+    MP::mul(S1, p.y, q.zzz);
+    MP::mul(S2, q.y, p.zzz);
+    fq_sub(P, U2, U1);
+    fq_sub(R, S2, S1);
+    if (fq_is_zero_modp(P)) {
+        if (fq_is_zero_modp(R)) g1q_double<MP>(p);
+        else g1q_set_inf(p);
+        return;
+    }
+    fq PP, PPP, Q, X3, t;
+    MP::sqr(PP, P);
+    MP::mul(PPP, P, PP);
+    MP::mul(Q, U1, PP);
+    MP::sqr(X3, R);
+    fq_sub_sub2_norm(X3, X3, PPP, Q);
+    fq_sub(t, Q, X3);
+    MP::mul(t, R, t);
+    MP::mul(S1, S1, PPP);
+    fq_sub_norm(p.y, t, S1);
+    MP::mul(t, p.zz, q.zz);
+    MP::mul(p.zz, t, PP);
+    MP::mul(t, p.zzz, q.zzz);
+    MP::mul(p.zzz, t, PPP);
+    p.x = X3;
+    p.affine = false;
+}
+
 template <class MP = FqInline> PE_HD void g1q_to_words32(uint32_t* w48, const g1q& p)
 {
     if (p.inf) {

@@ -129,6 +129,58 @@ void g1q_run_kernel_way(const uint32_t* rows24, int n, uint32_t* out48, int32_t*
     g1q_to_words32(out48, acc);
 }
 
+// k_g1_accumulate + k_g1_tree at the level of their formulas (round 6: the tree adds in S29): the n rows go to lanes of k rows each,
+// every lane accumulates the kernel's way, and the lanes' accumulators -- handed over as they are, lazy limbs and all -- are
+// reduced pairwise, level by level, with the complete add g1q_add.  out = the 48 words k_g1_finish would read; max_abs_limb = the
+// largest |limb| a coordinate held between two adds of the tree.
+void g1q_tree_run(const uint32_t* rows24, int n, int k, uint32_t* out48, int32_t* max_abs_limb)
+{
+    const int lanes = (n + k - 1) / k;
+    g1q* acc = new g1q[lanes > 0 ? lanes : 1];
+    for (int l = 0; l < lanes; ++l) {
+        g1q_set_inf(acc[l]);
+        for (int j = l * k; j < n && j < (l + 1) * k; ++j) {
+            const uint32_t* row = rows24 + 24 * j;
+            uint32_t any = 0;
+            for (int w = 0; w < 24; ++w) any |= row[w];
+            fq qx, qy;
+            fq_from_mont32(qx, row);
+            fq_from_mont32(qy, row + 12);
+            g1q_add_affine(acc[l], qx, qy, any == 0);
+        }
+        if (acc[l].inf) g1q_set_inf(acc[l]);  // all limbs zero: what the hand-over writes for an empty lane
+    }
+    int32_t worst = 0;
+    for (int m = lanes; m > 1; m = (m + 1) / 2) {
+        for (int i = 0; i < m / 2; ++i) {
+            g1q a = acc[2 * i];
+            // the tree learns "infinity" from the limbs (all zero), not from a flag
+            a.inf = fq_limbs_zero(a.zz);
+            g1q b = acc[2 * i + 1];
+            b.inf = fq_limbs_zero(b.zz);
+            a.affine = b.affine = false;
+            g1q_add(a, b);
+            if (a.inf) g1q_set_inf(a);
+            acc[i] = a;
+            const fq* cs[4] = {&a.x, &a.y, &a.zz, &a.zzz};
+            for (const fq* c : cs)
+                for (int t = 0; t < FQ_N - 1; ++t) {
+                    const int32_t v = c->l[t] < 0 ? -c->l[t] : c->l[t];
+                    if (v > worst) worst = v;
+                }
+        }
+        if (m & 1) acc[m / 2] = acc[m - 1];
+    }
+    if (max_abs_limb) *max_abs_limb = worst;
+    if (lanes == 0) { for (int w = 0; w < 48; ++w) out48[w] = 0; }
+    else {
+        g1q r = acc[0];
+        r.inf = fq_limbs_zero(r.zz);
+        g1q_to_words32(out48, r);
+    }
+    delete[] acc;
+}
+
 // fp_sqrt.h's fp_pow_pm3d4 as the decompression kernels run it: Montgomery words (R = 2^384) in and out
 void fq29_pow_pm3d4_words(const uint32_t* in12, uint32_t* out12, int32_t* max_abs_limb)
 {

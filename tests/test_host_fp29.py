@@ -252,6 +252,47 @@ def test_accumulation_edge_cases_of_the_group_law(lib):
     assert _run(lib, [g1.G] * 9) == g1.mul(9, g1.G)
 
 
+def _run_tree(lib, pts, k):
+    rows = np.array([w for pt in pts for w in _row(pt)], dtype=np.uint32) if pts else np.zeros(24, dtype=np.uint32)
+    out = np.zeros(48, dtype=np.uint32)
+    worst = C.c_int32(0)
+    lib.g1q_tree_run(ptr(rows, C.c_uint32), len(pts), k, ptr(out, C.c_uint32), C.byref(worst))
+    assert worst.value <= (1 << B), worst.value   # a table row's canonical limbs at most (a lane of one point passed up); sums are balanced
+    assert all(int(v) < P for v in [sum(int(out[12 * c + j]) << (32 * j) for j in range(12)) for c in range(4)])
+    return _point_of(out)
+
+
+def test_the_trees_adds_over_the_lanes_accumulators(lib):
+    """k_g1_tree since round 6: the lanes' accumulators arrive in the accumulation's own lazy form (X, Y carry-passed or a table
+    row, ZZ, ZZZ products or the constant one, all limbs zero = infinity) and are added in S29 with the complete add of
+    g1_s29.h (g1q_add: what the cooperative two- and four-lane adds of g1_kernels.hip spread over lanes and fall back to).
+    Lanes of k points reduced pairwise, level by level, against the oracle's sum: random points, every lane count up to a
+    workgroup's, empty lanes, and every special case of the group law BETWEEN lanes."""
+    rng = random.Random(77)
+    base = [g1.mul(rng.randrange(1, g1.R_ORDER), g1.G) for _ in range(96)]
+    for n, k in ((1, 4), (2, 1), (3, 1), (7, 2), (16, 4), (33, 4), (64, 1), (96, 16), (96, 5)):
+        assert _run_tree(lib, base[:n], k) == g1.sum_points(base[:n]), (n, k)
+    assert _run_tree(lib, [], 4) is None
+    A, Bp, Cp = base[0], base[1], base[2]
+    N = g1.neg
+    # whole lanes without a point (all-zero rows): infinity operands on either side, at the first level and later ones
+    assert _run_tree(lib, [None, None, A, Bp], 2) == g1.add(A, Bp)
+    assert _run_tree(lib, [A, Bp, None, None], 2) == g1.add(A, Bp)
+    assert _run_tree(lib, [None] * 8 + [A] + [None] * 7, 4) == A
+    assert _run_tree(lib, [None] * 16, 4) is None
+    # two lanes hold the same point / opposite points: the doubling and the cancellation inside the tree
+    assert _run_tree(lib, [A, A], 1) == g1.double(A)                              # affine + affine lanes
+    assert _run_tree(lib, [A, N(A)], 1) is None
+    assert _run_tree(lib, [A, Bp, A, Bp], 2) == g1.double(g1.add(A, Bp))          # XYZZ + XYZZ, equal
+    assert _run_tree(lib, [A, Bp, N(A), N(Bp)], 2) is None                        # ... and opposite
+    assert _run_tree(lib, [A, Bp, N(Bp), N(A), Cp], 2) == Cp                      # infinity met at the second level
+    assert _run_tree(lib, [A, Bp, g1.add(A, Bp), None], 2) == g1.double(g1.add(A, Bp))   # XYZZ lane + a lane of one (affine) point
+    assert _run_tree(lib, [A] * 64, 1) == g1.mul(64, A)                           # a doubling at every level
+    assert _run_tree(lib, [A] * 64, 4) == g1.mul(64, A)
+    seq = [g1.mul(i + 1, g1.G) for i in range(48)]                                # the synthetic registry's structured keys
+    assert _run_tree(lib, seq, 4) == g1.mul(48 * 49 // 2, g1.G)
+
+
 def test_generated_constants_are_current():
     """fp381_s29_consts.inc is what tools/gen_fp29_consts.py prints (everything in it follows from the prime)."""
     import sys
