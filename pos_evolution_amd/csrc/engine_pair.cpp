@@ -116,7 +116,9 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
     }
     pe_engine::HeldFc L = std::move(h->held);
     h->held = pe_engine::HeldFc{};
+    HostLap lap(&h->trace);
     int rc0 = launch_held_g1(h, L);
+    lap.mark("pair.0_held_g1");
     // a pair without a common shape goes out as two launches (the two are independent: any order)
     if (L.have_fc) {
         {
@@ -144,8 +146,9 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
                 launch_att_members(s, ma);
             }
         }
+        lap.mark("pair.1_three_pairs");
         int rb = PE_OK;
-        if (L.between) { rb = L.between(); if (rb && !rc0) rc0 = rb; }
+        if (L.between) { rb = L.between(); if (rb && !rc0) rc0 = rb; lap.mark("pair.2_between"); }
         ProfScope ps(h, PE_KERNEL_PAIR_UNION_TREE, s);
         if (rb) launch_bits_union(s, ua);  // no tree over weights whose exchange failed
         else if (!launch_pair_union_tree(s, ua, L.tree)) {
@@ -161,8 +164,10 @@ int launch_rows_paired(pe_engine* h, const IngestArgs& ia, const AttPlanArgs& pa
         launch_bits_union(s, ua);
     }
     const hipError_t e = hipGetLastError();
+    lap.mark("pair.3_union_tree");
     const int rc = after_tree(h, L);
     if (e != hipSuccess) return hip_fail(h, e, "launching the paired kernels");
+    lap.mark("pair.4_fence");
     if (h->streaming) complete_oldest_if_ready(h);  // as pe_get_head_async did behind its k_tree: the copy-out of the oldest
                                                     // pipeline, if the device is through with it
     return rc0 ? rc0 : rc;
